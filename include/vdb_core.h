@@ -1,0 +1,183 @@
+/*
+ * vdb_core.h -- C ABI of the MI355X (gfx950) search core for vectordb.
+ *
+ * One shared library (libvdbcore.so), plain pointers and sizes, no C++ or
+ * framework types.  Each entry point names the reference interface it
+ * replaces (paths relative to the reference checkout).  The reference is pure
+ * Python/NumPy, so "replaces" means: the NumPy expression or Python loop at
+ * that file:line is what the kernel behind the entry point computes.
+ *
+ * Conventions
+ *   - every function returns VDB_OK (0) or a negative vdb_status; the text of
+ *     the last failure on the calling thread is vdb_last_error();
+ *   - vectors are fp32, row-major, contiguous (index/base.py:435-469 coerces
+ *     every input to exactly that);
+ *   - row numbers are int64 on the host side, distances fp32;
+ *   - a filter is a little-endian packed bitmask: bit (i % 32) of word (i / 32)
+ *     set means row i passes (the host evaluates filter_fn / the metadata
+ *     filter once per row, index/base.py:125, core/collection.py:724);
+ *   - result slots that cannot be filled (fewer than k rows pass) hold
+ *     row = -1 and distance = +inf;
+ *   - ordering of results: ascending (distance, row); equal distances go to
+ *     the lower row number (= earlier insertion), the rule of every stable
+ *     sort in the reference (core/collection.py:757, index/pq.py:300); the
+ *     IVF search orders equal distances by scan position instead
+ *     (index/ivf.py:619-631);
+ *   - functions whose name ends in _dev take DEVICE pointers for queries,
+ *     masks and outputs plus a hipStream_t passed as void* (NULL = the
+ *     library's own stream); they enqueue work and do not synchronise.  The
+ *     plain forms take HOST pointers, copy, run, and return when the results
+ *     are in the caller's buffers.
+ */
+#ifndef VDB_CORE_H
+#define VDB_CORE_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef enum vdb_status {
+    VDB_OK = 0,
+    VDB_ERR_INVALID = -1,   /* bad argument: shape, metric, k            */
+    VDB_ERR_HIP = -2,       /* a HIP runtime call failed                 */
+    VDB_ERR_STATE = -3,     /* not initialised / not trained / empty     */
+    VDB_ERR_NOMEM = -4      /* device or host allocation failed          */
+} vdb_status;
+
+/* distance/metrics.py:453-490 -- the six metrics query_distances knows */
+typedef enum vdb_metric {
+    VDB_EUCLIDEAN = 0,      /* sqrt(max(|q|^2 + |c|^2 - 2 c.q, 0))       :453-459 */
+    VDB_EUCLIDEAN_SQ = 1,   /* max(|q|^2 + |c|^2 - 2 c.q, 0)             :461-466 */
+    VDB_COSINE = 2,         /* 1 - clip(c.q / (|q| |c|), -1, 1)          :468-481 */
+    VDB_DOT = 3,            /* -(c.q)                                    :483-484 */
+    VDB_MANHATTAN = 4,      /* sum |c - q|                               :486-487 */
+    VDB_CHEBYSHEV = 5,      /* max |c - q|                               :489-490 */
+    /* direct forms used by the per-pair scalar functions (IVF search,
+     * index/ivf.py:611-613,625) and by GPUDistanceCalculator
+     * (distance/gpu.py:118-120): */
+    VDB_EUCLIDEAN_DIRECT = 6,   /* sqrt(sum (q - c)^2), metrics.py:43    */
+    VDB_COSINE_PAIR = 7,        /* 1 - c.q/(|q||c|), 0 if |q||c| < 1e-8, metrics.py:92-100,123 */
+    VDB_EUCLIDEAN_SQ_DIRECT = 8 /* sum (q - c)^2, metrics.py:68-69       */
+} vdb_metric;
+
+/* ---- library ---------------------------------------------------------- */
+
+/* Select the GPU this process uses (one process per GPU).  Replaces the
+ * device selection of distance/gpu.py:63-67.  Idempotent. */
+int vdb_init(int device);
+const char* vdb_last_error(void);
+/* distance/gpu.py:205-225 get_gpu_info(): name (<=255 chars), total and free bytes */
+int vdb_device_info(char* name, int name_len, int64_t* mem_total, int64_t* mem_free);
+/* block until everything the library has enqueued on its own stream is done */
+int vdb_synchronize(void);
+
+/* ---- resident fp32 row matrix (FlatIndex storage, Collection matrix) ---
+ * index/flat.py:136-141,261,276-282 (growable fp32 matrix) and
+ * core/collection.py:809-828 (_ensure_matrix).  Appending also computes and
+ * keeps |c|^2 in NumPy's pairwise order (metrics.py:456) and |c| (:470), which
+ * the reference recomputes on every search. */
+typedef struct vdb_rows vdb_rows;
+int vdb_rows_create(vdb_rows** out, int dim);
+int vdb_rows_destroy(vdb_rows* h);
+int vdb_rows_append(vdb_rows* h, const float* rows, int64_t n);           /* flat.py:261 */
+int vdb_rows_append_dev(vdb_rows* h, const float* d_rows, int64_t n, int64_t ld, void* stream);
+int vdb_rows_set(vdb_rows* h, int64_t row, const float* vec);             /* flat.py:599, :201 */
+int vdb_rows_truncate(vdb_rows* h, int64_t n);                            /* flat.py:608-609 */
+int vdb_rows_size(const vdb_rows* h, int64_t* n);
+int vdb_rows_norms(vdb_rows* h, float* sqnorm_out, float* norm_out);      /* test hook: copies of the stored terms */
+
+/* FlatIndex.search / search_batch (index/flat.py:288-460), the search part of
+ * Collection.search (core/collection.py:733-758) and
+ * BatchDistanceCalculator.top_k (distance/batch.py:136-220):
+ * nq queries -> k best rows each.  out_dist / out_row are nq*k. */
+int vdb_flat_search(vdb_rows* h, int metric, const float* queries, int nq, int k,
+                    const uint32_t* mask, float* out_dist, int64_t* out_row);
+int vdb_flat_search_dev(vdb_rows* h, int metric, const float* d_queries, int nq, int k,
+                        const uint32_t* d_mask, float* d_out_dist, int64_t* d_out_row, void* stream);
+
+/* query_distances (distance/metrics.py:431-493), pairwise_* (:272-424),
+ * GPUDistanceCalculator.compute (distance/gpu.py:74-134): the full nq x n
+ * distance matrix, out[i*n + j] = distance(query i, row j). */
+int vdb_flat_distances(vdb_rows* h, int metric, const float* queries, int nq, float* out);
+int vdb_flat_distances_dev(vdb_rows* h, int metric, const float* d_queries, int nq, float* d_out, void* stream);
+
+/* FlatIndex.range_search (index/flat.py:501-572): rows with distance <= radius
+ * for one query, ascending (distance, row).  *count receives the number found;
+ * at most cap are written. */
+int vdb_flat_range_search(vdb_rows* h, int metric, const float* query, float radius,
+                          const uint32_t* mask, int64_t cap, float* out_dist, int64_t* out_row, int64_t* count);
+
+/* ---- nearest-centroid assignment ---------------------------------------
+ * KMeans._assign (index/ivf.py:228-231), IVFIndex._find_nearest_centroids_batch
+ * (:553-565) and _find_nearest_centroid (:546-551): argmin over centroids,
+ * taken on the FINAL distance value (after clamp and sqrt), first minimum.
+ * metric selects the arithmetic form (VDB_EUCLIDEAN = identity form of
+ * pairwise_euclidean; VDB_EUCLIDEAN_DIRECT = scalar form; ...). */
+int vdb_assign(const float* x, int64_t n, const float* centroids, int n_centroids, int dim,
+               int metric, int32_t* out_idx, float* out_dist);
+
+/* One Lloyd update (index/ivf.py:177-187, index/pq.py:160-169): per-cluster
+ * fp64 sums of the rows assigned to it and the member counts. */
+int vdb_kmeans_accumulate(const float* x, int64_t n, int dim, const int32_t* assign, int n_clusters,
+                          double* out_sums, int64_t* out_counts);
+
+/* ---- IVF ------------------------------------------------------------------
+ * Inverted lists stored contiguously in list order (CSR offsets), the
+ * device-side form of index/ivf.py:320 (dict of Python lists of VectorEntry). */
+typedef struct vdb_ivf vdb_ivf;
+int vdb_ivf_create(vdb_ivf** out, int dim, int metric);
+int vdb_ivf_destroy(vdb_ivf* h);
+int vdb_ivf_set_centroids(vdb_ivf* h, const float* centroids, int n_lists);   /* ivf.py:417 */
+/* rows in insertion order + the list each belongs to (ivf.py:526-542); replaces the content */
+int vdb_ivf_build(vdb_ivf* h, const float* rows, int64_t n, const int32_t* list_of_row);
+/* explicit list layout: row numbers of every list in scan order, concatenated,
+ * and n_lists+1 offsets (covers swap-removed lists, ivf.py:730-738) */
+int vdb_ivf_build_lists(vdb_ivf* h, const float* rows, int64_t n, const int64_t* list_rows, const int64_t* list_offsets);
+/* IVFIndex.search / search_batch (ivf.py:571-673).  mask is indexed by row
+ * number (insertion position). */
+int vdb_ivf_search(vdb_ivf* h, const float* queries, int nq, int k, int n_probe,
+                   const uint32_t* mask, float* out_dist, int64_t* out_row);
+int vdb_ivf_search_dev(vdb_ivf* h, const float* d_queries, int nq, int k, int n_probe,
+                       const uint32_t* d_mask, float* d_out_dist, int64_t* d_out_row, void* stream);
+/* probe selection alone (ivf.py:611-614): n_probe nearest lists per query, ascending */
+int vdb_ivf_probe(vdb_ivf* h, const float* queries, int nq, int n_probe, int32_t* out_lists, float* out_dist);
+/* bytes one search of this batch reads from the lists (sum of probed list lengths * dim * 4), for roofline accounting */
+int vdb_ivf_last_scan_rows(vdb_ivf* h, int64_t* rows_scanned);
+
+/* ---- PQ -------------------------------------------------------------------- */
+/* PQIndex._encode for a batch (index/pq.py:188-200) */
+int vdb_pq_encode(const float* x, int64_t n, const float* codebook, int m, int ksub, int dsub, uint8_t* out_codes);
+
+typedef struct vdb_pq vdb_pq;
+int vdb_pq_create(vdb_pq** out, int dim, int m, int ksub);
+int vdb_pq_destroy(vdb_pq* h);
+int vdb_pq_set_codebook(vdb_pq* h, const float* codebook);                  /* pq.py:140 */
+int vdb_pq_append_codes(vdb_pq* h, const uint8_t* codes, int64_t n);         /* pq.py:229 */
+int vdb_pq_append_codes_dev(vdb_pq* h, const uint8_t* d_codes, int64_t n, void* stream);
+int vdb_pq_append_rows(vdb_pq* h, const float* rows, int64_t n, uint8_t* out_codes_or_null); /* pq.py:228-231 */
+int vdb_pq_truncate(vdb_pq* h, int64_t n);
+int vdb_pq_set_code(vdb_pq* h, int64_t row, const uint8_t* code);
+int vdb_pq_size(const vdb_pq* h, int64_t* n);
+/* distance tables of one query (pq.py:270-283): m*ksub floats */
+int vdb_pq_lut(vdb_pq* h, const float* query, float* out_lut);
+/* PQIndex.search / search_batch (pq.py:247-327): tables, ADC scan with the
+ * bitmask tested in the scan, sqrt, top-k ascending (distance, row). */
+int vdb_pq_search(vdb_pq* h, const float* queries, int nq, int k,
+                  const uint32_t* mask, float* out_dist, int64_t* out_row);
+int vdb_pq_search_dev(vdb_pq* h, const float* d_queries, int nq, int k,
+                      const uint32_t* d_mask, float* d_out_dist, int64_t* d_out_row, void* stream);
+
+/* ---- cross-shard merge ------------------------------------------------------
+ * No counterpart in the reference (it is single-process).  After an
+ * all-gather of every shard's (distance, global row) lists: n_lists lists of k
+ * per query -> the k best per query under the (distance, row) order.
+ * Layout of the inputs: [n_lists][nq][k].  Device pointers. */
+int vdb_topk_merge_dev(const float* d_dist, const int64_t* d_row, int n_lists, int nq, int k,
+                       float* d_out_dist, int64_t* d_out_row, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* VDB_CORE_H */

@@ -1,0 +1,458 @@
+"""Parity of the HIP kernels, called through the C ABI, with the CPU oracle and
+with the golden vectors produced by the reference.
+
+Bars (written next to each check):
+  * bit-exact: row norms, Manhattan, Chebyshev, direct-form Euclidean, PQ codes /
+    tables / ADC distances, and every returned row number on those paths;
+  * fp32 dot-product metrics (BLAS in the reference, MFMA/fma here): distances
+    within 1e-4 relative (plus the cancellation floor of the identity form near
+    zero), id sets identical except rows whose reference distance ties the k-th
+    reference distance to rounding.
+"""
+
+import numpy as np
+import pytest
+
+from oracle import ref_numpy as R
+from conftest import load_golden, same_ids_or_near_ties
+
+pytestmark = pytest.mark.gpu
+
+RTOL = 1e-4
+METRICS6 = ("euclidean", "euclidean_squared", "cosine", "dot", "manhattan", "chebyshev")
+EXACT = ("manhattan", "chebyshev")
+
+
+@pytest.fixture(scope="module")
+def nat(native):
+    from vectordb_amd import _native
+    return _native
+
+
+def identity_atol(metric, q, x):
+    """Rounding floor of |q|^2+|c|^2-2c.q (a few ulps of the large terms) mapped
+    to the returned value."""
+    if metric == "euclidean_squared":
+        return 4e-6 * float(np.max(np.sum(x * x, axis=1)) + np.sum(q * q))
+    if metric == "euclidean":
+        return 2e-3
+    if metric == "dot":
+        return 1e-5 * float(np.max(np.abs(x).sum(axis=1)) * np.max(np.abs(q)))
+    return 2e-6
+
+
+def check_search(nat, x, queries, k, metric, mask=None):
+    store = nat.RowStore(x.shape[1])
+    store.append(x)
+    words = nat.pack_mask(mask)
+    dist, rows = store.search(queries, k, nat.METRIC_CODES[metric], words)
+    for i, q in enumerate(np.atleast_2d(queries)):
+        ref_rows, ref_dist = R.flat_search(q, x, k, metric, mask=mask)
+        full = R.query_distances(q, x, metric)
+        n_ref = len(ref_rows)
+        assert (rows[i, n_ref:] == -1).all() and np.isinf(dist[i, n_ref:]).all()
+        got_rows, got_dist = rows[i, :n_ref], dist[i, :n_ref]
+        assert len(set(got_rows)) == n_ref
+        if mask is not None:
+            assert mask[got_rows].all()
+        if metric in EXACT:
+            np.testing.assert_array_equal(got_rows, ref_rows)
+            np.testing.assert_array_equal(got_dist, ref_dist.astype(np.float32))
+        else:
+            atol = identity_atol(metric, q, x)
+            assert same_ids_or_near_ties(got_rows, ref_rows, lambda r: full[r], float(ref_dist[-1]), rtol=RTOL, atol=atol)
+            np.testing.assert_allclose(got_dist, ref_dist, rtol=RTOL, atol=atol)
+            assert (np.diff(got_dist) >= 0).all()
+    store.close()
+    return dist, rows
+
+
+# ------------------------------------------------------------------ norms
+
+@pytest.mark.parametrize("d", [1, 3, 7, 8, 13, 32, 100, 128, 130, 384, 768, 1000])
+def test_row_norms_bit_exact(nat, d):
+    rng = np.random.RandomState(d)
+    x = rng.randn(700, d).astype(np.float32)
+    store = nat.RowStore(d)
+    store.append(x[:300])
+    store.append(x[300:])           # second append grows the store
+    sq, nr = store.norms()
+    np.testing.assert_array_equal(sq, np.sum(x ** 2, axis=1))                 # metrics.py:456
+    np.testing.assert_array_equal(nr, np.linalg.norm(x, axis=1))              # metrics.py:470
+    store.close()
+
+
+def test_row_norms_golden(nat):
+    g = load_golden("metrics.npz")
+    for d in (3, 8, 13, 100, 130, 384, 768):
+        store = nat.RowStore(d)
+        store.append(g[f"d{d}_x"])
+        sq, _ = store.norms()
+        np.testing.assert_array_equal(sq, g[f"d{d}_sqnorm"])
+        store.close()
+
+
+# ------------------------------------------------------------------ flat search
+
+@pytest.mark.parametrize("metric", METRICS6)
+@pytest.mark.parametrize("nq", [1, 3, 12])        # 1,3: streaming scan; 12: matrix-core path (dot metrics)
+def test_flat_search_small_golden_inputs(nat, metric, nq):
+    g = load_golden("flat_small.npz")
+    x, q, mask = g["x"], g["q"][:nq], g["mask"]
+    for k in (1, 10, 37):                          # 37 > 32: two selection passes
+        check_search(nat, x, q, k, metric)
+    check_search(nat, x, q, 10, metric, mask=mask)
+
+
+@pytest.mark.parametrize("metric", METRICS6)
+def test_flat_search_vs_reference_golden(nat, metric):
+    """Against the reference's own FlatIndex.search outputs."""
+    g = load_golden("flat_small.npz")
+    x, q, mask = g["x"], g["q"], g["mask"]
+    store = nat.RowStore(x.shape[1])
+    store.append(x)
+    code = nat.METRIC_CODES[metric]
+    for k in (1, 10, 37):
+        dist, rows = store.search(q, k, code)
+        for i in range(len(q)):
+            full = R.query_distances(q[i], x, metric)
+            ref_rows, ref_dist = g[f"{metric}_k{k}_rows"][i], g[f"{metric}_k{k}_dist"][i]
+            atol = identity_atol(metric, q[i], x)
+            assert same_ids_or_near_ties(rows[i], ref_rows, lambda r: full[r], float(ref_dist[-1]), rtol=RTOL, atol=atol)
+            if metric in EXACT:
+                np.testing.assert_array_equal(dist[i], ref_dist.astype(np.float32))
+            else:
+                np.testing.assert_allclose(dist[i], ref_dist, rtol=RTOL, atol=atol)
+    dist, rows = store.search(q, 10, code, nat.pack_mask(mask))
+    for i in range(len(q)):
+        full = R.query_distances(q[i], x, metric)
+        ref_rows, ref_dist = g[f"{metric}_filter_rows"][i], g[f"{metric}_filter_dist"][i]
+        atol = identity_atol(metric, q[i], x)
+        assert same_ids_or_near_ties(rows[i], ref_rows, lambda r: full[r], float(ref_dist[-1]), rtol=RTOL, atol=atol)
+        np.testing.assert_allclose(dist[i], ref_dist, rtol=RTOL, atol=atol)
+    store.close()
+
+
+def test_flat_ties_go_to_lowest_row(nat):
+    g = load_golden("flat_small.npz")
+    x, q = g["x"], g["q"]
+    store = nat.RowStore(x.shape[1])
+    store.append(x)
+    # rows 3, 100, 900 are identical and query 0 equals them
+    for metric in ("manhattan", "chebyshev", "dot", "cosine"):
+        for batch in (q[:1], q[:8]):
+            _, rows = store.search(batch, 3, nat.METRIC_CODES[metric])
+            if metric in ("manhattan", "chebyshev"):
+                assert list(rows[0]) == [3, 100, 900]
+            else:
+                # the three copies have bit-identical distances on every path
+                d3 = R.query_distances(q[0], x, metric)
+                if np.argsort(d3, kind="stable")[0] == 3:
+                    assert list(rows[0]) == [3, 100, 900]
+    store.close()
+
+
+def test_flat_config1_golden(nat):
+    """BASELINE config 1 (10k x 128 euclidean, 100 queries, k=10) against the
+    reference's FlatIndex.search and Collection.search results."""
+    g = load_golden("flat_config1.npz")
+    np.random.seed(42)
+    x = np.random.randn(10000, 128).astype(np.float32)
+    np.random.seed(123)
+    q = np.random.randn(100, 128).astype(np.float32)
+    store = nat.RowStore(128)
+    store.append(x)
+    for batch in (True, False):
+        if batch:
+            dist, rows = store.search(q, 10, nat.EUCLIDEAN)
+        else:
+            out = [store.search(q[i], 10, nat.EUCLIDEAN) for i in range(100)]
+            dist = np.concatenate([o[0] for o in out]); rows = np.concatenate([o[1] for o in out])
+        for i in range(100):
+            full = R.query_distances(q[i], x, "euclidean")
+            for name in ("flat", "coll"):
+                ref_rows, ref_dist = g[f"{name}_rows"][i], g[f"{name}_dist"][i]
+                assert same_ids_or_near_ties(rows[i], ref_rows, lambda r: full[r], float(ref_dist[-1]), rtol=RTOL)
+                np.testing.assert_allclose(dist[i], ref_dist, rtol=RTOL)
+    mask = (np.arange(len(x)) % 4) == 1
+    dist, rows = store.search(q[:20], 10, nat.EUCLIDEAN, nat.pack_mask(mask))
+    for i in range(20):
+        assert set(rows[i]) == set(g["coll_filter_rows"][i])
+        np.testing.assert_allclose(dist[i], g["coll_filter_dist"][i], rtol=RTOL)
+    store.close()
+
+
+@pytest.mark.parametrize("n,d,nq", [(1, 4, 1), (5, 2, 2), (127, 33, 5), (129, 64, 130), (1000, 100, 17), (4097, 20, 4)])
+def test_flat_ragged_shapes(nat, n, d, nq):
+    rng = np.random.RandomState(n + d)
+    x = rng.randn(n, d).astype(np.float32)
+    q = rng.randn(nq, d).astype(np.float32)
+    for metric in ("euclidean", "cosine", "dot", "manhattan"):
+        for k in (1, 5, n + 3):                   # k > n is capped; the tail reads -1 / inf
+            check_search(nat, x, q, k, metric)
+
+
+def test_flat_zero_query_and_zero_rows_cosine(nat):
+    rng = np.random.RandomState(9)
+    x = rng.randn(500, 16).astype(np.float32)
+    x[5] = 0.0
+    q = np.zeros((6, 16), np.float32)
+    q[1:] = rng.randn(5, 16)
+    for nq in (1, 6):
+        store = nat.RowStore(16)
+        store.append(x)
+        dist, rows = store.search(q[:nq], 4, nat.COSINE)
+        np.testing.assert_array_equal(rows[0], [0, 1, 2, 3])            # all ones -> first rows (metrics.py:472-473)
+        np.testing.assert_array_equal(dist[0], np.ones(4, np.float32))
+        full = store.distances(q[:nq], nat.COSINE)
+        assert full[0].tolist() == [1.0] * 500
+        if nq > 1:
+            np.testing.assert_allclose(full[1], R.query_distances(q[1], x, "cosine"), rtol=RTOL, atol=2e-6)
+            assert full[1][5] == 1.0                                    # zero row: norm replaced by 1 -> similarity 0
+        store.close()
+
+
+def test_flat_empty_and_errors(nat):
+    store = nat.RowStore(8)
+    dist, rows = store.search(np.zeros((2, 8), np.float32), 3, nat.EUCLIDEAN)
+    assert (rows == -1).all() and np.isinf(dist).all()
+    with pytest.raises(ValueError):
+        store.append(np.zeros((3, 7), np.float32))
+    with pytest.raises(ValueError):
+        store.search(np.zeros((1, 8), np.float32), 3, 99)
+    with pytest.raises(ValueError):
+        store.search(np.zeros((1, 8), np.float32), 0, nat.EUCLIDEAN)
+    store.close()
+
+
+def test_flat_update_and_swap_remove(nat):
+    """index/flat.py:596-609: the last row is copied over the removed one and
+    the matrix shrinks by one."""
+    rng = np.random.RandomState(2)
+    x = rng.randn(300, 24).astype(np.float32)
+    q = rng.randn(5, 24).astype(np.float32)
+    store = nat.RowStore(24)
+    store.append(x)
+    y = x.copy()
+    y[17] = y[-1]
+    y = y[:-1]
+    store.set_row(17, x[-1])
+    store.truncate(299)
+    for metric in ("euclidean", "manhattan"):
+        dist, rows = store.search(q, 7, nat.METRIC_CODES[metric])
+        for i in range(5):
+            ref_rows, ref_dist = R.flat_search(q[i], y, 7, metric)
+            np.testing.assert_array_equal(rows[i], ref_rows)
+            np.testing.assert_allclose(dist[i], ref_dist, rtol=RTOL)
+    sq, _ = store.norms()
+    np.testing.assert_array_equal(sq, np.sum(y ** 2, axis=1))
+    store.close()
+
+
+# ------------------------------------------------------------------ full distance matrices
+
+@pytest.mark.parametrize("nq", [1, 2, 40])
+def test_distances_golden(nat, nq):
+    g = load_golden("metrics.npz")
+    for seed in (0, 42, 123):
+        x, q = g[f"s{seed}_x"], g[f"s{seed}_q"]
+        qs = np.stack([q] + [x[i] for i in range(nq - 1)])
+        store = nat.RowStore(x.shape[1])
+        store.append(x)
+        for metric in METRICS6:
+            out = store.distances(qs, nat.METRIC_CODES[metric])
+            ref = g[f"s{seed}_qd_{metric}"]
+            if metric in EXACT:
+                np.testing.assert_array_equal(out[0], ref)
+            else:
+                np.testing.assert_allclose(out[0], ref, rtol=RTOL, atol=identity_atol(metric, q, x))
+            for j in range(1, nq):
+                np.testing.assert_allclose(out[j], R.query_distances(qs[j], x, metric), rtol=RTOL,
+                                           atol=identity_atol(metric, qs[j], x))
+        # direct forms (the per-pair scalar functions, metrics.py:43,190,214)
+        out = store.distances(q, nat.EUCLIDEAN_DIRECT)
+        np.testing.assert_array_equal(out[0][:64].astype(np.float64), g[f"s{seed}_scalar_euclidean"])
+        out = store.distances(q, nat.COSINE_PAIR)
+        np.testing.assert_allclose(out[0][:64], g[f"s{seed}_scalar_cosine"], rtol=RTOL, atol=2e-6)
+        store.close()
+
+
+@pytest.mark.parametrize("d", [3, 8, 13, 100, 130, 384, 768])
+def test_distances_dims_golden(nat, d):
+    g = load_golden("metrics.npz")
+    x, q = g[f"d{d}_x"], g[f"d{d}_q"]
+    store = nat.RowStore(d)
+    store.append(x)
+    for metric in ("euclidean", "cosine", "dot", "manhattan", "chebyshev"):
+        out = store.distances(q, nat.METRIC_CODES[metric])[0]
+        ref = g[f"d{d}_qd_{metric}"]
+        if metric in EXACT:
+            np.testing.assert_array_equal(out, ref)
+        else:
+            np.testing.assert_allclose(out, ref, rtol=RTOL, atol=identity_atol(metric, q, x))
+    out = store.distances(q, nat.EUCLIDEAN_DIRECT)[0]
+    np.testing.assert_array_equal(out.astype(np.float64), g[f"d{d}_scalar_euclidean"])
+    store.close()
+
+
+def test_range_search_golden(nat):
+    g = load_golden("flat_small.npz")
+    x, q = g["x"], g["q"]
+    store = nat.RowStore(x.shape[1])
+    store.append(x)
+    dist, rows = store.range_search(q[2], 8.5, nat.EUCLIDEAN)
+    full = R.query_distances(q[2], x, "euclidean")
+    assert same_ids_or_near_ties(rows, g["range_rows"], lambda r: full[r], 8.5, rtol=RTOL)
+    assert (np.diff(dist) >= 0).all() and (dist <= 8.5).all()
+    store.close()
+
+
+# ------------------------------------------------------------------ assignment / IVF
+
+@pytest.mark.parametrize("metric", ["euclidean", "cosine", "manhattan", "dot"])
+def test_ivf_golden(nat, metric):
+    g = load_golden("ivf.npz")
+    x, q, mask = g["x"], g["q"], g["mask"]
+    cent = g[f"{metric}_centroids"]
+    code = nat.METRIC_CODES[metric]
+    # batch assignment (ivf.py:553-565): identity form for euclidean/cosine, scalar functions otherwise
+    idx, _ = nat.assign(x, cent, code if metric in ("euclidean", "cosine") else {"manhattan": nat.MANHATTAN, "dot": nat.DOT}[metric])
+    ref_assign = g[f"{metric}_assign_batch"]
+    diff = np.flatnonzero(idx != ref_assign)
+    if metric == "manhattan":
+        assert len(diff) == 0
+    else:
+        # a differing assignment must be a rounding-level tie between two centroids
+        for r in diff:
+            d = R.rows_scalar_metric(x[r], cent, metric)
+            assert abs(d[idx[r]] - d[ref_assign[r]]) <= 1e-5 * max(1.0, abs(d[ref_assign[r]]))
+        assert len(diff) <= 2
+    lists = nat.IvfLists(32, code)
+    lists.set_centroids(cent)
+    lists.build(x, ref_assign)
+    exact = metric in ("euclidean", "manhattan")
+    for npb in (1, 8, 32):
+        dist, rows = lists.search(q, 10, npb)
+        for i in range(len(q)):
+            ref_rows, ref_dist = g[f"{metric}_np{npb}_rows"][i], g[f"{metric}_np{npb}_dist"][i]
+            n = int((ref_rows >= 0).sum())
+            assert (rows[i, n:] == -1).all()
+            if exact:
+                np.testing.assert_array_equal(rows[i, :n], ref_rows[:n])          # same rows, same order
+                np.testing.assert_array_equal(dist[i, :n].astype(np.float64), ref_dist[:n])
+            else:
+                np.testing.assert_array_equal(np.sort(rows[i, :n]), np.sort(ref_rows[:n]))
+                np.testing.assert_allclose(dist[i, :n], ref_dist[:n], rtol=RTOL, atol=2e-6)
+    dist, rows = lists.search(q, 10, 8, nat.pack_mask(mask))
+    for i in range(len(q)):
+        ref_rows, ref_dist = g[f"{metric}_filter_rows"][i], g[f"{metric}_filter_dist"][i]
+        n = int((ref_rows >= 0).sum())
+        if exact:
+            np.testing.assert_array_equal(rows[i, :n], ref_rows[:n])
+            np.testing.assert_array_equal(dist[i, :n].astype(np.float64), ref_dist[:n])
+        else:
+            np.testing.assert_array_equal(np.sort(rows[i, :n]), np.sort(ref_rows[:n]))
+    # single-vector assignment (ivf.py:546-551): scalar functions
+    single_code = {"euclidean": nat.EUCLIDEAN_DIRECT, "cosine": nat.COSINE_PAIR, "manhattan": nat.MANHATTAN, "dot": nat.DOT}[metric]
+    idx1, _ = nat.assign(x[:300], cent, single_code)
+    ref1 = g[f"{metric}_assign_single"]
+    if exact:
+        np.testing.assert_array_equal(idx1, ref1)
+    else:
+        assert (idx1 != ref1).sum() <= 1
+    # probe order
+    probes, pd = lists.probe(q, 8)
+    for i in range(len(q)):
+        ref_p = R.ivf_probe_order(q[i], cent, metric, 8)
+        if exact:
+            np.testing.assert_array_equal(probes[i], ref_p)
+    lists.close()
+
+
+def test_ivf_large_nprobe_and_k(nat):
+    rng = np.random.RandomState(8)
+    x = rng.randn(3000, 16).astype(np.float32)
+    q = rng.randn(7, 16).astype(np.float32)
+    cent = R.kmeans_fit(x, 64, 5, seed=0)
+    assign = R.ivf_assign_batch(x, cent, "euclidean")
+    lists_ref = R.ivf_build_lists(assign, 64)
+    lists = nat.IvfLists(16, nat.EUCLIDEAN)
+    lists.set_centroids(cent)
+    lists.build(x, assign)
+    for npb, k in ((40, 10), (64, 50), (5, 100)):
+        dist, rows = lists.search(q, k, npb)
+        for i in range(len(q)):
+            ref_rows, ref_dist = R.ivf_search(q[i], x, cent, lists_ref, k, npb, "euclidean")
+            n = len(ref_rows)
+            np.testing.assert_array_equal(rows[i, :n], ref_rows)
+            np.testing.assert_array_equal(dist[i, :n].astype(np.float64), ref_dist)
+            assert (rows[i, n:] == -1).all()
+    assert lists.last_scan_rows() > 0
+    lists.close()
+
+
+def test_kmeans_accumulate(nat):
+    rng = np.random.RandomState(4)
+    x = rng.randn(5000, 24).astype(np.float32)
+    a = rng.randint(0, 37, size=5000).astype(np.int32)
+    sums, counts = nat.kmeans_accumulate(x, a, 40)
+    ref = np.zeros((40, 24), np.float64)
+    np.add.at(ref, a, x.astype(np.float64))
+    np.testing.assert_allclose(sums, ref, rtol=1e-12, atol=1e-12)
+    np.testing.assert_array_equal(counts, np.bincount(a, minlength=40))
+
+
+# ------------------------------------------------------------------ PQ
+
+def test_pq_golden(nat):
+    g = load_golden("pq.npz")
+    x, q, mask, book = g["x"], g["q"], g["mask"], g["codebook"]
+    np.testing.assert_array_equal(nat.pq_encode(x, book), g["codes"])              # pq.py:188-200, bit-exact
+    pq = nat.PqCodes(32, 4, 256)
+    pq.set_codebook(book)
+    codes = pq.append_rows(x[:700])
+    pq.append_codes(g["codes"][700:])
+    np.testing.assert_array_equal(codes, g["codes"][:700])
+    for i in range(len(q)):
+        np.testing.assert_array_equal(pq.lut(q[i]), R.pq_lut(q[i], book))           # pq.py:270-283
+    dist, rows = pq.search(q, 10)
+    np.testing.assert_array_equal(rows, g["rows"])
+    np.testing.assert_array_equal(dist, g["dist"])
+    dist, rows = pq.search(q, 10, nat.pack_mask(mask))
+    np.testing.assert_array_equal(rows, g["filter_rows"])
+    np.testing.assert_array_equal(dist, g["filter_dist"])
+    # full ordering (k = n): 38 selection passes
+    dist, rows = pq.search(q[:2], len(x))
+    for i in range(2):
+        ref_rows, ref_dist = R.pq_search(q[i], book, g["codes"], len(x))
+        np.testing.assert_array_equal(rows[i], ref_rows)
+        np.testing.assert_array_equal(dist[i], ref_dist)
+    pq.close()
+    small = nat.PqCodes(32, 8, 256)
+    small.set_codebook(g["small_codebook"])
+    np.testing.assert_array_equal(small.append_rows(x[:300]), g["small_codes"])
+    dist, rows = small.search(q[0], 10)
+    np.testing.assert_array_equal(rows[0], g["small_rows"])
+    np.testing.assert_array_equal(dist[0], g["small_dist"])
+    small.close()
+
+
+@pytest.mark.parametrize("m,dsub", [(16, 8), (8, 16), (3, 5), (2, 136)])
+def test_pq_shapes(nat, m, dsub):
+    rng = np.random.RandomState(m * dsub)
+    d = m * dsub
+    x = rng.randn(2500, d).astype(np.float32)
+    q = rng.randn(3, d).astype(np.float32)
+    book = rng.randn(m, 256, dsub).astype(np.float32)
+    codes = R.pq_encode(x, book)
+    np.testing.assert_array_equal(nat.pq_encode(x, book), codes)
+    pq = nat.PqCodes(d, m, 256)
+    pq.set_codebook(book)
+    pq.append_codes(codes)
+    mask = rng.rand(2500) < 0.3
+    dist, rows = pq.search(q, 10, nat.pack_mask(mask))
+    for i in range(3):
+        ref_rows, ref_dist = R.pq_search(q[i], book, codes, 10, mask=mask)
+        np.testing.assert_array_equal(rows[i], ref_rows)
+        np.testing.assert_array_equal(dist[i], ref_dist)
+    pq.close()

@@ -1,0 +1,448 @@
+"""ctypes binding of libvdbcore.so (the C ABI declared in include/vdb_core.h).
+
+There is no CPU fallback: if the library cannot be loaded, or a call fails,
+an exception is raised.  The status codes are mapped to the exception types
+the reference raises at the same places (ValueError for bad shapes/metrics,
+RuntimeError for state errors; index/base.py:443-449, index/ivf.py:459,595).
+"""
+
+from __future__ import annotations
+
+import ctypes as C
+import os
+import threading
+from typing import Optional
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "_lib", "libvdbcore.so")
+
+VDB_OK, VDB_ERR_INVALID, VDB_ERR_HIP, VDB_ERR_STATE, VDB_ERR_NOMEM = 0, -1, -2, -3, -4
+
+# vdb_metric
+EUCLIDEAN, EUCLIDEAN_SQ, COSINE, DOT, MANHATTAN, CHEBYSHEV = 0, 1, 2, 3, 4, 5
+EUCLIDEAN_DIRECT, COSINE_PAIR, EUCLIDEAN_SQ_DIRECT = 6, 7, 8
+
+METRIC_CODES = {
+    "euclidean": EUCLIDEAN,
+    "euclidean_squared": EUCLIDEAN_SQ,
+    "cosine": COSINE,
+    "dot": DOT,
+    "manhattan": MANHATTAN,
+    "chebyshev": CHEBYSHEV,
+}
+
+c_float_p = C.POINTER(C.c_float)
+c_i64_p = C.POINTER(C.c_int64)
+c_i32_p = C.POINTER(C.c_int32)
+c_u32_p = C.POINTER(C.c_uint32)
+c_u8_p = C.POINTER(C.c_uint8)
+c_double_p = C.POINTER(C.c_double)
+
+# name -> (restype, argtypes); every symbol declared in include/vdb_core.h
+SIGNATURES = {
+    "vdb_init": (C.c_int, [C.c_int]),
+    "vdb_last_error": (C.c_char_p, []),
+    "vdb_device_info": (C.c_int, [C.c_char_p, C.c_int, c_i64_p, c_i64_p]),
+    "vdb_synchronize": (C.c_int, []),
+    "vdb_rows_create": (C.c_int, [C.POINTER(C.c_void_p), C.c_int]),
+    "vdb_rows_destroy": (C.c_int, [C.c_void_p]),
+    "vdb_rows_append": (C.c_int, [C.c_void_p, c_float_p, C.c_int64]),
+    "vdb_rows_append_dev": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_int64, C.c_void_p]),
+    "vdb_rows_set": (C.c_int, [C.c_void_p, C.c_int64, c_float_p]),
+    "vdb_rows_truncate": (C.c_int, [C.c_void_p, C.c_int64]),
+    "vdb_rows_size": (C.c_int, [C.c_void_p, c_i64_p]),
+    "vdb_rows_norms": (C.c_int, [C.c_void_p, c_float_p, c_float_p]),
+    "vdb_flat_search": (C.c_int, [C.c_void_p, C.c_int, c_float_p, C.c_int, C.c_int, c_u32_p, c_float_p, c_i64_p]),
+    "vdb_flat_search_dev": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p,
+                                      C.c_void_p, C.c_void_p]),
+    "vdb_flat_distances": (C.c_int, [C.c_void_p, C.c_int, c_float_p, C.c_int, c_float_p]),
+    "vdb_flat_distances_dev": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p]),
+    "vdb_flat_range_search": (C.c_int, [C.c_void_p, C.c_int, c_float_p, C.c_float, c_u32_p, C.c_int64, c_float_p,
+                                        c_i64_p, c_i64_p]),
+    "vdb_assign": (C.c_int, [c_float_p, C.c_int64, c_float_p, C.c_int, C.c_int, C.c_int, c_i32_p, c_float_p]),
+    "vdb_kmeans_accumulate": (C.c_int, [c_float_p, C.c_int64, C.c_int, c_i32_p, C.c_int, c_double_p, c_i64_p]),
+    "vdb_ivf_create": (C.c_int, [C.POINTER(C.c_void_p), C.c_int, C.c_int]),
+    "vdb_ivf_destroy": (C.c_int, [C.c_void_p]),
+    "vdb_ivf_set_centroids": (C.c_int, [C.c_void_p, c_float_p, C.c_int]),
+    "vdb_ivf_build": (C.c_int, [C.c_void_p, c_float_p, C.c_int64, c_i32_p]),
+    "vdb_ivf_build_lists": (C.c_int, [C.c_void_p, c_float_p, C.c_int64, c_i64_p, c_i64_p]),
+    "vdb_ivf_search": (C.c_int, [C.c_void_p, c_float_p, C.c_int, C.c_int, C.c_int, c_u32_p, c_float_p, c_i64_p]),
+    "vdb_ivf_search_dev": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p,
+                                     C.c_void_p, C.c_void_p]),
+    "vdb_ivf_probe": (C.c_int, [C.c_void_p, c_float_p, C.c_int, C.c_int, c_i32_p, c_float_p]),
+    "vdb_ivf_last_scan_rows": (C.c_int, [C.c_void_p, c_i64_p]),
+    "vdb_pq_encode": (C.c_int, [c_float_p, C.c_int64, c_float_p, C.c_int, C.c_int, C.c_int, c_u8_p]),
+    "vdb_pq_create": (C.c_int, [C.POINTER(C.c_void_p), C.c_int, C.c_int, C.c_int]),
+    "vdb_pq_destroy": (C.c_int, [C.c_void_p]),
+    "vdb_pq_set_codebook": (C.c_int, [C.c_void_p, c_float_p]),
+    "vdb_pq_append_codes": (C.c_int, [C.c_void_p, c_u8_p, C.c_int64]),
+    "vdb_pq_append_codes_dev": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p]),
+    "vdb_pq_append_rows": (C.c_int, [C.c_void_p, c_float_p, C.c_int64, c_u8_p]),
+    "vdb_pq_truncate": (C.c_int, [C.c_void_p, C.c_int64]),
+    "vdb_pq_set_code": (C.c_int, [C.c_void_p, C.c_int64, c_u8_p]),
+    "vdb_pq_size": (C.c_int, [C.c_void_p, c_i64_p]),
+    "vdb_pq_lut": (C.c_int, [C.c_void_p, c_float_p, c_float_p]),
+    "vdb_pq_search": (C.c_int, [C.c_void_p, c_float_p, C.c_int, C.c_int, c_u32_p, c_float_p, c_i64_p]),
+    "vdb_pq_search_dev": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p,
+                                    C.c_void_p]),
+    "vdb_topk_merge_dev": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p,
+                                     C.c_void_p]),
+}
+
+_lib: Optional[C.CDLL] = None
+_lock = threading.Lock()
+
+
+class NativeError(RuntimeError):
+    """A HIP runtime failure or an allocation failure inside the library."""
+
+
+def load() -> C.CDLL:
+    """Load libvdbcore.so and bind every declared symbol.  Raises if the
+    library is missing: the HIP path is the only path."""
+    global _lib
+    with _lock:
+        if _lib is not None:
+            return _lib
+        if not os.path.exists(LIB_PATH):
+            raise ImportError(
+                f"{LIB_PATH} not found: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+                "or `make -C vectordb_amd/csrc`")
+        lib = C.CDLL(LIB_PATH)
+        for name, (res, args) in SIGNATURES.items():
+            fn = getattr(lib, name)
+            fn.restype = res
+            fn.argtypes = args
+        _lib = lib
+        return lib
+
+
+def last_error() -> str:
+    msg = load().vdb_last_error()
+    return msg.decode("utf-8", "replace") if msg else ""
+
+
+def check(status: int) -> None:
+    if status == VDB_OK:
+        return
+    msg = last_error()
+    if status == VDB_ERR_INVALID:
+        raise ValueError(msg)
+    if status == VDB_ERR_STATE:
+        raise RuntimeError(msg)
+    if status == VDB_ERR_NOMEM:
+        raise MemoryError(msg)
+    raise NativeError(msg)
+
+
+_initialised = False
+
+
+def init(device: Optional[int] = None) -> None:
+    """One process per GPU: LOCAL_RANK picks the device unless one is given."""
+    global _initialised
+    if device is None:
+        if _initialised:
+            return
+        device = int(os.environ.get("LOCAL_RANK", "0"))
+    check(load().vdb_init(int(device)))
+    _initialised = True
+
+
+def device_info() -> dict:
+    init()
+    name = C.create_string_buffer(256)
+    total, free = C.c_int64(0), C.c_int64(0)
+    check(load().vdb_device_info(name, 256, C.byref(total), C.byref(free)))
+    return {"name": name.value.decode(), "memory_total": total.value, "memory_free": free.value}
+
+
+# ---------------------------------------------------------------- numpy helpers
+
+def f32(a) -> np.ndarray:
+    return np.ascontiguousarray(a, dtype=np.float32)
+
+
+def fptr(a: Optional[np.ndarray]):
+    return None if a is None else a.ctypes.data_as(c_float_p)
+
+
+def pack_mask(mask) -> Optional[np.ndarray]:
+    """Boolean row mask -> little-endian packed uint32 words (bit i%32 of word i//32)."""
+    if mask is None:
+        return None
+    m = np.asarray(mask, dtype=bool)
+    bits = np.packbits(m, bitorder="little")
+    pad = (-len(bits)) % 4
+    if pad:
+        bits = np.concatenate([bits, np.zeros(pad, dtype=np.uint8)])
+    return np.ascontiguousarray(bits.view("<u4"))
+
+
+def u32ptr(a: Optional[np.ndarray]):
+    return None if a is None else a.ctypes.data_as(c_u32_p)
+
+
+class RowStore:
+    """Owner of a vdb_rows handle (resident fp32 matrix + norms)."""
+
+    def __init__(self, dim: int):
+        init()
+        self.lib = load()
+        self.dim = int(dim)
+        self.h = C.c_void_p()
+        check(self.lib.vdb_rows_create(C.byref(self.h), self.dim))
+
+    def close(self):
+        if getattr(self, "h", None) is not None and self.h:
+            self.lib.vdb_rows_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def __len__(self):
+        n = C.c_int64(0)
+        check(self.lib.vdb_rows_size(self.h, C.byref(n)))
+        return n.value
+
+    def append(self, rows: np.ndarray) -> None:
+        rows = f32(rows)
+        if rows.ndim != 2 or rows.shape[1] != self.dim:
+            raise ValueError(f"Vector dimension {rows.shape[-1]} != index dimension {self.dim}")
+        check(self.lib.vdb_rows_append(self.h, fptr(rows), rows.shape[0]))
+
+    def append_device(self, ptr: int, n: int, ld: int, stream: int = 0) -> None:
+        check(self.lib.vdb_rows_append_dev(self.h, C.c_void_p(ptr), n, ld, C.c_void_p(stream)))
+
+    def set_row(self, row: int, vec: np.ndarray) -> None:
+        vec = f32(vec)
+        check(self.lib.vdb_rows_set(self.h, int(row), fptr(vec)))
+
+    def truncate(self, n: int) -> None:
+        check(self.lib.vdb_rows_truncate(self.h, int(n)))
+
+    def norms(self):
+        n = len(self)
+        sq, nr = np.empty(n, np.float32), np.empty(n, np.float32)
+        check(self.lib.vdb_rows_norms(self.h, fptr(sq), fptr(nr)))
+        return sq, nr
+
+    def search(self, queries: np.ndarray, k: int, metric: int, mask_words: Optional[np.ndarray] = None):
+        q = f32(queries)
+        if q.ndim == 1:
+            q = q[None, :]
+        nq = q.shape[0]
+        dist = np.empty((nq, k), np.float32)
+        rows = np.empty((nq, k), np.int64)
+        check(self.lib.vdb_flat_search(self.h, metric, fptr(q), nq, k, u32ptr(mask_words), fptr(dist),
+                                       rows.ctypes.data_as(c_i64_p)))
+        return dist, rows
+
+    def search_device(self, q_ptr: int, nq: int, k: int, metric: int, out_dist_ptr: int, out_row_ptr: int,
+                      mask_ptr: int = 0, stream: int = 0) -> None:
+        check(self.lib.vdb_flat_search_dev(self.h, metric, C.c_void_p(q_ptr), nq, k, C.c_void_p(mask_ptr or None),
+                                           C.c_void_p(out_dist_ptr), C.c_void_p(out_row_ptr), C.c_void_p(stream or None)))
+
+    def distances(self, queries: np.ndarray, metric: int) -> np.ndarray:
+        q = f32(queries)
+        if q.ndim == 1:
+            q = q[None, :]
+        out = np.empty((q.shape[0], len(self)), np.float32)
+        check(self.lib.vdb_flat_distances(self.h, metric, fptr(q), q.shape[0], fptr(out)))
+        return out
+
+    def range_search(self, query: np.ndarray, radius: float, metric: int, mask_words=None, cap: Optional[int] = None):
+        q = f32(query)
+        cap = len(self) if cap is None else int(cap)
+        dist = np.empty(max(cap, 1), np.float32)
+        rows = np.empty(max(cap, 1), np.int64)
+        cnt = C.c_int64(0)
+        check(self.lib.vdb_flat_range_search(self.h, metric, fptr(q), float(radius), u32ptr(mask_words), cap,
+                                             fptr(dist), rows.ctypes.data_as(c_i64_p), C.byref(cnt)))
+        return dist[:cnt.value], rows[:cnt.value]
+
+
+def assign(x: np.ndarray, centroids: np.ndarray, metric: int):
+    init()
+    x, c = f32(x), f32(centroids)
+    idx = np.empty(len(x), np.int32)
+    dist = np.empty(len(x), np.float32)
+    check(load().vdb_assign(fptr(x), len(x), fptr(c), len(c), x.shape[1], metric,
+                            idx.ctypes.data_as(c_i32_p), fptr(dist)))
+    return idx, dist
+
+
+def kmeans_accumulate(x: np.ndarray, assign_idx: np.ndarray, n_clusters: int):
+    init()
+    x = f32(x)
+    a = np.ascontiguousarray(assign_idx, dtype=np.int32)
+    sums = np.empty((n_clusters, x.shape[1]), np.float64)
+    counts = np.empty(n_clusters, np.int64)
+    check(load().vdb_kmeans_accumulate(fptr(x), len(x), x.shape[1], a.ctypes.data_as(c_i32_p), n_clusters,
+                                       sums.ctypes.data_as(c_double_p), counts.ctypes.data_as(c_i64_p)))
+    return sums, counts
+
+
+def pq_encode(x: np.ndarray, codebook: np.ndarray) -> np.ndarray:
+    init()
+    x, b = f32(x), f32(codebook)
+    m, ksub, dsub = b.shape
+    codes = np.empty((len(x), m), np.uint8)
+    check(load().vdb_pq_encode(fptr(x), len(x), fptr(b), m, ksub, dsub, codes.ctypes.data_as(c_u8_p)))
+    return codes
+
+
+class IvfLists:
+    """Owner of a vdb_ivf handle (centroids + inverted lists in list order)."""
+
+    def __init__(self, dim: int, metric: int):
+        init()
+        self.lib = load()
+        self.dim = int(dim)
+        self.h = C.c_void_p()
+        check(self.lib.vdb_ivf_create(C.byref(self.h), self.dim, metric))
+
+    def close(self):
+        if getattr(self, "h", None) is not None and self.h:
+            self.lib.vdb_ivf_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def set_centroids(self, centroids: np.ndarray) -> None:
+        c = f32(centroids)
+        check(self.lib.vdb_ivf_set_centroids(self.h, fptr(c), len(c)))
+
+    def build(self, rows: np.ndarray, list_of_row: np.ndarray) -> None:
+        rows = f32(rows).reshape(-1, self.dim)
+        a = np.ascontiguousarray(list_of_row, dtype=np.int32)
+        check(self.lib.vdb_ivf_build(self.h, fptr(rows), len(rows), a.ctypes.data_as(c_i32_p)))
+
+    def build_lists(self, rows: np.ndarray, list_rows: np.ndarray, list_offsets: np.ndarray) -> None:
+        rows = f32(rows).reshape(-1, self.dim)
+        lr = np.ascontiguousarray(list_rows, dtype=np.int64)
+        lo = np.ascontiguousarray(list_offsets, dtype=np.int64)
+        check(self.lib.vdb_ivf_build_lists(self.h, fptr(rows), len(rows), lr.ctypes.data_as(c_i64_p),
+                                           lo.ctypes.data_as(c_i64_p)))
+
+    def search(self, queries: np.ndarray, k: int, n_probe: int, mask_words=None):
+        q = f32(queries)
+        if q.ndim == 1:
+            q = q[None, :]
+        nq = q.shape[0]
+        dist = np.empty((nq, k), np.float32)
+        rows = np.empty((nq, k), np.int64)
+        check(self.lib.vdb_ivf_search(self.h, fptr(q), nq, k, n_probe, u32ptr(mask_words), fptr(dist),
+                                      rows.ctypes.data_as(c_i64_p)))
+        return dist, rows
+
+    def search_device(self, q_ptr: int, nq: int, k: int, n_probe: int, out_dist_ptr: int, out_row_ptr: int,
+                      mask_ptr: int = 0, stream: int = 0) -> None:
+        check(self.lib.vdb_ivf_search_dev(self.h, C.c_void_p(q_ptr), nq, k, n_probe, C.c_void_p(mask_ptr or None),
+                                          C.c_void_p(out_dist_ptr), C.c_void_p(out_row_ptr), C.c_void_p(stream or None)))
+
+    def probe(self, queries: np.ndarray, n_probe: int):
+        q = f32(queries)
+        if q.ndim == 1:
+            q = q[None, :]
+        lists = np.empty((q.shape[0], n_probe), np.int32)
+        dist = np.empty((q.shape[0], n_probe), np.float32)
+        check(self.lib.vdb_ivf_probe(self.h, fptr(q), q.shape[0], n_probe, lists.ctypes.data_as(c_i32_p), fptr(dist)))
+        return lists, dist
+
+    def last_scan_rows(self) -> int:
+        n = C.c_int64(0)
+        check(self.lib.vdb_ivf_last_scan_rows(self.h, C.byref(n)))
+        return n.value
+
+
+class PqCodes:
+    """Owner of a vdb_pq handle (codebook + resident codes)."""
+
+    def __init__(self, dim: int, m: int, ksub: int):
+        init()
+        self.lib = load()
+        self.dim, self.m, self.ksub = int(dim), int(m), int(ksub)
+        self.h = C.c_void_p()
+        check(self.lib.vdb_pq_create(C.byref(self.h), self.dim, self.m, self.ksub))
+
+    def close(self):
+        if getattr(self, "h", None) is not None and self.h:
+            self.lib.vdb_pq_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def __len__(self):
+        n = C.c_int64(0)
+        check(self.lib.vdb_pq_size(self.h, C.byref(n)))
+        return n.value
+
+    def set_codebook(self, codebook: np.ndarray) -> None:
+        b = f32(codebook)
+        if b.shape != (self.m, self.ksub, self.dim // self.m):
+            raise ValueError(f"codebook shape {b.shape} != {(self.m, self.ksub, self.dim // self.m)}")
+        check(self.lib.vdb_pq_set_codebook(self.h, fptr(b)))
+
+    def append_codes(self, codes: np.ndarray) -> None:
+        c = np.ascontiguousarray(codes, dtype=np.uint8).reshape(-1, self.m)
+        check(self.lib.vdb_pq_append_codes(self.h, c.ctypes.data_as(c_u8_p), len(c)))
+
+    def append_codes_device(self, ptr: int, n: int, stream: int = 0) -> None:
+        check(self.lib.vdb_pq_append_codes_dev(self.h, C.c_void_p(ptr), n, C.c_void_p(stream or None)))
+
+    def append_rows(self, rows: np.ndarray) -> np.ndarray:
+        rows = f32(rows).reshape(-1, self.dim)
+        codes = np.empty((len(rows), self.m), np.uint8)
+        check(self.lib.vdb_pq_append_rows(self.h, fptr(rows), len(rows), codes.ctypes.data_as(c_u8_p)))
+        return codes
+
+    def truncate(self, n: int) -> None:
+        check(self.lib.vdb_pq_truncate(self.h, int(n)))
+
+    def set_code(self, row: int, code: np.ndarray) -> None:
+        c = np.ascontiguousarray(code, dtype=np.uint8)
+        check(self.lib.vdb_pq_set_code(self.h, int(row), c.ctypes.data_as(c_u8_p)))
+
+    def lut(self, query: np.ndarray) -> np.ndarray:
+        q = f32(query)
+        out = np.empty((self.m, self.ksub), np.float32)
+        check(self.lib.vdb_pq_lut(self.h, fptr(q), fptr(out)))
+        return out
+
+    def search(self, queries: np.ndarray, k: int, mask_words=None):
+        q = f32(queries)
+        if q.ndim == 1:
+            q = q[None, :]
+        nq = q.shape[0]
+        dist = np.empty((nq, k), np.float32)
+        rows = np.empty((nq, k), np.int64)
+        check(self.lib.vdb_pq_search(self.h, fptr(q), nq, k, u32ptr(mask_words), fptr(dist),
+                                     rows.ctypes.data_as(c_i64_p)))
+        return dist, rows
+
+    def search_device(self, q_ptr: int, nq: int, k: int, out_dist_ptr: int, out_row_ptr: int,
+                      mask_ptr: int = 0, stream: int = 0) -> None:
+        check(self.lib.vdb_pq_search_dev(self.h, C.c_void_p(q_ptr), nq, k, C.c_void_p(mask_ptr or None),
+                                         C.c_void_p(out_dist_ptr), C.c_void_p(out_row_ptr), C.c_void_p(stream or None)))
+
+
+def topk_merge_device(dist_ptr: int, row_ptr: int, n_lists: int, nq: int, k: int,
+                      out_dist_ptr: int, out_row_ptr: int, stream: int = 0) -> None:
+    init()
+    check(load().vdb_topk_merge_dev(C.c_void_p(dist_ptr), C.c_void_p(row_ptr), n_lists, nq, k,
+                                    C.c_void_p(out_dist_ptr), C.c_void_p(out_row_ptr), C.c_void_p(stream or None)))

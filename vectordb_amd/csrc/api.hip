@@ -1,0 +1,1067 @@
+// C ABI of libvdbcore.so (see include/vdb_core.h): handles, workspaces and
+// the orchestration of the kernels.  No arithmetic on the distances happens on
+// the host; this file only moves buffers and launches kernels.
+#include "vdb_internal.h"
+
+#include <algorithm>
+#include <cstdarg>
+#include <limits>
+#include <numeric>
+
+namespace vdb {
+
+// ============================================================== plumbing
+static thread_local std::string g_err;
+
+void set_error(const char* fmt, ...) {
+    char buf[1024];
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(buf, sizeof(buf), fmt, ap);
+    va_end(ap);
+    g_err = buf;
+}
+
+Context& ctx() {
+    static Context c;
+    return c;
+}
+
+int ensure_init() {
+    if (ctx().device >= 0) return VDB_OK;
+    return vdb_init(0);
+}
+
+int DevBuf::reserve(size_t bytes) {
+    if (bytes <= cap) return VDB_OK;
+    if (p) { VDB_HIP(hipFree(p)); p = nullptr; cap = 0; }
+    const size_t want = std::max(bytes, (size_t)256);
+    VDB_HIP(hipMalloc(&p, want));
+    cap = want;
+    return VDB_OK;
+}
+
+int DevBuf::reserve_keep(size_t bytes, size_t keep_bytes, hipStream_t s) {
+    if (bytes <= cap) return VDB_OK;
+    size_t want = std::max(bytes, cap + cap / 2);
+    want = std::max(want, (size_t)4096);
+    void* np = nullptr;
+    VDB_HIP(hipMalloc(&np, want));
+    if (p && keep_bytes) VDB_HIP(hipMemcpyAsync(np, p, keep_bytes, hipMemcpyDeviceToDevice, s));
+    if (p) { VDB_HIP(hipStreamSynchronize(s)); VDB_HIP(hipFree(p)); }
+    p = np;
+    cap = want;
+    return VDB_OK;
+}
+
+void DevBuf::release() {
+    if (p) (void)hipFree(p);
+    p = nullptr;
+    cap = 0;
+}
+
+static void plan_rec(int n, std::vector<int>& leaves, std::vector<int>& folds) {
+    if (n <= 128) { leaves.push_back(n); folds.push_back(0); return; }
+    int h = n / 2;
+    h -= h % 8;
+    plan_rec(h, leaves, folds);
+    plan_rec(n - h, leaves, folds);
+    folds.back() += 1;
+}
+
+int make_sum_plan(int n, SumPlan* plan) {
+    std::vector<int> leaves, folds;
+    plan_rec(std::max(n, 1), leaves, folds);
+    VDB_REQUIRE((int)leaves.size() <= SumPlan::MAX_LEAVES, "dimension %d is too large (max 8192)", n);
+    memset(plan, 0, sizeof(*plan));
+    plan->n_leaves = (int)leaves.size();
+    for (size_t i = 0; i < leaves.size(); ++i) { plan->leaf_len[i] = (short)leaves[i]; plan->folds[i] = (unsigned char)folds[i]; }
+    return VDB_OK;
+}
+
+static hipStream_t pick_stream(void* s) { return s ? reinterpret_cast<hipStream_t>(s) : ctx().stream; }
+
+// ============================================================== small kernels
+__global__ void pad_rows_kernel(const float* __restrict__ src, int64_t src_ld, int dim, int64_t n,
+                                const int* __restrict__ perm, float* __restrict__ dst, int dst_ld) {
+    const int64_t total = n * dst_ld;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t r = i / dst_ld;
+        const int c = (int)(i - r * dst_ld);
+        const int64_t sr = perm ? perm[r] : r;
+        dst[i] = c < dim ? src[sr * src_ld + c] : 0.0f;
+    }
+}
+
+__global__ void fill_results_kernel(float* d, int64_t* i, int64_t total) {
+    for (int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; t < total; t += (int64_t)gridDim.x * blockDim.x) {
+        if (d) d[t] = INFINITY;
+        if (i) i[t] = -1;
+    }
+}
+
+static int grid_for(int64_t total) { return (int)std::min<int64_t>((total + 255) / 256, 16384); }
+
+int launch_pad_rows(const float* src, int64_t src_ld, int dim, int64_t n, float* dst, int dst_ld, hipStream_t s) {
+    if (n <= 0) return VDB_OK;
+    hipLaunchKernelGGL(pad_rows_kernel, dim3(grid_for(n * dst_ld)), dim3(256), 0, s, src, src_ld, dim, n,
+                       (const int*)nullptr, dst, dst_ld);
+    VDB_HIP(hipGetLastError());
+    return VDB_OK;
+}
+
+static int fill_results(float* d, int64_t* i, int64_t total, hipStream_t s) {
+    if (total <= 0) return VDB_OK;
+    hipLaunchKernelGGL(fill_results_kernel, dim3(grid_for(total)), dim3(256), 0, s, d, i, total);
+    VDB_HIP(hipGetLastError());
+    return VDB_OK;
+}
+
+// ============================================================== workspaces
+struct Workspace {
+    DevBuf q_buf, q_sq, q_nrm, part_d, part_i, lb_d, lb_k, mask, out_d, out_i, dist, probes, probe_d, lut, stage;
+    void release() {
+        DevBuf* all[] = {&q_buf, &q_sq, &q_nrm, &part_d, &part_i, &lb_d, &lb_k, &mask, &out_d, &out_i, &dist,
+                         &probes, &probe_d, &lut, &stage};
+        for (DevBuf* b : all) b->release();
+    }
+};
+
+static bool is_dot_metric(int m) {
+    return m == VDB_EUCLIDEAN || m == VDB_EUCLIDEAN_SQ || m == VDB_COSINE || m == VDB_DOT;
+}
+static bool valid_metric(int m) { return m >= VDB_EUCLIDEAN && m <= VDB_EUCLIDEAN_SQ_DIRECT; }
+static const int GEMM_MIN_NQ = 4;     // below this the streaming scan reads the rows once per query and wins
+
+// queries -> padded device rows + their |q|^2, |q| in NumPy order
+static int prepare_queries(Workspace& ws, const float* d_q, int nq, int dim, int ld, const SumPlan& plan,
+                           const float** q_out, hipStream_t s) {
+    if (ld == dim) {
+        *q_out = d_q;
+    } else {
+        VDB_TRY(ws.q_buf.reserve((size_t)nq * ld * sizeof(float)));
+        VDB_TRY(launch_pad_rows(d_q, dim, dim, nq, ws.q_buf.as<float>(), ld, s));
+        *q_out = ws.q_buf.as<float>();
+    }
+    VDB_TRY(ws.q_sq.reserve((size_t)nq * sizeof(float)));
+    VDB_TRY(ws.q_nrm.reserve((size_t)nq * sizeof(float)));
+    VDB_TRY(launch_row_norms(*q_out, ld, dim, nq, plan, ws.q_sq.as<float>(), ws.q_nrm.as<float>(), s));
+    return VDB_OK;
+}
+
+}  // namespace vdb
+
+using namespace vdb;
+
+// ============================================================== row store
+struct vdb_rows {
+    Rows r;
+    DevBuf data, sq, nrm;
+    Workspace ws;
+};
+
+static int rows_reserve(vdb_rows* h, int64_t n_total, hipStream_t s) {
+    Rows& r = h->r;
+    if (n_total <= r.cap) return VDB_OK;
+    int64_t cap = std::max<int64_t>(n_total, r.cap + r.cap / 2);
+    cap = std::max<int64_t>(cap, 1024);
+    VDB_TRY(h->data.reserve_keep((size_t)cap * r.ld * sizeof(float), (size_t)r.n * r.ld * sizeof(float), s));
+    VDB_TRY(h->sq.reserve_keep((size_t)cap * sizeof(float), (size_t)r.n * sizeof(float), s));
+    VDB_TRY(h->nrm.reserve_keep((size_t)cap * sizeof(float), (size_t)r.n * sizeof(float), s));
+    r.cap = cap;
+    r.data = h->data.as<float>();
+    r.sq = h->sq.as<float>();
+    r.nrm = h->nrm.as<float>();
+    return VDB_OK;
+}
+
+static int rows_append_dev_impl(vdb_rows* h, const float* d_rows, int64_t n, int64_t src_ld, hipStream_t s) {
+    Rows& r = h->r;
+    if (n <= 0) return VDB_OK;
+    VDB_TRY(rows_reserve(h, r.n + n, s));
+    float* dst = r.data + r.n * r.ld;
+    if (src_ld == r.ld && r.ld == r.dim) {
+        VDB_HIP(hipMemcpyAsync(dst, d_rows, (size_t)n * r.ld * sizeof(float), hipMemcpyDeviceToDevice, s));
+    } else {
+        hipLaunchKernelGGL(pad_rows_kernel, dim3(grid_for(n * r.ld)), dim3(256), 0, s, d_rows, src_ld, r.dim, n,
+                           (const int*)nullptr, dst, r.ld);
+        VDB_HIP(hipGetLastError());
+    }
+    VDB_TRY(launch_row_norms(dst, r.ld, r.dim, n, r.plan, r.sq + r.n, r.nrm + r.n, s));
+    r.n += n;
+    return VDB_OK;
+}
+
+// ---- flat search on device pointers ------------------------------------
+static int flat_search_impl(vdb_rows* h, int metric, const float* d_q, int nq, int k, const uint32_t* d_mask,
+                            float* d_out_d, int64_t* d_out_i, int* d_out_i32, hipStream_t s) {
+    Rows& r = h->r;
+    Workspace& ws = h->ws;
+    VDB_REQUIRE(valid_metric(metric), "unknown metric code %d", metric);
+    VDB_REQUIRE(nq >= 0 && k >= 1, "need nq >= 0 and k >= 1 (got nq=%d, k=%d)", nq, k);
+    if (nq == 0) return VDB_OK;
+    const int64_t k_eff = std::min<int64_t>(k, r.n);
+    if (k_eff < k) {
+        VDB_REQUIRE(d_out_i32 == nullptr || r.n > 0, "empty row set");
+        VDB_TRY(fill_results(d_out_d, d_out_i, (int64_t)nq * k, s));
+    }
+    if (r.n == 0) return VDB_OK;
+
+    const float* q = nullptr;
+    VDB_TRY(prepare_queries(ws, d_q, nq, r.dim, r.ld, r.plan, &q, s));
+    const bool gemm = is_dot_metric(metric) && nq >= GEMM_MIN_NQ;
+
+    int n_cand = 0, splits = 1;
+    if (gemm) {
+        VDB_TRY(flat_gemm_num_cand(r.n, nq, k, &n_cand));
+    } else {
+        const int64_t ntiles = (r.n + 255) / 256;
+        splits = (int)std::max<int64_t>(1, std::min<int64_t>(ntiles, (8 * ctx().num_cus + nq - 1) / nq));
+        n_cand = splits;
+    }
+    const int kmax = (int)std::min<int64_t>(KMAX_FUSED, k_eff);
+    VDB_TRY(ws.part_d.reserve((size_t)nq * n_cand * kmax * sizeof(float)));
+    VDB_TRY(ws.part_i.reserve((size_t)nq * n_cand * kmax * sizeof(int)));
+    const bool multi = k_eff > KMAX_FUSED;
+    if (multi) {
+        VDB_TRY(ws.lb_d.reserve((size_t)nq * sizeof(float)));
+        VDB_TRY(ws.lb_k.reserve((size_t)nq * sizeof(int64_t)));
+    }
+
+    for (int64_t done = 0; done < k_eff; done += KMAX_FUSED) {
+        const int kk = (int)std::min<int64_t>(KMAX_FUSED, k_eff - done);
+        const float* lb_d = (done > 0) ? ws.lb_d.as<float>() : nullptr;
+        const int64_t* lb_k = (done > 0) ? ws.lb_k.as<int64_t>() : nullptr;
+        if (gemm) {
+            VDB_TRY(launch_flat_gemm_topk(r, metric, q, ws.q_sq.as<float>(), ws.q_nrm.as<float>(), nq, kk, d_mask,
+                                          lb_d, lb_k, ws.part_d.as<float>(), ws.part_i.as<int>(), n_cand, s));
+        } else {
+            ScanJob j{};
+            j.data = r.data; j.ld = r.ld; j.dim = r.dim; j.row_sq = r.sq; j.row_nrm = r.nrm; j.plan = r.plan;
+            j.metric = metric; j.q = q; j.ldq = r.ld; j.nq = nq; j.q_sq = ws.q_sq.as<float>(); j.q_nrm = ws.q_nrm.as<float>();
+            j.n = r.n; j.mask = d_mask; j.lb_d = lb_d; j.lb_k = lb_k; j.k = kk; j.splits = splits;
+            j.part_d = ws.part_d.as<float>(); j.part_i = ws.part_i.as<int>();
+            VDB_TRY(launch_scan(j, s));
+        }
+        SelectOut o{d_out_d, d_out_i, d_out_i32, k, (int)done,
+                    multi ? ws.lb_d.as<float>() : nullptr, multi ? ws.lb_k.as<int64_t>() : nullptr};
+        VDB_TRY(launch_select(ws.part_d.as<float>(), ws.part_i.as<int>(), nq, n_cand, kk, 1 << 30, nullptr, 0, o, s));
+    }
+    return VDB_OK;
+}
+
+static int flat_distances_impl(vdb_rows* h, int metric, const float* d_q, int nq, float* d_out, hipStream_t s) {
+    Rows& r = h->r;
+    Workspace& ws = h->ws;
+    VDB_REQUIRE(valid_metric(metric), "unknown metric code %d", metric);
+    if (nq <= 0 || r.n == 0) return VDB_OK;
+    const float* q = nullptr;
+    VDB_TRY(prepare_queries(ws, d_q, nq, r.dim, r.ld, r.plan, &q, s));
+    if (is_dot_metric(metric) && nq >= GEMM_MIN_NQ)
+        return launch_flat_gemm_dist(r, metric, q, ws.q_sq.as<float>(), ws.q_nrm.as<float>(), nq, d_out, s);
+    ScanJob j{};
+    j.data = r.data; j.ld = r.ld; j.dim = r.dim; j.row_sq = r.sq; j.row_nrm = r.nrm; j.plan = r.plan;
+    j.metric = metric; j.q = q; j.ldq = r.ld; j.nq = nq; j.q_sq = ws.q_sq.as<float>(); j.q_nrm = ws.q_nrm.as<float>();
+    j.n = r.n; j.k = 0; j.dist_out = d_out;
+    const int64_t ntiles = (r.n + 255) / 256;
+    j.splits = (int)std::max<int64_t>(1, std::min<int64_t>(ntiles, (8 * ctx().num_cus + nq - 1) / nq));
+    return launch_scan(j, s);
+}
+
+// copy a host bitmask of n bits to the workspace
+static int upload_mask(Workspace& ws, const uint32_t* mask, int64_t n, const uint32_t** d_mask, hipStream_t s) {
+    *d_mask = nullptr;
+    if (!mask) return VDB_OK;
+    const size_t words = (size_t)((n + 31) / 32);
+    VDB_TRY(ws.mask.reserve(words * sizeof(uint32_t) + 16));
+    VDB_HIP(hipMemcpyAsync(ws.mask.p, mask, words * sizeof(uint32_t), hipMemcpyHostToDevice, s));
+    *d_mask = ws.mask.as<uint32_t>();
+    return VDB_OK;
+}
+
+// host-pointer wrapper: queries up, results down
+template <class F>
+static int with_host_io(Workspace& ws, const float* queries, int nq, int dim, int k, float* out_dist, int64_t* out_row,
+                        hipStream_t s, F&& run) {
+    if (nq <= 0) return VDB_OK;
+    VDB_TRY(ws.stage.reserve((size_t)nq * dim * sizeof(float)));
+    VDB_TRY(ws.out_d.reserve((size_t)nq * k * sizeof(float)));
+    VDB_TRY(ws.out_i.reserve((size_t)nq * k * sizeof(int64_t)));
+    VDB_HIP(hipMemcpyAsync(ws.stage.p, queries, (size_t)nq * dim * sizeof(float), hipMemcpyHostToDevice, s));
+    VDB_TRY(run(ws.stage.as<float>(), ws.out_d.as<float>(), ws.out_i.as<int64_t>()));
+    if (out_dist) VDB_HIP(hipMemcpyAsync(out_dist, ws.out_d.p, (size_t)nq * k * sizeof(float), hipMemcpyDeviceToHost, s));
+    if (out_row) VDB_HIP(hipMemcpyAsync(out_row, ws.out_i.p, (size_t)nq * k * sizeof(int64_t), hipMemcpyDeviceToHost, s));
+    VDB_HIP(hipStreamSynchronize(s));
+    return VDB_OK;
+}
+
+// ============================================================== IVF handle
+struct vdb_ivf {
+    int dim = 0, metric = 0;
+    vdb_rows* centroids = nullptr;      // n_lists rows
+    vdb_rows* members = nullptr;        // all rows, stored in list order
+    DevBuf list_off;                    // int64 [n_lists + 1]
+    DevBuf row_ids;                     // int   [n]  row number of every stored position
+    std::vector<int64_t> h_list_off;
+    int n_lists = 0;
+    int64_t last_scan_rows = -1;
+    int last_nq = 0, last_nprobe = 0;
+    Workspace ws;
+};
+
+// ============================================================== PQ handle
+struct vdb_pq {
+    int dim = 0, m = 0, ksub = 0, dsub = 0;
+    bool trained = false;
+    SumPlan plan;                       // over one sub-vector
+    DevBuf book;                        // float [m][ksub][dsub]
+    DevBuf codes;                       // uint8 [cap][m]
+    int64_t n = 0, cap = 0;
+    Workspace ws;
+    Workspace io;                       // staging of the host-pointer entry points
+};
+
+static int scan_metric_of(int metric) {
+    // the per-pair scalar functions behind get_metric_fn (distance/registry.py:95-177)
+    switch (metric) {
+        case VDB_EUCLIDEAN: return VDB_EUCLIDEAN_DIRECT;
+        case VDB_EUCLIDEAN_SQ: return VDB_EUCLIDEAN_SQ_DIRECT;
+        case VDB_COSINE: return VDB_COSINE_PAIR;
+        default: return metric;
+    }
+}
+
+extern "C" {
+
+// ============================================================== library
+int vdb_init(int device) {
+    Context& c = ctx();
+    if (c.device == device && c.stream) return VDB_OK;
+    int count = 0;
+    VDB_HIP(hipGetDeviceCount(&count));
+    VDB_REQUIRE(device >= 0 && device < count, "device %d out of range (%d visible)", device, count);
+    VDB_HIP(hipSetDevice(device));
+    hipDeviceProp_t prop;
+    VDB_HIP(hipGetDeviceProperties(&prop, device));
+    if (!c.stream) VDB_HIP(hipStreamCreateWithFlags(&c.stream, hipStreamNonBlocking));
+    c.device = device;
+    c.num_cus = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
+    return VDB_OK;
+}
+
+const char* vdb_last_error(void) { return g_err.c_str(); }
+
+int vdb_device_info(char* name, int name_len, int64_t* mem_total, int64_t* mem_free) {
+    VDB_TRY(ensure_init());
+    hipDeviceProp_t prop;
+    VDB_HIP(hipGetDeviceProperties(&prop, ctx().device));
+    if (name && name_len > 0) { strncpy(name, prop.name, name_len - 1); name[name_len - 1] = 0; }
+    size_t fr = 0, tot = 0;
+    VDB_HIP(hipMemGetInfo(&fr, &tot));
+    if (mem_total) *mem_total = (int64_t)tot;
+    if (mem_free) *mem_free = (int64_t)fr;
+    return VDB_OK;
+}
+
+int vdb_synchronize(void) {
+    VDB_TRY(ensure_init());
+    VDB_HIP(hipStreamSynchronize(ctx().stream));
+    return VDB_OK;
+}
+
+// ============================================================== rows
+int vdb_rows_create(vdb_rows** out, int dim) {
+    VDB_TRY(ensure_init());
+    VDB_REQUIRE(out != nullptr, "null output handle");
+    VDB_REQUIRE(dim >= 1 && dim <= 8192, "dimension must be in 1..8192, got %d", dim);
+    vdb_rows* h = new vdb_rows();
+    h->r.dim = dim;
+    h->r.ld = round_up(dim, 4);
+    VDB_TRY(make_sum_plan(dim, &h->r.plan));
+    *out = h;
+    return VDB_OK;
+}
+
+int vdb_rows_destroy(vdb_rows* h) {
+    if (!h) return VDB_OK;
+    std::lock_guard<std::mutex> g(ctx().mu);
+    (void)hipStreamSynchronize(ctx().stream);
+    h->data.release(); h->sq.release(); h->nrm.release(); h->ws.release();
+    delete h;
+    return VDB_OK;
+}
+
+int vdb_rows_append(vdb_rows* h, const float* rows, int64_t n) {
+    VDB_REQUIRE(h && (rows || n == 0) && n >= 0, "bad arguments to vdb_rows_append");
+    if (n == 0) return VDB_OK;
+    std::lock_guard<std::mutex> g(ctx().mu);
+    hipStream_t s = ctx().stream;
+    Rows& r = h->r;
+    VDB_TRY(rows_reserve(h, r.n + n, s));
+    if (r.ld == r.dim) {
+        float* dst = r.data + r.n * r.ld;
+        VDB_HIP(hipMemcpyAsync(dst, rows, (size_t)n * r.dim * sizeof(float), hipMemcpyHostToDevice, s));
+        VDB_TRY(launch_row_norms(dst, r.ld, r.dim, n, r.plan, r.sq + r.n, r.nrm + r.n, s));
+        r.n += n;
+    } else {
+        // stage in chunks, pad on the device
+        const int64_t chunk = std::max<int64_t>(1, (int64_t)(64 << 20) / (r.dim * (int64_t)sizeof(float)));
+        for (int64_t o = 0; o < n; o += chunk) {
+            const int64_t c = std::min(chunk, n - o);
+            VDB_TRY(h->ws.stage.reserve((size_t)c * r.dim * sizeof(float)));
+            VDB_HIP(hipMemcpyAsync(h->ws.stage.p, rows + o * r.dim, (size_t)c * r.dim * sizeof(float), hipMemcpyHostToDevice, s));
+            VDB_TRY(rows_append_dev_impl(h, h->ws.stage.as<float>(), c, r.dim, s));
+            VDB_HIP(hipStreamSynchronize(s));
+        }
+    }
+    VDB_HIP(hipStreamSynchronize(s));
+    return VDB_OK;
+}
+
+int vdb_rows_append_dev(vdb_rows* h, const float* d_rows, int64_t n, int64_t ld, void* stream) {
+    VDB_REQUIRE(h && (d_rows || n == 0) && n >= 0 && ld >= h->r.dim, "bad arguments to vdb_rows_append_dev");
+    std::lock_guard<std::mutex> g(ctx().mu);
+    return rows_append_dev_impl(h, d_rows, n, ld, pick_stream(stream));
+}
+
+int vdb_rows_set(vdb_rows* h, int64_t row, const float* vec) {
+    VDB_REQUIRE(h && vec && row >= 0 && row < h->r.n, "row %lld out of range", (long long)row);
+    std::lock_guard<std::mutex> g(ctx().mu);
+    hipStream_t s = ctx().stream;
+    Rows& r = h->r;
+    float* dst = r.data + row * r.ld;
+    VDB_HIP(hipMemcpyAsync(dst, vec, (size_t)r.dim * sizeof(float), hipMemcpyHostToDevice, s));   // padding stays zero
+    VDB_TRY(launch_row_norms(dst, r.ld, r.dim, 1, r.plan, r.sq + row, r.nrm + row, s));
+    VDB_HIP(hipStreamSynchronize(s));
+    return VDB_OK;
+}
+
+int vdb_rows_truncate(vdb_rows* h, int64_t n) {
+    VDB_REQUIRE(h && n >= 0 && n <= h->r.n, "cannot truncate %lld rows to %lld", h ? (long long)h->r.n : 0LL, (long long)n);
+    std::lock_guard<std::mutex> g(ctx().mu);
+    h->r.n = n;
+    return VDB_OK;
+}
+
+int vdb_rows_size(const vdb_rows* h, int64_t* n) {
+    VDB_REQUIRE(h && n, "null argument");
+    *n = h->r.n;
+    return VDB_OK;
+}
+
+int vdb_rows_norms(vdb_rows* h, float* sqnorm_out, float* norm_out) {
+    VDB_REQUIRE(h, "null handle");
+    std::lock_guard<std::mutex> g(ctx().mu);
+    hipStream_t s = ctx().stream;
+    if (h->r.n == 0) return VDB_OK;
+    if (sqnorm_out) VDB_HIP(hipMemcpyAsync(sqnorm_out, h->r.sq, (size_t)h->r.n * sizeof(float), hipMemcpyDeviceToHost, s));
+    if (norm_out) VDB_HIP(hipMemcpyAsync(norm_out, h->r.nrm, (size_t)h->r.n * sizeof(float), hipMemcpyDeviceToHost, s));
+    VDB_HIP(hipStreamSynchronize(s));
+    return VDB_OK;
+}
+
+// ============================================================== flat
+int vdb_flat_search_dev(vdb_rows* h, int metric, const float* d_queries, int nq, int k, const uint32_t* d_mask,
+                        float* d_out_dist, int64_t* d_out_row, void* stream) {
+    VDB_REQUIRE(h && (d_queries || nq == 0), "null argument");
+    std::lock_guard<std::mutex> g(ctx().mu);
+    return flat_search_impl(h, metric, d_queries, nq, k, d_mask, d_out_dist, d_out_row, nullptr, pick_stream(stream));
+}
+
+int vdb_flat_search(vdb_rows* h, int metric, const float* queries, int nq, int k, const uint32_t* mask,
+                    float* out_dist, int64_t* out_row) {
+    VDB_REQUIRE(h && (queries || nq == 0), "null argument");
+    VDB_REQUIRE(k >= 1, "k must be >= 1, got %d", k);
+    std::lock_guard<std::mutex> g(ctx().mu);
+    hipStream_t s = ctx().stream;
+    const uint32_t* d_mask = nullptr;
+    VDB_TRY(upload_mask(h->ws, mask, h->r.n, &d_mask, s));
+    return with_host_io(h->ws, queries, nq, h->r.dim, k, out_dist, out_row, s,
+                        [&](const float* dq, float* dd, int64_t* di) {
+                            return flat_search_impl(h, metric, dq, nq, k, d_mask, dd, di, nullptr, s);
+                        });
+}
+
+int vdb_flat_distances_dev(vdb_rows* h, int metric, const float* d_queries, int nq, float* d_out, void* stream) {
+    VDB_REQUIRE(h && (d_queries || nq == 0), "null argument");
+    std::lock_guard<std::mutex> g(ctx().mu);
+    return flat_distances_impl(h, metric, d_queries, nq, d_out, pick_stream(stream));
+}
+
+int vdb_flat_distances(vdb_rows* h, int metric, const float* queries, int nq, float* out) {
+    VDB_REQUIRE(h && (queries || nq == 0) && (out || nq == 0), "null argument");
+    if (nq <= 0 || h->r.n == 0) return VDB_OK;
+    std::lock_guard<std::mutex> g(ctx().mu);
+    hipStream_t s = ctx().stream;
+    Workspace& ws = h->ws;
+    VDB_TRY(ws.stage.reserve((size_t)nq * h->r.dim * sizeof(float)));
+    VDB_TRY(ws.dist.reserve((size_t)nq * h->r.n * sizeof(float)));
+    VDB_HIP(hipMemcpyAsync(ws.stage.p, queries, (size_t)nq * h->r.dim * sizeof(float), hipMemcpyHostToDevice, s));
+    VDB_TRY(flat_distances_impl(h, metric, ws.stage.as<float>(), nq, ws.dist.as<float>(), s));
+    VDB_HIP(hipMemcpyAsync(out, ws.dist.p, (size_t)nq * h->r.n * sizeof(float), hipMemcpyDeviceToHost, s));
+    VDB_HIP(hipStreamSynchronize(s));
+    return VDB_OK;
+}
+
+int vdb_flat_range_search(vdb_rows* h, int metric, const float* query, float radius, const uint32_t* mask,
+                          int64_t cap, float* out_dist, int64_t* out_row, int64_t* count) {
+    VDB_REQUIRE(h && query && count, "null argument");
+    VDB_REQUIRE(valid_metric(metric), "unknown metric code %d", metric);
+    std::lock_guard<std::mutex> g(ctx().mu);
+    hipStream_t s = ctx().stream;
+    Rows& r = h->r;
+    Workspace& ws = h->ws;
+    *count = 0;
+    if (r.n == 0 || cap <= 0) return VDB_OK;
+    const uint32_t* d_mask = nullptr;
+    VDB_TRY(upload_mask(ws, mask, r.n, &d_mask, s));
+    VDB_TRY(ws.stage.reserve((size_t)r.dim * sizeof(float)));
+    VDB_HIP(hipMemcpyAsync(ws.stage.p, query, (size_t)r.dim * sizeof(float), hipMemcpyHostToDevice, s));
+    const float* q = nullptr;
+    VDB_TRY(prepare_queries(ws, ws.stage.as<float>(), 1, r.dim, r.ld, r.plan, &q, s));
+    const int kk = KMAX_FUSED;
+    const int64_t ntiles = (r.n + 255) / 256;
+    const int splits = (int)std::max<int64_t>(1, std::min<int64_t>(ntiles, 8 * ctx().num_cus));
+    VDB_TRY(ws.part_d.reserve((size_t)splits * kk * sizeof(float)));
+    VDB_TRY(ws.part_i.reserve((size_t)splits * kk * sizeof(int)));
+    VDB_TRY(ws.lb_d.reserve(sizeof(float)));
+    VDB_TRY(ws.lb_k.reserve(sizeof(int64_t)));
+    VDB_TRY(ws.out_d.reserve(kk * sizeof(float)));
+    VDB_TRY(ws.out_i.reserve(kk * sizeof(int64_t)));
+    float hd[KMAX_FUSED];
+    int64_t hi[KMAX_FUSED];
+    bool first = true;
+    while (*count < cap) {
+        ScanJob j{};
+        j.data = r.data; j.ld = r.ld; j.dim = r.dim; j.row_sq = r.sq; j.row_nrm = r.nrm; j.plan = r.plan;
+        j.metric = metric; j.q = q; j.ldq = r.ld; j.nq = 1; j.q_sq = ws.q_sq.as<float>(); j.q_nrm = ws.q_nrm.as<float>();
+        j.n = r.n; j.mask = d_mask; j.k = kk; j.splits = splits;
+        j.lb_d = first ? nullptr : ws.lb_d.as<float>(); j.lb_k = first ? nullptr : ws.lb_k.as<int64_t>();
+        j.part_d = ws.part_d.as<float>(); j.part_i = ws.part_i.as<int>();
+        j.radius = radius; j.use_radius = 1;
+        VDB_TRY(launch_scan(j, s));
+        SelectOut o{ws.out_d.as<float>(), ws.out_i.as<int64_t>(), nullptr, kk, 0, ws.lb_d.as<float>(), ws.lb_k.as<int64_t>()};
+        VDB_TRY(launch_select(ws.part_d.as<float>(), ws.part_i.as<int>(), 1, splits, kk, 1 << 30, nullptr, 0, o, s));
+        VDB_HIP(hipMemcpyAsync(hd, ws.out_d.p, kk * sizeof(float), hipMemcpyDeviceToHost, s));
+        VDB_HIP(hipMemcpyAsync(hi, ws.out_i.p, kk * sizeof(int64_t), hipMemcpyDeviceToHost, s));
+        VDB_HIP(hipStreamSynchronize(s));
+        first = false;
+        int got = 0;
+        for (int i = 0; i < kk && hi[i] >= 0 && *count < cap; ++i, ++got) {
+            if (out_dist) out_dist[*count] = hd[i];
+            if (out_row) out_row[*count] = hi[i];
+            ++*count;
+        }
+        if (got < kk) break;
+    }
+    return VDB_OK;
+}
+
+// ============================================================== assignment / k-means
+int vdb_assign(const float* x, int64_t n, const float* centroids, int n_centroids, int dim, int metric,
+               int32_t* out_idx, float* out_dist) {
+    VDB_TRY(ensure_init());
+    VDB_REQUIRE(x && centroids && n >= 0 && n_centroids >= 1 && dim >= 1, "bad arguments to vdb_assign");
+    VDB_REQUIRE(valid_metric(metric), "unknown metric code %d", metric);
+    if (n == 0) return VDB_OK;
+    vdb_rows* c = nullptr;
+    VDB_TRY(vdb_rows_create(&c, dim));
+    int st = vdb_rows_append(c, centroids, n_centroids);
+    if (st == VDB_OK) {
+        std::lock_guard<std::mutex> g(ctx().mu);
+        hipStream_t s = ctx().stream;
+        Workspace& ws = c->ws;
+        const int64_t chunk = std::max<int64_t>(1024, std::min<int64_t>(n, (int64_t)(256 << 20) / (dim * (int64_t)sizeof(float))));
+        DevBuf i32;
+        for (int64_t o = 0; o < n && st == VDB_OK; o += chunk) {
+            const int nq = (int)std::min(chunk, n - o);
+            auto body = [&]() -> int {
+                VDB_TRY(ws.stage.reserve((size_t)nq * dim * sizeof(float)));
+                VDB_TRY(ws.out_d.reserve((size_t)nq * sizeof(float)));
+                VDB_TRY(i32.reserve((size_t)nq * sizeof(int)));
+                VDB_HIP(hipMemcpyAsync(ws.stage.p, x + o * dim, (size_t)nq * dim * sizeof(float), hipMemcpyHostToDevice, s));
+                VDB_TRY(flat_search_impl(c, metric, ws.stage.as<float>(), nq, 1, nullptr, ws.out_d.as<float>(), nullptr,
+                                         i32.as<int>(), s));
+                if (out_idx) VDB_HIP(hipMemcpyAsync(out_idx + o, i32.p, (size_t)nq * sizeof(int), hipMemcpyDeviceToHost, s));
+                if (out_dist) VDB_HIP(hipMemcpyAsync(out_dist + o, ws.out_d.p, (size_t)nq * sizeof(float), hipMemcpyDeviceToHost, s));
+                VDB_HIP(hipStreamSynchronize(s));
+                return VDB_OK;
+            };
+            st = body();
+        }
+        i32.release();
+    }
+    std::string keep = g_err;
+    vdb_rows_destroy(c);
+    if (st != VDB_OK) g_err = keep;
+    return st;
+}
+
+int vdb_kmeans_accumulate(const float* x, int64_t n, int dim, const int32_t* assign, int n_clusters,
+                          double* out_sums, int64_t* out_counts) {
+    VDB_TRY(ensure_init());
+    VDB_REQUIRE(x && assign && out_sums && out_counts && n >= 0 && dim >= 1 && n_clusters >= 1,
+                "bad arguments to vdb_kmeans_accumulate");
+    std::lock_guard<std::mutex> g(ctx().mu);
+    hipStream_t s = ctx().stream;
+    DevBuf sums, counts, xs, as;
+    auto body = [&]() -> int {
+        VDB_TRY(sums.reserve((size_t)n_clusters * dim * sizeof(double)));
+        VDB_TRY(counts.reserve((size_t)n_clusters * sizeof(unsigned long long)));
+        VDB_HIP(hipMemsetAsync(sums.p, 0, (size_t)n_clusters * dim * sizeof(double), s));
+        VDB_HIP(hipMemsetAsync(counts.p, 0, (size_t)n_clusters * sizeof(unsigned long long), s));
+        const int64_t chunk = std::max<int64_t>(1024, (int64_t)(256 << 20) / (dim * (int64_t)sizeof(float)));
+        for (int64_t o = 0; o < n; o += chunk) {
+            const int64_t c = std::min(chunk, n - o);
+            VDB_TRY(xs.reserve((size_t)c * dim * sizeof(float)));
+            VDB_TRY(as.reserve((size_t)c * sizeof(int)));
+            VDB_HIP(hipMemcpyAsync(xs.p, x + o * dim, (size_t)c * dim * sizeof(float), hipMemcpyHostToDevice, s));
+            VDB_HIP(hipMemcpyAsync(as.p, assign + o, (size_t)c * sizeof(int), hipMemcpyHostToDevice, s));
+            VDB_TRY(launch_kmeans_accumulate(xs.as<float>(), c, dim, dim, as.as<int>(), n_clusters, sums.as<double>(),
+                                             counts.as<unsigned long long>(), s));
+            VDB_HIP(hipStreamSynchronize(s));
+        }
+        VDB_HIP(hipMemcpyAsync(out_sums, sums.p, (size_t)n_clusters * dim * sizeof(double), hipMemcpyDeviceToHost, s));
+        VDB_HIP(hipMemcpyAsync(out_counts, counts.p, (size_t)n_clusters * sizeof(int64_t), hipMemcpyDeviceToHost, s));
+        VDB_HIP(hipStreamSynchronize(s));
+        return VDB_OK;
+    };
+    const int st = body();
+    sums.release(); counts.release(); xs.release(); as.release();
+    return st;
+}
+
+// ============================================================== IVF
+int vdb_ivf_create(vdb_ivf** out, int dim, int metric) {
+    VDB_TRY(ensure_init());
+    VDB_REQUIRE(out != nullptr, "null output handle");
+    VDB_REQUIRE(valid_metric(metric), "unknown metric code %d", metric);
+    vdb_ivf* h = new vdb_ivf();
+    h->dim = dim;
+    h->metric = metric;
+    int st = vdb_rows_create(&h->centroids, dim);
+    if (st == VDB_OK) st = vdb_rows_create(&h->members, dim);
+    if (st != VDB_OK) { vdb_rows_destroy(h->centroids); delete h; return st; }
+    *out = h;
+    return VDB_OK;
+}
+
+int vdb_ivf_destroy(vdb_ivf* h) {
+    if (!h) return VDB_OK;
+    vdb_rows_destroy(h->centroids);
+    vdb_rows_destroy(h->members);
+    std::lock_guard<std::mutex> g(ctx().mu);
+    h->list_off.release(); h->row_ids.release(); h->ws.release();
+    delete h;
+    return VDB_OK;
+}
+
+int vdb_ivf_set_centroids(vdb_ivf* h, const float* centroids, int n_lists) {
+    VDB_REQUIRE(h && centroids && n_lists >= 1, "bad arguments to vdb_ivf_set_centroids");
+    VDB_TRY(vdb_rows_truncate(h->centroids, 0));
+    VDB_TRY(vdb_rows_append(h->centroids, centroids, n_lists));
+    h->n_lists = n_lists;
+    h->h_list_off.assign(n_lists + 1, 0);
+    VDB_TRY(vdb_rows_truncate(h->members, 0));
+    return VDB_OK;
+}
+
+int vdb_ivf_build_lists(vdb_ivf* h, const float* rows, int64_t n, const int64_t* list_rows, const int64_t* list_offsets) {
+    VDB_REQUIRE(h && h->n_lists >= 1, "centroids must be set before the lists are built");
+    VDB_REQUIRE(n >= 0 && (n == 0 || (rows && list_rows)) && list_offsets, "bad arguments to vdb_ivf_build_lists");
+    VDB_REQUIRE(list_offsets[0] == 0 && list_offsets[h->n_lists] == n, "list offsets do not cover %lld rows", (long long)n);
+    VDB_REQUIRE(n < (int64_t)0x7fffffff, "at most 2^31-1 rows per device");
+    for (int l = 0; l < h->n_lists; ++l)
+        VDB_REQUIRE(list_offsets[l] <= list_offsets[l + 1], "list offsets must be non-decreasing");
+    std::vector<int> perm((size_t)n);
+    for (int64_t i = 0; i < n; ++i) {
+        VDB_REQUIRE(list_rows[i] >= 0 && list_rows[i] < n, "row number %lld out of range", (long long)list_rows[i]);
+        perm[(size_t)i] = (int)list_rows[i];
+    }
+    std::lock_guard<std::mutex> g(ctx().mu);
+    hipStream_t s = ctx().stream;
+    vdb_rows* m = h->members;
+    m->r.n = 0;
+    h->h_list_off.assign(list_offsets, list_offsets + h->n_lists + 1);
+    VDB_TRY(h->list_off.reserve((size_t)(h->n_lists + 1) * sizeof(int64_t)));
+    VDB_HIP(hipMemcpyAsync(h->list_off.p, list_offsets, (size_t)(h->n_lists + 1) * sizeof(int64_t), hipMemcpyHostToDevice, s));
+    if (n == 0) { VDB_HIP(hipStreamSynchronize(s)); return VDB_OK; }
+    VDB_TRY(h->row_ids.reserve((size_t)n * sizeof(int)));
+    VDB_HIP(hipMemcpyAsync(h->row_ids.p, perm.data(), (size_t)n * sizeof(int), hipMemcpyHostToDevice, s));
+    VDB_TRY(rows_reserve(m, n, s));
+    // rows up in insertion order, gathered into list order on the device
+    DevBuf raw;
+    int st = raw.reserve((size_t)n * h->dim * sizeof(float));
+    if (st == VDB_OK) {
+        auto body = [&]() -> int {
+            VDB_HIP(hipMemcpyAsync(raw.p, rows, (size_t)n * h->dim * sizeof(float), hipMemcpyHostToDevice, s));
+            hipLaunchKernelGGL(pad_rows_kernel, dim3(grid_for(n * m->r.ld)), dim3(256), 0, s, raw.as<float>(), (int64_t)h->dim,
+                               h->dim, n, h->row_ids.as<int>(), m->r.data, m->r.ld);
+            VDB_HIP(hipGetLastError());
+            VDB_TRY(launch_row_norms(m->r.data, m->r.ld, m->r.dim, n, m->r.plan, m->r.sq, m->r.nrm, s));
+            VDB_HIP(hipStreamSynchronize(s));
+            return VDB_OK;
+        };
+        st = body();
+    }
+    raw.release();
+    if (st == VDB_OK) m->r.n = n;
+    return st;
+}
+
+int vdb_ivf_build(vdb_ivf* h, const float* rows, int64_t n, const int32_t* list_of_row) {
+    VDB_REQUIRE(h && h->n_lists >= 1, "centroids must be set before the lists are built");
+    VDB_REQUIRE(n >= 0 && (n == 0 || (rows && list_of_row)), "bad arguments to vdb_ivf_build");
+    std::vector<int64_t> off((size_t)h->n_lists + 1, 0), order((size_t)n);
+    for (int64_t i = 0; i < n; ++i) {
+        VDB_REQUIRE(list_of_row[i] >= 0 && list_of_row[i] < h->n_lists, "list number %d out of range", list_of_row[i]);
+        off[(size_t)list_of_row[i] + 1]++;
+    }
+    for (int l = 0; l < h->n_lists; ++l) off[l + 1] += off[l];
+    std::vector<int64_t> cur(off.begin(), off.end() - 1);
+    for (int64_t i = 0; i < n; ++i) order[(size_t)cur[list_of_row[i]]++] = i;      // stable: insertion order inside a list
+    return vdb_ivf_build_lists(h, rows, n, order.data(), off.data());
+}
+
+static int ivf_probe_impl(vdb_ivf* h, const float* q_pad_unused, const float* d_q, int nq, int n_probe, int* d_probes,
+                          float* d_probe_dist, hipStream_t s) {
+    (void)q_pad_unused;
+    Workspace& ws = h->ws;
+    const int cm = scan_metric_of(h->metric);
+    if (n_probe <= KMAX_FUSED) {
+        VDB_TRY(flat_search_impl(h->centroids, cm, d_q, nq, n_probe, nullptr, d_probe_dist, nullptr, d_probes, s));
+    } else {
+        VDB_REQUIRE(h->n_lists <= 16384, "n_probe > %d needs n_lists <= 16384", KMAX_FUSED);
+        VDB_TRY(ws.dist.reserve((size_t)nq * h->n_lists * sizeof(float)));
+        VDB_TRY(flat_distances_impl(h->centroids, cm, d_q, nq, ws.dist.as<float>(), s));
+        VDB_TRY(launch_row_sort_topk(ws.dist.as<float>(), nq, h->n_lists, n_probe, d_probe_dist, d_probes, s));
+    }
+    return VDB_OK;
+}
+
+static int ivf_search_impl(vdb_ivf* h, const float* d_q, int nq, int k, int n_probe, const uint32_t* d_mask,
+                           float* d_out_d, int64_t* d_out_i, hipStream_t s) {
+    VDB_REQUIRE(h->n_lists >= 1, "index is not trained");
+    VDB_REQUIRE(nq >= 0 && k >= 1 && n_probe >= 1, "need nq >= 0, k >= 1, n_probe >= 1");
+    if (nq == 0) return VDB_OK;
+    n_probe = std::min(n_probe, h->n_lists);
+    vdb_rows* m = h->members;
+    Workspace& ws = h->ws;
+    VDB_TRY(fill_results(d_out_d, d_out_i, (int64_t)nq * k, s));
+    if (m->r.n == 0) return VDB_OK;
+
+    VDB_TRY(ws.probes.reserve((size_t)nq * n_probe * sizeof(int)));
+    VDB_TRY(ws.probe_d.reserve((size_t)nq * n_probe * sizeof(float)));
+    VDB_TRY(ivf_probe_impl(h, nullptr, d_q, nq, n_probe, ws.probes.as<int>(), ws.probe_d.as<float>(), s));
+    h->last_nq = nq; h->last_nprobe = n_probe; h->last_scan_rows = -1;
+
+    const float* q = nullptr;
+    VDB_TRY(prepare_queries(ws, d_q, nq, m->r.dim, m->r.ld, m->r.plan, &q, s));
+    const int64_t units = (int64_t)nq * n_probe;
+    const int64_t avg_tiles = std::max<int64_t>(1, (m->r.n / std::max(1, h->n_lists) + 255) / 256);
+    const int splits = (int)std::max<int64_t>(1, std::min<int64_t>(avg_tiles, (8 * ctx().num_cus + units - 1) / units));
+    const int n_cand = n_probe * splits;
+    const int64_t k_eff = std::min<int64_t>(k, m->r.n);
+    const int kmax = (int)std::min<int64_t>(KMAX_FUSED, k_eff);
+    VDB_TRY(ws.part_d.reserve((size_t)nq * n_cand * kmax * sizeof(float)));
+    VDB_TRY(ws.part_i.reserve((size_t)nq * n_cand * kmax * sizeof(int)));
+    const bool multi = k_eff > KMAX_FUSED;
+    if (multi) {
+        VDB_TRY(ws.lb_d.reserve((size_t)nq * sizeof(float)));
+        VDB_TRY(ws.lb_k.reserve((size_t)nq * sizeof(int64_t)));
+    }
+    for (int64_t done = 0; done < k_eff; done += KMAX_FUSED) {
+        const int kk = (int)std::min<int64_t>(KMAX_FUSED, k_eff - done);
+        ScanJob j{};
+        j.data = m->r.data; j.ld = m->r.ld; j.dim = m->r.dim; j.row_sq = m->r.sq; j.row_nrm = m->r.nrm; j.plan = m->r.plan;
+        j.metric = scan_metric_of(h->metric);
+        j.q = q; j.ldq = m->r.ld; j.nq = nq; j.q_sq = ws.q_sq.as<float>(); j.q_nrm = ws.q_nrm.as<float>();
+        j.n = m->r.n; j.list_off = h->list_off.as<int64_t>(); j.probes = ws.probes.as<int>(); j.n_probe = n_probe;
+        j.row_ids = h->row_ids.as<int>(); j.mask = d_mask;
+        j.lb_d = done > 0 ? ws.lb_d.as<float>() : nullptr; j.lb_k = done > 0 ? ws.lb_k.as<int64_t>() : nullptr;
+        j.k = kk; j.splits = splits; j.part_d = ws.part_d.as<float>(); j.part_i = ws.part_i.as<int>();
+        VDB_TRY(launch_scan(j, s));
+        SelectOut o{d_out_d, d_out_i, nullptr, k, (int)done,
+                    multi ? ws.lb_d.as<float>() : nullptr, multi ? ws.lb_k.as<int64_t>() : nullptr};
+        VDB_TRY(launch_select(ws.part_d.as<float>(), ws.part_i.as<int>(), nq, n_cand, kk, splits, h->row_ids.as<int>(), 0, o, s));
+    }
+    return VDB_OK;
+}
+
+int vdb_ivf_search_dev(vdb_ivf* h, const float* d_queries, int nq, int k, int n_probe, const uint32_t* d_mask,
+                       float* d_out_dist, int64_t* d_out_row, void* stream) {
+    VDB_REQUIRE(h && (d_queries || nq == 0), "null argument");
+    std::lock_guard<std::mutex> g(ctx().mu);
+    return ivf_search_impl(h, d_queries, nq, k, n_probe, d_mask, d_out_dist, d_out_row, pick_stream(stream));
+}
+
+int vdb_ivf_search(vdb_ivf* h, const float* queries, int nq, int k, int n_probe, const uint32_t* mask,
+                   float* out_dist, int64_t* out_row) {
+    VDB_REQUIRE(h && (queries || nq == 0), "null argument");
+    VDB_REQUIRE(k >= 1, "k must be >= 1, got %d", k);
+    std::lock_guard<std::mutex> g(ctx().mu);
+    hipStream_t s = ctx().stream;
+    const uint32_t* d_mask = nullptr;
+    VDB_TRY(upload_mask(h->ws, mask, h->members->r.n, &d_mask, s));
+    return with_host_io(h->members->ws, queries, nq, h->dim, k, out_dist, out_row, s,
+                        [&](const float* dq, float* dd, int64_t* di) {
+                            return ivf_search_impl(h, dq, nq, k, n_probe, d_mask, dd, di, s);
+                        });
+}
+
+int vdb_ivf_probe(vdb_ivf* h, const float* queries, int nq, int n_probe, int32_t* out_lists, float* out_dist) {
+    VDB_REQUIRE(h && (queries || nq == 0) && h->n_lists >= 1 && n_probe >= 1, "bad arguments to vdb_ivf_probe");
+    if (nq <= 0) return VDB_OK;
+    std::lock_guard<std::mutex> g(ctx().mu);
+    hipStream_t s = ctx().stream;
+    Workspace& ws = h->ws;
+    n_probe = std::min(n_probe, h->n_lists);
+    VDB_TRY(ws.stage.reserve((size_t)nq * h->dim * sizeof(float)));
+    VDB_TRY(ws.probes.reserve((size_t)nq * n_probe * sizeof(int)));
+    VDB_TRY(ws.probe_d.reserve((size_t)nq * n_probe * sizeof(float)));
+    VDB_HIP(hipMemcpyAsync(ws.stage.p, queries, (size_t)nq * h->dim * sizeof(float), hipMemcpyHostToDevice, s));
+    VDB_TRY(ivf_probe_impl(h, nullptr, ws.stage.as<float>(), nq, n_probe, ws.probes.as<int>(), ws.probe_d.as<float>(), s));
+    if (out_lists) VDB_HIP(hipMemcpyAsync(out_lists, ws.probes.p, (size_t)nq * n_probe * sizeof(int), hipMemcpyDeviceToHost, s));
+    if (out_dist) VDB_HIP(hipMemcpyAsync(out_dist, ws.probe_d.p, (size_t)nq * n_probe * sizeof(float), hipMemcpyDeviceToHost, s));
+    VDB_HIP(hipStreamSynchronize(s));
+    return VDB_OK;
+}
+
+int vdb_ivf_last_scan_rows(vdb_ivf* h, int64_t* rows_scanned) {
+    VDB_REQUIRE(h && rows_scanned, "null argument");
+    std::lock_guard<std::mutex> g(ctx().mu);
+    hipStream_t s = ctx().stream;
+    *rows_scanned = 0;
+    const size_t cnt = (size_t)h->last_nq * h->last_nprobe;
+    if (cnt == 0 || h->ws.probes.cap < cnt * sizeof(int)) return VDB_OK;
+    std::vector<int> probes(cnt);
+    VDB_HIP(hipDeviceSynchronize());
+    VDB_HIP(hipMemcpyAsync(probes.data(), h->ws.probes.p, cnt * sizeof(int), hipMemcpyDeviceToHost, s));
+    VDB_HIP(hipStreamSynchronize(s));
+    int64_t total = 0;
+    for (int l : probes)
+        if (l >= 0 && l < h->n_lists) total += h->h_list_off[l + 1] - h->h_list_off[l];
+    *rows_scanned = total;
+    return VDB_OK;
+}
+
+// ============================================================== PQ
+int vdb_pq_encode(const float* x, int64_t n, const float* codebook, int m, int ksub, int dsub, uint8_t* out_codes) {
+    VDB_TRY(ensure_init());
+    VDB_REQUIRE(x && codebook && out_codes && n >= 0 && m >= 1 && ksub >= 1 && ksub <= 256 && dsub >= 1,
+                "bad arguments to vdb_pq_encode");
+    if (n == 0) return VDB_OK;
+    std::lock_guard<std::mutex> g(ctx().mu);
+    hipStream_t s = ctx().stream;
+    SumPlan plan;
+    VDB_TRY(make_sum_plan(dsub, &plan));
+    const int dim = m * dsub;
+    DevBuf book, xs, codes;
+    auto body = [&]() -> int {
+        VDB_TRY(book.reserve((size_t)m * ksub * dsub * sizeof(float)));
+        VDB_HIP(hipMemcpyAsync(book.p, codebook, (size_t)m * ksub * dsub * sizeof(float), hipMemcpyHostToDevice, s));
+        const int64_t chunk = std::max<int64_t>(1024, (int64_t)(256 << 20) / (dim * (int64_t)sizeof(float)));
+        for (int64_t o = 0; o < n; o += chunk) {
+            const int64_t c = std::min(chunk, n - o);
+            VDB_TRY(xs.reserve((size_t)c * dim * sizeof(float)));
+            VDB_TRY(codes.reserve((size_t)c * m));
+            VDB_HIP(hipMemcpyAsync(xs.p, x + o * dim, (size_t)c * dim * sizeof(float), hipMemcpyHostToDevice, s));
+            VDB_TRY(launch_pq_encode(xs.as<float>(), c, dim, book.as<float>(), m, ksub, dsub, plan, codes.as<uint8_t>(), s));
+            VDB_HIP(hipMemcpyAsync(out_codes + o * m, codes.p, (size_t)c * m, hipMemcpyDeviceToHost, s));
+            VDB_HIP(hipStreamSynchronize(s));
+        }
+        return VDB_OK;
+    };
+    const int st = body();
+    book.release(); xs.release(); codes.release();
+    return st;
+}
+
+int vdb_pq_create(vdb_pq** out, int dim, int m, int ksub) {
+    VDB_TRY(ensure_init());
+    VDB_REQUIRE(out != nullptr, "null output handle");
+    VDB_REQUIRE(dim >= 1 && m >= 1 && dim % m == 0, "dimension %d must be divisible by the number of sub-vectors %d", dim, m);
+    VDB_REQUIRE(ksub >= 1 && ksub <= 256, "codewords per sub-space must be in 1..256, got %d", ksub);
+    vdb_pq* h = new vdb_pq();
+    h->dim = dim; h->m = m; h->ksub = ksub; h->dsub = dim / m;
+    VDB_TRY(make_sum_plan(h->dsub, &h->plan));
+    *out = h;
+    return VDB_OK;
+}
+
+int vdb_pq_destroy(vdb_pq* h) {
+    if (!h) return VDB_OK;
+    std::lock_guard<std::mutex> g(ctx().mu);
+    (void)hipStreamSynchronize(ctx().stream);
+    h->book.release(); h->codes.release(); h->ws.release(); h->io.release();
+    delete h;
+    return VDB_OK;
+}
+
+int vdb_pq_set_codebook(vdb_pq* h, const float* codebook) {
+    VDB_REQUIRE(h && codebook, "null argument");
+    std::lock_guard<std::mutex> g(ctx().mu);
+    hipStream_t s = ctx().stream;
+    const size_t bytes = (size_t)h->m * h->ksub * h->dsub * sizeof(float);
+    VDB_TRY(h->book.reserve(bytes));
+    VDB_HIP(hipMemcpyAsync(h->book.p, codebook, bytes, hipMemcpyHostToDevice, s));
+    VDB_HIP(hipStreamSynchronize(s));
+    h->trained = true;
+    return VDB_OK;
+}
+
+static int pq_reserve(vdb_pq* h, int64_t n_total, hipStream_t s) {
+    if (n_total <= h->cap) return VDB_OK;
+    int64_t cap = std::max<int64_t>(n_total, h->cap + h->cap / 2);
+    cap = std::max<int64_t>(cap, 4096);
+    VDB_TRY(h->codes.reserve_keep((size_t)cap * h->m + 16, (size_t)h->n * h->m, s));
+    h->cap = cap;
+    return VDB_OK;
+}
+
+int vdb_pq_append_codes(vdb_pq* h, const uint8_t* codes, int64_t n) {
+    VDB_REQUIRE(h && (codes || n == 0) && n >= 0, "bad arguments to vdb_pq_append_codes");
+    if (n == 0) return VDB_OK;
+    std::lock_guard<std::mutex> g(ctx().mu);
+    hipStream_t s = ctx().stream;
+    VDB_TRY(pq_reserve(h, h->n + n, s));
+    VDB_HIP(hipMemcpyAsync(h->codes.as<uint8_t>() + h->n * h->m, codes, (size_t)n * h->m, hipMemcpyHostToDevice, s));
+    VDB_HIP(hipStreamSynchronize(s));
+    h->n += n;
+    return VDB_OK;
+}
+
+int vdb_pq_append_codes_dev(vdb_pq* h, const uint8_t* d_codes, int64_t n, void* stream) {
+    VDB_REQUIRE(h && (d_codes || n == 0) && n >= 0, "bad arguments to vdb_pq_append_codes_dev");
+    if (n == 0) return VDB_OK;
+    std::lock_guard<std::mutex> g(ctx().mu);
+    hipStream_t s = pick_stream(stream);
+    VDB_TRY(pq_reserve(h, h->n + n, s));
+    VDB_HIP(hipMemcpyAsync(h->codes.as<uint8_t>() + h->n * h->m, d_codes, (size_t)n * h->m, hipMemcpyDeviceToDevice, s));
+    h->n += n;
+    return VDB_OK;
+}
+
+int vdb_pq_append_rows(vdb_pq* h, const float* rows, int64_t n, uint8_t* out_codes_or_null) {
+    VDB_REQUIRE(h && (rows || n == 0) && n >= 0, "bad arguments to vdb_pq_append_rows");
+    VDB_REQUIRE(h->trained, "codebook not set");
+    if (n == 0) return VDB_OK;
+    std::lock_guard<std::mutex> g(ctx().mu);
+    hipStream_t s = ctx().stream;
+    VDB_TRY(pq_reserve(h, h->n + n, s));
+    const int64_t chunk = std::max<int64_t>(1024, (int64_t)(256 << 20) / (h->dim * (int64_t)sizeof(float)));
+    for (int64_t o = 0; o < n; o += chunk) {
+        const int64_t c = std::min(chunk, n - o);
+        VDB_TRY(h->ws.stage.reserve((size_t)c * h->dim * sizeof(float)));
+        VDB_HIP(hipMemcpyAsync(h->ws.stage.p, rows + o * h->dim, (size_t)c * h->dim * sizeof(float), hipMemcpyHostToDevice, s));
+        uint8_t* dst = h->codes.as<uint8_t>() + (h->n + o) * h->m;
+        VDB_TRY(launch_pq_encode(h->ws.stage.as<float>(), c, h->dim, h->book.as<float>(), h->m, h->ksub, h->dsub, h->plan, dst, s));
+        if (out_codes_or_null)
+            VDB_HIP(hipMemcpyAsync(out_codes_or_null + o * h->m, dst, (size_t)c * h->m, hipMemcpyDeviceToHost, s));
+        VDB_HIP(hipStreamSynchronize(s));
+    }
+    h->n += n;
+    return VDB_OK;
+}
+
+int vdb_pq_truncate(vdb_pq* h, int64_t n) {
+    VDB_REQUIRE(h && n >= 0 && n <= h->n, "cannot truncate to %lld rows", (long long)n);
+    std::lock_guard<std::mutex> g(ctx().mu);
+    h->n = n;
+    return VDB_OK;
+}
+
+int vdb_pq_set_code(vdb_pq* h, int64_t row, const uint8_t* code) {
+    VDB_REQUIRE(h && code && row >= 0 && row < h->n, "row %lld out of range", (long long)row);
+    std::lock_guard<std::mutex> g(ctx().mu);
+    hipStream_t s = ctx().stream;
+    VDB_HIP(hipMemcpyAsync(h->codes.as<uint8_t>() + row * h->m, code, (size_t)h->m, hipMemcpyHostToDevice, s));
+    VDB_HIP(hipStreamSynchronize(s));
+    return VDB_OK;
+}
+
+int vdb_pq_size(const vdb_pq* h, int64_t* n) {
+    VDB_REQUIRE(h && n, "null argument");
+    *n = h->n;
+    return VDB_OK;
+}
+
+int vdb_pq_lut(vdb_pq* h, const float* query, float* out_lut) {
+    VDB_REQUIRE(h && query && out_lut, "null argument");
+    VDB_REQUIRE(h->trained, "codebook not set");
+    std::lock_guard<std::mutex> g(ctx().mu);
+    hipStream_t s = ctx().stream;
+    Workspace& ws = h->ws;
+    const size_t lut_bytes = (size_t)h->m * h->ksub * sizeof(float);
+    VDB_TRY(ws.stage.reserve((size_t)h->dim * sizeof(float)));
+    VDB_TRY(ws.lut.reserve(lut_bytes));
+    VDB_HIP(hipMemcpyAsync(ws.stage.p, query, (size_t)h->dim * sizeof(float), hipMemcpyHostToDevice, s));
+    VDB_TRY(launch_pq_lut(ws.stage.as<float>(), h->dim, 1, h->book.as<float>(), h->m, h->ksub, h->dsub, h->plan, ws.lut.as<float>(), s));
+    VDB_HIP(hipMemcpyAsync(out_lut, ws.lut.p, lut_bytes, hipMemcpyDeviceToHost, s));
+    VDB_HIP(hipStreamSynchronize(s));
+    return VDB_OK;
+}
+
+static int pq_search_impl(vdb_pq* h, const float* d_q, int nq, int k, const uint32_t* d_mask,
+                          float* d_out_d, int64_t* d_out_i, hipStream_t s) {
+    VDB_REQUIRE(h->trained, "index is not trained");
+    VDB_REQUIRE(nq >= 0 && k >= 1, "need nq >= 0 and k >= 1");
+    if (nq == 0) return VDB_OK;
+    Workspace& ws = h->ws;
+    const int64_t k_eff = std::min<int64_t>(k, h->n);
+    if (k_eff < k) VDB_TRY(fill_results(d_out_d, d_out_i, (int64_t)nq * k, s));
+    if (h->n == 0) return VDB_OK;
+    VDB_TRY(ws.lut.reserve((size_t)nq * h->m * h->ksub * sizeof(float)));
+    VDB_TRY(launch_pq_lut(d_q, h->dim, nq, h->book.as<float>(), h->m, h->ksub, h->dsub, h->plan, ws.lut.as<float>(), s));
+    const int64_t ntiles = (h->n + 255) / 256;
+    const int splits = (int)std::max<int64_t>(1, std::min<int64_t>(ntiles, (8 * ctx().num_cus + nq - 1) / nq));
+    const int kmax = (int)std::min<int64_t>(KMAX_FUSED, k_eff);
+    VDB_TRY(ws.part_d.reserve((size_t)nq * splits * kmax * sizeof(float)));
+    VDB_TRY(ws.part_i.reserve((size_t)nq * splits * kmax * sizeof(int)));
+    const bool multi = k_eff > KMAX_FUSED;
+    if (multi) {
+        VDB_TRY(ws.lb_d.reserve((size_t)nq * sizeof(float)));
+        VDB_TRY(ws.lb_k.reserve((size_t)nq * sizeof(int64_t)));
+    }
+    for (int64_t done = 0; done < k_eff; done += KMAX_FUSED) {
+        const int kk = (int)std::min<int64_t>(KMAX_FUSED, k_eff - done);
+        VDB_TRY(launch_pq_scan(h->codes.as<uint8_t>(), h->n, h->m, h->ksub, ws.lut.as<float>(), nq, kk, d_mask,
+                               done > 0 ? ws.lb_d.as<float>() : nullptr, done > 0 ? ws.lb_k.as<int64_t>() : nullptr, splits,
+                               ws.part_d.as<float>(), ws.part_i.as<int>(), nullptr, s));
+        SelectOut o{d_out_d, d_out_i, nullptr, k, (int)done,
+                    multi ? ws.lb_d.as<float>() : nullptr, multi ? ws.lb_k.as<int64_t>() : nullptr};
+        VDB_TRY(launch_select(ws.part_d.as<float>(), ws.part_i.as<int>(), nq, splits, kk, 1 << 30, nullptr, 0, o, s));
+    }
+    return VDB_OK;
+}
+
+int vdb_pq_search_dev(vdb_pq* h, const float* d_queries, int nq, int k, const uint32_t* d_mask,
+                      float* d_out_dist, int64_t* d_out_row, void* stream) {
+    VDB_REQUIRE(h && (d_queries || nq == 0), "null argument");
+    std::lock_guard<std::mutex> g(ctx().mu);
+    return pq_search_impl(h, d_queries, nq, k, d_mask, d_out_dist, d_out_row, pick_stream(stream));
+}
+
+int vdb_pq_search(vdb_pq* h, const float* queries, int nq, int k, const uint32_t* mask, float* out_dist, int64_t* out_row) {
+    VDB_REQUIRE(h && (queries || nq == 0), "null argument");
+    VDB_REQUIRE(k >= 1, "k must be >= 1, got %d", k);
+    std::lock_guard<std::mutex> g(ctx().mu);
+    hipStream_t s = ctx().stream;
+    const uint32_t* d_mask = nullptr;
+    VDB_TRY(upload_mask(h->ws, mask, h->n, &d_mask, s));
+    return with_host_io(h->io, queries, nq, h->dim, k, out_dist, out_row, s,
+                        [&](const float* dq, float* dd, int64_t* di) {
+                            return pq_search_impl(h, dq, nq, k, d_mask, dd, di, s);
+                        });
+}
+
+// ============================================================== cross-shard merge
+int vdb_topk_merge_dev(const float* d_dist, const int64_t* d_row, int n_lists, int nq, int k,
+                       float* d_out_dist, int64_t* d_out_row, void* stream) {
+    VDB_TRY(ensure_init());
+    VDB_REQUIRE(d_dist && d_row && d_out_dist && d_out_row && n_lists >= 1 && nq >= 0 && k >= 1,
+                "bad arguments to vdb_topk_merge_dev");
+    return launch_select_i64(d_dist, d_row, n_lists, nq, k, d_out_dist, d_out_row, pick_stream(stream));
+}
+
+}  // extern "C"

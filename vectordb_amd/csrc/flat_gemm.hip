@@ -1,0 +1,300 @@
+// Batched distance + top-k for the Flat index on the fp32 matrix cores.
+//
+// Computes, for a tile of 128 queries against a slab of database rows, the dot
+// products c.q with v_mfma_f32_32x32x2_f32 (exact fp32 fma chains), turns each
+// into the final distance value exactly as the reference's query_distances
+// does (distance/metrics.py:453-484: |q|^2+|c|^2-2c.q -> clamp -> sqrt;
+// c.q/(|q||c|) -> clip -> 1-s; -(c.q)) and keeps the k best per query without
+// ever writing the nq x n matrix (index/flat.py:331,354-362 materialise it).
+//
+// Orientation: the MFMA "A" operand is the database tile, "B" the query tile,
+// so in the 32x32 accumulator a lane owns ONE query (column = lane & 31) and
+// 16 database rows.  Selection is therefore lane-local: every thread keeps a
+// sorted list of its k best (distance, row) in LDS and filters new values
+// against a threshold shared with the one other lane that owns the same query.
+//
+// Block = 256 threads = 4 waves; wave w owns queries [32w, 32w+32) of the
+// tile and all 128 database rows of the current tile (4 accumulators of
+// 32x32).  K is walked in steps of 32 staged through LDS (row stride 36
+// floats: conflict-free ds_read_b128 fragment reads).
+#include "vdb_internal.h"
+#include "vdb_device.h"
+
+namespace vdb {
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+static constexpr int TM = 128;      // database rows per tile
+static constexpr int TQ = 128;      // queries per tile
+static constexpr int TK = 32;       // K step
+static constexpr int LW = TK + 4;   // padded LDS row width in floats
+static constexpr int NT = LIST_NT;  // threads per block
+
+struct GemmParams {
+    const float* rows; int64_t n; int ld;
+    const float* row_sq; const float* row_nrm;
+    const float* q; int nq;
+    const float* q_sq; const float* q_nrm;
+    const uint32_t* mask;
+    const float* lb_d; const int64_t* lb_k;
+    int k;
+    int n_tiles, n_slabs, tiles_per_slab, n_qtiles;
+    float* part_d; int* part_i; int n_cand;
+    float* dist_out;
+};
+
+// ---- final distance value from the dot product, per metric ---------------
+template <int METRIC>
+__device__ __forceinline__ float finish(float dot, float row_term, float q_term) {
+    if (METRIC == VDB_DOT) {
+        return -dot;
+    } else if (METRIC == VDB_COSINE) {
+        // q_term = |q| (or +inf for a zero query -> similarity 0 -> distance 1);
+        // row_term = |c| with the <1e-8 -> 1 substitution already applied
+        float sim = dot / (q_term * row_term);
+        sim = fminf(fmaxf(sim, -1.0f), 1.0f);
+        return 1.0f - sim;
+    } else {
+        // (|q|^2 + |c|^2) - 2*dot : 2*dot is exact, so one fma rounds like the
+        // reference's separate multiply and subtract
+        float sq = fmaxf(__fmaf_rn(-2.0f, dot, q_term + row_term), 0.0f);
+        return METRIC == VDB_EUCLIDEAN ? __fsqrt_rn(sq) : sq;
+    }
+}
+
+template <int METRIC, bool TOPK>
+__global__ __launch_bounds__(NT, 2) void flat_gemm_kernel(GemmParams p) {
+    extern __shared__ __align__(16) float smem[];
+    float* As = smem;                   // [TM][LW]  database rows
+    float* Bs = As + TM * LW;           // [TQ][LW]  queries
+    float* Rs = Bs + TQ * LW;           // [TM]      per-row term (|c|^2 or |c|)
+    float* Ld = Rs + TM;                // [k][NT]   per-thread best distances
+    int* Li = reinterpret_cast<int*>(Ld + (TOPK ? p.k : 0) * NT);
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = tid >> 6;
+    const int half = lane >> 5;
+    const int col = lane & 31;
+
+    // blocks that work on the same slab of rows (one per query tile) get the
+    // same blockIdx % 8, i.e. the same XCD and L2, and adjacent dispatch slots
+    const int per_group = 8 * p.n_qtiles;
+    const int grp = blockIdx.x / per_group;
+    const int rem = blockIdx.x - grp * per_group;
+    const int slab = grp * 8 + (rem & 7);
+    const int qt = rem >> 3;
+    if (slab >= p.n_slabs) return;
+    const int tile0 = slab * p.tiles_per_slab;
+    const int tile1 = min(tile0 + p.tiles_per_slab, p.n_tiles);
+
+    const int my_q = qt * TQ + wave * 32 + col;
+    const bool q_ok = my_q < p.nq;
+    const int my_q_ld = min(my_q, p.nq - 1);
+    float q_term = 0.0f;
+    if (METRIC == VDB_COSINE) {
+        q_term = p.q_nrm[my_q_ld];
+        if (q_term < 1e-8f) q_term = INFINITY;      // metrics.py:472-473: all ones
+    } else if (METRIC != VDB_DOT) {
+        q_term = p.q_sq[my_q_ld];
+    }
+    float lbd = -INFINITY;
+    int64_t lbk = -1;
+    if (TOPK && p.lb_d) { lbd = p.lb_d[my_q_ld]; lbk = p.lb_k[my_q_ld]; }
+
+    float own_kth = INFINITY, thr = INFINITY;
+    if (TOPK) {
+        list_init(Ld, Li, p.k, tid);
+    }
+
+    const int ksteps = (p.ld + TK - 1) / TK;
+    const int srow = tid >> 3;          // staging: row within a 32-row pass
+    const int skc = (tid & 7) * 4;      // staging: float offset inside the K step
+    const int64_t q_base = (int64_t)qt * TQ;
+
+    float4 ra[4], rb[4];
+    auto issue_loads = [&](int tile, int ks) {
+        const int kk = ks * TK + skc;
+        const bool kin = kk < p.ld;
+        const int64_t rbase = (int64_t)tile * TM;
+#pragma unroll
+        for (int ps = 0; ps < 4; ++ps) {
+            const int r = ps * 32 + srow;
+            const int64_t gr = min(rbase + r, p.n - 1);
+            const int64_t gq = min(q_base + r, (int64_t)p.nq - 1);
+            ra[ps] = kin ? *reinterpret_cast<const float4*>(p.rows + gr * p.ld + kk) : make_float4(0, 0, 0, 0);
+            rb[ps] = kin ? *reinterpret_cast<const float4*>(p.q + gq * p.ld + kk) : make_float4(0, 0, 0, 0);
+        }
+    };
+
+    if (tile0 < tile1) issue_loads(tile0, 0);
+
+    for (int tile = tile0; tile < tile1; ++tile) {
+        const int64_t rbase = (int64_t)tile * TM;
+        f32x16 acc[4];
+#pragma unroll
+        for (int s = 0; s < 4; ++s)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) acc[s][e] = 0.0f;
+
+        for (int ks = 0; ks < ksteps; ++ks) {
+            __syncthreads();            // everyone is done reading the previous step (and Rs)
+#pragma unroll
+            for (int ps = 0; ps < 4; ++ps) {
+                const int r = ps * 32 + srow;
+                *reinterpret_cast<float4*>(As + r * LW + skc) = ra[ps];
+                *reinterpret_cast<float4*>(Bs + r * LW + skc) = rb[ps];
+            }
+            if (ks == 0 && METRIC != VDB_DOT && tid < TM) {
+                const int64_t gr = min(rbase + tid, p.n - 1);
+                float t = (METRIC == VDB_COSINE) ? p.row_nrm[gr] : p.row_sq[gr];
+                if (METRIC == VDB_COSINE && t < 1e-8f) t = 1.0f;    // metrics.py:476
+                Rs[tid] = t;
+            }
+            __syncthreads();
+            // prefetch the next step (possibly of the next tile) while computing
+            if (ks + 1 < ksteps) issue_loads(tile, ks + 1);
+            else if (tile + 1 < tile1) issue_loads(tile + 1, 0);
+
+            const float* bq = Bs + (wave * 32 + col) * LW + half * 4;
+            const float* ar = As + col * LW + half * 4;
+#pragma unroll
+            for (int ch = 0; ch < 4; ++ch) {
+                const float4 b = *reinterpret_cast<const float4*>(bq + ch * 8);
+                float4 a[4];
+#pragma unroll
+                for (int s = 0; s < 4; ++s) a[s] = *reinterpret_cast<const float4*>(ar + s * 32 * LW + ch * 8);
+#pragma unroll
+                for (int s = 0; s < 4; ++s) {
+                    acc[s] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[s].x, b.x, acc[s], 0, 0, 0);
+                    acc[s] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[s].y, b.y, acc[s], 0, 0, 0);
+                    acc[s] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[s].z, b.z, acc[s], 0, 0, 0);
+                    acc[s] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[s].w, b.w, acc[s], 0, 0, 0);
+                }
+            }
+        }
+
+        // ---- epilogue: lane owns query `my_q`, rows rbase + 32s + 8g + 4*half + j
+        const bool tail = rbase + TM > p.n;
+#pragma unroll
+        for (int s = 0; s < 4; ++s) {
+            uint32_t bits = 0xffffffffu;
+            if (TOPK) {
+                const int64_t r0 = rbase + s * 32;
+                if (p.mask) bits = (r0 < p.n) ? p.mask[r0 >> 5] : 0u;
+                if (tail) {
+                    const int64_t left = p.n - r0;
+                    bits = left <= 0 ? 0u : (left >= 32 ? bits : (bits & ((1u << left) - 1u)));
+                }
+                bits >>= (4 * half);
+            }
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                float4 rt = make_float4(0, 0, 0, 0);
+                if (METRIC != VDB_DOT) rt = *reinterpret_cast<const float4*>(Rs + s * 32 + 8 * g + 4 * half);
+                const float rts[4] = {rt.x, rt.y, rt.z, rt.w};
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const float d = finish<METRIC>(acc[s][g * 4 + j], rts[j], q_term);
+                    const int row = (int)(rbase + s * 32 + 8 * g + 4 * half + j);
+                    if (TOPK) {
+                        if (d <= thr && ((bits >> (8 * g + j)) & 1u)) {
+                            // exclusive lower bound of a multi-pass search
+                            const bool above = (d > lbd) || (d == lbd && (int64_t)row > lbk);
+                            if (above && d < own_kth) {
+                                own_kth = list_insert(Ld + tid, Li + tid, p.k, d, row);
+                                thr = fminf(thr, own_kth);
+                            }
+                        }
+                    } else {
+                        if (q_ok && row < p.n) p.dist_out[(int64_t)my_q * p.n + row] = d;
+                    }
+                }
+            }
+        }
+        if (TOPK) {
+            // the other half-wave lane with the same query may hold a tighter bound
+            thr = fminf(own_kth, __shfl_xor(own_kth, 32));
+        }
+    }
+
+    if (TOPK && q_ok) {
+        float* od = p.part_d + ((int64_t)my_q * p.n_cand + slab * 2 + half) * p.k;
+        int* oi = p.part_i + ((int64_t)my_q * p.n_cand + slab * 2 + half) * p.k;
+        for (int i = 0; i < p.k; ++i) { od[i] = Ld[i * NT + tid]; oi[i] = Li[i * NT + tid]; }
+    }
+}
+
+// --------------------------------------------------------------------------
+static void plan_grid(int64_t n, int nq, int num_cus, int* n_tiles, int* n_qtiles, int* n_slabs, int* tiles_per_slab) {
+    *n_tiles = (int)((n + TM - 1) / TM);
+    *n_qtiles = (nq + TQ - 1) / TQ;
+    int want = (2 * num_cus + *n_qtiles - 1) / *n_qtiles;      // ~2 blocks per CU in total
+    if (want < 1) want = 1;
+    if (want > *n_tiles) want = *n_tiles;
+    *tiles_per_slab = (*n_tiles + want - 1) / want;
+    *n_slabs = (*n_tiles + *tiles_per_slab - 1) / *tiles_per_slab;
+}
+
+int flat_gemm_num_cand(int64_t n, int nq, int k, int* n_cand) {
+    int nt, nqt, ns, tps;
+    plan_grid(n, nq, ctx().num_cus, &nt, &nqt, &ns, &tps);
+    *n_cand = ns * 2;
+    return VDB_OK;
+}
+
+template <bool TOPK>
+static int launch_gemm(const Rows& r, int metric, GemmParams& p, hipStream_t s) {
+    plan_grid(p.n, p.nq, ctx().num_cus, &p.n_tiles, &p.n_qtiles, &p.n_slabs, &p.tiles_per_slab);
+    if (!TOPK) {
+        // distance output: one slab per tile row block keeps the grid large
+    }
+    const int groups = (p.n_slabs + 7) / 8;
+    const dim3 grid(groups * 8 * p.n_qtiles);
+    const size_t lds = (size_t)(2 * TM * LW + TM) * sizeof(float) + (TOPK ? (size_t)p.k * NT * 8 : 0);
+#define VDB_LAUNCH_GEMM(M)                                                                     \
+    case M: {                                                                                  \
+        auto kern = flat_gemm_kernel<M, TOPK>;                                                 \
+        VDB_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern),                       \
+                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));    \
+        hipLaunchKernelGGL(kern, grid, dim3(NT), lds, s, p);                                   \
+        break;                                                                                 \
+    }
+    switch (metric) {
+        VDB_LAUNCH_GEMM(VDB_EUCLIDEAN)
+        VDB_LAUNCH_GEMM(VDB_EUCLIDEAN_SQ)
+        VDB_LAUNCH_GEMM(VDB_COSINE)
+        VDB_LAUNCH_GEMM(VDB_DOT)
+        default:
+            set_error("metric %d has no matrix-core path", metric);
+            return VDB_ERR_INVALID;
+    }
+#undef VDB_LAUNCH_GEMM
+    VDB_HIP(hipGetLastError());
+    return VDB_OK;
+}
+
+int launch_flat_gemm_topk(const Rows& r, int metric, const float* q, const float* q_sq, const float* q_nrm,
+                          int nq, int k, const uint32_t* mask, const float* lb_d, const int64_t* lb_k,
+                          float* part_d, int* part_i, int n_cand, hipStream_t s) {
+    VDB_REQUIRE(k >= 1 && k <= KMAX_FUSED, "fused selection supports 1 <= k <= %d, got %d", KMAX_FUSED, k);
+    VDB_REQUIRE(r.n >= 1 && nq >= 1, "empty search");
+    GemmParams p{};
+    p.rows = r.data; p.n = r.n; p.ld = r.ld; p.row_sq = r.sq; p.row_nrm = r.nrm;
+    p.q = q; p.nq = nq; p.q_sq = q_sq; p.q_nrm = q_nrm;
+    p.mask = mask; p.lb_d = lb_d; p.lb_k = lb_k; p.k = k;
+    p.part_d = part_d; p.part_i = part_i; p.n_cand = n_cand; p.dist_out = nullptr;
+    return launch_gemm<true>(r, metric, p, s);
+}
+
+int launch_flat_gemm_dist(const Rows& r, int metric, const float* q, const float* q_sq, const float* q_nrm,
+                          int nq, float* out, hipStream_t s) {
+    VDB_REQUIRE(r.n >= 1 && nq >= 1, "empty distance computation");
+    GemmParams p{};
+    p.rows = r.data; p.n = r.n; p.ld = r.ld; p.row_sq = r.sq; p.row_nrm = r.nrm;
+    p.q = q; p.nq = nq; p.q_sq = q_sq; p.q_nrm = q_nrm;
+    p.k = 0; p.dist_out = out;
+    return launch_gemm<false>(r, metric, p, s);
+}
+
+}  // namespace vdb

@@ -1,0 +1,229 @@
+// Product-quantisation kernels.
+//
+//  pq_lut_kernel    : the per-query distance tables of PQIndex.search
+//                     (index/pq.py:270-283): table[m][c] = np.sum((codebook[m][c] - q_m)**2)
+//  pq_encode_kernel : PQIndex._encode (index/pq.py:188-200): per sub-space the
+//                     first codeword of minimum direct-form squared distance
+//  pq_scan_kernel   : the ADC scan (index/pq.py:287-297): codes streamed from
+//                     HBM one row per lane, the query's table in LDS, fp32 sum
+//                     in sub-space order 0..m-1 (what Python's sum() does there),
+//                     sqrt, filter bit tested in the scan, k best kept.
+//
+// All three reproduce the reference's fp32 results bit for bit: the sums over
+// a sub-vector follow NumPy's pairwise order and nothing is contracted to fma.
+#include "vdb_internal.h"
+#include "vdb_device.h"
+
+namespace vdb {
+
+// np.sum((a - b)**2) over n contiguous elements, n <= 128 (one pairwise leaf)
+__device__ __forceinline__ static float np_leaf_sqdiff(const float* a, const float* b, int n) {
+    if (n < 8) {
+        float r = 0.0f;
+        for (int i = 0; i < n; ++i) { const float d = a[i] - b[i]; r = r + d * d; }
+        return r;
+    }
+    float r[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) { const float d = a[j] - b[j]; r[j] = d * d; }
+    int i = 8;
+    for (; i + 8 <= n; i += 8) {
+#pragma unroll
+        for (int j = 0; j < 8; ++j) { const float d = a[i + j] - b[i + j]; r[j] = r[j] + d * d; }
+    }
+    float res = ((r[0] + r[1]) + (r[2] + r[3])) + ((r[4] + r[5]) + (r[6] + r[7]));
+    for (; i < n; ++i) { const float d = a[i] - b[i]; res = res + d * d; }
+    return res;
+}
+
+// any n: walk the plan (leaves left to right, fold pending partial sums)
+__device__ static float np_sum_sqdiff(const float* a, const float* b, int n, const SumPlan& plan) {
+    if (n <= 128) return np_leaf_sqdiff(a, b, n);
+    float st[8];
+    int sp = 0, pos = 0;
+    for (int l = 0; l < plan.n_leaves; ++l) {
+        const int len = plan.leaf_len[l];
+        const float v = np_leaf_sqdiff(a + pos, b + pos, len);
+        pos += len;
+        // static-index push/fold so the stack stays in registers
+        int f = plan.folds[l];
+        float top = v;
+        while (f > 0) { top = st[sp - 1] + top; --sp; --f; }
+        st[sp++] = top;
+    }
+    return st[0];
+}
+
+// ---------------------------------------------------------------- tables
+__global__ __launch_bounds__(256) void pq_lut_kernel(const float* __restrict__ q, int ldq,
+                                                     const float* __restrict__ book, int m, int ksub, int dsub,
+                                                     SumPlan plan, float* __restrict__ lut) {
+    extern __shared__ __align__(16) float qs[];
+    const int sub = blockIdx.x, qi = blockIdx.y;
+    for (int i = threadIdx.x; i < dsub; i += blockDim.x) qs[i] = q[(int64_t)qi * ldq + sub * dsub + i];
+    __syncthreads();
+    for (int c = threadIdx.x; c < ksub; c += blockDim.x) {
+        const float* cw = book + ((int64_t)sub * ksub + c) * dsub;
+        lut[((int64_t)qi * m + sub) * ksub + c] = np_sum_sqdiff(cw, qs, dsub, plan);
+    }
+}
+
+// ---------------------------------------------------------------- encode
+// block = 256 rows of one sub-space; codewords of that sub-space in LDS
+__global__ __launch_bounds__(256) void pq_encode_kernel(const float* __restrict__ x, int64_t n, int ldx,
+                                                        const float* __restrict__ book, int m, int ksub, int dsub,
+                                                        SumPlan plan, uint8_t* __restrict__ codes) {
+    extern __shared__ __align__(16) float sm[];
+    float* cb = sm;                         // [ksub][dsub]
+    float* xs = sm + ksub * dsub;           // [256][dsub + 1]
+    const int sub = blockIdx.y;
+    const int tid = threadIdx.x;
+    const int64_t row0 = (int64_t)blockIdx.x * 256;
+    for (int i = tid; i < ksub * dsub; i += 256) cb[i] = book[(int64_t)sub * ksub * dsub + i];
+    for (int i = tid; i < 256 * dsub; i += 256) {
+        const int r = i / dsub, j = i - r * dsub;
+        const int64_t gr = min(row0 + r, n - 1);
+        xs[r * (dsub + 1) + j] = x[gr * ldx + sub * dsub + j];
+    }
+    __syncthreads();
+    const int64_t row = row0 + tid;
+    if (row >= n) return;
+    const float* mine = xs + tid * (dsub + 1);
+    float best = INFINITY;
+    int best_c = 0;
+    for (int c = 0; c < ksub; ++c) {
+        const float d = np_sum_sqdiff(cb + c * dsub, mine, dsub, plan);
+        if (d < best) { best = d; best_c = c; }       // strict: first minimum wins (np.argmin)
+    }
+    codes[row * m + sub] = (uint8_t)best_c;
+}
+
+// ---------------------------------------------------------------- scan
+struct PqScanParams {
+    const uint8_t* codes; int64_t n; int m; int ksub;
+    const float* lut;                // [nq][m][ksub]
+    const uint32_t* mask;
+    const float* lb_d; const int64_t* lb_k;
+    int k; int splits;
+    float* part_d; int* part_i;      // [nq][splits][k]
+    float* dist_out;                 // optional [nq][n]
+};
+
+template <int M>     // M > 0: compile-time number of sub-spaces (multiple of 4); 0: run-time
+__global__ __launch_bounds__(256) void pq_scan_kernel(PqScanParams p) {
+    extern __shared__ __align__(16) float sm[];
+    const int m = M > 0 ? M : p.m;
+    float* T = sm;                                  // [m][ksub]
+    float* Ld = T + m * p.ksub;
+    int* Li = reinterpret_cast<int*>(Ld + p.k * LIST_NT);
+    int* Red = Li + p.k * LIST_NT;
+    const int tid = threadIdx.x;
+    const int split = blockIdx.x, qi = blockIdx.y;
+    const int k = p.k;
+
+    const float* lut = p.lut + (int64_t)qi * m * p.ksub;
+    for (int i = tid; i < m * p.ksub; i += 256) T[i] = lut[i];
+    list_init(Ld, Li, k, tid);
+    float own_kth = INFINITY;
+    float lbd = -INFINITY; int64_t lbk = -1;
+    if (p.lb_d) { lbd = p.lb_d[qi]; lbk = p.lb_k[qi]; }
+    __syncthreads();
+
+    const int64_t ntiles = (p.n + 255) / 256;
+    const int64_t per = (ntiles + p.splits - 1) / p.splits;
+    const int64_t t0 = split * per, t1 = min(t0 + per, ntiles);
+    for (int64_t t = t0; t < t1; ++t) {
+        const int64_t row = t * 256 + tid;
+        if (row >= p.n) continue;
+        float acc;
+        if (M > 0) {
+            uint32_t w[M > 0 ? M / 4 : 1];
+            if (M % 16 == 0) {
+                const uint4* src = reinterpret_cast<const uint4*>(p.codes + row * M);
+#pragma unroll
+                for (int i = 0; i < M / 16; ++i) {
+                    const uint4 v = src[i];
+                    w[4 * i] = v.x; w[4 * i + 1] = v.y; w[4 * i + 2] = v.z; w[4 * i + 3] = v.w;
+                }
+            } else if (M % 8 == 0) {
+                const uint2* src = reinterpret_cast<const uint2*>(p.codes + row * M);
+#pragma unroll
+                for (int i = 0; i < M / 8; ++i) { const uint2 v = src[i]; w[2 * i] = v.x; w[2 * i + 1] = v.y; }
+            } else {
+                const uint32_t* src = reinterpret_cast<const uint32_t*>(p.codes + row * M);
+#pragma unroll
+                for (int i = 0; i < M / 4; ++i) w[i] = src[i];
+            }
+            acc = T[w[0] & 0xff];
+#pragma unroll
+            for (int j = 1; j < M; ++j) acc = acc + T[j * p.ksub + ((w[j >> 2] >> (8 * (j & 3))) & 0xff)];
+        } else {
+            const uint8_t* src = p.codes + row * m;
+            acc = T[src[0]];
+            for (int j = 1; j < m; ++j) acc = acc + T[j * p.ksub + src[j]];
+        }
+        const float d = __fsqrt_rn(acc);
+        if (p.dist_out) p.dist_out[(int64_t)qi * p.n + row] = d;
+        if (k == 0) continue;
+        if (p.mask && !((p.mask[row >> 5] >> (row & 31)) & 1u)) continue;
+        const bool above = (d > lbd) || (d == lbd && row > lbk);
+        if (above && d < own_kth) own_kth = list_insert(Ld + tid, Li + tid, k, d, (int)row);
+    }
+    if (k == 0) return;
+    float* od = p.part_d + ((int64_t)qi * p.splits + split) * k;
+    int* oi = p.part_i + ((int64_t)qi * p.splits + split) * k;
+    block_reduce_lists(Ld, Li, k, tid, Red, od, oi);
+}
+
+// ---------------------------------------------------------------- launchers
+int launch_pq_lut(const float* q, int ldq, int nq, const float* book, int m, int ksub, int dsub,
+                  const SumPlan& plan, float* lut, hipStream_t s) {
+    if (nq <= 0) return VDB_OK;
+    hipLaunchKernelGGL(pq_lut_kernel, dim3(m, nq), dim3(256), (size_t)dsub * sizeof(float), s,
+                       q, ldq, book, m, ksub, dsub, plan, lut);
+    VDB_HIP(hipGetLastError());
+    return VDB_OK;
+}
+
+int launch_pq_encode(const float* x, int64_t n, int ldx, const float* book, int m, int ksub, int dsub,
+                     const SumPlan& plan, uint8_t* codes, hipStream_t s) {
+    if (n <= 0) return VDB_OK;
+    const size_t lds = ((size_t)ksub * dsub + 256 * (size_t)(dsub + 1)) * sizeof(float);
+    VDB_REQUIRE(lds <= 160 * 1024, "sub-space of %d dims x %d codewords needs %zu bytes of LDS", dsub, ksub, lds);
+    VDB_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(pq_encode_kernel),
+                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    hipLaunchKernelGGL(pq_encode_kernel, dim3((unsigned)((n + 255) / 256), m), dim3(256), lds, s,
+                       x, n, ldx, book, m, ksub, dsub, plan, codes);
+    VDB_HIP(hipGetLastError());
+    return VDB_OK;
+}
+
+int launch_pq_scan(const uint8_t* codes, int64_t n, int m, int ksub, const float* lut, int nq, int k,
+                   const uint32_t* mask, const float* lb_d, const int64_t* lb_k, int splits,
+                   float* part_d, int* part_i, float* dist_out, hipStream_t s) {
+    VDB_REQUIRE(k >= 0 && k <= KMAX_FUSED, "scan supports k <= %d, got %d", KMAX_FUSED, k);
+    PqScanParams p{codes, n, m, ksub, lut, mask, lb_d, lb_k, k, splits, part_d, part_i, dist_out};
+    const size_t lds = (size_t)m * ksub * sizeof(float) + (size_t)k * LIST_NT * 8 + 12 * sizeof(int);
+    VDB_REQUIRE(lds <= 160 * 1024, "%d sub-spaces x %d codewords with k=%d need %zu bytes of LDS", m, ksub, k, lds);
+    const dim3 grid(splits, nq);
+#define VDB_LAUNCH_PQ(MM)                                                                      \
+    {                                                                                          \
+        auto kern = pq_scan_kernel<MM>;                                                        \
+        VDB_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern),                       \
+                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));    \
+        hipLaunchKernelGGL(kern, grid, dim3(256), lds, s, p);                                  \
+    }
+    switch (m) {
+        case 4: VDB_LAUNCH_PQ(4) break;
+        case 8: VDB_LAUNCH_PQ(8) break;
+        case 16: VDB_LAUNCH_PQ(16) break;
+        case 32: VDB_LAUNCH_PQ(32) break;
+        case 64: VDB_LAUNCH_PQ(64) break;
+        default: VDB_LAUNCH_PQ(0) break;
+    }
+#undef VDB_LAUNCH_PQ
+    VDB_HIP(hipGetLastError());
+    return VDB_OK;
+}
+
+}  // namespace vdb

@@ -1,0 +1,153 @@
+// Final selection stages.
+//
+//  select_kernel   : per query, merge many ascending candidate lists of k into
+//                    the k best under the (distance, tie key) order.  Stands for
+//                    the argpartition+argsort of index/flat.py:354-362 and the
+//                    stable list.sort of core/collection.py:757,
+//                    index/ivf.py:631 and index/pq.py:300, applied to the
+//                    per-block survivors instead of all n rows.
+//  row_sort_kernel : full ascending sort of one row of distances (n <= 16384)
+//                    in LDS; np.argsort(centroid_distances)[:n_probe]
+//                    (index/ivf.py:614) when n_probe is large.
+#include "vdb_internal.h"
+#include "vdb_device.h"
+
+namespace vdb {
+
+template <class IdxT> struct IdxTraits;
+template <> struct IdxTraits<int> {
+    __device__ static bool empty(int v) { return v == EMPTY_IDX; }
+};
+template <> struct IdxTraits<int64_t> {
+    __device__ static bool empty(int64_t v) { return v < 0; }
+};
+
+// one wave per query
+template <class IdxT>
+__global__ __launch_bounds__(64) void select_kernel(const float* __restrict__ d, const IdxT* __restrict__ idx,
+                                                    int64_t q_stride, int64_t l_stride, int n_lists, int k,
+                                                    int tie_group, const int* __restrict__ idx_map, int64_t idx_offset,
+                                                    SelectOut o) {
+    extern __shared__ int heads[];
+    const int q = blockIdx.x;
+    const int lane = threadIdx.x;
+    for (int l = lane; l < n_lists; l += 64) heads[l] = 0;
+    __syncthreads();
+    const float* dq = d + (int64_t)q * q_stride;
+    const IdxT* iq = idx + (int64_t)q * q_stride;
+
+    float last_d = INFINITY;
+    int64_t last_key = INT64_MAX;
+    for (int round = 0; round < k; ++round) {
+        float bd = INFINITY;
+        int64_t bkey = INT64_MAX;
+        int64_t bidx = -1;
+        int bl = 0x7fffffff;
+        for (int l = lane; l < n_lists; l += 64) {
+            const int h = heads[l];
+            if (h >= k) continue;
+            const float v = dq[(int64_t)l * l_stride + h];
+            const IdxT id = iq[(int64_t)l * l_stride + h];
+            if (IdxTraits<IdxT>::empty(id)) continue;
+            const int64_t key = (sizeof(IdxT) == 4) ? (((int64_t)(l / tie_group) << 32) | (uint32_t)id) : (int64_t)id;
+            if (v < bd || (v == bd && key < bkey)) { bd = v; bkey = key; bidx = (int64_t)id; bl = l; }
+        }
+#pragma unroll
+        for (int off = 32; off >= 1; off >>= 1) {
+            const float d2 = __shfl_xor(bd, off);
+            const int64_t k2 = __shfl_xor(bkey, off);
+            const int64_t i2 = __shfl_xor(bidx, off);
+            const int l2 = __shfl_xor(bl, off);
+            if (d2 < bd || (d2 == bd && (k2 < bkey || (k2 == bkey && l2 < bl)))) { bd = d2; bkey = k2; bidx = i2; bl = l2; }
+        }
+        if (lane == 0) {
+            int64_t row = -1;
+            float dist = INFINITY;
+            if (bl != 0x7fffffff) {
+                heads[bl] += 1;
+                row = (idx_map ? (int64_t)idx_map[bidx] : bidx) + idx_offset;
+                dist = bd;
+                last_d = bd;
+                last_key = bkey;
+            } else {
+                last_d = INFINITY;
+                last_key = INT64_MAX;
+            }
+            const int64_t at = (int64_t)q * o.out_stride + o.out_off + round;
+            if (o.out_d) o.out_d[at] = dist;
+            if (o.out_i) o.out_i[at] = row;
+            if (o.out_i32) o.out_i32[at] = (int)row;
+        }
+        __syncthreads();
+    }
+    if (lane == 0 && o.last_d) { o.last_d[q] = last_d; o.last_key[q] = last_key; }
+}
+
+int launch_select(const float* part_d, const int* part_i, int nq, int n_cand, int k, int tie_group,
+                  const int* idx_map, int64_t idx_offset, const SelectOut& o, hipStream_t s) {
+    if (nq <= 0) return VDB_OK;
+    if (tie_group < 1) tie_group = 1;
+    hipLaunchKernelGGL(select_kernel<int>, dim3(nq), dim3(64), (size_t)n_cand * sizeof(int), s,
+                       part_d, part_i, (int64_t)n_cand * k, (int64_t)k, n_cand, k, tie_group, idx_map, idx_offset, o);
+    VDB_HIP(hipGetLastError());
+    return VDB_OK;
+}
+
+// lists laid out [n_lists][nq][k] (the shape an all-gather of per-shard results produces)
+int launch_select_i64(const float* d, const int64_t* i, int n_lists, int nq, int k,
+                      float* out_d, int64_t* out_i, hipStream_t s) {
+    if (nq <= 0) return VDB_OK;
+    SelectOut o{out_d, out_i, nullptr, k, 0, nullptr, nullptr};
+    hipLaunchKernelGGL(select_kernel<int64_t>, dim3(nq), dim3(64), (size_t)n_lists * sizeof(int), s,
+                       d, i, (int64_t)k, (int64_t)nq * k, n_lists, k, 1, (const int*)nullptr, (int64_t)0, o);
+    VDB_HIP(hipGetLastError());
+    return VDB_OK;
+}
+
+// --------------------------------------------------------------------------
+// bitonic sort of one row in LDS, ascending (value, index)
+__global__ __launch_bounds__(256) void row_sort_kernel(const float* __restrict__ dist, int n, int n_pad, int k,
+                                                       float* __restrict__ out_d, int* __restrict__ out_i) {
+    extern __shared__ __align__(16) float sm[];
+    float* key = sm;
+    int* val = reinterpret_cast<int*>(sm + n_pad);
+    const int q = blockIdx.x;
+    const int tid = threadIdx.x;
+    for (int i = tid; i < n_pad; i += 256) {
+        key[i] = i < n ? dist[(int64_t)q * n + i] : INFINITY;
+        val[i] = i < n ? i : EMPTY_IDX;
+    }
+    __syncthreads();
+    for (int size = 2; size <= n_pad; size <<= 1) {
+        for (int stride = size >> 1; stride > 0; stride >>= 1) {
+            for (int t = tid; t < n_pad / 2; t += 256) {
+                const int lo = 2 * t - (t & (stride - 1));
+                const int hi = lo + stride;
+                const bool up = (lo & size) == 0;
+                const float a = key[lo], b = key[hi];
+                const int ia = val[lo], ib = val[hi];
+                const bool a_gt_b = (a > b) || (a == b && ia > ib) || (a != a && b == b);   // NaN sorts last
+                if (a_gt_b == up) { key[lo] = b; key[hi] = a; val[lo] = ib; val[hi] = ia; }
+            }
+            __syncthreads();
+        }
+    }
+    for (int i = tid; i < k; i += 256) {
+        out_d[(int64_t)q * k + i] = i < n ? key[i] : INFINITY;
+        out_i[(int64_t)q * k + i] = i < n ? val[i] : EMPTY_IDX;
+    }
+}
+
+int launch_row_sort_topk(const float* dist, int nq, int n, int k, float* out_d, int* out_i, hipStream_t s) {
+    VDB_REQUIRE(n >= 1 && n <= 16384, "row sort handles 1..16384 values per row, got %d", n);
+    int n_pad = 2;
+    while (n_pad < n) n_pad <<= 1;
+    const size_t lds = (size_t)n_pad * 8;
+    VDB_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(row_sort_kernel),
+                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    hipLaunchKernelGGL(row_sort_kernel, dim3(nq), dim3(256), lds, s, dist, n, n_pad, k, out_d, out_i);
+    VDB_HIP(hipGetLastError());
+    return VDB_OK;
+}
+
+}  // namespace vdb

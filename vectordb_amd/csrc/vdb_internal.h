@@ -1,0 +1,173 @@
+// Internal declarations shared by the kernels and the C-ABI layer of
+// libvdbcore.so.  gfx950 (MI355X) only.
+#pragma once
+
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+#include <mutex>
+#include <string>
+#include <vector>
+
+#include "../../include/vdb_core.h"
+
+namespace vdb {
+
+// ---------------------------------------------------------------- errors
+void set_error(const char* fmt, ...);
+
+#define VDB_HIP(call)                                                                \
+    do {                                                                             \
+        hipError_t e__ = (call);                                                     \
+        if (e__ != hipSuccess) {                                                     \
+            vdb::set_error("%s failed: %s (%s:%d)", #call, hipGetErrorString(e__),   \
+                           __FILE__, __LINE__);                                      \
+            return (e__ == hipErrorOutOfMemory) ? VDB_ERR_NOMEM : VDB_ERR_HIP;       \
+        }                                                                            \
+    } while (0)
+
+#define VDB_REQUIRE(cond, ...)                                                       \
+    do {                                                                             \
+        if (!(cond)) {                                                               \
+            vdb::set_error(__VA_ARGS__);                                             \
+            return VDB_ERR_INVALID;                                                  \
+        }                                                                            \
+    } while (0)
+
+#define VDB_TRY(expr)                                                                \
+    do {                                                                             \
+        int s__ = (expr);                                                            \
+        if (s__ != VDB_OK) return s__;                                               \
+    } while (0)
+
+// ---------------------------------------------------------------- device state
+struct Context {
+    int device = -1;
+    hipStream_t stream = nullptr;   // the library's own stream
+    int num_cus = 256;
+    std::mutex mu;                  // serialises calls that share workspaces
+};
+Context& ctx();
+int ensure_init();
+
+// A grow-only device buffer (workspace).
+struct DevBuf {
+    void* p = nullptr;
+    size_t cap = 0;
+    int reserve(size_t bytes);      // may reallocate (contents lost)
+    int reserve_keep(size_t bytes, size_t keep_bytes, hipStream_t s);  // grows geometrically, keeps a prefix
+    void release();
+    template <class T> T* as() const { return reinterpret_cast<T*>(p); }
+};
+
+static inline int round_up(int x, int m) { return (x + m - 1) / m * m; }
+static inline int64_t round_up64(int64_t x, int64_t m) { return (x + m - 1) / m * m; }
+static inline int ceil_div(int64_t a, int64_t b) { return (int)((a + b - 1) / b); }
+
+// ---------------------------------------------------------------- summation plan
+// NumPy sums a contiguous fp32 run of length n pairwise: blocks of at most 128
+// elements are reduced with 8 strided accumulators combined as
+// ((r0+r1)+(r2+r3))+((r4+r5)+(r6+r7)) plus a sequential tail; longer runs are
+// split at (n/2 rounded down to a multiple of 8) and the halves added.  The
+// plan lists the leaf blocks left to right and, after each leaf, how many
+// pending partial sums are folded (right into left).  Kernels that must match
+// np.sum bit for bit walk this plan.
+struct SumPlan {
+    static const int MAX_LEAVES = 64;      // dim <= 8192
+    int n_leaves;
+    short leaf_len[MAX_LEAVES];
+    unsigned char folds[MAX_LEAVES];
+};
+int make_sum_plan(int n, SumPlan* plan);
+
+// ---------------------------------------------------------------- row store
+struct Rows {
+    int dim = 0;
+    int ld = 0;             // floats per stored row: dim rounded up to 4, zero padded
+    int64_t n = 0;
+    int64_t cap = 0;
+    float* data = nullptr;  // [cap][ld]
+    float* sq = nullptr;    // [cap]  np.sum(row**2)
+    float* nrm = nullptr;   // [cap]  sqrt(sq)
+    SumPlan plan;
+};
+
+// ---------------------------------------------------------------- kernel launchers (device pointers)
+enum { KMAX_FUSED = 32 };   // largest k the fused selection keeps per thread in LDS
+
+// row norms in NumPy order: sq[i] = np.sum(row_i**2), nrm[i] = sqrt(sq[i])
+int launch_row_norms(const float* data, int ld, int dim, int64_t n, const SumPlan& plan,
+                     float* sq, float* nrm, hipStream_t s);
+
+// copy n rows of `dim` floats (source leading dimension src_ld) into padded rows of dst_ld floats
+int launch_pad_rows(const float* src, int64_t src_ld, int dim, int64_t n, float* dst, int dst_ld, hipStream_t s);
+
+// MFMA path: fused distance + per-slab top-k for the four dot-product metrics.
+// part_* hold n_cand candidate lists of k per query: layout [nq][n_cand][k].
+int flat_gemm_num_cand(int64_t n, int nq, int k, int* n_cand);
+int launch_flat_gemm_topk(const Rows& r, int metric, const float* q, const float* q_sq, const float* q_nrm,
+                          int nq, int k, const uint32_t* mask, const float* lb_d, const int64_t* lb_k,
+                          float* part_d, int* part_i, int n_cand, hipStream_t s);
+// MFMA path, full distance matrix out[nq][n]
+int launch_flat_gemm_dist(const Rows& r, int metric, const float* q, const float* q_sq, const float* q_nrm,
+                          int nq, float* out, hipStream_t s);
+
+// streaming path (one thread per row, row tile staged through LDS)
+struct ScanJob {
+    const float* data; int ld; int dim;
+    const float* row_sq; const float* row_nrm;
+    SumPlan plan;
+    int metric;
+    // queries
+    const float* q; int ldq; int nq;
+    const float* q_sq; const float* q_nrm;
+    // rows: either a flat range [0, n) ...
+    int64_t n;
+    // ... or inverted lists: list_off[n_lists+1], probes[nq][n_probe]
+    const int64_t* list_off; const int* probes; int n_probe;
+    const int* row_ids;           // row number of every stored position (lists) or null (= position)
+    const uint32_t* mask;         // indexed by row number
+    const float* lb_d; const int64_t* lb_k;   // exclusive lower bound (distance, tie key) per query, or null
+    int k;
+    int splits;                   // blocks per (query[, probe])
+    // outputs
+    float* part_d; int* part_i;   // [nq][n_cand][k] candidate lists (idx = scan position or row)
+    float* dist_out;              // full distances [nq][n] (flat range only) or null
+    float radius; int use_radius; // keep only rows with distance <= radius
+};
+int scan_num_cand(const ScanJob& j, int* n_cand);
+int launch_scan(const ScanJob& j, hipStream_t s);
+
+// final selection: per query, the k best of n_cand ascending candidate lists of k,
+// layout [nq][n_cand][k], under the (distance, tie key) order with
+// tie key = (candidate list / tie_group) << 32 | idx.  idx_map (optional)
+// translates a selected idx to a row number; idx_offset is added afterwards.
+struct SelectOut {
+    float* out_d; int64_t* out_i; int* out_i32;   // any of the index outputs may be null
+    int out_stride; int out_off;                  // result r of query q goes to [q*out_stride + out_off + r]
+    float* last_d; int64_t* last_key;             // (distance, tie key) of the last result, for a follow-up pass
+};
+int launch_select(const float* part_d, const int* part_i, int nq, int n_cand, int k, int tie_group,
+                  const int* idx_map, int64_t idx_offset, const SelectOut& o, hipStream_t s);
+// lists laid out [n_lists][nq][k] with int64 rows (negative = empty)
+int launch_select_i64(const float* d, const int64_t* i, int n_lists, int nq, int k,
+                      float* out_d, int64_t* out_i, hipStream_t s);
+
+// sort every row of a [nq][n] matrix (n <= 16384) ascending by (value, index); writes the first k of each
+int launch_row_sort_topk(const float* dist, int nq, int n, int k, float* out_d, int* out_i, hipStream_t s);
+
+// PQ
+int launch_pq_lut(const float* q, int ldq, int nq, const float* book, int m, int ksub, int dsub,
+                  const SumPlan& plan, float* lut, hipStream_t s);
+int launch_pq_encode(const float* x, int64_t n, int ldx, const float* book, int m, int ksub, int dsub,
+                     const SumPlan& plan, uint8_t* codes, hipStream_t s);
+int launch_pq_scan(const uint8_t* codes, int64_t n, int m, int ksub, const float* lut, int nq, int k,
+                   const uint32_t* mask, const float* lb_d, const int64_t* lb_k, int splits,
+                   float* part_d, int* part_i, float* dist_out, hipStream_t s);
+// k-means
+int launch_kmeans_accumulate(const float* x, int64_t n, int dim, int ldx, const int* assign, int n_clusters,
+                             double* sums, unsigned long long* counts, hipStream_t s);
+
+}  // namespace vdb
