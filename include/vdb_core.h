@@ -72,6 +72,15 @@ const char* vdb_last_error(void);
 int vdb_device_info(char* name, int name_len, int64_t* mem_total, int64_t* mem_free);
 /* block until everything the library has enqueued on its own stream is done */
 int vdb_synchronize(void);
+/* Kernel timing for roofline accounting (no counterpart in the reference; its
+ * only timers are wall clocks around Collection.search, query/executor.py:255-272).
+ * While enabled, every launch of a path's dominant kernel (the MFMA flat
+ * kernel, the streaming scan, the PQ scan) is bracketed by HIP events on the
+ * stream it is launched on.  vdb_profile_read waits for those events, returns
+ * the summed kernel time in milliseconds and the number of launches since the
+ * last read, and clears the record. */
+int vdb_profile_enable(int on);
+int vdb_profile_read(float* kernel_ms, int* launches);
 
 /* ---- resident fp32 row matrix (FlatIndex storage, Collection matrix) ---
  * index/flat.py:136-141,261,276-282 (growable fp32 matrix) and

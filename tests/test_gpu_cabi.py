@@ -30,15 +30,34 @@ def nat(native):
 
 
 def identity_atol(metric, q, x):
-    """Rounding floor of |q|^2+|c|^2-2c.q (a few ulps of the large terms) mapped
-    to the returned value."""
-    if metric == "euclidean_squared":
+    """Rounding floor of the dot-product forms: a few ulps of the large terms
+    that cancel in |q|^2+|c|^2-2c.q (squared domain for both Euclidean
+    metrics), of sum|c_i q_i| for dot, of 1.0 for cosine."""
+    if metric in ("euclidean", "euclidean_squared"):
         return 4e-6 * float(np.max(np.sum(x * x, axis=1)) + np.sum(q * q))
-    if metric == "euclidean":
-        return 2e-3
     if metric == "dot":
         return 1e-5 * float(np.max(np.abs(x).sum(axis=1)) * np.max(np.abs(q)))
     return 2e-6
+
+
+def assert_close(metric, got, ref, q, x):
+    """1e-4 relative, plus the cancellation floor.  Euclidean is compared in the
+    squared domain, where the identity form's error is additive."""
+    got = np.asarray(got, dtype=np.float64)
+    ref = np.asarray(ref, dtype=np.float64)
+    atol = identity_atol(metric, q, x)
+    if metric == "euclidean":
+        np.testing.assert_allclose(got ** 2, ref ** 2, rtol=2 * RTOL, atol=atol)
+    else:
+        np.testing.assert_allclose(got, ref, rtol=RTOL, atol=atol)
+
+
+def ids_atol(metric, q, x, kth):
+    """Distance slack within which two rows count as tied at the k-th place."""
+    a = identity_atol(metric, q, x)
+    if metric == "euclidean":
+        return a / max(2.0 * abs(kth), np.sqrt(a))
+    return a
 
 
 def check_search(nat, x, queries, k, metric, mask=None):
@@ -59,9 +78,9 @@ def check_search(nat, x, queries, k, metric, mask=None):
             np.testing.assert_array_equal(got_rows, ref_rows)
             np.testing.assert_array_equal(got_dist, ref_dist.astype(np.float32))
         else:
-            atol = identity_atol(metric, q, x)
+            atol = ids_atol(metric, q, x, float(ref_dist[-1]))
             assert same_ids_or_near_ties(got_rows, ref_rows, lambda r: full[r], float(ref_dist[-1]), rtol=RTOL, atol=atol)
-            np.testing.assert_allclose(got_dist, ref_dist, rtol=RTOL, atol=atol)
+            assert_close(metric, got_dist, ref_dist, q, x)
             assert (np.diff(got_dist) >= 0).all()
     store.close()
     return dist, rows
@@ -117,19 +136,19 @@ def test_flat_search_vs_reference_golden(nat, metric):
         for i in range(len(q)):
             full = R.query_distances(q[i], x, metric)
             ref_rows, ref_dist = g[f"{metric}_k{k}_rows"][i], g[f"{metric}_k{k}_dist"][i]
-            atol = identity_atol(metric, q[i], x)
+            atol = ids_atol(metric, q[i], x, float(ref_dist[-1]))
             assert same_ids_or_near_ties(rows[i], ref_rows, lambda r: full[r], float(ref_dist[-1]), rtol=RTOL, atol=atol)
             if metric in EXACT:
                 np.testing.assert_array_equal(dist[i], ref_dist.astype(np.float32))
             else:
-                np.testing.assert_allclose(dist[i], ref_dist, rtol=RTOL, atol=atol)
+                assert_close(metric, dist[i], ref_dist, q[i], x)
     dist, rows = store.search(q, 10, code, nat.pack_mask(mask))
     for i in range(len(q)):
         full = R.query_distances(q[i], x, metric)
         ref_rows, ref_dist = g[f"{metric}_filter_rows"][i], g[f"{metric}_filter_dist"][i]
-        atol = identity_atol(metric, q[i], x)
+        atol = ids_atol(metric, q[i], x, float(ref_dist[-1]))
         assert same_ids_or_near_ties(rows[i], ref_rows, lambda r: full[r], float(ref_dist[-1]), rtol=RTOL, atol=atol)
-        np.testing.assert_allclose(dist[i], ref_dist, rtol=RTOL, atol=atol)
+        assert_close(metric, dist[i], ref_dist, q[i], x)
     store.close()
 
 
@@ -265,10 +284,9 @@ def test_distances_golden(nat, nq):
             if metric in EXACT:
                 np.testing.assert_array_equal(out[0], ref)
             else:
-                np.testing.assert_allclose(out[0], ref, rtol=RTOL, atol=identity_atol(metric, q, x))
+                assert_close(metric, out[0], ref, q, x)
             for j in range(1, nq):
-                np.testing.assert_allclose(out[j], R.query_distances(qs[j], x, metric), rtol=RTOL,
-                                           atol=identity_atol(metric, qs[j], x))
+                assert_close(metric, out[j], R.query_distances(qs[j], x, metric), qs[j], x)
         # direct forms (the per-pair scalar functions, metrics.py:43,190,214)
         out = store.distances(q, nat.EUCLIDEAN_DIRECT)
         np.testing.assert_array_equal(out[0][:64].astype(np.float64), g[f"s{seed}_scalar_euclidean"])
@@ -289,7 +307,7 @@ def test_distances_dims_golden(nat, d):
         if metric in EXACT:
             np.testing.assert_array_equal(out, ref)
         else:
-            np.testing.assert_allclose(out, ref, rtol=RTOL, atol=identity_atol(metric, q, x))
+            assert_close(metric, out, ref, q, x)
     out = store.distances(q, nat.EUCLIDEAN_DIRECT)[0]
     np.testing.assert_array_equal(out.astype(np.float64), g[f"d{d}_scalar_euclidean"])
     store.close()

@@ -46,6 +46,8 @@ SIGNATURES = {
     "vdb_last_error": (C.c_char_p, []),
     "vdb_device_info": (C.c_int, [C.c_char_p, C.c_int, c_i64_p, c_i64_p]),
     "vdb_synchronize": (C.c_int, []),
+    "vdb_profile_enable": (C.c_int, [C.c_int]),
+    "vdb_profile_read": (C.c_int, [c_float_p, C.POINTER(C.c_int)]),
     "vdb_rows_create": (C.c_int, [C.POINTER(C.c_void_p), C.c_int]),
     "vdb_rows_destroy": (C.c_int, [C.c_void_p]),
     "vdb_rows_append": (C.c_int, [C.c_void_p, c_float_p, C.c_int64]),
@@ -157,6 +159,21 @@ def device_info() -> dict:
     total, free = C.c_int64(0), C.c_int64(0)
     check(load().vdb_device_info(name, 256, C.byref(total), C.byref(free)))
     return {"name": name.value.decode(), "memory_total": total.value, "memory_free": free.value}
+
+
+def synchronize() -> None:
+    check(load().vdb_synchronize())
+
+
+def profile_enable(on: bool) -> None:
+    check(load().vdb_profile_enable(1 if on else 0))
+
+
+def profile_read():
+    """(summed dominant-kernel milliseconds, launches) since the last read."""
+    ms, n = C.c_float(0.0), C.c_int(0)
+    check(load().vdb_profile_read(C.byref(ms), C.byref(n)))
+    return ms.value, n.value
 
 
 # ---------------------------------------------------------------- numpy helpers

@@ -32,6 +32,26 @@ int ensure_init() {
     return vdb_init(0);
 }
 
+// ---- kernel timing ---------------------------------------------------------
+static bool g_profile = false;
+static std::mutex g_prof_mu;
+static std::vector<std::pair<hipEvent_t, hipEvent_t>> g_prof_events;
+
+KernelTimer::KernelTimer(hipStream_t stream, bool enabled) : s(stream) {
+    if (!g_profile || !enabled) return;
+    if (hipEventCreate(&start) != hipSuccess) { start = nullptr; return; }
+    (void)hipEventRecord(start, s);
+}
+
+KernelTimer::~KernelTimer() {
+    if (!start) return;
+    hipEvent_t stop = nullptr;
+    if (hipEventCreate(&stop) != hipSuccess) { (void)hipEventDestroy(start); return; }
+    (void)hipEventRecord(stop, s);
+    std::lock_guard<std::mutex> g(g_prof_mu);
+    g_prof_events.emplace_back(start, stop);
+}
+
 int DevBuf::reserve(size_t bytes) {
     if (bytes <= cap) return VDB_OK;
     if (p) { VDB_HIP(hipFree(p)); p = nullptr; cap = 0; }
@@ -360,6 +380,31 @@ int vdb_device_info(char* name, int name_len, int64_t* mem_total, int64_t* mem_f
     VDB_HIP(hipMemGetInfo(&fr, &tot));
     if (mem_total) *mem_total = (int64_t)tot;
     if (mem_free) *mem_free = (int64_t)fr;
+    return VDB_OK;
+}
+
+int vdb_profile_enable(int on) {
+    std::lock_guard<std::mutex> g(g_prof_mu);
+    g_profile = on != 0;
+    return VDB_OK;
+}
+
+int vdb_profile_read(float* kernel_ms, int* launches) {
+    std::lock_guard<std::mutex> g(g_prof_mu);
+    float total = 0.0f;
+    int n = 0;
+    for (auto& e : g_prof_events) {
+        float ms = 0.0f;
+        if (hipEventSynchronize(e.second) == hipSuccess && hipEventElapsedTime(&ms, e.first, e.second) == hipSuccess) {
+            total += ms;
+            ++n;
+        }
+        (void)hipEventDestroy(e.first);
+        (void)hipEventDestroy(e.second);
+    }
+    g_prof_events.clear();
+    if (kernel_ms) *kernel_ms = total;
+    if (launches) *launches = n;
     return VDB_OK;
 }
 

@@ -58,7 +58,7 @@ __device__ __forceinline__ float finish(float dot, float row_term, float q_term)
         // (|q|^2 + |c|^2) - 2*dot : 2*dot is exact, so one fma rounds like the
         // reference's separate multiply and subtract
         float sq = fmaxf(__fmaf_rn(-2.0f, dot, q_term + row_term), 0.0f);
-        return METRIC == VDB_EUCLIDEAN ? __fsqrt_rn(sq) : sq;
+        return METRIC == VDB_EUCLIDEAN ? sqrtf(sq) : sq;
     }
 }
 
@@ -252,6 +252,7 @@ static int launch_gemm(const Rows& r, int metric, GemmParams& p, hipStream_t s) 
     const int groups = (p.n_slabs + 7) / 8;
     const dim3 grid(groups * 8 * p.n_qtiles);
     const size_t lds = (size_t)(2 * TM * LW + TM) * sizeof(float) + (TOPK ? (size_t)p.k * NT * 8 : 0);
+    KernelTimer timer(s);
 #define VDB_LAUNCH_GEMM(M)                                                                     \
     case M: {                                                                                  \
         auto kern = flat_gemm_kernel<M, TOPK>;                                                 \

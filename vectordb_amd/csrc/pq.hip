@@ -69,26 +69,33 @@ __global__ __launch_bounds__(256) void pq_lut_kernel(const float* __restrict__ q
 }
 
 // ---------------------------------------------------------------- encode
-// block = 256 rows of one sub-space; codewords of that sub-space in LDS
+// block = 256 rows of one sub-space.  The sub-space's codewords and the rows'
+// sub-vectors are staged in LDS when they fit (CB_LDS / X_LDS), otherwise read
+// from global memory through the caches.
+template <bool CB_LDS, bool X_LDS>
 __global__ __launch_bounds__(256) void pq_encode_kernel(const float* __restrict__ x, int64_t n, int ldx,
                                                         const float* __restrict__ book, int m, int ksub, int dsub,
                                                         SumPlan plan, uint8_t* __restrict__ codes) {
     extern __shared__ __align__(16) float sm[];
-    float* cb = sm;                         // [ksub][dsub]
-    float* xs = sm + ksub * dsub;           // [256][dsub + 1]
+    float* cb_s = sm;                                       // [ksub][dsub]
+    float* xs = sm + (CB_LDS ? ksub * dsub : 0);            // [256][dsub + 1]
     const int sub = blockIdx.y;
     const int tid = threadIdx.x;
     const int64_t row0 = (int64_t)blockIdx.x * 256;
-    for (int i = tid; i < ksub * dsub; i += 256) cb[i] = book[(int64_t)sub * ksub * dsub + i];
-    for (int i = tid; i < 256 * dsub; i += 256) {
-        const int r = i / dsub, j = i - r * dsub;
-        const int64_t gr = min(row0 + r, n - 1);
-        xs[r * (dsub + 1) + j] = x[gr * ldx + sub * dsub + j];
-    }
+    const float* book_sub = book + (int64_t)sub * ksub * dsub;
+    if (CB_LDS)
+        for (int i = tid; i < ksub * dsub; i += 256) cb_s[i] = book_sub[i];
+    if (X_LDS)
+        for (int i = tid; i < 256 * dsub; i += 256) {
+            const int r = i / dsub, j = i - r * dsub;
+            const int64_t gr = min(row0 + r, n - 1);
+            xs[r * (dsub + 1) + j] = x[gr * ldx + sub * dsub + j];
+        }
     __syncthreads();
     const int64_t row = row0 + tid;
     if (row >= n) return;
-    const float* mine = xs + tid * (dsub + 1);
+    const float* cb = CB_LDS ? cb_s : book_sub;
+    const float* mine = X_LDS ? xs + tid * (dsub + 1) : x + row * ldx + sub * dsub;
     float best = INFINITY;
     int best_c = 0;
     for (int c = 0; c < ksub; ++c) {
@@ -162,7 +169,7 @@ __global__ __launch_bounds__(256) void pq_scan_kernel(PqScanParams p) {
             acc = T[src[0]];
             for (int j = 1; j < m; ++j) acc = acc + T[j * p.ksub + src[j]];
         }
-        const float d = __fsqrt_rn(acc);
+        const float d = sqrtf(acc);
         if (p.dist_out) p.dist_out[(int64_t)qi * p.n + row] = d;
         if (k == 0) continue;
         if (p.mask && !((p.mask[row >> 5] >> (row & 31)) & 1u)) continue;
@@ -188,12 +195,25 @@ int launch_pq_lut(const float* q, int ldq, int nq, const float* book, int m, int
 int launch_pq_encode(const float* x, int64_t n, int ldx, const float* book, int m, int ksub, int dsub,
                      const SumPlan& plan, uint8_t* codes, hipStream_t s) {
     if (n <= 0) return VDB_OK;
-    const size_t lds = ((size_t)ksub * dsub + 256 * (size_t)(dsub + 1)) * sizeof(float);
-    VDB_REQUIRE(lds <= 160 * 1024, "sub-space of %d dims x %d codewords needs %zu bytes of LDS", dsub, ksub, lds);
-    VDB_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(pq_encode_kernel),
-                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    hipLaunchKernelGGL(pq_encode_kernel, dim3((unsigned)((n + 255) / 256), m), dim3(256), lds, s,
-                       x, n, ldx, book, m, ksub, dsub, plan, codes);
+    const size_t cb_bytes = (size_t)ksub * dsub * sizeof(float);
+    const size_t x_bytes = 256 * (size_t)(dsub + 1) * sizeof(float);
+    const size_t budget = 96 * 1024;
+    const bool cb_lds = cb_bytes <= budget;
+    const bool x_lds = (cb_lds ? cb_bytes : 0) + x_bytes <= budget;
+    const size_t lds = (cb_lds ? cb_bytes : 0) + (x_lds ? x_bytes : 0);
+    const dim3 grid((unsigned)((n + 255) / 256), m);
+#define VDB_LAUNCH_ENC(C, X)                                                                   \
+    {                                                                                          \
+        auto kern = pq_encode_kernel<C, X>;                                                    \
+        VDB_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern),                       \
+                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));    \
+        hipLaunchKernelGGL(kern, grid, dim3(256), lds, s, x, n, ldx, book, m, ksub, dsub, plan, codes); \
+    }
+    if (cb_lds && x_lds) VDB_LAUNCH_ENC(true, true)
+    else if (cb_lds) VDB_LAUNCH_ENC(true, false)
+    else if (x_lds) VDB_LAUNCH_ENC(false, true)
+    else VDB_LAUNCH_ENC(false, false)
+#undef VDB_LAUNCH_ENC
     VDB_HIP(hipGetLastError());
     return VDB_OK;
 }
@@ -206,6 +226,7 @@ int launch_pq_scan(const uint8_t* codes, int64_t n, int m, int ksub, const float
     const size_t lds = (size_t)m * ksub * sizeof(float) + (size_t)k * LIST_NT * 8 + 12 * sizeof(int);
     VDB_REQUIRE(lds <= 160 * 1024, "%d sub-spaces x %d codewords with k=%d need %zu bytes of LDS", m, ksub, k, lds);
     const dim3 grid(splits, nq);
+    KernelTimer timer(s);
 #define VDB_LAUNCH_PQ(MM)                                                                      \
     {                                                                                          \
         auto kern = pq_scan_kernel<MM>;                                                        \

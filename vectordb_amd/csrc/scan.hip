@@ -196,17 +196,17 @@ __global__ __launch_bounds__(NT) void scan_kernel(ScanParams p) {
 
         if (p.metric == METRIC_SQNORM) {
             p.dist_out[pos] = sum;
-            p.nrm_out[pos] = __fsqrt_rn(sum);
+            p.nrm_out[pos] = sqrtf(sum);
             continue;
         }
 
         // ---- final distance value
         float d;
         switch (p.metric) {
-            case VDB_EUCLIDEAN_DIRECT: d = __fsqrt_rn(sum); break;
+            case VDB_EUCLIDEAN_DIRECT: d = sqrtf(sum); break;
             case VDB_EUCLIDEAN: case VDB_EUCLIDEAN_SQ: {
                 const float sq = fmaxf(__fmaf_rn(-2.0f, sum, q_sq + p.row_sq[pos]), 0.0f);
-                d = p.metric == VDB_EUCLIDEAN ? __fsqrt_rn(sq) : sq;
+                d = p.metric == VDB_EUCLIDEAN ? sqrtf(sq) : sq;
                 break;
             }
             case VDB_COSINE: {
@@ -259,6 +259,7 @@ static int launch_scan_params(ScanParams& p, int units, hipStream_t s) {
     const dim3 grid(units, p.splits);
     const size_t lds = scan_lds_bytes(p.ld, p.k);
     VDB_REQUIRE(lds <= 160 * 1024, "dimension %d with k=%d needs %zu bytes of LDS", p.dim, p.k, lds);
+    KernelTimer timer(p.metric == METRIC_SQNORM ? nullptr : s, p.metric != METRIC_SQNORM);
 #define VDB_LAUNCH_SCAN(O)                                                                     \
     case O: {                                                                                  \
         auto kern = scan_kernel<O>;                                                            \

@@ -52,6 +52,14 @@ struct Context {
 Context& ctx();
 int ensure_init();
 
+// HIP-event bracket around a dominant kernel launch (no-op unless profiling is on)
+struct KernelTimer {
+    hipStream_t s;
+    hipEvent_t start = nullptr;
+    explicit KernelTimer(hipStream_t stream, bool enabled = true);
+    ~KernelTimer();
+};
+
 // A grow-only device buffer (workspace).
 struct DevBuf {
     void* p = nullptr;
