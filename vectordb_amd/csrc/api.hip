@@ -139,9 +139,9 @@ static int fill_results(float* d, int64_t* i, int64_t total, hipStream_t s) {
 
 // ============================================================== workspaces
 struct Workspace {
-    DevBuf q_buf, q_sq, q_nrm, part_d, part_i, lb_d, lb_k, mask, out_d, out_i, dist, probes, probe_d, lut, stage;
+    DevBuf q_buf, q_sq, q_nrm, part_d, part_i, lb_d, lb_k, thr_d, thr_k, mask, out_d, out_i, dist, probes, probe_d, lut, stage;
     void release() {
-        DevBuf* all[] = {&q_buf, &q_sq, &q_nrm, &part_d, &part_i, &lb_d, &lb_k, &mask, &out_d, &out_i, &dist,
+        DevBuf* all[] = {&q_buf, &q_sq, &q_nrm, &part_d, &part_i, &lb_d, &lb_k, &thr_d, &thr_k, &mask, &out_d, &out_i, &dist,
                          &probes, &probe_d, &lut, &stage};
         for (DevBuf* b : all) b->release();
     }
@@ -231,21 +231,37 @@ static int flat_search_impl(vdb_rows* h, int metric, const float* d_q, int nq, i
     VDB_TRY(prepare_queries(ws, d_q, nq, r.dim, r.ld, r.plan, &q, s));
     const bool gemm = is_dot_metric(metric) && nq >= GEMM_MIN_NQ;
 
-    int n_cand = 0, splits = 1;
+    int n_cand = 0, splits = 1, sample_tiles = 0, sample_stride = 1, n_cand_sample = 0;
     if (gemm) {
         VDB_TRY(flat_gemm_num_cand(r.n, nq, k, &n_cand));
+        VDB_TRY(flat_gemm_sample_plan(r.n, &sample_tiles, &sample_stride));
+        if (sample_tiles > 0) VDB_TRY(flat_gemm_num_cand_tiles(sample_tiles, nq, &n_cand_sample));
     } else {
         const int64_t ntiles = (r.n + 255) / 256;
         splits = (int)std::max<int64_t>(1, std::min<int64_t>(ntiles, (8 * ctx().num_cus + nq - 1) / nq));
         n_cand = splits;
     }
     const int kmax = (int)std::min<int64_t>(KMAX_FUSED, k_eff);
-    VDB_TRY(ws.part_d.reserve((size_t)nq * n_cand * kmax * sizeof(float)));
-    VDB_TRY(ws.part_i.reserve((size_t)nq * n_cand * kmax * sizeof(int)));
+    const int cand_max = std::max(n_cand, n_cand_sample);
+    VDB_TRY(ws.part_d.reserve((size_t)nq * cand_max * kmax * sizeof(float)));
+    VDB_TRY(ws.part_i.reserve((size_t)nq * cand_max * kmax * sizeof(int)));
     const bool multi = k_eff > KMAX_FUSED;
     if (multi) {
         VDB_TRY(ws.lb_d.reserve((size_t)nq * sizeof(float)));
         VDB_TRY(ws.lb_k.reserve((size_t)nq * sizeof(int64_t)));
+    }
+    const float* thr_init = nullptr;
+    if (sample_tiles > 0) {
+        // k-th best distance over a strided sample of the rows: an upper bound of the
+        // k-th best over all rows, used as the initial filter threshold of the full pass
+        VDB_TRY(ws.thr_d.reserve((size_t)nq * sizeof(float)));
+        VDB_TRY(ws.thr_k.reserve((size_t)nq * sizeof(int64_t)));
+        VDB_TRY(launch_flat_gemm_topk(r, metric, q, ws.q_sq.as<float>(), ws.q_nrm.as<float>(), nq, kmax, d_mask,
+                                      nullptr, nullptr, nullptr, sample_tiles, sample_stride,
+                                      ws.part_d.as<float>(), ws.part_i.as<int>(), n_cand_sample, s));
+        SelectOut so{nullptr, nullptr, nullptr, kmax, 0, ws.thr_d.as<float>(), ws.thr_k.as<int64_t>()};
+        VDB_TRY(launch_select(ws.part_d.as<float>(), ws.part_i.as<int>(), nq, n_cand_sample, kmax, 1 << 30, nullptr, 0, so, s));
+        thr_init = ws.thr_d.as<float>();
     }
 
     for (int64_t done = 0; done < k_eff; done += KMAX_FUSED) {
@@ -254,7 +270,8 @@ static int flat_search_impl(vdb_rows* h, int metric, const float* d_q, int nq, i
         const int64_t* lb_k = (done > 0) ? ws.lb_k.as<int64_t>() : nullptr;
         if (gemm) {
             VDB_TRY(launch_flat_gemm_topk(r, metric, q, ws.q_sq.as<float>(), ws.q_nrm.as<float>(), nq, kk, d_mask,
-                                          lb_d, lb_k, ws.part_d.as<float>(), ws.part_i.as<int>(), n_cand, s));
+                                          lb_d, lb_k, done == 0 ? thr_init : nullptr, 0, 1,
+                                          ws.part_d.as<float>(), ws.part_i.as<int>(), n_cand, s));
         } else {
             ScanJob j{};
             j.data = r.data; j.ld = r.ld; j.dim = r.dim; j.row_sq = r.sq; j.row_nrm = r.nrm; j.plan = r.plan;

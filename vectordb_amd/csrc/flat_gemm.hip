@@ -13,6 +13,13 @@
 // sorted list of its k best (distance, row) in LDS and filters new values
 // against a threshold shared with the one other lane that owns the same query.
 //
+// The per-value work in the epilogue is a cheap conservative filter in the
+// dot-product domain (one or two VALU operations and a compare); the exact
+// distance (division, sqrt) and the list insertion run only for a 32x32
+// accumulator in which some value passed.  The filter threshold can be
+// warm-started from the k-th best distance of a strided sample of the rows
+// (any subset's k-th best bounds the k-th best of the whole set from above).
+//
 // Block = 256 threads = 4 waves; wave w owns queries [32w, 32w+32) of the
 // tile and all 128 database rows of the current tile (4 accumulators of
 // 32x32).  K is walked in steps of 32 staged through LDS (row stride 36
@@ -37,8 +44,11 @@ struct GemmParams {
     const float* q_sq; const float* q_nrm;
     const uint32_t* mask;
     const float* lb_d; const int64_t* lb_k;
+    const float* thr_init;          // optional per-query upper bound of the k-th best distance
     int k;
-    int n_tiles, n_slabs, tiles_per_slab, n_qtiles;
+    int n_tiles;                    // tiles visited by this launch
+    int tile_stride;                // visited tile t is database tile t * tile_stride
+    int n_slabs, tiles_per_slab, n_qtiles;
     float* part_d; int* part_i; int n_cand;
     float* dist_out;
 };
@@ -60,6 +70,51 @@ __device__ __forceinline__ float finish(float dot, float row_term, float q_term)
         float sq = fmaxf(__fmaf_rn(-2.0f, dot, q_term + row_term), 0.0f);
         return METRIC == VDB_EUCLIDEAN ? sqrtf(sq) : sq;
     }
+}
+
+// ---- conservative filter: never rejects a value whose exact distance is <= thr
+template <int METRIC>
+__device__ __forceinline__ float filter_bound(float thr, float q_term) {
+    if (METRIC == VDB_DOT) return -thr;                                     // pass: dot >= bound
+    if (METRIC == VDB_EUCLIDEAN_SQ) return thr;                             // pass: raw <= bound
+    if (METRIC == VDB_EUCLIDEAN) return thr * thr * 1.000001f;              // sqrt_rn(x) <= thr  =>  x <= thr^2 (1 + 2^-22)
+    // cosine, pass: dot >= bound * |c|.  1 - clip(dot/(|q||c|)) <= thr implies
+    // dot/(|q||c|) >= 1 - thr - 5e-7 after every rounding on both sides.
+    if (q_term == INFINITY) return (1.0f <= thr) ? -INFINITY : INFINITY;    // zero query: every distance is exactly 1
+    if (thr >= 2.0f) return -INFINITY;
+    return ((1.0f - thr) - 3e-6f) * q_term;
+}
+
+template <int METRIC>
+__device__ __forceinline__ bool filter_pass(float dot, float row_term, float q_term, float bound) {
+    if (METRIC == VDB_DOT) return dot >= bound;
+    if (METRIC == VDB_COSINE) return dot >= bound * row_term;
+    return __fmaf_rn(-2.0f, dot, q_term + row_term) <= bound;
+}
+
+// Exact distances and list insertion for one 32x32 accumulator of the calling
+// lane (16 rows of its query).  Out of line: it runs for a small fraction of
+// the accumulators once the lists have warmed up.
+template <int METRIC>
+__device__ __noinline__ float epilogue_slow(f32x16 acc, float4 t0, float4 t1, float4 t2, float4 t3, float q_term,
+                                            uint32_t bits, int row0, float lbd, int64_t lbk, float thr, float own_kth,
+                                            float* ld, int* li, int k) {
+    const float rts[16] = {t0.x, t0.y, t0.z, t0.w, t1.x, t1.y, t1.z, t1.w, t2.x, t2.y, t2.z, t2.w, t3.x, t3.y, t3.z, t3.w};
+#pragma unroll
+    for (int e = 0; e < 16; ++e) {
+        const int off = 8 * (e >> 2) + (e & 3);          // row offset inside the lane's share of the sub-tile
+        if (!((bits >> off) & 1u)) continue;
+        const float d = finish<METRIC>(acc[e], rts[e], q_term);
+        const int row = row0 + off;
+        if (d <= thr) {
+            const bool above = (d > lbd) || (d == lbd && (int64_t)row > lbk);   // exclusive bound of a follow-up pass
+            if (above && d < own_kth) {
+                own_kth = list_insert(ld, li, k, d, row);
+                thr = fminf(thr, own_kth);
+            }
+        }
+    }
+    return own_kth;
 }
 
 template <int METRIC, bool TOPK>
@@ -105,7 +160,9 @@ __global__ __launch_bounds__(NT, 2) void flat_gemm_kernel(GemmParams p) {
     float own_kth = INFINITY, thr = INFINITY;
     if (TOPK) {
         list_init(Ld, Li, p.k, tid);
+        if (p.thr_init) thr = p.thr_init[my_q_ld];
     }
+    float bound = filter_bound<METRIC>(thr, q_term);
 
     const int ksteps = (p.ld + TK - 1) / TK;
     const int srow = tid >> 3;          // staging: row within a 32-row pass
@@ -116,7 +173,7 @@ __global__ __launch_bounds__(NT, 2) void flat_gemm_kernel(GemmParams p) {
     auto issue_loads = [&](int tile, int ks) {
         const int kk = ks * TK + skc;
         const bool kin = kk < p.ld;
-        const int64_t rbase = (int64_t)tile * TM;
+        const int64_t rbase = (int64_t)tile * p.tile_stride * TM;
 #pragma unroll
         for (int ps = 0; ps < 4; ++ps) {
             const int r = ps * 32 + srow;
@@ -130,7 +187,7 @@ __global__ __launch_bounds__(NT, 2) void flat_gemm_kernel(GemmParams p) {
     if (tile0 < tile1) issue_loads(tile0, 0);
 
     for (int tile = tile0; tile < tile1; ++tile) {
-        const int64_t rbase = (int64_t)tile * TM;
+        const int64_t rbase = (int64_t)tile * p.tile_stride * TM;
         f32x16 acc[4];
 #pragma unroll
         for (int s = 0; s < 4; ++s)
@@ -156,65 +213,87 @@ __global__ __launch_bounds__(NT, 2) void flat_gemm_kernel(GemmParams p) {
             if (ks + 1 < ksteps) issue_loads(tile, ks + 1);
             else if (tile + 1 < tile1) issue_loads(tile + 1, 0);
 
+            // all fragment reads of this K step go out first; the MFMAs then start as
+            // soon as their own operands have landed while the rest are still in flight
             const float* bq = Bs + (wave * 32 + col) * LW + half * 4;
             const float* ar = As + col * LW + half * 4;
+            float4 bf[4], af[4][4];
 #pragma unroll
             for (int ch = 0; ch < 4; ++ch) {
-                const float4 b = *reinterpret_cast<const float4*>(bq + ch * 8);
-                float4 a[4];
+                bf[ch] = *reinterpret_cast<const float4*>(bq + ch * 8);
 #pragma unroll
-                for (int s = 0; s < 4; ++s) a[s] = *reinterpret_cast<const float4*>(ar + s * 32 * LW + ch * 8);
+                for (int s = 0; s < 4; ++s) af[ch][s] = *reinterpret_cast<const float4*>(ar + s * 32 * LW + ch * 8);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int ch = 0; ch < 4; ++ch) {
 #pragma unroll
                 for (int s = 0; s < 4; ++s) {
-                    acc[s] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[s].x, b.x, acc[s], 0, 0, 0);
-                    acc[s] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[s].y, b.y, acc[s], 0, 0, 0);
-                    acc[s] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[s].z, b.z, acc[s], 0, 0, 0);
-                    acc[s] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[s].w, b.w, acc[s], 0, 0, 0);
+                    acc[s] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[ch][s].x, bf[ch].x, acc[s], 0, 0, 0);
+                    acc[s] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[ch][s].y, bf[ch].y, acc[s], 0, 0, 0);
+                    acc[s] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[ch][s].z, bf[ch].z, acc[s], 0, 0, 0);
+                    acc[s] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[ch][s].w, bf[ch].w, acc[s], 0, 0, 0);
                 }
             }
         }
 
         // ---- epilogue: lane owns query `my_q`, rows rbase + 32s + 8g + 4*half + j
-        const bool tail = rbase + TM > p.n;
+        if (TOPK) {
+            const bool tail = rbase + TM > p.n;
+            const bool masked = tail || p.mask != nullptr;
 #pragma unroll
-        for (int s = 0; s < 4; ++s) {
-            uint32_t bits = 0xffffffffu;
-            if (TOPK) {
-                const int64_t r0 = rbase + s * 32;
-                if (p.mask) bits = (r0 < p.n) ? p.mask[r0 >> 5] : 0u;
-                if (tail) {
+            for (int s = 0; s < 4; ++s) {
+                uint32_t bits = 0xffffffffu;
+                if (masked) {
+                    const int64_t r0 = rbase + s * 32;
+                    if (p.mask) bits = (r0 < p.n) ? p.mask[r0 >> 5] : 0u;
                     const int64_t left = p.n - r0;
-                    bits = left <= 0 ? 0u : (left >= 32 ? bits : (bits & ((1u << left) - 1u)));
+                    if (left < 32) bits = left <= 0 ? 0u : (bits & ((1u << left) - 1u));
+                    bits >>= (4 * half);
                 }
-                bits >>= (4 * half);
-            }
+                float4 t[4];
 #pragma unroll
-            for (int g = 0; g < 4; ++g) {
-                float4 rt = make_float4(0, 0, 0, 0);
-                if (METRIC != VDB_DOT) rt = *reinterpret_cast<const float4*>(Rs + s * 32 + 8 * g + 4 * half);
-                const float rts[4] = {rt.x, rt.y, rt.z, rt.w};
+                for (int g = 0; g < 4; ++g) {
+                    t[g] = make_float4(0, 0, 0, 0);
+                    if (METRIC != VDB_DOT) t[g] = *reinterpret_cast<const float4*>(Rs + s * 32 + 8 * g + 4 * half);
+                }
+                bool any = false;
 #pragma unroll
-                for (int j = 0; j < 4; ++j) {
-                    const float d = finish<METRIC>(acc[s][g * 4 + j], rts[j], q_term);
-                    const int row = (int)(rbase + s * 32 + 8 * g + 4 * half + j);
-                    if (TOPK) {
-                        if (d <= thr && ((bits >> (8 * g + j)) & 1u)) {
-                            // exclusive lower bound of a multi-pass search
-                            const bool above = (d > lbd) || (d == lbd && (int64_t)row > lbk);
-                            if (above && d < own_kth) {
-                                own_kth = list_insert(Ld + tid, Li + tid, p.k, d, row);
-                                thr = fminf(thr, own_kth);
-                            }
-                        }
-                    } else {
-                        if (q_ok && row < p.n) p.dist_out[(int64_t)my_q * p.n + row] = d;
+                for (int g = 0; g < 4; ++g) {
+                    const float rts[4] = {t[g].x, t[g].y, t[g].z, t[g].w};
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) {
+                        bool pass = filter_pass<METRIC>(acc[s][g * 4 + j], rts[j], q_term, bound);
+                        if (masked) pass = pass && ((bits >> (8 * g + j)) & 1u);
+                        any = any || pass;
                     }
                 }
+                if (any) {
+                    own_kth = epilogue_slow<METRIC>(acc[s], t[0], t[1], t[2], t[3], q_term, bits,
+                                                    (int)(rbase + s * 32 + 4 * half), lbd, lbk, thr, own_kth,
+                                                    Ld + tid, Li + tid, p.k);
+                    thr = fminf(thr, own_kth);
+                    bound = filter_bound<METRIC>(thr, q_term);
+                }
             }
-        }
-        if (TOPK) {
             // the other half-wave lane with the same query may hold a tighter bound
-            thr = fminf(own_kth, __shfl_xor(own_kth, 32));
+            const float shared = fminf(thr, __shfl_xor(thr, 32));
+            if (shared < thr) { thr = shared; bound = filter_bound<METRIC>(thr, q_term); }
+        } else {
+#pragma unroll
+            for (int s = 0; s < 4; ++s)
+#pragma unroll
+                for (int g = 0; g < 4; ++g) {
+                    float4 rt = make_float4(0, 0, 0, 0);
+                    if (METRIC != VDB_DOT) rt = *reinterpret_cast<const float4*>(Rs + s * 32 + 8 * g + 4 * half);
+                    const float rts[4] = {rt.x, rt.y, rt.z, rt.w};
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) {
+                        const int64_t row = rbase + s * 32 + 8 * g + 4 * half + j;
+                        if (q_ok && row < p.n)
+                            p.dist_out[(int64_t)my_q * p.n + row] = finish<METRIC>(acc[s][g * 4 + j], rts[j], q_term);
+                    }
+                }
         }
     }
 
@@ -226,33 +305,46 @@ __global__ __launch_bounds__(NT, 2) void flat_gemm_kernel(GemmParams p) {
 }
 
 // --------------------------------------------------------------------------
-static void plan_grid(int64_t n, int nq, int num_cus, int* n_tiles, int* n_qtiles, int* n_slabs, int* tiles_per_slab) {
-    *n_tiles = (int)((n + TM - 1) / TM);
+static void plan_grid(int n_tiles, int nq, int num_cus, int* n_qtiles, int* n_slabs, int* tiles_per_slab) {
     *n_qtiles = (nq + TQ - 1) / TQ;
     int want = (2 * num_cus + *n_qtiles - 1) / *n_qtiles;      // ~2 blocks per CU in total
     if (want < 1) want = 1;
-    if (want > *n_tiles) want = *n_tiles;
-    *tiles_per_slab = (*n_tiles + want - 1) / want;
-    *n_slabs = (*n_tiles + *tiles_per_slab - 1) / *tiles_per_slab;
+    if (want > n_tiles) want = n_tiles;
+    *tiles_per_slab = (n_tiles + want - 1) / want;
+    *n_slabs = (n_tiles + *tiles_per_slab - 1) / *tiles_per_slab;
 }
 
 int flat_gemm_num_cand(int64_t n, int nq, int k, int* n_cand) {
-    int nt, nqt, ns, tps;
-    plan_grid(n, nq, ctx().num_cus, &nt, &nqt, &ns, &tps);
+    int nqt, ns, tps;
+    plan_grid((int)((n + TM - 1) / TM), nq, ctx().num_cus, &nqt, &ns, &tps);
     *n_cand = ns * 2;
     return VDB_OK;
 }
 
+int flat_gemm_num_cand_tiles(int n_tiles, int nq, int* n_cand) {
+    int nqt, ns, tps;
+    plan_grid(n_tiles, nq, ctx().num_cus, &nqt, &ns, &tps);
+    *n_cand = ns * 2;
+    return VDB_OK;
+}
+
+int flat_gemm_sample_plan(int64_t n, int* sample_tiles, int* tile_stride) {
+    // a strided sample of ~1/64 of the tiles (at least 128 of them) once the set is large
+    const int n_tiles = (int)((n + TM - 1) / TM);
+    if (n_tiles < 2048) { *sample_tiles = 0; *tile_stride = 1; return VDB_OK; }
+    int want = std::max(128, n_tiles / 64);
+    *tile_stride = n_tiles / want;
+    *sample_tiles = want;
+    return VDB_OK;
+}
+
 template <bool TOPK>
-static int launch_gemm(const Rows& r, int metric, GemmParams& p, hipStream_t s) {
-    plan_grid(p.n, p.nq, ctx().num_cus, &p.n_tiles, &p.n_qtiles, &p.n_slabs, &p.tiles_per_slab);
-    if (!TOPK) {
-        // distance output: one slab per tile row block keeps the grid large
-    }
+static int launch_gemm(int metric, GemmParams& p, hipStream_t s) {
+    plan_grid(p.n_tiles, p.nq, ctx().num_cus, &p.n_qtiles, &p.n_slabs, &p.tiles_per_slab);
     const int groups = (p.n_slabs + 7) / 8;
     const dim3 grid(groups * 8 * p.n_qtiles);
     const size_t lds = (size_t)(2 * TM * LW + TM) * sizeof(float) + (TOPK ? (size_t)p.k * NT * 8 : 0);
-    KernelTimer timer(s);
+    KernelTimer timer(s, p.tile_stride == 1);
 #define VDB_LAUNCH_GEMM(M)                                                                     \
     case M: {                                                                                  \
         auto kern = flat_gemm_kernel<M, TOPK>;                                                 \
@@ -277,15 +369,18 @@ static int launch_gemm(const Rows& r, int metric, GemmParams& p, hipStream_t s) 
 
 int launch_flat_gemm_topk(const Rows& r, int metric, const float* q, const float* q_sq, const float* q_nrm,
                           int nq, int k, const uint32_t* mask, const float* lb_d, const int64_t* lb_k,
+                          const float* thr_init, int sample_tiles, int tile_stride,
                           float* part_d, int* part_i, int n_cand, hipStream_t s) {
     VDB_REQUIRE(k >= 1 && k <= KMAX_FUSED, "fused selection supports 1 <= k <= %d, got %d", KMAX_FUSED, k);
     VDB_REQUIRE(r.n >= 1 && nq >= 1, "empty search");
     GemmParams p{};
     p.rows = r.data; p.n = r.n; p.ld = r.ld; p.row_sq = r.sq; p.row_nrm = r.nrm;
     p.q = q; p.nq = nq; p.q_sq = q_sq; p.q_nrm = q_nrm;
-    p.mask = mask; p.lb_d = lb_d; p.lb_k = lb_k; p.k = k;
+    p.mask = mask; p.lb_d = lb_d; p.lb_k = lb_k; p.thr_init = thr_init; p.k = k;
+    p.n_tiles = sample_tiles > 0 ? sample_tiles : (int)((r.n + TM - 1) / TM);
+    p.tile_stride = sample_tiles > 0 ? tile_stride : 1;
     p.part_d = part_d; p.part_i = part_i; p.n_cand = n_cand; p.dist_out = nullptr;
-    return launch_gemm<true>(r, metric, p, s);
+    return launch_gemm<true>(metric, p, s);
 }
 
 int launch_flat_gemm_dist(const Rows& r, int metric, const float* q, const float* q_sq, const float* q_nrm,
@@ -295,7 +390,9 @@ int launch_flat_gemm_dist(const Rows& r, int metric, const float* q, const float
     p.rows = r.data; p.n = r.n; p.ld = r.ld; p.row_sq = r.sq; p.row_nrm = r.nrm;
     p.q = q; p.nq = nq; p.q_sq = q_sq; p.q_nrm = q_nrm;
     p.k = 0; p.dist_out = out;
-    return launch_gemm<false>(r, metric, p, s);
+    p.n_tiles = (int)((r.n + TM - 1) / TM);
+    p.tile_stride = 1;
+    return launch_gemm<false>(metric, p, s);
 }
 
 }  // namespace vdb

@@ -115,8 +115,13 @@ int launch_pad_rows(const float* src, int64_t src_ld, int dim, int64_t n, float*
 // MFMA path: fused distance + per-slab top-k for the four dot-product metrics.
 // part_* hold n_cand candidate lists of k per query: layout [nq][n_cand][k].
 int flat_gemm_num_cand(int64_t n, int nq, int k, int* n_cand);
+int flat_gemm_num_cand_tiles(int n_tiles, int nq, int* n_cand);
+// strided row sample used to warm-start the selection threshold: number of
+// 128-row tiles to visit (0 = not worth it) and the stride between them
+int flat_gemm_sample_plan(int64_t n, int* sample_tiles, int* tile_stride);
 int launch_flat_gemm_topk(const Rows& r, int metric, const float* q, const float* q_sq, const float* q_nrm,
                           int nq, int k, const uint32_t* mask, const float* lb_d, const int64_t* lb_k,
+                          const float* thr_init, int sample_tiles, int tile_stride,
                           float* part_d, int* part_i, int n_cand, hipStream_t s);
 // MFMA path, full distance matrix out[nq][n]
 int launch_flat_gemm_dist(const Rows& r, int metric, const float* q, const float* q_sq, const float* q_nrm,
