@@ -15,8 +15,8 @@
 //
 // The per-value work in the epilogue is a cheap conservative filter in the
 // dot-product domain (one or two VALU operations and a compare); the exact
-// distance (division, sqrt) and the list insertion run only for a 32x32
-// accumulator in which some value passed.  The filter threshold can be
+// distance (division, sqrt) and the list insertion run only for the values
+// that passed.  The filter threshold can be
 // warm-started from the k-th best distance of a strided sample of the rows
 // (any subset's k-th best bounds the k-th best of the whole set from above).
 //
@@ -51,6 +51,7 @@ struct GemmParams {
     int n_slabs, tiles_per_slab, n_qtiles;
     float* part_d; int* part_i; int n_cand;
     float* dist_out;
+    int diag;                       // timing experiments only (VDB_DIAG): 1 = no epilogue, 2 = no exact/insert stage, 4 = no row terms
 };
 
 // ---- final distance value from the dot product, per metric ---------------
@@ -92,29 +93,14 @@ __device__ __forceinline__ bool filter_pass(float dot, float row_term, float q_t
     return __fmaf_rn(-2.0f, dot, q_term + row_term) <= bound;
 }
 
-// Exact distances and list insertion for one 32x32 accumulator of the calling
-// lane (16 rows of its query).  Out of line: it runs for a small fraction of
-// the accumulators once the lists have warmed up.
-template <int METRIC>
-__device__ __noinline__ float epilogue_slow(f32x16 acc, float4 t0, float4 t1, float4 t2, float4 t3, float q_term,
-                                            uint32_t bits, int row0, float lbd, int64_t lbk, float thr, float own_kth,
-                                            float* ld, int* li, int k) {
-    const float rts[16] = {t0.x, t0.y, t0.z, t0.w, t1.x, t1.y, t1.z, t1.w, t2.x, t2.y, t2.z, t2.w, t3.x, t3.y, t3.z, t3.w};
-#pragma unroll
-    for (int e = 0; e < 16; ++e) {
-        const int off = 8 * (e >> 2) + (e & 3);          // row offset inside the lane's share of the sub-tile
-        if (!((bits >> off) & 1u)) continue;
-        const float d = finish<METRIC>(acc[e], rts[e], q_term);
-        const int row = row0 + off;
-        if (d <= thr) {
-            const bool above = (d > lbd) || (d == lbd && (int64_t)row > lbk);   // exclusive bound of a follow-up pass
-            if (above && d < own_kth) {
-                own_kth = list_insert(ld, li, k, d, row);
-                thr = fminf(thr, own_kth);
-            }
-        }
-    }
-    return own_kth;
+// element e (lane-varying) of a 16-register accumulator: binary tree of selects
+__device__ __forceinline__ float pick16(const f32x16& a, int e) {
+    const bool b0 = e & 1, b1 = e & 2, b2 = e & 4, b3 = e & 8;
+    const float p0 = b0 ? a[1] : a[0], p1 = b0 ? a[3] : a[2], p2 = b0 ? a[5] : a[4], p3 = b0 ? a[7] : a[6];
+    const float p4 = b0 ? a[9] : a[8], p5 = b0 ? a[11] : a[10], p6 = b0 ? a[13] : a[12], p7 = b0 ? a[15] : a[14];
+    const float q0 = b1 ? p1 : p0, q1 = b1 ? p3 : p2, q2 = b1 ? p5 : p4, q3 = b1 ? p7 : p6;
+    const float r0 = b2 ? q1 : q0, r1 = b2 ? q3 : q2;
+    return b3 ? r1 : r0;
 }
 
 template <int METRIC, bool TOPK>
@@ -202,7 +188,7 @@ __global__ __launch_bounds__(NT, 2) void flat_gemm_kernel(GemmParams p) {
                 *reinterpret_cast<float4*>(As + r * LW + skc) = ra[ps];
                 *reinterpret_cast<float4*>(Bs + r * LW + skc) = rb[ps];
             }
-            if (ks == 0 && METRIC != VDB_DOT && tid < TM) {
+            if (ks == 0 && METRIC != VDB_DOT && tid < TM && !(p.diag & 4)) {
                 const int64_t gr = min(rbase + tid, p.n - 1);
                 float t = (METRIC == VDB_COSINE) ? p.row_nrm[gr] : p.row_sq[gr];
                 if (METRIC == VDB_COSINE && t < 1e-8f) t = 1.0f;    // metrics.py:476
@@ -238,7 +224,10 @@ __global__ __launch_bounds__(NT, 2) void flat_gemm_kernel(GemmParams p) {
         }
 
         // ---- epilogue: lane owns query `my_q`, rows rbase + 32s + 8g + 4*half + j
-        if (TOPK) {
+        if (TOPK && (p.diag & 1)) {
+#pragma unroll
+            for (int s = 0; s < 4; ++s) asm volatile("" ::"v"(acc[s]));
+        } else if (TOPK) {
             const bool tail = rbase + TM > p.n;
             const bool masked = tail || p.mask != nullptr;
 #pragma unroll
@@ -257,7 +246,8 @@ __global__ __launch_bounds__(NT, 2) void flat_gemm_kernel(GemmParams p) {
                     t[g] = make_float4(0, 0, 0, 0);
                     if (METRIC != VDB_DOT) t[g] = *reinterpret_cast<const float4*>(Rs + s * 32 + 8 * g + 4 * half);
                 }
-                bool any = false;
+                // cheap filter over the 16 values of this accumulator -> per-lane bit set
+                uint32_t hits = 0;
 #pragma unroll
                 for (int g = 0; g < 4; ++g) {
                     const float rts[4] = {t[g].x, t[g].y, t[g].z, t[g].w};
@@ -265,14 +255,37 @@ __global__ __launch_bounds__(NT, 2) void flat_gemm_kernel(GemmParams p) {
                     for (int j = 0; j < 4; ++j) {
                         bool pass = filter_pass<METRIC>(acc[s][g * 4 + j], rts[j], q_term, bound);
                         if (masked) pass = pass && ((bits >> (8 * g + j)) & 1u);
-                        any = any || pass;
+                        hits |= pass ? (1u << (g * 4 + j)) : 0u;
                     }
                 }
-                if (any) {
-                    own_kth = epilogue_slow<METRIC>(acc[s], t[0], t[1], t[2], t[3], q_term, bits,
-                                                    (int)(rbase + s * 32 + 4 * half), lbd, lbk, thr, own_kth,
-                                                    Ld + tid, Li + tid, p.k);
-                    thr = fminf(thr, own_kth);
+                // exact distance and insertion, only for the values that passed
+                if (hits && !(p.diag & 2)) {
+                    float* ld = Ld + tid;
+                    int* li = Li + tid;
+                    do {
+                        const int e = __ffs(hits) - 1;
+                        hits &= hits - 1;
+                        const int off = 8 * (e >> 2) + (e & 3) + 4 * half;     // row inside the 32-row sub-tile
+                        const float rt = (METRIC != VDB_DOT) ? Rs[s * 32 + off] : 0.0f;
+                        const float d = finish<METRIC>(pick16(acc[s], e), rt, q_term);
+                        const int row = (int)(rbase + s * 32 + off);
+                        const bool above = (d > lbd) || (d == lbd && (int64_t)row > lbk);   // exclusive bound of a follow-up pass
+                        if (d <= thr && above && d < own_kth) {
+                            // rows reach a lane in ascending order: an equal distance stays behind
+                            int pos = p.k - 1;
+                            while (pos > 0) {
+                                const float prev = ld[(pos - 1) * NT];
+                                if (!(prev > d)) break;
+                                ld[pos * NT] = prev;
+                                li[pos * NT] = li[(pos - 1) * NT];
+                                --pos;
+                            }
+                            ld[pos * NT] = d;
+                            li[pos * NT] = row;
+                            own_kth = ld[(p.k - 1) * NT];
+                            thr = fminf(thr, own_kth);
+                        }
+                    } while (hits);
                     bound = filter_bound<METRIC>(thr, q_term);
                 }
             }
@@ -343,6 +356,8 @@ static int launch_gemm(int metric, GemmParams& p, hipStream_t s) {
     plan_grid(p.n_tiles, p.nq, ctx().num_cus, &p.n_qtiles, &p.n_slabs, &p.tiles_per_slab);
     const int groups = (p.n_slabs + 7) / 8;
     const dim3 grid(groups * 8 * p.n_qtiles);
+    static const int diag = getenv("VDB_DIAG") ? atoi(getenv("VDB_DIAG")) : 0;
+    p.diag = diag;
     const size_t lds = (size_t)(2 * TM * LW + TM) * sizeof(float) + (TOPK ? (size_t)p.k * NT * 8 : 0);
     KernelTimer timer(s, p.tile_stride == 1);
 #define VDB_LAUNCH_GEMM(M)                                                                     \
