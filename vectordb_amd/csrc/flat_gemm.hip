@@ -51,7 +51,8 @@ struct GemmParams {
     int n_slabs, tiles_per_slab, n_qtiles;
     float* part_d; int* part_i; int n_cand;
     float* dist_out;
-    int diag;                       // timing experiments only (VDB_DIAG): 1 = no epilogue, 2 = no exact/insert stage, 4 = no row terms
+    int diag;                       // timing experiments only (env VDB_DIAG, results are wrong when set): 1 no epilogue,
+                                    // 2 no exact/insert stage, 4 no row terms, 8 no staging loads, 16 no LDS staging, 32 one block per CU
 };
 
 // ---- final distance value from the dot product, per metric ---------------
@@ -155,18 +156,41 @@ __global__ __launch_bounds__(NT, 2) void flat_gemm_kernel(GemmParams p) {
     const int skc = (tid & 7) * 4;      // staging: float offset inside the K step
     const int64_t q_base = (int64_t)qt * TQ;
 
+    // staging addresses: a wave-uniform base (tile, K step) plus a 32-bit per-thread
+    // offset (row inside the tile, float4 inside the K step), so a K step costs
+    // eight loads and no per-thread address arithmetic
+    const bool k_tail = (p.ld % TK) != 0;
+    uint32_t offb[4], offa[4];
+#pragma unroll
+    for (int ps = 0; ps < 4; ++ps) {
+        const int64_t gq = min(q_base + ps * 32 + srow, (int64_t)p.nq - 1) - q_base;
+        offb[ps] = (uint32_t)(gq * p.ld + skc);
+        offa[ps] = (uint32_t)((ps * 32 + srow) * p.ld + skc);
+    }
+    const float* qbase_ptr = p.q + q_base * p.ld;
     float4 ra[4], rb[4];
     auto issue_loads = [&](int tile, int ks) {
-        const int kk = ks * TK + skc;
-        const bool kin = kk < p.ld;
         const int64_t rbase = (int64_t)tile * p.tile_stride * TM;
+        const float* abase = p.rows + rbase * p.ld + ks * TK;
+        const float* bbase = qbase_ptr + ks * TK;
+        if (rbase + TM > p.n) {             // last tile: rows past the end re-read the last row (masked out later)
 #pragma unroll
-        for (int ps = 0; ps < 4; ++ps) {
-            const int r = ps * 32 + srow;
-            const int64_t gr = min(rbase + r, p.n - 1);
-            const int64_t gq = min(q_base + r, (int64_t)p.nq - 1);
-            ra[ps] = kin ? *reinterpret_cast<const float4*>(p.rows + gr * p.ld + kk) : make_float4(0, 0, 0, 0);
-            rb[ps] = kin ? *reinterpret_cast<const float4*>(p.q + gq * p.ld + kk) : make_float4(0, 0, 0, 0);
+            for (int ps = 0; ps < 4; ++ps)
+                offa[ps] = (uint32_t)(min((int64_t)(ps * 32 + srow), p.n - 1 - rbase) * p.ld + skc);
+        }
+        if (k_tail && ks == ksteps - 1) {
+            const bool kin = ks * TK + skc < p.ld;
+#pragma unroll
+            for (int ps = 0; ps < 4; ++ps) {
+                ra[ps] = kin ? *reinterpret_cast<const float4*>(abase + offa[ps]) : make_float4(0, 0, 0, 0);
+                rb[ps] = kin ? *reinterpret_cast<const float4*>(bbase + offb[ps]) : make_float4(0, 0, 0, 0);
+            }
+        } else {
+#pragma unroll
+            for (int ps = 0; ps < 4; ++ps) {
+                ra[ps] = *reinterpret_cast<const float4*>(abase + offa[ps]);
+                rb[ps] = *reinterpret_cast<const float4*>(bbase + offb[ps]);
+            }
         }
     };
 
@@ -181,12 +205,14 @@ __global__ __launch_bounds__(NT, 2) void flat_gemm_kernel(GemmParams p) {
             for (int e = 0; e < 16; ++e) acc[s][e] = 0.0f;
 
         for (int ks = 0; ks < ksteps; ++ks) {
-            __syncthreads();            // everyone is done reading the previous step (and Rs)
+            if (!(p.diag & 16)) __syncthreads();            // everyone is done reading the previous step (and Rs)
+            if (!(p.diag & 16)) {
 #pragma unroll
             for (int ps = 0; ps < 4; ++ps) {
                 const int r = ps * 32 + srow;
                 *reinterpret_cast<float4*>(As + r * LW + skc) = ra[ps];
                 *reinterpret_cast<float4*>(Bs + r * LW + skc) = rb[ps];
+            }
             }
             if (ks == 0 && METRIC != VDB_DOT && tid < TM && !(p.diag & 4)) {
                 const int64_t gr = min(rbase + tid, p.n - 1);
@@ -194,10 +220,12 @@ __global__ __launch_bounds__(NT, 2) void flat_gemm_kernel(GemmParams p) {
                 if (METRIC == VDB_COSINE && t < 1e-8f) t = 1.0f;    // metrics.py:476
                 Rs[tid] = t;
             }
-            __syncthreads();
+            if (!(p.diag & 16)) __syncthreads();
             // prefetch the next step (possibly of the next tile) while computing
-            if (ks + 1 < ksteps) issue_loads(tile, ks + 1);
-            else if (tile + 1 < tile1) issue_loads(tile + 1, 0);
+            if (!(p.diag & 8)) {
+                if (ks + 1 < ksteps) issue_loads(tile, ks + 1);
+                else if (tile + 1 < tile1) issue_loads(tile + 1, 0);
+            }
 
             // all fragment reads of this K step go out first; the MFMAs then start as
             // soon as their own operands have landed while the rest are still in flight
@@ -358,7 +386,8 @@ static int launch_gemm(int metric, GemmParams& p, hipStream_t s) {
     const dim3 grid(groups * 8 * p.n_qtiles);
     static const int diag = getenv("VDB_DIAG") ? atoi(getenv("VDB_DIAG")) : 0;
     p.diag = diag;
-    const size_t lds = (size_t)(2 * TM * LW + TM) * sizeof(float) + (TOPK ? (size_t)p.k * NT * 8 : 0);
+    size_t lds = (size_t)(2 * TM * LW + TM) * sizeof(float) + (TOPK ? (size_t)p.k * NT * 8 : 0);
+    if (diag & 32) lds = 100 * 1024;       // one block per CU
     KernelTimer timer(s, p.tile_stride == 1);
 #define VDB_LAUNCH_GEMM(M)                                                                     \
     case M: {                                                                                  \
