@@ -1,0 +1,278 @@
+"""``Collection.search(query, k, filter)`` -- entry point (A) of the reference's
+hot path (core/collection.py:693-807) -- on the MI355X search core.
+
+Only what the search path needs is here: records with ids and metadata, the
+lazily rebuilt dense matrix (core/collection.py:809-828) mirrored in HBM, the
+metadata filter turned into a row bitmask, and the reference's result and
+score conventions.  CRUD bookkeeping beyond that, persistence and the query
+engine stay with the reference.
+"""
+
+from __future__ import annotations
+
+import time
+import uuid
+from dataclasses import dataclass, field
+from typing import Any, Dict, List, Optional, Union
+
+import numpy as np
+
+from .. import _native as N
+from ..distance.metrics import _QUERY_METRICS
+
+
+class VectorExistsError(Exception):
+    """core/exceptions.py: a vector with the given id already exists."""
+
+
+@dataclass
+class SearchResult:                                        # core/collection.py:103-123
+    id: str
+    distance: float
+    score: float
+    vector: Optional[np.ndarray] = None
+    metadata: Dict[str, Any] = field(default_factory=dict)
+
+    def to_dict(self, include_vector: bool = False) -> Dict[str, Any]:
+        out = {"id": self.id, "distance": self.distance, "score": self.score, "metadata": self.metadata}
+        if include_vector and self.vector is not None:
+            out["vector"] = self.vector.tolist()
+        return out
+
+
+def _validate_vector(vector, expected_dimension: int) -> np.ndarray:
+    """core/vector.py:364-414"""
+    if not isinstance(vector, np.ndarray):
+        vector = np.array(vector, dtype=np.float32)
+    if vector.dtype != np.float32:
+        vector = vector.astype(np.float32)
+    if vector.ndim != 1:
+        raise ValueError(f"Vector must be 1D, got {vector.ndim}D")
+    if len(vector) == 0:
+        raise ValueError("Vector cannot be empty")
+    if len(vector) != expected_dimension:
+        raise ValueError(f"Vector dimension {len(vector)} doesn't match expected {expected_dimension}")
+    if not np.isfinite(vector).all():
+        raise ValueError("Vector contains NaN or Inf values")
+    return vector
+
+
+def _normalize_vector(vector: np.ndarray, eps: float = 1e-12) -> np.ndarray:
+    """utils/normalization.py:9-33"""
+    vector = vector.copy()
+    norm = np.linalg.norm(vector)
+    if norm < eps:
+        return vector
+    vector /= norm
+    return vector
+
+
+class MetadataFilter:
+    """Row predicate with the semantics of MetadataIndex.query
+    (core/collection.py:183-282): AND over fields; a plain value (or list of
+    values) means equality with any of them; operator dicts support $in, $nin,
+    $exists, $gt, $gte, $lt, $lte, $ne, and the LAST operator of a dict decides
+    (each branch there overwrites or extends one shared set); a record's list
+    value matches through any of its elements; records lacking the field never
+    match."""
+
+    def __init__(self, filters: Dict[str, Any]):
+        self.filters = filters
+
+    @staticmethod
+    def _values(v):
+        return v if isinstance(v, list) else [v]
+
+    @staticmethod
+    def _cmp(a, op, b) -> bool:
+        try:
+            if op == "$gt":
+                return a > b
+            if op == "$gte":
+                return a >= b
+            if op == "$lt":
+                return a < b
+            if op == "$lte":
+                return a <= b
+            if op == "$ne":
+                return a != b
+        except TypeError:
+            return False
+        return False
+
+    def _field_matches(self, have, cond) -> bool:
+        vals = [tuple(v) if isinstance(v, list) else v for v in self._values(have)]
+        if not isinstance(cond, dict):
+            wanted = [tuple(v) if isinstance(v, list) else v for v in self._values(cond)]
+            return any(v in wanted for v in vals)
+        matched = False
+        for op, arg in cond.items():
+            if op == "$in":
+                matched = matched or any(v in list(arg) for v in vals)
+            elif op == "$nin":
+                matched = not any(v in list(arg) for v in vals)
+            elif op == "$exists":
+                matched = matched or bool(arg)
+            elif op in ("$gt", "$gte", "$lt", "$lte", "$ne"):
+                matched = matched or any(self._cmp(v, op, arg) for v in vals)
+        return matched
+
+    def __call__(self, metadata: Dict[str, Any]) -> bool:
+        if not self.filters:
+            return False
+        for key, cond in self.filters.items():
+            if key not in metadata:
+                return False
+            if not self._field_matches(metadata[key], cond):
+                return False
+        return True
+
+
+class Collection:
+    """core/collection.py:302-828 (search path)."""
+
+    def __init__(self, name: str, dimension: int, metric: str = "euclidean", normalize: bool = False,
+                 max_vectors: Optional[int] = None, enable_metadata_index: bool = True):
+        self.name = name
+        self.dimension = dimension
+        self.metric = metric
+        self.normalize = normalize
+        self.max_vectors = max_vectors
+        self.enable_metadata_index = enable_metadata_index
+        self._vectors: Dict[str, np.ndarray] = {}          # insertion-ordered, like the reference's dict of records
+        self._metadata: Dict[str, Dict[str, Any]] = {}
+        self._matrix_dirty = True
+        self._ids: List[str] = []
+        self._store: Optional[N.RowStore] = None
+        self._created_at = self._updated_at = time.time()
+
+    def __len__(self) -> int:
+        return len(self._vectors)
+
+    def __contains__(self, id: str) -> bool:
+        return id in self._vectors
+
+    # ------------------------------------------------------------ writes
+    def add(self, id: str, vector, metadata: Optional[Dict[str, Any]] = None, overwrite: bool = False) -> str:
+        id = id if id else str(uuid.uuid4())
+        vector = _validate_vector(vector, self.dimension)
+        if self.normalize:
+            vector = _normalize_vector(vector)
+        if id in self._vectors and not overwrite:
+            raise VectorExistsError(f"Vector with ID '{id}' already exists")
+        if id not in self._vectors and self.max_vectors and len(self._vectors) >= self.max_vectors:
+            raise ValueError(f"Collection at maximum capacity ({self.max_vectors})")
+        self._vectors[id] = vector
+        self._metadata[id] = dict(metadata or {})
+        self._matrix_dirty = True
+        self._updated_at = time.time()
+        return id
+
+    def add_batch(self, vectors: List[Dict[str, Any]], overwrite: bool = False, on_error: str = "raise") -> Dict[str, Any]:
+        res = {"success_count": 0, "error_count": 0, "errors": []}
+        for item in vectors:
+            try:
+                self.add(item.get("id", str(uuid.uuid4())), item["vector"], item.get("metadata", {}), overwrite)
+                res["success_count"] += 1
+            except Exception as e:
+                res["error_count"] += 1
+                res["errors"].append({"id": item.get("id"), "error": str(e)})
+                if on_error == "raise":
+                    raise
+        return res
+
+    def get(self, id: str, include_vector: bool = True) -> Optional[Dict[str, Any]]:
+        if id not in self._vectors:
+            return None
+        out = {"id": id, "metadata": self._metadata[id].copy()}
+        if include_vector:
+            out["vector"] = self._vectors[id].copy()
+        return out
+
+    def delete(self, id: str) -> bool:
+        if id not in self._vectors:
+            return False
+        del self._vectors[id], self._metadata[id]
+        self._matrix_dirty = True
+        return True
+
+    def clear(self) -> int:
+        n = len(self._vectors)
+        self._vectors.clear(); self._metadata.clear()
+        self._matrix_dirty = True
+        return n
+
+    # ------------------------------------------------------------ search
+    def _ensure_matrix(self) -> None:
+        """core/collection.py:809-828: rebuild the dense matrix (here: the
+        device mirror) after any write; row order = insertion order."""
+        if not self._matrix_dirty and self._store is not None:
+            return
+        if self._store is None:
+            self._store = N.RowStore(self.dimension)
+        self._store.truncate(0)
+        self._ids = list(self._vectors.keys())
+        if self._ids:
+            self._store.append(np.stack([self._vectors[i] for i in self._ids]).astype(np.float32))
+        self._matrix_dirty = False
+
+    def _search_device(self, queries: np.ndarray, k: int, filter: Optional[Dict[str, Any]]):
+        if self.metric not in _QUERY_METRICS:
+            raise ValueError(f"Unknown metric: {self.metric}")
+        self._ensure_matrix()
+        words = None
+        if filter and self.enable_metadata_index:
+            pred = MetadataFilter(filter)
+            mask = np.fromiter((pred(self._metadata[i]) for i in self._ids), dtype=bool, count=len(self._ids))
+            if not mask.any():
+                return None
+            words = N.pack_mask(mask)
+        k = min(k, len(self._ids))
+        return self._store.search(queries, k, _QUERY_METRICS[self.metric], words)
+
+    def _results(self, dist_row, rows_row, include_vector: bool, include_metadata: bool) -> List[SearchResult]:
+        keep = rows_row >= 0
+        dist_row, rows_row = dist_row[keep], rows_row[keep]
+        out = []
+        dmax = dist_row[-1] if len(dist_row) else 1.0
+        for d, r in zip(dist_row, rows_row):
+            id = self._ids[r]
+            score = 1.0 - (d / (dmax + 1e-8)) if dmax > 0 else 1.0           # core/collection.py:762-771 (fp32 scalars)
+            out.append(SearchResult(id=id, distance=float(d), score=float(score),
+                                    vector=self._vectors[id].copy() if include_vector else None,
+                                    metadata=self._metadata[id].copy() if include_metadata else {}))
+        return out
+
+    def search(self, query, k: int = 10, filter: Optional[Dict[str, Any]] = None, include_vector: bool = False,
+               include_metadata: bool = True) -> List[SearchResult]:
+        if len(self._vectors) == 0:
+            return []
+        query = _validate_vector(query, self.dimension)
+        if self.normalize:
+            query = _normalize_vector(query)
+        if k <= 0:
+            return []
+        found = self._search_device(query[None, :], k, filter)
+        if found is None:
+            return []
+        return self._results(found[0][0], found[1][0], include_vector, include_metadata)
+
+    def search_batch(self, queries: Union[np.ndarray, List[List[float]]], k: int = 10,
+                     filter: Optional[Dict[str, Any]] = None, include_vector: bool = False) -> List[List[SearchResult]]:
+        """One device call for the batch (the reference loops over ``search``,
+        core/collection.py:803-807)."""
+        queries = np.atleast_2d(np.asarray(queries, dtype=np.float32))
+        if len(self._vectors) == 0:
+            return [[] for _ in range(len(queries))]
+        qs = np.stack([_validate_vector(q, self.dimension) for q in queries])
+        if self.normalize:
+            qs = np.stack([_normalize_vector(q) for q in qs])
+        found = self._search_device(qs, k, filter)
+        if found is None:
+            return [[] for _ in range(len(qs))]
+        return [self._results(found[0][i], found[1][i], include_vector, True) for i in range(len(qs))]
+
+    def __del__(self):
+        store = getattr(self, "_store", None)
+        if store is not None:
+            store.close()
