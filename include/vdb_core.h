@@ -24,10 +24,12 @@
  *     IVF search orders equal distances by scan position instead
  *     (index/ivf.py:619-631);
  *   - functions whose name ends in _dev take DEVICE pointers for queries,
- *     masks and outputs plus a hipStream_t passed as void* (NULL = the
- *     library's own stream); they enqueue work and do not synchronise.  The
- *     plain forms take HOST pointers, copy, run, and return when the results
- *     are in the caller's buffers.
+ *     masks and outputs plus the hipStream_t to enqueue on, passed as void*
+ *     (NULL = the HIP null stream); they enqueue work and do not synchronise.
+ *     The plain forms take HOST pointers, copy, run on a stream of the library
+ *     (a blocking stream, i.e. ordered with the null stream) and return when
+ *     the results are in the caller's buffers.  Calls on one handle share its
+ *     workspaces: order them yourself when they go to different streams.
  */
 #ifndef VDB_CORE_H
 #define VDB_CORE_H

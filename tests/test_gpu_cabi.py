@@ -474,3 +474,55 @@ def test_pq_shapes(nat, m, dsub):
         np.testing.assert_array_equal(rows[i], ref_rows)
         np.testing.assert_array_equal(dist[i], ref_dist)
     pq.close()
+
+
+# ------------------------------------------------------------------ cross-shard merge
+
+@pytest.mark.parametrize("shards", [2, 8])
+def test_sharded_merge_equals_single_store(nat, shards):
+    """G row shards searched separately on one GPU, merged by the same kernel an
+    all-gather feeds on a multi-GPU node: result equals the unsharded search."""
+    import torch
+    from vectordb_amd.sharded import HipFlatBackend, ShardedFlat, shard_range
+    rng = np.random.RandomState(shards)
+    x = rng.randn(5003, 40).astype(np.float32)
+    x[4000] = x[12]
+    x[2500] = x[12]
+    q = rng.randn(33, 40).astype(np.float32)
+    q[0] = x[12]
+    k = 10
+    dev = torch.device("cuda", 0)
+    tq = torch.from_numpy(q).to(dev)
+    for metric, code in (("manhattan", nat.MANHATTAN), ("cosine", nat.COSINE)):
+        gd = torch.empty((shards, len(q), k), device=dev, dtype=torch.float32)
+        gr = torch.empty((shards, len(q), k), device=dev, dtype=torch.int64)
+        for r in range(shards):
+            lo, hi = shard_range(len(x), shards, r)
+            be = HipFlatBackend(40, code)
+            be.add_device(torch.from_numpy(x[lo:hi]).to(dev))
+            d, rows = ShardedFlat(be, hi - lo, 0, 1).search(tq, k)         # local search, local row numbers
+            gd[r] = d
+            gr[r] = rows + (rows >= 0).to(torch.int64) * lo              # what rank r contributes to the all-gather
+            ref_r, ref_d = R.flat_search(q[1], x[lo:hi], k, metric)
+            if metric == "manhattan":
+                np.testing.assert_array_equal(rows[1].cpu().numpy(), ref_r)
+            torch.cuda.synchronize()
+            be.store.close()
+        od = torch.empty((len(q), k), device=dev, dtype=torch.float32)
+        orow = torch.empty((len(q), k), device=dev, dtype=torch.int64)
+        nat.topk_merge_device(gd.data_ptr(), gr.data_ptr(), shards, len(q), k, od.data_ptr(), orow.data_ptr(),
+                              stream=torch.cuda.current_stream().cuda_stream)
+        torch.cuda.synchronize()
+        od, orow = od.cpu().numpy(), orow.cpu().numpy()
+        single = nat.RowStore(40)
+        single.append(x)
+        sd, sr = single.search(q, k, code)
+        single.close()
+        if metric == "manhattan":
+            np.testing.assert_array_equal(orow, sr)
+            np.testing.assert_array_equal(od, sd)
+            assert list(orow[0][:3]) == [12, 2500, 4000]
+        else:
+            for i in range(len(q)):
+                assert set(orow[i]) == set(sr[i])
+            np.testing.assert_allclose(od, sd, rtol=1e-6, atol=1e-6)

@@ -112,6 +112,13 @@ def load() -> C.CDLL:
             raise ImportError(
                 f"{LIB_PATH} not found: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
                 "or `make -C vectordb_amd/csrc`")
+        # PyTorch ships its own libamdhip64.so.7; the HIP runtime that is loaded first
+        # serves the whole process.  Tensors handed to the *_dev entry points must
+        # come from the same runtime instance, so torch's copy goes first.
+        try:
+            import torch  # noqa: F401
+        except ImportError:
+            pass
         lib = C.CDLL(LIB_PATH)
         for name, (res, args) in SIGNATURES.items():
             fn = getattr(lib, name)

@@ -99,7 +99,8 @@ int make_sum_plan(int n, SumPlan* plan) {
     return VDB_OK;
 }
 
-static hipStream_t pick_stream(void* s) { return s ? reinterpret_cast<hipStream_t>(s) : ctx().stream; }
+// *_dev entry points enqueue on the caller's stream; NULL is the HIP null stream
+static hipStream_t pick_stream(void* s) { return reinterpret_cast<hipStream_t>(s); }
 
 // ============================================================== small kernels
 __global__ void pad_rows_kernel(const float* __restrict__ src, int64_t src_ld, int dim, int64_t n,
@@ -380,7 +381,8 @@ int vdb_init(int device) {
     VDB_HIP(hipSetDevice(device));
     hipDeviceProp_t prop;
     VDB_HIP(hipGetDeviceProperties(&prop, device));
-    if (!c.stream) VDB_HIP(hipStreamCreateWithFlags(&c.stream, hipStreamNonBlocking));
+    // a blocking stream: ordered with work the caller put on the null stream
+    if (!c.stream) VDB_HIP(hipStreamCreateWithFlags(&c.stream, hipStreamDefault));
     c.device = device;
     c.num_cus = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
     return VDB_OK;

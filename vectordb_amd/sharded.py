@@ -79,7 +79,8 @@ class ShardedFlat:
             lr.add_((lr >= 0).to(torch.int64) * self.lo)       # local -> global row numbers; -1 stays -1
         if self.world == 1:
             return ld, lr
-        dist.all_gather_into_tensor(gd, ld, group=self.group)
-        dist.all_gather_into_tensor(gr, lr, group=self.group)
+        # output = the ranks' (nq, k) blocks concatenated along dim 0, i.e. [rank][query][k]
+        dist.all_gather_into_tensor(gd.view(self.world * nq, k), ld, group=self.group)
+        dist.all_gather_into_tensor(gr.view(self.world * nq, k), lr, group=self.group)
         self.backend.merge(gd, gr, k, od, orow)
         return od, orow
