@@ -122,8 +122,14 @@ def main() -> None:
     flop_per_launch = 2.0 * nq * (hi - lo) * d
     kern_ms = kernel_ms / max(launches, 1)
     achieved = flop_per_launch / (kern_ms * 1e-3) / 1e12 if launches else 0.0
+    traffic = None          # HBM bytes per launch from the committed rocprofv3 PMC passes (same workload), if present
+    try:
+        if (n_total, d, nq, world) == (N_ROWS, DIM, N_QUERIES, 1):
+            traffic = json.load(open(os.path.join(ROOT, "profiles", "bench_traffic.json")))["hbm_bytes_per_launch"]
+    except Exception:
+        traffic = None
     roofline = {"bound": "mfma", "achieved": round(achieved, 2), "peak": MFMA_F32_PEAK_TFLOPS, "unit": "TFLOP/s",
-                "frac": round(achieved / MFMA_F32_PEAK_TFLOPS, 4), "traffic": None,
+                "frac": round(achieved / MFMA_F32_PEAK_TFLOPS, 4), "traffic": traffic,
                 "kernel": "flat_gemm_kernel<cosine>", "kernel_ms": round(kern_ms, 4), "launches": launches,
                 "flop_per_launch": flop_per_launch}
 
