@@ -1,0 +1,193 @@
+#!/usr/bin/env python3
+"""Secondary measurements for the other rows of the hot path (not the driver's
+headline bench): bandwidth-bound scans and build steps at BASELINE.json sizes,
+each rated against the HBM roofline with its algorithmic bytes.
+
+    python bench_paths.py [--only flat1,l1,ivf,pq,assign,encode] [--scale 1.0]
+
+Prints one JSON line per path.  Inputs are synthetic standard-normal (or
+uniform random codes) and resident in HBM before timing.
+"""
+
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+HBM_PEAK_GBS = 8000.0
+MFMA_F32_PEAK = 157.3
+
+
+def timed(fn, steps, warmup=2):
+    from vectordb_amd import _native
+    for _ in range(warmup):
+        fn()
+    torch.cuda.synchronize()
+    _native.profile_read()
+    _native.profile_enable(True)
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        fn()
+    torch.cuda.synchronize()
+    wall = (time.perf_counter() - t0) / steps
+    _native.profile_enable(False)
+    ms, n = _native.profile_read()
+    return wall, (ms / n * 1e-3 if n else float("nan")), n // max(steps, 1)
+
+
+def emit(name, **kw):
+    print(json.dumps({"path": name, **kw}), flush=True)
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--only", default="flat1,l1,ivf,pq,assign,encode")
+    ap.add_argument("--scale", type=float, default=1.0, help="scale the row counts (1.0 = BASELINE sizes)")
+    args = ap.parse_args()
+    only = set(args.only.split(","))
+    from vectordb_amd import _native as N
+    N.init(0)
+    dev = torch.device("cuda", 0)
+    stream = 0
+    gen = torch.Generator(device=dev)
+
+    def randn(n, d, seed):
+        gen.manual_seed(seed)
+        return torch.randn((n, d), device=dev, dtype=torch.float32, generator=gen)
+
+    def outputs(nq, k):
+        return (torch.empty((nq, k), device=dev, dtype=torch.float32), torch.empty((nq, k), device=dev, dtype=torch.int64))
+
+    # ---- Flat, one query at a time (streaming scan), cosine 1M x 384 and Manhattan 1M x 128
+    for name, metric, n, d in (("flat1", N.COSINE, int(1_000_000 * args.scale), 384),
+                               ("l1", N.MANHATTAN, int(1_000_000 * args.scale), 128)):
+        if name not in only:
+            continue
+        rows = randn(n, d, 42)
+        store = N.RowStore(d)
+        store.append_device(rows.data_ptr(), n, d, stream)
+        torch.cuda.synchronize()
+        del rows
+        q = randn(1, d, 123)
+        od, orow = outputs(1, 10)
+        wall, kern, launches = timed(lambda: store.search_device(q.data_ptr(), 1, 10, metric, od.data_ptr(), orow.data_ptr()), 20)
+        nbytes = n * d * 4
+        emit(name, workload=f"Flat {'cosine' if metric == N.COSINE else 'manhattan'} {n}x{d} fp32, 1 query, k=10",
+             qps=round(1 / wall, 1), ms_per_query=round(wall * 1e3, 4), kernel_ms=round(kern * 1e3, 4),
+             roofline={"bound": "hbm", "achieved": round(nbytes / kern / 1e9, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                       "frac": round(nbytes / kern / 1e9 / HBM_PEAK_GBS, 4), "bytes_per_launch": nbytes})
+        store.close()
+        torch.cuda.empty_cache()
+
+    # ---- nearest-centroid assignment: n x 4096 x 128 (MFMA)
+    if "assign" in only:
+        n, k, d = int(1_048_576 * args.scale), 4096, 128
+        x = randn(n, d, 42)
+        cent = N.RowStore(d)
+        cent.append_device(x.data_ptr(), k, d, stream)
+        od, orow = outputs(n, 1)
+        wall, kern, _ = timed(lambda: cent.search_device(x.data_ptr(), n, 1, N.EUCLIDEAN, od.data_ptr(), orow.data_ptr()), 5)
+        flop = 2.0 * n * k * d
+        emit("assign", workload=f"k-means assignment {n} rows x {k} centroids x {d}", rows_per_s=round(n / wall, 1),
+             ms=round(wall * 1e3, 3), kernel_ms=round(kern * 1e3, 3),
+             roofline={"bound": "mfma", "achieved": round(flop / kern / 1e12, 2), "peak": MFMA_F32_PEAK, "unit": "TFLOP/s",
+                       "frac": round(flop / kern / 1e12 / MFMA_F32_PEAK, 4), "flop_per_launch": flop})
+        cent.close()
+        del x, od, orow
+        torch.cuda.empty_cache()
+
+    # ---- IVF nlist=4096 nprobe=32 over 10M x 128
+    if "ivf" in only:
+        n, d, nlist, nprobe = int(10_000_000 * args.scale), 128, 4096, 32
+        rng = np.random.default_rng(42)
+        x = rng.standard_normal((n, d), dtype=np.float32)
+        # a short k-means on a sample (device assignment + accumulation) so that the lists are balanced like trained ones
+        sample = x[rng.choice(n, min(n, 64 * nlist), replace=False)]
+        cent = sample[rng.choice(len(sample), nlist, replace=False)].copy()
+        t0 = time.perf_counter()
+        for _ in range(6):
+            a, _d = N.assign(sample, cent, N.EUCLIDEAN)
+            sums, counts = N.kmeans_accumulate(sample, a, nlist)
+            nz = counts > 0
+            cent[nz] = (sums[nz] / counts[nz, None]).astype(np.float32)
+        t_train = time.perf_counter() - t0
+        t0 = time.perf_counter()
+        assign, _ = N.assign(x, cent, N.EUCLIDEAN)
+        t_assign = time.perf_counter() - t0
+        lists = N.IvfLists(d, N.EUCLIDEAN)
+        lists.set_centroids(cent)
+        t0 = time.perf_counter()
+        lists.build(x, assign)
+        t_build = time.perf_counter() - t0
+        for nq in (1, 1024):
+            q = randn(nq, d, 123)
+            od, orow = outputs(nq, 10)
+            wall, kern, launches = timed(lambda: lists.search_device(q.data_ptr(), nq, 10, nprobe, od.data_ptr(), orow.data_ptr()), 10)
+            scanned = lists.last_scan_rows()
+            nbytes = (nq * nlist + scanned) * d * 4
+            emit("ivf", workload=f"IVF nlist={nlist} nprobe={nprobe}, {n}x{d}, batch {nq}, k=10",
+                 qps=round(nq / wall, 1), ms_per_batch=round(wall * 1e3, 4), kernel_ms_avg=round(kern * 1e3, 4),
+                 kernels_per_batch=launches, rows_scanned_per_query=scanned // nq,
+                 train_s=round(t_train, 2), assign_s=round(t_assign, 2), build_s=round(t_build, 2),
+                 longest_list=int(np.bincount(assign, minlength=nlist).max()),
+                 roofline={"bound": "hbm", "achieved": round(nbytes / wall / 1e9, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                           "frac": round(nbytes / wall / 1e9 / HBM_PEAK_GBS, 4), "bytes_per_batch": nbytes,
+                           "note": "algorithmic bytes / whole-batch wall time (probe + scan + select)"})
+        lists.close()
+        del x
+        torch.cuda.empty_cache()
+
+    # ---- PQ m=16 nbits=8 ADC scan over 100M codes with a filter bitmask
+    if "pq" in only:
+        n, m, d = int(100_000_000 * args.scale), 16, 128
+        pq = N.PqCodes(d, m, 256)
+        rng = np.random.default_rng(7)
+        pq.set_codebook(rng.standard_normal((m, 256, d // m), dtype=np.float32))
+        chunk = 10_000_000
+        for s in range(0, n, chunk):
+            c = min(chunk, n - s)
+            codes = torch.randint(0, 256, (c, m), device=dev, dtype=torch.uint8)
+            pq.append_codes_device(codes.data_ptr(), c, stream)
+            torch.cuda.synchronize()
+        del codes
+        for sel in (None, 0.5, 0.01):
+            mask = None
+            if sel is not None:
+                bits = (torch.rand(((n + 31) // 32) * 32, device=dev) < sel).view(-1, 32)
+                weights = (2 ** torch.arange(32, device=dev, dtype=torch.int64))
+                mask = (bits.to(torch.int64) * weights).sum(1).to(torch.int32).contiguous()   # wraps: same 32 bits
+                del bits
+            for nq in (1, 8):
+                q = randn(nq, d, 123)
+                od, orow = outputs(nq, 10)
+                mp = mask.data_ptr() if mask is not None else 0
+                wall, kern, launches = timed(lambda: pq.search_device(q.data_ptr(), nq, 10, od.data_ptr(), orow.data_ptr(), mask_ptr=mp), 10)
+                nbytes = nq * (n * m + (n // 8 if mask is not None else 0))
+                emit("pq", workload=f"PQ m={m} nbits=8 ADC scan, {n} codes, batch {nq}, filter={sel}",
+                     qps=round(nq / wall, 2), ms_per_batch=round(wall * 1e3, 4), kernel_ms=round(kern * 1e3, 4),
+                     roofline={"bound": "hbm", "achieved": round(nbytes / kern / 1e9, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                               "frac": round(nbytes / kern / 1e9 / HBM_PEAK_GBS, 4), "bytes_per_launch": nbytes})
+        pq.close()
+        torch.cuda.empty_cache()
+
+    # ---- PQ encode throughput
+    if "encode" in only:
+        n, m, d = int(1_000_000 * args.scale), 16, 128
+        rng = np.random.default_rng(3)
+        x = rng.standard_normal((n, d), dtype=np.float32)
+        book = rng.standard_normal((m, 256, d // m), dtype=np.float32)
+        N.pq_encode(x[:1000], book)
+        t0 = time.perf_counter()
+        N.pq_encode(x, book)
+        dt = time.perf_counter() - t0
+        emit("encode", workload=f"PQ encode {n}x{d}, m={m}, host buffers in and out", rows_per_s=round(n / dt, 1), s=round(dt, 3))
+
+
+if __name__ == "__main__":
+    main()

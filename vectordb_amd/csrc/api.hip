@@ -5,6 +5,7 @@
 
 #include <algorithm>
 #include <cstdarg>
+#include <functional>
 #include <limits>
 #include <numeric>
 
@@ -141,9 +142,11 @@ static int fill_results(float* d, int64_t* i, int64_t total, hipStream_t s) {
 // ============================================================== workspaces
 struct Workspace {
     DevBuf q_buf, q_sq, q_nrm, part_d, part_i, lb_d, lb_k, thr_d, thr_k, mask, out_d, out_i, dist, probes, probe_d, lut, stage;
+    DevBuf cand, seg_row_off, seg_q_off, seg_item_off, sq_qid, sq_out, cand_off, list_cnt, cursor, slots, items;
     void release() {
         DevBuf* all[] = {&q_buf, &q_sq, &q_nrm, &part_d, &part_i, &lb_d, &lb_k, &thr_d, &thr_k, &mask, &out_d, &out_i, &dist,
-                         &probes, &probe_d, &lut, &stage};
+                         &probes, &probe_d, &lut, &stage, &cand, &seg_row_off, &seg_q_off, &seg_item_off, &sq_qid, &sq_out,
+                         &cand_off, &list_cnt, &cursor, &slots, &items};
         for (DevBuf* b : all) b->release();
     }
 };
@@ -157,10 +160,11 @@ static const int GEMM_MIN_NQ = 4;     // below this the streaming scan reads the
 // queries -> padded device rows + their |q|^2, |q| in NumPy order
 static int prepare_queries(Workspace& ws, const float* d_q, int nq, int dim, int ld, const SumPlan& plan,
                            const float** q_out, hipStream_t s) {
-    if (ld == dim) {
+    if (ld == dim && dim % 8 == 0) {
         *q_out = d_q;
     } else {
-        VDB_TRY(ws.q_buf.reserve((size_t)nq * ld * sizeof(float)));
+        // the streaming kernel reads whole groups of 8 floats: keep 8 readable floats behind the last row
+        VDB_TRY(ws.q_buf.reserve((size_t)nq * ld * sizeof(float) + 64));
         VDB_TRY(launch_pad_rows(d_q, dim, dim, nq, ws.q_buf.as<float>(), ld, s));
         *q_out = ws.q_buf.as<float>();
     }
@@ -213,6 +217,76 @@ static int rows_append_dev_impl(vdb_rows* h, const float* d_rows, int64_t n, int
     return VDB_OK;
 }
 
+
+// ---- streaming scan of all rows for a block of queries: candidate buffer [nq][n] of streamed sums
+static const int64_t CAND_BUDGET = (int64_t)1 << 30;      // bytes of candidate buffer per pass
+
+static int reserve_stream_plan(Workspace& ws, int n_seg, int64_t n_pairs, int64_t items_cap, StreamPlanBufs* b) {
+    VDB_TRY(ws.seg_row_off.reserve((size_t)(n_seg + 1) * sizeof(int64_t)));
+    VDB_TRY(ws.seg_q_off.reserve((size_t)(n_seg + 1) * sizeof(int)));
+    VDB_TRY(ws.seg_item_off.reserve((size_t)(n_seg + 1) * sizeof(int64_t)));
+    VDB_TRY(ws.sq_qid.reserve((size_t)std::max<int64_t>(n_pairs, 1) * sizeof(int)));
+    VDB_TRY(ws.sq_out.reserve((size_t)std::max<int64_t>(n_pairs, 1) * sizeof(int64_t)));
+    VDB_TRY(ws.items.reserve((size_t)std::max<int64_t>(items_cap, 1) * sizeof(StreamItem)));
+    b->items = ws.items.as<StreamItem>(); b->items_cap = items_cap;
+    b->seg_row_off = ws.seg_row_off.as<int64_t>(); b->seg_q_off = ws.seg_q_off.as<int>();
+    b->seg_item_off = ws.seg_item_off.as<int64_t>(); b->sq_qid = ws.sq_qid.as<int>(); b->sq_out = ws.sq_out.as<int64_t>();
+    return VDB_OK;
+}
+
+static int stream_flat_sums(Workspace& ws, const Rows& r, int metric, const float* q, int nq, float* out, hipStream_t s) {
+    StreamPlanBufs b{};
+    const int group = nq == 1 ? 1 : 8;
+    VDB_TRY(reserve_stream_plan(ws, 1, nq, ((r.n + 255) / 256) * ((nq + group - 1) / group), &b));
+    VDB_TRY(launch_flat_plan(r.n, nq, group, r.n, b, s));
+    StreamJob j{};
+    j.data = r.data; j.ld = r.ld; j.dim = r.dim; j.plan = r.plan;
+    j.op = op_of_metric(metric); j.post = post_of_metric(metric);
+    j.q = q; j.ldq = r.ld; j.group = group; j.n_seg = 1;
+    j.seg_row_off = b.seg_row_off; j.seg_q_off = b.seg_q_off; j.seg_item_off = b.seg_item_off;
+    j.sq_qid = b.sq_qid; j.sq_out = b.sq_out; j.items = b.items; j.items_cap = b.items_cap; j.out = out; j.timed = true;
+    return launch_stream_sums(j, s);
+}
+
+// streamed search of a flat row set (any metric): per block of queries, sums -> candidate buffer -> k best
+static int stream_flat_search(vdb_rows* h, int metric, const float* q, int nq, int k, int64_t k_eff, const uint32_t* d_mask,
+                              float* d_out_d, int64_t* d_out_i, int* d_out_i32, hipStream_t s) {
+    Rows& r = h->r;
+    Workspace& ws = h->ws;
+    const int q_block = (int)std::max<int64_t>(1, std::min<int64_t>(nq, CAND_BUDGET / (r.n * (int64_t)sizeof(float))));
+    const int64_t ntiles = (r.n + 255) / 256;
+    const int kmax = (int)std::min<int64_t>(KMAX_FUSED, k_eff);
+    const bool multi = k_eff > KMAX_FUSED;
+    VDB_TRY(ws.cand.reserve((size_t)q_block * r.n * sizeof(float)));
+    if (multi) {
+        VDB_TRY(ws.lb_d.reserve((size_t)q_block * sizeof(float)));
+        VDB_TRY(ws.lb_k.reserve((size_t)q_block * sizeof(int64_t)));
+    }
+    for (int q0 = 0; q0 < nq; q0 += q_block) {
+        const int nb = std::min(q_block, nq - q0);
+        // enough blocks to fill the chip, at least 8 tiles each
+        const int splits = (int)std::max<int64_t>(1, std::min<int64_t>((ntiles + 7) / 8, (2 * ctx().num_cus + nb - 1) / nb));
+        VDB_TRY(ws.part_d.reserve((size_t)nb * splits * kmax * sizeof(float)));
+        VDB_TRY(ws.part_i.reserve((size_t)nb * splits * kmax * sizeof(int)));
+        VDB_TRY(stream_flat_sums(ws, r, metric, q + (int64_t)q0 * r.ld, nb, ws.cand.as<float>(), s));
+        for (int64_t done = 0; done < k_eff; done += KMAX_FUSED) {
+            const int kk = (int)std::min<int64_t>(KMAX_FUSED, k_eff - done);
+            CandJob c{};
+            c.cand = ws.cand.as<float>(); c.cand_stride = r.n; c.nq = nb; c.n = r.n; c.mask = d_mask;
+            c.metric = metric; c.q_sq = ws.q_sq.as<float>() + q0; c.q_nrm = ws.q_nrm.as<float>() + q0;
+            c.row_sq = r.sq; c.row_nrm = r.nrm;
+            c.lb_d = done > 0 ? ws.lb_d.as<float>() : nullptr; c.lb_k = done > 0 ? ws.lb_k.as<int64_t>() : nullptr;
+            c.k = kk; c.splits = splits; c.part_d = ws.part_d.as<float>(); c.part_i = ws.part_i.as<int>();
+            VDB_TRY(launch_topk_cand(c, s));
+            SelectOut o{d_out_d ? d_out_d + (int64_t)q0 * k : nullptr, d_out_i ? d_out_i + (int64_t)q0 * k : nullptr,
+                        d_out_i32 ? d_out_i32 + (int64_t)q0 * k : nullptr, k, (int)done,
+                        multi ? ws.lb_d.as<float>() : nullptr, multi ? ws.lb_k.as<int64_t>() : nullptr};
+            VDB_TRY(launch_select(ws.part_d.as<float>(), ws.part_i.as<int>(), nb, splits, kk, 1 << 30, nullptr, 0, o, s));
+        }
+    }
+    return VDB_OK;
+}
+
 // ---- flat search on device pointers ------------------------------------
 static int flat_search_impl(vdb_rows* h, int metric, const float* d_q, int nq, int k, const uint32_t* d_mask,
                             float* d_out_d, int64_t* d_out_i, int* d_out_i32, hipStream_t s) {
@@ -231,17 +305,12 @@ static int flat_search_impl(vdb_rows* h, int metric, const float* d_q, int nq, i
     const float* q = nullptr;
     VDB_TRY(prepare_queries(ws, d_q, nq, r.dim, r.ld, r.plan, &q, s));
     const bool gemm = is_dot_metric(metric) && nq >= GEMM_MIN_NQ;
+    if (!gemm) return stream_flat_search(h, metric, q, nq, k, k_eff, d_mask, d_out_d, d_out_i, d_out_i32, s);
 
-    int n_cand = 0, splits = 1, sample_tiles = 0, sample_stride = 1, n_cand_sample = 0;
-    if (gemm) {
-        VDB_TRY(flat_gemm_num_cand(r.n, nq, k, &n_cand));
-        VDB_TRY(flat_gemm_sample_plan(r.n, &sample_tiles, &sample_stride));
-        if (sample_tiles > 0) VDB_TRY(flat_gemm_num_cand_tiles(sample_tiles, nq, &n_cand_sample));
-    } else {
-        const int64_t ntiles = (r.n + 255) / 256;
-        splits = (int)std::max<int64_t>(1, std::min<int64_t>(ntiles, (8 * ctx().num_cus + nq - 1) / nq));
-        n_cand = splits;
-    }
+    int n_cand = 0, sample_tiles = 0, sample_stride = 1, n_cand_sample = 0;
+    VDB_TRY(flat_gemm_num_cand(r.n, nq, k, &n_cand));
+    VDB_TRY(flat_gemm_sample_plan(r.n, &sample_tiles, &sample_stride));
+    if (sample_tiles > 0) VDB_TRY(flat_gemm_num_cand_tiles(sample_tiles, nq, &n_cand_sample));
     const int kmax = (int)std::min<int64_t>(KMAX_FUSED, k_eff);
     const int cand_max = std::max(n_cand, n_cand_sample);
     VDB_TRY(ws.part_d.reserve((size_t)nq * cand_max * kmax * sizeof(float)));
@@ -269,18 +338,9 @@ static int flat_search_impl(vdb_rows* h, int metric, const float* d_q, int nq, i
         const int kk = (int)std::min<int64_t>(KMAX_FUSED, k_eff - done);
         const float* lb_d = (done > 0) ? ws.lb_d.as<float>() : nullptr;
         const int64_t* lb_k = (done > 0) ? ws.lb_k.as<int64_t>() : nullptr;
-        if (gemm) {
-            VDB_TRY(launch_flat_gemm_topk(r, metric, q, ws.q_sq.as<float>(), ws.q_nrm.as<float>(), nq, kk, d_mask,
-                                          lb_d, lb_k, done == 0 ? thr_init : nullptr, 0, 1,
-                                          ws.part_d.as<float>(), ws.part_i.as<int>(), n_cand, s));
-        } else {
-            ScanJob j{};
-            j.data = r.data; j.ld = r.ld; j.dim = r.dim; j.row_sq = r.sq; j.row_nrm = r.nrm; j.plan = r.plan;
-            j.metric = metric; j.q = q; j.ldq = r.ld; j.nq = nq; j.q_sq = ws.q_sq.as<float>(); j.q_nrm = ws.q_nrm.as<float>();
-            j.n = r.n; j.mask = d_mask; j.lb_d = lb_d; j.lb_k = lb_k; j.k = kk; j.splits = splits;
-            j.part_d = ws.part_d.as<float>(); j.part_i = ws.part_i.as<int>();
-            VDB_TRY(launch_scan(j, s));
-        }
+        VDB_TRY(launch_flat_gemm_topk(r, metric, q, ws.q_sq.as<float>(), ws.q_nrm.as<float>(), nq, kk, d_mask,
+                                      lb_d, lb_k, done == 0 ? thr_init : nullptr, 0, 1,
+                                      ws.part_d.as<float>(), ws.part_i.as<int>(), n_cand, s));
         SelectOut o{d_out_d, d_out_i, d_out_i32, k, (int)done,
                     multi ? ws.lb_d.as<float>() : nullptr, multi ? ws.lb_k.as<int64_t>() : nullptr};
         VDB_TRY(launch_select(ws.part_d.as<float>(), ws.part_i.as<int>(), nq, n_cand, kk, 1 << 30, nullptr, 0, o, s));
@@ -297,13 +357,8 @@ static int flat_distances_impl(vdb_rows* h, int metric, const float* d_q, int nq
     VDB_TRY(prepare_queries(ws, d_q, nq, r.dim, r.ld, r.plan, &q, s));
     if (is_dot_metric(metric) && nq >= GEMM_MIN_NQ)
         return launch_flat_gemm_dist(r, metric, q, ws.q_sq.as<float>(), ws.q_nrm.as<float>(), nq, d_out, s);
-    ScanJob j{};
-    j.data = r.data; j.ld = r.ld; j.dim = r.dim; j.row_sq = r.sq; j.row_nrm = r.nrm; j.plan = r.plan;
-    j.metric = metric; j.q = q; j.ldq = r.ld; j.nq = nq; j.q_sq = ws.q_sq.as<float>(); j.q_nrm = ws.q_nrm.as<float>();
-    j.n = r.n; j.k = 0; j.dist_out = d_out;
-    const int64_t ntiles = (r.n + 255) / 256;
-    j.splits = (int)std::max<int64_t>(1, std::min<int64_t>(ntiles, (8 * ctx().num_cus + nq - 1) / nq));
-    return launch_scan(j, s);
+    VDB_TRY(stream_flat_sums(ws, r, metric, q, nq, d_out, s));
+    return launch_finish_dist(metric, ws.q_sq.as<float>(), ws.q_nrm.as<float>(), r.sq, r.nrm, d_out, nq, r.n, s);
 }
 
 // copy a host bitmask of n bits to the workspace
@@ -341,7 +396,19 @@ struct vdb_ivf {
     DevBuf list_off;                    // int64 [n_lists + 1]
     DevBuf row_ids;                     // int   [n]  row number of every stored position
     std::vector<int64_t> h_list_off;
+    std::vector<int64_t> len_desc;      // list lengths, longest first
     int n_lists = 0;
+    // rows in the n_probe longest lists: the most candidates one query can have
+    int64_t probe_bound(int n_probe) {
+        if (len_desc.size() != (size_t)n_lists) {
+            len_desc.resize(n_lists);
+            for (int l = 0; l < n_lists; ++l) len_desc[l] = h_list_off[l + 1] - h_list_off[l];
+            std::sort(len_desc.begin(), len_desc.end(), std::greater<int64_t>());
+        }
+        int64_t t = 0;
+        for (int i = 0; i < std::min(n_probe, n_lists); ++i) t += len_desc[i];
+        return t;
+    }
     int64_t last_scan_rows = -1;
     int last_nq = 0, last_nprobe = 0;
     Workspace ws;
@@ -383,6 +450,10 @@ int vdb_init(int device) {
     VDB_HIP(hipGetDeviceProperties(&prop, device));
     // a blocking stream: ordered with work the caller put on the null stream
     if (!c.stream) VDB_HIP(hipStreamCreateWithFlags(&c.stream, hipStreamDefault));
+    if (!c.zeros) {
+        VDB_HIP(hipMalloc(reinterpret_cast<void**>(&c.zeros), 256));
+        VDB_HIP(hipMemset(c.zeros, 0, 256));
+    }
     c.device = device;
     c.num_cus = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
     return VDB_OK;
@@ -726,6 +797,7 @@ int vdb_ivf_set_centroids(vdb_ivf* h, const float* centroids, int n_lists) {
     VDB_TRY(vdb_rows_append(h->centroids, centroids, n_lists));
     h->n_lists = n_lists;
     h->h_list_off.assign(n_lists + 1, 0);
+    h->len_desc.clear();
     VDB_TRY(vdb_rows_truncate(h->members, 0));
     return VDB_OK;
 }
@@ -747,6 +819,7 @@ int vdb_ivf_build_lists(vdb_ivf* h, const float* rows, int64_t n, const int64_t*
     vdb_rows* m = h->members;
     m->r.n = 0;
     h->h_list_off.assign(list_offsets, list_offsets + h->n_lists + 1);
+    h->len_desc.clear();
     VDB_TRY(h->list_off.reserve((size_t)(h->n_lists + 1) * sizeof(int64_t)));
     VDB_HIP(hipMemcpyAsync(h->list_off.p, list_offsets, (size_t)(h->n_lists + 1) * sizeof(int64_t), hipMemcpyHostToDevice, s));
     if (n == 0) { VDB_HIP(hipStreamSynchronize(s)); return VDB_OK; }
@@ -814,6 +887,16 @@ static int ivf_search_impl(vdb_ivf* h, const float* d_q, int nq, int k, int n_pr
     VDB_TRY(fill_results(d_out_d, d_out_i, (int64_t)nq * k, s));
     if (m->r.n == 0) return VDB_OK;
 
+    const int64_t k_eff = std::min<int64_t>(k, m->r.n);
+    const int kmax = (int)std::min<int64_t>(KMAX_FUSED, k_eff);
+    const bool multi = k_eff > KMAX_FUSED;
+    const int sm = scan_metric_of(h->metric);
+    // a query's candidate slots: at most the n_probe longest lists
+    const int64_t cand_stride = round_up64(std::max<int64_t>(h->probe_bound(n_probe), 1), 64);
+    VDB_REQUIRE(cand_stride < (int64_t)0x7fffffff, "n_probe=%d lists can hold more than 2^31 rows", n_probe);
+    const int q_block = (int)std::max<int64_t>(1, std::min<int64_t>(nq, CAND_BUDGET / (cand_stride * (int64_t)sizeof(float))));
+    const int group = nq == 1 ? 1 : 8;
+
     VDB_TRY(ws.probes.reserve((size_t)nq * n_probe * sizeof(int)));
     VDB_TRY(ws.probe_d.reserve((size_t)nq * n_probe * sizeof(float)));
     VDB_TRY(ivf_probe_impl(h, nullptr, d_q, nq, n_probe, ws.probes.as<int>(), ws.probe_d.as<float>(), s));
@@ -821,33 +904,55 @@ static int ivf_search_impl(vdb_ivf* h, const float* d_q, int nq, int k, int n_pr
 
     const float* q = nullptr;
     VDB_TRY(prepare_queries(ws, d_q, nq, m->r.dim, m->r.ld, m->r.plan, &q, s));
-    const int64_t units = (int64_t)nq * n_probe;
-    const int64_t avg_tiles = std::max<int64_t>(1, (m->r.n / std::max(1, h->n_lists) + 255) / 256);
-    const int splits = (int)std::max<int64_t>(1, std::min<int64_t>(avg_tiles, (8 * ctx().num_cus + units - 1) / units));
-    const int n_cand = n_probe * splits;
-    const int64_t k_eff = std::min<int64_t>(k, m->r.n);
-    const int kmax = (int)std::min<int64_t>(KMAX_FUSED, k_eff);
-    VDB_TRY(ws.part_d.reserve((size_t)nq * n_cand * kmax * sizeof(float)));
-    VDB_TRY(ws.part_i.reserve((size_t)nq * n_cand * kmax * sizeof(int)));
-    const bool multi = k_eff > KMAX_FUSED;
+    StreamPlanBufs b{};
+    // every (query, probe) pair adds at most ceil(list rows / 256) items
+    VDB_TRY(reserve_stream_plan(ws, h->n_lists, (int64_t)q_block * n_probe, (int64_t)q_block * (cand_stride / 256 + n_probe), &b));
+    VDB_TRY(ws.cand.reserve((size_t)q_block * cand_stride * sizeof(float)));
+    VDB_TRY(ws.cand_off.reserve((size_t)q_block * (n_probe + 1) * sizeof(int64_t)));
+    VDB_TRY(ws.list_cnt.reserve((size_t)h->n_lists * sizeof(int)));
+    VDB_TRY(ws.cursor.reserve((size_t)h->n_lists * sizeof(int)));
+    VDB_TRY(ws.slots.reserve((size_t)nq * k * sizeof(int)));
     if (multi) {
-        VDB_TRY(ws.lb_d.reserve((size_t)nq * sizeof(float)));
-        VDB_TRY(ws.lb_k.reserve((size_t)nq * sizeof(int64_t)));
+        VDB_TRY(ws.lb_d.reserve((size_t)q_block * sizeof(float)));
+        VDB_TRY(ws.lb_k.reserve((size_t)q_block * sizeof(int64_t)));
     }
-    for (int64_t done = 0; done < k_eff; done += KMAX_FUSED) {
-        const int kk = (int)std::min<int64_t>(KMAX_FUSED, k_eff - done);
-        ScanJob j{};
-        j.data = m->r.data; j.ld = m->r.ld; j.dim = m->r.dim; j.row_sq = m->r.sq; j.row_nrm = m->r.nrm; j.plan = m->r.plan;
-        j.metric = scan_metric_of(h->metric);
-        j.q = q; j.ldq = m->r.ld; j.nq = nq; j.q_sq = ws.q_sq.as<float>(); j.q_nrm = ws.q_nrm.as<float>();
-        j.n = m->r.n; j.list_off = h->list_off.as<int64_t>(); j.probes = ws.probes.as<int>(); j.n_probe = n_probe;
-        j.row_ids = h->row_ids.as<int>(); j.mask = d_mask;
-        j.lb_d = done > 0 ? ws.lb_d.as<float>() : nullptr; j.lb_k = done > 0 ? ws.lb_k.as<int64_t>() : nullptr;
-        j.k = kk; j.splits = splits; j.part_d = ws.part_d.as<float>(); j.part_i = ws.part_i.as<int>();
-        VDB_TRY(launch_scan(j, s));
-        SelectOut o{d_out_d, d_out_i, nullptr, k, (int)done,
-                    multi ? ws.lb_d.as<float>() : nullptr, multi ? ws.lb_k.as<int64_t>() : nullptr};
-        VDB_TRY(launch_select(ws.part_d.as<float>(), ws.part_i.as<int>(), nq, n_cand, kk, splits, h->row_ids.as<int>(), 0, o, s));
+    const int64_t avg_tiles = std::max<int64_t>(1, ((int64_t)n_probe * (m->r.n / std::max(1, h->n_lists)) + 255) / 256);
+
+    for (int q0 = 0; q0 < nq; q0 += q_block) {
+        const int nb = std::min(q_block, nq - q0);
+        const int* probes = ws.probes.as<int>() + (int64_t)q0 * n_probe;
+        VDB_TRY(launch_ivf_plan(probes, nb, n_probe, h->list_off.as<int64_t>(), h->n_lists, group, cand_stride,
+                                ws.list_cnt.as<int>(), ws.cursor.as<int>(), ws.cand_off.as<int64_t>(), b, s));
+        StreamJob j{};
+        j.data = m->r.data; j.ld = m->r.ld; j.dim = m->r.dim; j.plan = m->r.plan;
+        j.op = op_of_metric(sm); j.post = post_of_metric(sm);
+        j.q = q + (int64_t)q0 * m->r.ld; j.ldq = m->r.ld; j.group = group; j.n_seg = h->n_lists;
+        j.seg_row_off = h->list_off.as<int64_t>(); j.seg_q_off = b.seg_q_off; j.seg_item_off = b.seg_item_off;
+        j.sq_qid = b.sq_qid; j.sq_out = b.sq_out; j.items = b.items; j.items_cap = b.items_cap;
+        j.out = ws.cand.as<float>(); j.timed = true;
+        VDB_TRY(launch_stream_sums(j, s));
+
+        const int splits = (int)std::max<int64_t>(1, std::min<int64_t>((avg_tiles + 7) / 8, (2 * ctx().num_cus + nb - 1) / nb));
+        VDB_TRY(ws.part_d.reserve((size_t)nb * splits * kmax * sizeof(float)));
+        VDB_TRY(ws.part_i.reserve((size_t)nb * splits * kmax * sizeof(int)));
+        for (int64_t done = 0; done < k_eff; done += KMAX_FUSED) {
+            const int kk = (int)std::min<int64_t>(KMAX_FUSED, k_eff - done);
+            CandJob c{};
+            c.cand = ws.cand.as<float>(); c.cand_stride = cand_stride; c.nq = nb; c.n = 0;
+            c.probes = probes; c.n_probe = n_probe; c.n_lists = h->n_lists; c.list_off = h->list_off.as<int64_t>();
+            c.row_ids = h->row_ids.as<int>(); c.mask = d_mask;
+            c.metric = sm; c.q_sq = ws.q_sq.as<float>() + q0; c.q_nrm = ws.q_nrm.as<float>() + q0;
+            c.row_sq = m->r.sq; c.row_nrm = m->r.nrm;
+            c.lb_d = done > 0 ? ws.lb_d.as<float>() : nullptr; c.lb_k = done > 0 ? ws.lb_k.as<int64_t>() : nullptr;
+            c.k = kk; c.splits = splits; c.part_d = ws.part_d.as<float>(); c.part_i = ws.part_i.as<int>();
+            VDB_TRY(launch_topk_cand(c, s));
+            SelectOut o{d_out_d + (int64_t)q0 * k, nullptr, ws.slots.as<int>() + (int64_t)q0 * k, k, (int)done,
+                        multi ? ws.lb_d.as<float>() : nullptr, multi ? ws.lb_k.as<int64_t>() : nullptr};
+            VDB_TRY(launch_select(ws.part_d.as<float>(), ws.part_i.as<int>(), nb, splits, kk, 1 << 30, nullptr, 0, o, s));
+            VDB_TRY(launch_ivf_rows(ws.slots.as<int>() + (int64_t)q0 * k, nb, kk, k, (int)done, probes, n_probe, h->n_lists,
+                                    ws.cand_off.as<int64_t>(), h->list_off.as<int64_t>(), h->row_ids.as<int>(),
+                                    d_out_i + (int64_t)q0 * k, s));
+        }
     }
     return VDB_OK;
 }

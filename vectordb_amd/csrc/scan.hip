@@ -24,18 +24,7 @@ static constexpr int CK = 32;           // floats of every row staged per step
 static constexpr int LW = CK + 4;       // padded LDS row width
 static constexpr int MAXSTACK = 8;
 
-enum ScanOp { OP_DOT = 0, OP_SQDIFF = 1, OP_ABSDIFF = 2, OP_MAXABS = 3, OP_SQ = 4 };
 enum { METRIC_SQNORM = 100 };
-
-__host__ __device__ static inline int op_of_metric(int metric) {
-    switch (metric) {
-        case VDB_EUCLIDEAN: case VDB_EUCLIDEAN_SQ: case VDB_COSINE: case VDB_DOT: case VDB_COSINE_PAIR: return OP_DOT;
-        case VDB_EUCLIDEAN_DIRECT: case VDB_EUCLIDEAN_SQ_DIRECT: return OP_SQDIFF;
-        case VDB_MANHATTAN: return OP_ABSDIFF;
-        case VDB_CHEBYSHEV: return OP_MAXABS;
-        default: return OP_SQ;
-    }
-}
 
 struct ScanParams {
     const float* data; int ld; int dim;

@@ -1,0 +1,698 @@
+// Streaming distance pipeline for the bandwidth-bound searches:
+//
+//   stream_sums_kernel : per (row, query) the reduction  sum_j term(row_j, q_j)
+//                        (or max_j) in NumPy's pairwise order, for row chunks of
+//                        256 rows against groups of up to G queries.  Rows are
+//                        read from HBM once per chunk with asynchronous
+//                        global->LDS loads, several stages ahead of the
+//                        arithmetic; the values go to a candidate buffer.
+//   topk_cand_kernel   : per query, the distance finish (norm terms, clamp,
+//                        sqrt), the filter bitmask, and the k best of that
+//                        query's slice of the candidate buffer.
+//   finish_dist_kernel : the distance finish alone (full distance rows).
+//
+// Served by this pipeline:
+//   - Manhattan / Chebyshev, which have no GEMM form (distance/metrics.py:486-490);
+//   - single queries and small batches of any metric (FlatIndex.search,
+//     index/flat.py:331; Collection.search, core/collection.py:750);
+//   - the per-pair distances of the IVF search: centroid ranking
+//     (index/ivf.py:611-614) and the scan of the probed lists (:619-628).
+//     For a batch the probed lists are inverted (list -> queries that probe
+//     it), so a list chunk is read once and serves up to G queries.
+//
+// Work is cut into items = (row chunk of a segment, query group of that
+// segment).  A flat search is one segment holding every row and every query;
+// an IVF scan has one segment per inverted list.  Blocks take items
+// round-robin; every block walks its items' 32-float stages as one sequence so
+// loads for the next item are in flight while the current one is summed.
+#include "vdb_internal.h"
+#include "vdb_device.h"
+
+namespace vdb {
+
+static constexpr int S_NT = 256;                  // threads = rows per chunk
+static constexpr int S_CK = 32;                   // floats of every row per stage: one 128-byte line
+static constexpr int S_STAGE = S_NT * S_CK;       // floats per stage buffer (32 KiB)
+static constexpr int S_GLDS_PER_STAGE = 9;        // LDS-DMA instructions one wave issues per stage: 8 row pieces + 1 query piece
+
+// One LDS-DMA instruction: every lane fetches 16 bytes from its own global address; the
+// wave's 1 KiB lands at lds_dst (a wave-uniform LDS byte address) in lane order.  Written
+// as asm so that the compiler neither counts it nor drains it before later LDS reads;
+// completion is awaited with wait_loads() below.
+__device__ __forceinline__ void glds16(const float* gsrc, unsigned lds_dst) {
+    unsigned keep;
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
+                 : "=&s"(keep) : "v"(gsrc), "s"(lds_dst) : "memory");
+}
+
+// uniform (scalar-cache) load: the address must be the same in every lane
+template <class T> __device__ __forceinline__ T uload(const T* p) {
+    return *reinterpret_cast<const __attribute__((address_space(4))) T*>(reinterpret_cast<uintptr_t>(p));
+}
+
+struct StreamParams {
+    const float* data; int ld; int dim;
+    int n_leaves; int leaf_len[SumPlan::MAX_LEAVES]; int folds[SumPlan::MAX_LEAVES];   // SumPlan, dword fields (scalar loads)
+    int post;                         // StreamPost applied to the sum before it is stored
+    int nbuf;                         // stage buffers in LDS
+    int diag;                         // timing experiments: 1 = no loads, 2 = no arithmetic
+    const float* q; int ldq;
+    const float* zeros;               // >= 16 zero bytes, source of the columns past ld
+    int n_seg;
+    const int64_t* seg_row_off;       // [n_seg+1] stored row range of a segment
+    const int* seg_q_off;             // [n_seg+1] range of the segment's queries in sq_*
+    const int64_t* seg_item_off;      // [n_seg+1] first item of a segment
+    const StreamItem* items;          // [seg_item_off[n_seg]] the decoded items
+    int64_t items_cap;
+    const int* sq_qid;                // query number
+    const int64_t* sq_out;            // where that query's value for the segment's row 0 goes
+    float* out;
+};
+
+template <int OP> __device__ __forceinline__ float s_term(float x, float q) {
+    if (OP == OP_SQDIFF) { const float d = q - x; return d * d; }
+    if (OP == OP_ABSDIFF || OP == OP_MAXABS) return fabsf(x - q);
+    if (OP == OP_SQ) return x * x;
+    return x * q;
+}
+template <int OP> __device__ __forceinline__ float s_comb(float a, float b) {
+    return OP == OP_MAXABS ? fmaxf(a, b) : a + b;
+}
+template <int OP> __device__ __forceinline__ float s_accum(float r, float x, float q) {
+    if (OP == OP_DOT) return __fmaf_rn(x, q, r);
+    return s_comb<OP>(r, s_term<OP>(x, q));
+}
+template <int OP> __device__ __forceinline__ float s_tree(const float* r) {
+    return s_comb<OP>(s_comb<OP>(s_comb<OP>(r[0], r[1]), s_comb<OP>(r[2], r[3])),
+                      s_comb<OP>(s_comb<OP>(r[4], r[5]), s_comb<OP>(r[6], r[7])));
+}
+
+typedef float f2 __attribute__((ext_vector_type(2)));     // two accumulators: the packed fp32 VALU forms
+template <int OP> __device__ __forceinline__ f2 s_accum2(f2 r, f2 x, f2 q) {
+    if (OP == OP_DOT) return __builtin_elementwise_fma(x, q, r);
+    if (OP == OP_SQDIFF) { const f2 d = q - x; return r + d * d; }
+    if (OP == OP_SQ) return r + x * x;
+    const f2 d = __builtin_elementwise_abs(x - q);
+    if (OP == OP_MAXABS) return f2{fmaxf(r.x, d.x), fmaxf(r.y, d.y)};
+    return r + d;
+}
+template <int OP> __device__ __forceinline__ float s_tree2(const f2* a) {
+    return s_comb<OP>(s_comb<OP>(s_comb<OP>(a[0].x, a[0].y), s_comb<OP>(a[1].x, a[1].y)),
+                      s_comb<OP>(s_comb<OP>(a[2].x, a[2].y), s_comb<OP>(a[3].x, a[3].y)));
+}
+
+typedef int i8v __attribute__((ext_vector_type(8)));
+struct Item {
+    int64_t row0;        // first stored row of the chunk
+    int64_t out_rel;     // chunk's first row relative to its segment's first row
+    int rows;            // rows in the chunk (1..256)
+    int qbeg;            // first query entry of the group
+    int qcnt;            // queries in the group (1..G)
+};
+static_assert(sizeof(StreamItem) == 32, "one item is one 32-byte scalar load");
+
+__device__ __forceinline__ Item load_item(const StreamParams& p, int64_t item) {
+    const i8v w = uload(reinterpret_cast<const i8v*>(p.items + item));
+    Item it;
+    it.row0 = ((int64_t)(uint32_t)w[1] << 32) | (uint32_t)w[0];
+    it.out_rel = ((int64_t)(uint32_t)w[3] << 32) | (uint32_t)w[2];
+    it.rows = w[4]; it.qbeg = w[5]; it.qcnt = w[6];
+    return it;
+}
+
+__device__ __forceinline__ void wait_loads(int stages_behind) {
+    // the wave's LDS-DMA loads retire in order: leaving `stages_behind` later stages
+    // outstanding means the stage in front of them has landed
+    static_assert(S_GLDS_PER_STAGE == 9, "the immediates below are multiples of the per-stage count");
+    if (stages_behind >= 2) asm volatile("s_waitcnt vmcnt(18)" ::: "memory");
+    else if (stages_behind == 1) asm volatile("s_waitcnt vmcnt(9)" ::: "memory");
+    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+}
+
+template <int OP, int G>
+__global__ __launch_bounds__(S_NT) void stream_sums_kernel(const StreamParams p) {
+    extern __shared__ __align__(16) float smem[];
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int nbuf = p.nbuf;
+    constexpr int H = G >= 4 ? 4 : G;             // queries per unit of the arithmetic loop
+    constexpr int U = G / H;
+    constexpr int SLOT = S_STAGE + G * S_CK;      // floats per stage slot: 256 row pieces, then the G query pieces
+    float* St = smem + nbuf * SLOT;               // [depth][G][256] pending partial sums (more than one leaf only)
+
+    const int ksteps = (p.ld + S_CK - 1) / S_CK;
+    const int64_t total_items = min(uload(p.seg_item_off + p.n_seg), p.items_cap);
+    const int64_t first = blockIdx.x;
+    if (first >= total_items) return;
+    const int64_t my_items = (total_items - first + gridDim.x - 1) / gridDim.x;
+    const int64_t n_stages = my_items * ksteps;
+    const bool one_leaf = p.n_leaves == 1;
+
+    // ---- producer: stage -> LDS.  Row r of the chunk sits at r*32 floats; its
+    // 16-byte piece c is stored at piece position c ^ ((r >> 1) & 7), which makes
+    // the one-row-per-thread 16-byte reads below conflict free.
+    int64_t pn = 0, p_item = first;
+    int p_ks = 0;
+    Item p_it = load_item(p, p_item);
+    const int piece = lane & 7;
+    // query pieces: the stage's 32 floats of each of the group's queries, 8 lanes per query.
+    // G == 8: wave w fetches queries 2w and 2w+1; G == 1: every wave fetches the same piece.
+    constexpr int QL = G == 8 ? 16 : 8;           // lanes per wave that fetch query pieces
+    const int qg0 = G == 8 ? wave * 2 : 0;       // first of this wave's (at most two) queries
+    auto issue = [&]() {
+        const unsigned slot = (unsigned)(uintptr_t)(smem + (int)(pn % nbuf) * SLOT);
+        const unsigned base = __builtin_amdgcn_readfirstlane(slot + wave * 64 * S_CK * (unsigned)sizeof(float));
+        if (lane < QL) {
+            const int id0 = uload(p.sq_qid + p_it.qbeg + min(qg0, p_it.qcnt - 1));
+            const int id1 = uload(p.sq_qid + p_it.qbeg + min(qg0 + 1, p_it.qcnt - 1));
+            const int id = (lane >> 3) ? id1 : id0;
+            const int col = p_ks * S_CK + piece * 4;
+            const float* src = (col < p.ld) ? p.q + (int64_t)id * p.ldq + col : p.zeros;
+            const unsigned qbase = __builtin_amdgcn_readfirstlane(
+                slot + (S_STAGE + (G == 8 ? wave * 2 * S_CK : 0)) * (unsigned)sizeof(float));
+            glds16(src, qbase);
+        }
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            const int r = wave * 64 + i * 8 + (lane >> 3);
+            const int64_t pos = p_it.row0 + min(r, p_it.rows - 1);
+            const int c = piece ^ ((r >> 1) & 7);
+            const int col = p_ks * S_CK + c * 4;
+            const float* src = (col < p.ld) ? p.data + pos * p.ld + col : p.zeros;
+            glds16(src, base + i * 8 * S_CK * (unsigned)sizeof(float));
+        }
+        ++pn;
+        if (++p_ks == ksteps) {
+            p_ks = 0;
+            p_item += gridDim.x;
+            if (pn < n_stages) p_it = load_item(p, p_item);
+        }
+    };
+    for (int i = 0; i < nbuf - 1; ++i)
+        if (pn < n_stages) issue();
+
+    // ---- consumer.  Control flow (leaf boundaries, tails) depends on the dimension
+    // only, so it is uniform; inside a branch the G queries are straight-line code.
+    // Query slots past the group's count repeat its last query and are not stored.
+    int64_t c_item = first;
+    int c_ks = 0;
+    Item c_it = p_it;
+    f2 acc[G][4];
+    float res[G];
+    int leaf = 0, in_leaf = 0, sp = 0, L = 0;
+    const int sw = (tid >> 1) & 7;
+
+    for (int64_t n = 0; n < n_stages; ++n) {
+        wait_loads((int)(pn - n - 1));
+        __builtin_amdgcn_s_barrier();
+        if (pn < n_stages) { if (p.diag & 1) ++pn; else issue(); }
+
+        if (c_ks == 0) {
+            c_it = load_item(p, c_item);
+#pragma unroll
+            for (int g = 0; g < G; ++g) {
+#pragma unroll
+                for (int j = 0; j < 4; ++j) acc[g][j] = f2{0.0f, 0.0f};
+            }
+            leaf = 0; in_leaf = 0; sp = 0; L = p.leaf_len[0];
+        }
+
+        const float* xb = smem + (int)(n % nbuf) * SLOT + tid * S_CK;
+        const float* qb = smem + (int)(n % nbuf) * SLOT + S_STAGE;
+        float4 xv[8];
+#pragma unroll
+        for (int c = 0; c < 8; ++c) xv[c] = *reinterpret_cast<const float4*>(xb + ((c ^ sw) << 2));
+
+        // the stage's query values, fetched one unit (8 floats of H queries) ahead of their use
+        float4 qv[2][H][2];
+        auto load_q = [&](int buf, int unit) {
+            const float* src = qb + (unit % U) * H * S_CK + (unit / U) * 8;
+#pragma unroll
+            for (int h = 0; h < H; ++h) {
+                qv[buf][h][0] = *reinterpret_cast<const float4*>(src + h * S_CK);
+                qv[buf][h][1] = *reinterpret_cast<const float4*>(src + h * S_CK + 4);
+            }
+        };
+        load_q(0, 0);
+
+#pragma unroll
+        for (int unit = 0; unit < (S_CK / 8) * U; ++unit) {
+            const int grp = unit / U, g0 = (unit % U) * H;
+            if (unit + 1 < (S_CK / 8) * U) load_q((unit + 1) & 1, unit + 1);
+            const int kpos = c_ks * S_CK + grp * 8;
+            if (kpos < p.dim && !(p.diag & 2)) {
+                const f2 x2[4] = {f2{xv[2 * grp].x, xv[2 * grp].y}, f2{xv[2 * grp].z, xv[2 * grp].w},
+                                  f2{xv[2 * grp + 1].x, xv[2 * grp + 1].y}, f2{xv[2 * grp + 1].z, xv[2 * grp + 1].w}};
+                const int cnt = min(8, L - in_leaf);
+                if (cnt == 8) {
+                    // 8 strided accumulators, zero at the start of a leaf (0 + t == t for these terms)
+#pragma unroll
+                    for (int h = 0; h < H; ++h) {
+                        const float4 qa = qv[unit & 1][h][0], qc = qv[unit & 1][h][1];
+                        const f2 q2[4] = {f2{qa.x, qa.y}, f2{qa.z, qa.w}, f2{qc.x, qc.y}, f2{qc.z, qc.w}};
+#pragma unroll
+                        for (int j = 0; j < 4; ++j) acc[g0 + h][j] = s_accum2<OP>(acc[g0 + h][j], x2[j], q2[j]);
+                    }
+                    if (in_leaf + 8 == L) {
+#pragma unroll
+                        for (int h = 0; h < H; ++h) res[g0 + h] = s_tree2<OP>(acc[g0 + h]);
+                    }
+                } else {
+                    // sequential tail of the leaf (or a leaf shorter than 8)
+                    const float xs[8] = {x2[0].x, x2[0].y, x2[1].x, x2[1].y, x2[2].x, x2[2].y, x2[3].x, x2[3].y};
+#pragma unroll
+                    for (int h = 0; h < H; ++h) {
+                        const float4 qa = qv[unit & 1][h][0], qc = qv[unit & 1][h][1];
+                        const float qs[8] = {qa.x, qa.y, qa.z, qa.w, qc.x, qc.y, qc.z, qc.w};
+                        float r = in_leaf == 0 ? 0.0f : s_tree2<OP>(acc[g0 + h]);
+#pragma unroll
+                        for (int j = 0; j < 8; ++j)
+                            if (j < cnt) r = s_comb<OP>(r, s_term<OP>(xs[j], qs[j]));
+                        res[g0 + h] = r;
+                    }
+                }
+                if (unit % U == U - 1) {
+                    in_leaf += cnt;
+                    if (in_leaf == L) {
+                        if (!one_leaf) {
+                            // leaf finished: push, then fold pending partial sums right into left
+#pragma unroll
+                            for (int g = 0; g < G; ++g) St[(sp * G + g) * S_NT + tid] = res[g];
+                            ++sp;
+                            for (int f = 0; f < p.folds[leaf]; ++f) {
+#pragma unroll
+                                for (int g = 0; g < G; ++g) {
+                                    const float b = St[((sp - 1) * G + g) * S_NT + tid];
+                                    const float a = St[((sp - 2) * G + g) * S_NT + tid];
+                                    St[((sp - 2) * G + g) * S_NT + tid] = s_comb<OP>(a, b);
+                                }
+                                --sp;
+                            }
+                        }
+                        ++leaf;
+                        in_leaf = 0;
+                        L = (leaf < p.n_leaves) ? p.leaf_len[leaf] : 0;
+#pragma unroll
+                        for (int g = 0; g < G; ++g) {
+#pragma unroll
+                            for (int j = 0; j < 4; ++j) acc[g][j] = f2{0.0f, 0.0f};
+                        }
+                    }
+                }
+            }
+        }
+
+        if (++c_ks == ksteps) {
+            c_ks = 0;
+            c_item += gridDim.x;
+            const int64_t chunk_off = c_it.out_rel + tid;
+            const bool live = tid < c_it.rows;
+#pragma unroll
+            for (int g = 0; g < G; ++g) {
+                if (g < c_it.qcnt) {
+                    float v = one_leaf ? res[g] : St[g * S_NT + tid];
+                    if (p.post == POST_SQRT) v = sqrtf(v);
+                    else if (p.post == POST_NEG) v = -v;
+                    const int64_t ob = uload(p.sq_out + c_it.qbeg + g);
+                    if (live) p.out[ob + chunk_off] = v;
+                }
+            }
+        }
+    }
+}
+
+// --------------------------------------------------------------------------
+static int stream_depth(const SumPlan& plan) {
+    int sp = 0, depth = 0;
+    for (int i = 0; i < plan.n_leaves; ++i) {
+        ++sp;
+        depth = std::max(depth, sp);
+        sp -= plan.folds[i];
+    }
+    return plan.n_leaves > 1 ? depth : 0;
+}
+
+int launch_stream_sums(const StreamJob& j, hipStream_t s) {
+    VDB_REQUIRE(j.group == 1 || j.group == 8, "query group must be 1 or 8");
+    VDB_REQUIRE(j.ld % 4 == 0 && j.ld >= j.dim, "stored rows must be padded to a multiple of 4 floats");
+    StreamParams p{};
+    p.data = j.data; p.ld = j.ld; p.dim = j.dim; p.post = j.post;
+    p.n_leaves = j.plan.n_leaves;
+    for (int i = 0; i < j.plan.n_leaves; ++i) { p.leaf_len[i] = j.plan.leaf_len[i]; p.folds[i] = j.plan.folds[i]; }
+    p.q = j.q; p.ldq = j.ldq; p.zeros = ctx().zeros;
+    p.n_seg = j.n_seg; p.seg_row_off = j.seg_row_off; p.seg_q_off = j.seg_q_off; p.seg_item_off = j.seg_item_off;
+    p.sq_qid = j.sq_qid; p.sq_out = j.sq_out; p.out = j.out; p.items = j.items; p.items_cap = j.items_cap;
+    const size_t stack = (size_t)stream_depth(j.plan) * j.group * S_NT * sizeof(float);
+    const size_t budget = 160 * 1024;
+    const size_t slot = (size_t)(S_STAGE + j.group * S_CK) * sizeof(float);
+    VDB_REQUIRE(stack + 2 * slot <= budget, "dimension %d is too large for the streaming scan", j.dim);
+    p.nbuf = (int)std::min<size_t>(4, (budget - stack) / slot);
+    const size_t lds = (size_t)p.nbuf * slot + stack;
+    static const int diag = getenv("VDB_STREAM_DIAG") ? atoi(getenv("VDB_STREAM_DIAG")) : 0;
+    p.diag = diag;
+    const int grid = ctx().num_cus;               // one block per CU (LDS-bound); blocks past the item count leave at once
+    KernelTimer timer(s, j.timed);
+#define VDB_LAUNCH_STREAM(O, GG)                                                                \
+    {                                                                                            \
+        auto kern = stream_sums_kernel<O, GG>;                                                   \
+        VDB_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern),                         \
+                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));      \
+        hipLaunchKernelGGL(kern, dim3(grid), dim3(S_NT), lds, s, p);                             \
+    }
+#define VDB_LAUNCH_STREAM_OP(O)                                                                  \
+    case O:                                                                                      \
+        if (j.group == 1) VDB_LAUNCH_STREAM(O, 1) else VDB_LAUNCH_STREAM(O, 8)                    \
+        break;
+    switch (j.op) {
+        VDB_LAUNCH_STREAM_OP(OP_DOT)
+        VDB_LAUNCH_STREAM_OP(OP_SQDIFF)
+        VDB_LAUNCH_STREAM_OP(OP_ABSDIFF)
+        VDB_LAUNCH_STREAM_OP(OP_MAXABS)
+        default: VDB_REQUIRE(false, "unknown streaming op %d", j.op);
+    }
+#undef VDB_LAUNCH_STREAM_OP
+#undef VDB_LAUNCH_STREAM
+    VDB_HIP(hipGetLastError());
+    return VDB_OK;
+}
+
+// --------------------------------------------------------------------------
+static int launch_build_items(const StreamPlanBufs& b, const int64_t* seg_row_off, int n_seg, int group, hipStream_t s);
+
+// plan of a flat scan: one segment with every row and every query
+__global__ void flat_plan_kernel(int64_t n, int nq, int group, int64_t out_stride,
+                                 int64_t* seg_row_off, int* seg_q_off, int64_t* seg_item_off,
+                                 int* sq_qid, int64_t* sq_out) {
+    const int t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t == 0) {
+        seg_row_off[0] = 0; seg_row_off[1] = n;
+        seg_q_off[0] = 0; seg_q_off[1] = nq;
+        seg_item_off[0] = 0;
+        seg_item_off[1] = ((n + S_NT - 1) / S_NT) * ((nq + group - 1) / group);
+    }
+    if (t < nq) { sq_qid[t] = t; sq_out[t] = (int64_t)t * out_stride; }
+}
+
+int launch_flat_plan(int64_t n, int nq, int group, int64_t out_stride, const StreamPlanBufs& b, hipStream_t s) {
+    hipLaunchKernelGGL(flat_plan_kernel, dim3((nq + 255) / 256), dim3(256), 0, s, n, nq, group, out_stride,
+                       b.seg_row_off, b.seg_q_off, b.seg_item_off, b.sq_qid, b.sq_out);
+    VDB_HIP(hipGetLastError());
+    return launch_build_items(b, b.seg_row_off, 1, group, s);
+}
+
+
+// expands the per-segment item counts into the item table (one thread per item)
+__global__ void build_items_kernel(int n_seg, int group, const int64_t* __restrict__ seg_row_off,
+                                   const int* __restrict__ seg_q_off, const int64_t* __restrict__ seg_item_off,
+                                   int64_t cap, StreamItem* __restrict__ items) {
+    const int64_t total = min(seg_item_off[n_seg], cap);
+    for (int64_t item = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; item < total; item += (int64_t)gridDim.x * blockDim.x) {
+        int lo = 0, hi = n_seg;                      // seg_item_off[lo] <= item < seg_item_off[hi]
+        while (hi - lo > 1) {
+            const int mid = (lo + hi) >> 1;
+            if (seg_item_off[mid] <= item) lo = mid; else hi = mid;
+        }
+        const int64_t local = item - seg_item_off[lo];
+        const int q0 = seg_q_off[lo];
+        const int nqs = seg_q_off[lo + 1] - q0;
+        const int groups = (nqs + group - 1) / group;
+        const int64_t chunk = local / groups;
+        const int grp = (int)(local - chunk * groups);
+        const int64_t r0 = seg_row_off[lo], r1 = seg_row_off[lo + 1];
+        StreamItem it;
+        it.out_rel = chunk * S_NT;
+        it.row0 = r0 + it.out_rel;
+        it.rows = (int)min<int64_t>(S_NT, r1 - it.row0);
+        it.qbeg = q0 + grp * group;
+        it.qcnt = min(group, nqs - grp * group);
+        it.pad = 0;
+        items[item] = it;
+    }
+}
+
+static int launch_build_items(const StreamPlanBufs& b, const int64_t* seg_row_off, int n_seg, int group, hipStream_t s) {
+    const int grid = (int)std::max<int64_t>(1, std::min<int64_t>((b.items_cap + 255) / 256, 4096));
+    hipLaunchKernelGGL(build_items_kernel, dim3(grid), dim3(256), 0, s, n_seg, group, seg_row_off, b.seg_q_off,
+                       b.seg_item_off, b.items_cap, b.items);
+    VDB_HIP(hipGetLastError());
+    return VDB_OK;
+}
+
+// --------------------------------------------------------------------------
+// plan of an IVF list scan.  probes[nq][n_probe] lists the probed inverted lists
+// of every query in ranking order.  Candidate slot of (query q, probe p, list row
+// r) = q * cand_stride + cand_off[q][p] + r, so a query's slots follow the order
+// in which the reference visits its candidates (index/ivf.py:619-628).
+// A probe entry outside [0, n_lists) (a query whose centroid distances are all NaN has
+// no ranking) stands for an empty list.
+__global__ void ivf_plan_count_kernel(const int* __restrict__ probes, int nq, int n_probe, int n_lists,
+                                      const int64_t* __restrict__ list_off, int* __restrict__ list_cnt,
+                                      int64_t* __restrict__ cand_off) {
+    const int q = blockIdx.x * blockDim.x + threadIdx.x;
+    if (q >= nq) return;
+    int64_t run = 0;
+    for (int pr = 0; pr < n_probe; ++pr) {
+        const int l = probes[(int64_t)q * n_probe + pr];
+        cand_off[(int64_t)q * (n_probe + 1) + pr] = run;
+        if (l < 0 || l >= n_lists) continue;
+        run += list_off[l + 1] - list_off[l];
+        atomicAdd(&list_cnt[l], 1);
+    }
+    cand_off[(int64_t)q * (n_probe + 1) + n_probe] = run;
+}
+
+// exclusive scans over the lists: query entries and items (single block)
+__global__ __launch_bounds__(1024) void ivf_plan_scan_kernel(const int* __restrict__ list_cnt, const int64_t* __restrict__ list_off,
+                                                             int n_lists, int group, int* __restrict__ seg_q_off,
+                                                             int64_t* __restrict__ seg_item_off, int* __restrict__ cursor) {
+    __shared__ int64_t sh_items[1024];
+    __shared__ int sh_cnt[1024];
+    __shared__ int64_t carry_items;
+    __shared__ int carry_cnt;
+    const int tid = threadIdx.x;
+    if (tid == 0) { carry_items = 0; carry_cnt = 0; }
+    __syncthreads();
+    for (int base = 0; base < n_lists; base += 1024) {
+        const int l = base + tid;
+        int c = 0;
+        int64_t items = 0;
+        if (l < n_lists) {
+            c = list_cnt[l];
+            const int64_t len = list_off[l + 1] - list_off[l];
+            items = ((len + S_NT - 1) / S_NT) * ((c + group - 1) / group);
+        }
+        sh_cnt[tid] = c;
+        sh_items[tid] = items;
+        __syncthreads();
+        for (int off = 1; off < 1024; off <<= 1) {
+            int a = 0;
+            int64_t b = 0;
+            if (tid >= off) { a = sh_cnt[tid - off]; b = sh_items[tid - off]; }
+            __syncthreads();
+            sh_cnt[tid] += a;
+            sh_items[tid] += b;
+            __syncthreads();
+        }
+        if (l < n_lists) {
+            seg_q_off[l] = carry_cnt + sh_cnt[tid] - c;
+            seg_item_off[l] = carry_items + sh_items[tid] - items;
+            cursor[l] = carry_cnt + sh_cnt[tid] - c;
+        }
+        __syncthreads();
+        if (tid == 1023) { carry_cnt += sh_cnt[1023]; carry_items += sh_items[1023]; }
+        __syncthreads();
+    }
+    if (tid == 0) { seg_q_off[n_lists] = carry_cnt; seg_item_off[n_lists] = carry_items; }
+}
+
+__global__ void ivf_plan_fill_kernel(const int* __restrict__ probes, int nq, int n_probe, int n_lists, int64_t cand_stride,
+                                     const int64_t* __restrict__ cand_off, int* __restrict__ cursor,
+                                     int* __restrict__ sq_qid, int64_t* __restrict__ sq_out) {
+    const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= (int64_t)nq * n_probe) return;
+    const int q = (int)(t / n_probe), pr = (int)(t - (int64_t)q * n_probe);
+    const int l = probes[t];
+    if (l < 0 || l >= n_lists) return;
+    const int slot = atomicAdd(&cursor[l], 1);
+    sq_qid[slot] = q;
+    sq_out[slot] = (int64_t)q * cand_stride + cand_off[(int64_t)q * (n_probe + 1) + pr];
+}
+
+int launch_ivf_plan(const int* probes, int nq, int n_probe, const int64_t* list_off, int n_lists, int group,
+                    int64_t cand_stride, int* list_cnt, int* cursor, int64_t* cand_off, const StreamPlanBufs& b,
+                    hipStream_t s) {
+    VDB_HIP(hipMemsetAsync(list_cnt, 0, (size_t)n_lists * sizeof(int), s));
+    hipLaunchKernelGGL(ivf_plan_count_kernel, dim3((nq + 255) / 256), dim3(256), 0, s, probes, nq, n_probe, n_lists,
+                       list_off, list_cnt, cand_off);
+    hipLaunchKernelGGL(ivf_plan_scan_kernel, dim3(1), dim3(1024), 0, s, list_cnt, list_off, n_lists, group, b.seg_q_off,
+                       b.seg_item_off, cursor);
+    const int64_t total = (int64_t)nq * n_probe;
+    hipLaunchKernelGGL(ivf_plan_fill_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, probes, nq, n_probe,
+                       n_lists, cand_stride, cand_off, cursor, b.sq_qid, b.sq_out);
+    VDB_HIP(hipGetLastError());
+    return launch_build_items(b, list_off, n_lists, group, s);
+}
+
+// --------------------------------------------------------------------------
+// distance finish: the streamed sum -> the metric's value
+struct Finish {
+    int metric;
+    const float* q_sq; const float* q_nrm;       // per query
+    const float* row_sq; const float* row_nrm;   // per stored row
+};
+
+__device__ __forceinline__ float finish_value(const Finish& f, float sum, float q_sq, float q_nrm, int64_t pos) {
+    switch (f.metric) {
+        case VDB_EUCLIDEAN: case VDB_EUCLIDEAN_SQ: {
+            const float sq = fmaxf(__fmaf_rn(-2.0f, sum, q_sq + f.row_sq[pos]), 0.0f);     // metrics.py:456-462
+            return f.metric == VDB_EUCLIDEAN ? sqrtf(sq) : sq;
+        }
+        case VDB_COSINE: {
+            if (q_nrm < 1e-8f) return 1.0f;                          // metrics.py:472-473
+            float cn = f.row_nrm[pos];
+            if (cn < 1e-8f) cn = 1.0f;                               // metrics.py:476
+            const float sim = fminf(fmaxf(sum / (q_nrm * cn), -1.0f), 1.0f);
+            return 1.0f - sim;
+        }
+        case VDB_COSINE_PAIR: {
+            const float den = q_nrm * f.row_nrm[pos];                // metrics.py:96-100
+            const float sim = den < 1e-8f ? 0.0f : sum / den;
+            return 1.0f - sim;
+        }
+        default: return sum;      // already final (direct forms, Manhattan, Chebyshev, negated dot)
+    }
+}
+
+__global__ void finish_dist_kernel(Finish f, float* __restrict__ v, int nq, int64_t n) {
+    const int64_t total = (int64_t)nq * n;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+        const int q = (int)(i / n);
+        const int64_t pos = i - (int64_t)q * n;
+        v[i] = finish_value(f, v[i], f.q_sq ? f.q_sq[q] : 0.0f, f.q_nrm ? f.q_nrm[q] : 0.0f, pos);
+    }
+}
+
+int launch_finish_dist(int metric, const float* q_sq, const float* q_nrm, const float* row_sq, const float* row_nrm,
+                       float* v, int nq, int64_t n, hipStream_t s) {
+    if (metric != VDB_EUCLIDEAN && metric != VDB_EUCLIDEAN_SQ && metric != VDB_COSINE && metric != VDB_COSINE_PAIR)
+        return VDB_OK;
+    Finish f{metric, q_sq, q_nrm, row_sq, row_nrm};
+    const int64_t total = (int64_t)nq * n;
+    hipLaunchKernelGGL(finish_dist_kernel, dim3((unsigned)std::min<int64_t>((total + 255) / 256, 16384)), dim3(256), 0, s,
+                       f, v, nq, n);
+    VDB_HIP(hipGetLastError());
+    return VDB_OK;
+}
+
+// --------------------------------------------------------------------------
+// per query: finish, filter and keep the k best candidates of its slice
+struct CandParams {
+    const float* cand; int64_t cand_stride;      // query q owns cand[q*cand_stride ...]
+    int64_t n;                                   // flat: candidates per query (slot = stored row)
+    const int* probes; int n_probe; int n_lists; // lists: probed lists of every query, or null
+    const int64_t* list_off;
+    const int* row_ids;                          // stored position -> row number (null = identity)
+    const uint32_t* mask;                        // by row number
+    Finish fin;
+    const float* lb_d; const int64_t* lb_k;      // exclusive lower bound (distance, slot) per query
+    float radius; int use_radius;
+    int k; int splits;
+    float* part_d; int* part_i;                  // [nq][splits][k], idx = candidate slot
+};
+
+__global__ __launch_bounds__(LIST_NT) void topk_cand_kernel(CandParams p) {
+    extern __shared__ __align__(16) float smem[];
+    float* Ld = smem;
+    int* Li = reinterpret_cast<int*>(Ld + p.k * LIST_NT);
+    int* Red = Li + p.k * LIST_NT;
+    const int tid = threadIdx.x;
+    const int qi = blockIdx.x, split = blockIdx.y;
+    const int k = p.k;
+    list_init(Ld, Li, k, tid);
+    float own_kth = INFINITY;
+    const float q_sq = p.fin.q_sq ? p.fin.q_sq[qi] : 0.0f;
+    const float q_nrm = p.fin.q_nrm ? p.fin.q_nrm[qi] : 0.0f;
+    float lbd = -INFINITY;
+    int64_t lbk = -1;
+    if (p.lb_d) { lbd = p.lb_d[qi]; lbk = p.lb_k[qi]; }
+    const float* cq = p.cand + (int64_t)qi * p.cand_stride;
+
+    const int n_runs = p.probes ? p.n_probe : 1;
+    int64_t slot0 = 0;          // first slot of the run
+    int64_t tile0 = 0;          // tiles before the run
+    for (int run = 0; run < n_runs; ++run) {
+        int64_t pos0 = 0, len = p.n;
+        if (p.probes) {
+            const int l = p.probes[(int64_t)qi * p.n_probe + run];
+            len = 0;
+            if (l >= 0 && l < p.n_lists) { pos0 = p.list_off[l]; len = p.list_off[l + 1] - pos0; }
+        }
+        const int64_t tiles = (len + LIST_NT - 1) / LIST_NT;
+        // tiles are dealt to the splits round-robin over the whole slice
+        int64_t t = (split - tile0 % p.splits + p.splits) % p.splits;
+        for (; t < tiles; t += p.splits) {
+            const int64_t r = t * LIST_NT + tid;
+            if (r >= len) continue;
+            const int64_t pos = pos0 + r;
+            const int64_t slot = slot0 + r;
+            const float d = finish_value(p.fin, cq[slot], q_sq, q_nrm, pos);
+            const int row = p.row_ids ? p.row_ids[pos] : (int)pos;
+            if (p.mask && !((p.mask[row >> 5] >> (row & 31)) & 1u)) continue;
+            if (p.use_radius && !(d <= p.radius)) continue;
+            const bool above = (d > lbd) || (d == lbd && slot > lbk);
+            if (above && d < own_kth) own_kth = list_insert(Ld + tid, Li + tid, k, d, (int)slot);
+        }
+        slot0 += len;
+        tile0 += tiles;
+    }
+    float* od = p.part_d + ((int64_t)qi * p.splits + split) * k;
+    int* oi = p.part_i + ((int64_t)qi * p.splits + split) * k;
+    block_reduce_lists(Ld, Li, k, tid, Red, od, oi);
+}
+
+int launch_topk_cand(const CandJob& j, hipStream_t s) {
+    VDB_REQUIRE(j.k >= 1 && j.k <= KMAX_FUSED, "candidate selection supports k <= %d, got %d", KMAX_FUSED, j.k);
+    CandParams p{};
+    p.cand = j.cand; p.cand_stride = j.cand_stride; p.n = j.n; p.probes = j.probes; p.n_probe = j.n_probe; p.n_lists = j.n_lists;
+    p.list_off = j.list_off; p.row_ids = j.row_ids; p.mask = j.mask;
+    p.fin = Finish{j.metric, j.q_sq, j.q_nrm, j.row_sq, j.row_nrm};
+    p.lb_d = j.lb_d; p.lb_k = j.lb_k; p.radius = j.radius; p.use_radius = j.use_radius;
+    p.k = j.k; p.splits = j.splits; p.part_d = j.part_d; p.part_i = j.part_i;
+    const size_t lds = (size_t)j.k * LIST_NT * 8 + 12 * sizeof(int);
+    VDB_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(topk_cand_kernel),
+                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    hipLaunchKernelGGL(topk_cand_kernel, dim3(j.nq, j.splits), dim3(LIST_NT), lds, s, p);
+    VDB_HIP(hipGetLastError());
+    return VDB_OK;
+}
+
+// candidate slot -> row number for the results of a list scan
+__global__ void ivf_rows_kernel(const int* __restrict__ slots, int nq, int k, int out_stride, int out_off,
+                                const int* __restrict__ probes, int n_probe, int n_lists, const int64_t* __restrict__ cand_off,
+                                const int64_t* __restrict__ list_off, const int* __restrict__ row_ids,
+                                int64_t* __restrict__ out_rows) {
+    const int t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= nq * k) return;
+    const int q = t / k, r = t - q * k;
+    const int64_t at = (int64_t)q * out_stride + out_off + r;
+    const int slot = slots[at];
+    if (slot < 0) { out_rows[at] = -1; return; }
+    const int64_t* co = cand_off + (int64_t)q * (n_probe + 1);
+    int lo = 0, hi = n_probe;                   // co[lo] <= slot < co[hi]
+    while (hi - lo > 1) {
+        const int mid = (lo + hi) >> 1;
+        if (co[mid] <= slot) lo = mid; else hi = mid;
+    }
+    const int l = probes[(int64_t)q * n_probe + lo];
+    out_rows[at] = (l >= 0 && l < n_lists) ? (int64_t)row_ids[list_off[l] + (slot - co[lo])] : -1;
+}
+
+int launch_ivf_rows(const int* slots, int nq, int k, int out_stride, int out_off, const int* probes, int n_probe, int n_lists,
+                    const int64_t* cand_off, const int64_t* list_off, const int* row_ids, int64_t* out_rows, hipStream_t s) {
+    if (nq <= 0 || k <= 0) return VDB_OK;
+    hipLaunchKernelGGL(ivf_rows_kernel, dim3((nq * k + 255) / 256), dim3(256), 0, s, slots, nq, k, out_stride, out_off,
+                       probes, n_probe, n_lists, cand_off, list_off, row_ids, out_rows);
+    VDB_HIP(hipGetLastError());
+    return VDB_OK;
+}
+
+}  // namespace vdb

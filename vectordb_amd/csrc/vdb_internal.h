@@ -47,6 +47,7 @@ struct Context {
     int device = -1;
     hipStream_t stream = nullptr;   // the library's own stream
     int num_cus = 256;
+    float* zeros = nullptr;         // 256 zero bytes in device memory
     std::mutex mu;                  // serialises calls that share workspaces
 };
 Context& ctx();
@@ -152,6 +153,67 @@ struct ScanJob {
 };
 int scan_num_cand(const ScanJob& j, int* n_cand);
 int launch_scan(const ScanJob& j, hipStream_t s);
+
+// streaming pipeline: pairwise-ordered sums for (row chunk, query group) items -> candidate buffer
+enum ScanOp { OP_DOT = 0, OP_SQDIFF = 1, OP_ABSDIFF = 2, OP_MAXABS = 3, OP_SQ = 4 };
+enum StreamPost { POST_NONE = 0, POST_SQRT = 1, POST_NEG = 2 };
+static inline int op_of_metric(int metric) {
+    switch (metric) {
+        case VDB_EUCLIDEAN: case VDB_EUCLIDEAN_SQ: case VDB_COSINE: case VDB_DOT: case VDB_COSINE_PAIR: return OP_DOT;
+        case VDB_EUCLIDEAN_DIRECT: case VDB_EUCLIDEAN_SQ_DIRECT: return OP_SQDIFF;
+        case VDB_MANHATTAN: return OP_ABSDIFF;
+        case VDB_CHEBYSHEV: return OP_MAXABS;
+        default: return OP_SQ;
+    }
+}
+static inline int post_of_metric(int metric) {
+    return metric == VDB_EUCLIDEAN_DIRECT ? POST_SQRT : (metric == VDB_DOT ? POST_NEG : POST_NONE);
+}
+struct StreamItem {                 // one (row chunk, query group) unit of work
+    int64_t row0;                   // first stored row of the chunk
+    int64_t out_rel;                // chunk's first row relative to the first row of its segment
+    int rows;                       // rows in the chunk (1..256)
+    int qbeg; int qcnt;             // the group's entries in sq_qid / sq_out
+    int pad;
+};
+struct StreamPlanBufs {             // device arrays describing the items of one launch
+    int64_t* seg_row_off; int* seg_q_off; int64_t* seg_item_off;   // [n_seg + 1] each
+    int* sq_qid; int64_t* sq_out;                                  // one entry per (segment, query) pair
+    StreamItem* items; int64_t items_cap;                          // item table and its capacity
+};
+struct StreamJob {
+    const float* data; int ld; int dim; SumPlan plan;
+    int op; int post;
+    const float* q; int ldq;        // query rows; readable up to 8 floats past the last row
+    int group;                      // queries per item: 1 or 8
+    int n_seg;
+    const int64_t* seg_row_off; const int* seg_q_off; const int64_t* seg_item_off;
+    const int* sq_qid; const int64_t* sq_out;
+    const StreamItem* items; int64_t items_cap;
+    float* out;
+    bool timed;
+};
+int launch_stream_sums(const StreamJob& j, hipStream_t s);
+int launch_flat_plan(int64_t n, int nq, int group, int64_t out_stride, const StreamPlanBufs& b, hipStream_t s);
+int launch_ivf_plan(const int* probes, int nq, int n_probe, const int64_t* list_off, int n_lists, int group,
+                    int64_t cand_stride, int* list_cnt, int* cursor, int64_t* cand_off, const StreamPlanBufs& b,
+                    hipStream_t s);
+// in-place distance finish of a [nq][n] matrix of streamed sums (identity-form L2 and cosine only)
+int launch_finish_dist(int metric, const float* q_sq, const float* q_nrm, const float* row_sq, const float* row_nrm,
+                       float* v, int nq, int64_t n, hipStream_t s);
+// per query: finish + filter + k best of its slice of the candidate buffer -> part lists [nq][splits][k]
+struct CandJob {
+    const float* cand; int64_t cand_stride; int nq;
+    int64_t n;                                        // flat: candidates per query (slot = stored row)
+    const int* probes; int n_probe; int n_lists; const int64_t* list_off;   // lists (probes == null: flat)
+    const int* row_ids; const uint32_t* mask;
+    int metric; const float* q_sq; const float* q_nrm; const float* row_sq; const float* row_nrm;
+    const float* lb_d; const int64_t* lb_k; float radius; int use_radius;
+    int k; int splits; float* part_d; int* part_i;
+};
+int launch_topk_cand(const CandJob& j, hipStream_t s);
+int launch_ivf_rows(const int* slots, int nq, int k, int out_stride, int out_off, const int* probes, int n_probe, int n_lists,
+                    const int64_t* cand_off, const int64_t* list_off, const int* row_ids, int64_t* out_rows, hipStream_t s);
 
 // final selection: per query, the k best of n_cand ascending candidate lists of k,
 // layout [nq][n_cand][k], under the (distance, tie key) order with
