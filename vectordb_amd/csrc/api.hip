@@ -142,11 +142,11 @@ static int fill_results(float* d, int64_t* i, int64_t total, hipStream_t s) {
 // ============================================================== workspaces
 struct Workspace {
     DevBuf q_buf, q_sq, q_nrm, part_d, part_i, lb_d, lb_k, thr_d, thr_k, mask, out_d, out_i, dist, probes, probe_d, lut, stage;
-    DevBuf cand, seg_row_off, seg_q_off, seg_item_off, sq_qid, sq_out, cand_off, list_cnt, cursor, slots, items;
+    DevBuf cand, seg_row_off, seg_q_off, seg_item_off, sq_qid, sq_out, cand_off, tile_off, list_cnt, cursor, slots, items;
     void release() {
         DevBuf* all[] = {&q_buf, &q_sq, &q_nrm, &part_d, &part_i, &lb_d, &lb_k, &thr_d, &thr_k, &mask, &out_d, &out_i, &dist,
                          &probes, &probe_d, &lut, &stage, &cand, &seg_row_off, &seg_q_off, &seg_item_off, &sq_qid, &sq_out,
-                         &cand_off, &list_cnt, &cursor, &slots, &items};
+                         &cand_off, &tile_off, &list_cnt, &cursor, &slots, &items};
         for (DevBuf* b : all) b->release();
     }
 };
@@ -221,6 +221,16 @@ static int rows_append_dev_impl(vdb_rows* h, const float* d_rows, int64_t n, int
 // ---- streaming scan of all rows for a block of queries: candidate buffer [nq][n] of streamed sums
 static const int64_t CAND_BUDGET = (int64_t)1 << 30;      // bytes of candidate buffer per pass
 
+// blocks per query of the candidate selection: enough to fill the chip several times over
+// and to keep a thread's serial walk short (each step waits on dependent loads)
+static int cand_splits(int64_t tiles, int nq) {
+    static const int forced = getenv("VDB_CAND_SPLITS") ? atoi(getenv("VDB_CAND_SPLITS")) : 0;
+    if (forced > 0) return (int)std::min<int64_t>(tiles, forced);
+    const int64_t by_chip = (4 * (int64_t)ctx().num_cus + nq - 1) / nq;
+    const int64_t by_walk = (tiles + 63) / 64;
+    return (int)std::max<int64_t>(1, std::min<int64_t>(tiles, std::max(by_chip, by_walk)));
+}
+
 static int reserve_stream_plan(Workspace& ws, int n_seg, int64_t n_pairs, int64_t items_cap, StreamPlanBufs* b) {
     VDB_TRY(ws.seg_row_off.reserve((size_t)(n_seg + 1) * sizeof(int64_t)));
     VDB_TRY(ws.seg_q_off.reserve((size_t)(n_seg + 1) * sizeof(int)));
@@ -265,9 +275,10 @@ static int stream_flat_search(vdb_rows* h, int metric, const float* q, int nq, i
     for (int q0 = 0; q0 < nq; q0 += q_block) {
         const int nb = std::min(q_block, nq - q0);
         // enough blocks to fill the chip, at least 8 tiles each
-        const int splits = (int)std::max<int64_t>(1, std::min<int64_t>((ntiles + 7) / 8, (2 * ctx().num_cus + nb - 1) / nb));
-        VDB_TRY(ws.part_d.reserve((size_t)nb * splits * kmax * sizeof(float)));
-        VDB_TRY(ws.part_i.reserve((size_t)nb * splits * kmax * sizeof(int)));
+        const int splits = cand_splits(ntiles, nb);
+        const int n_cand = splits * topk_cand_lists_per_split();
+        VDB_TRY(ws.part_d.reserve((size_t)nb * n_cand * kmax * sizeof(float)));
+        VDB_TRY(ws.part_i.reserve((size_t)nb * n_cand * kmax * sizeof(int)));
         VDB_TRY(stream_flat_sums(ws, r, metric, q + (int64_t)q0 * r.ld, nb, ws.cand.as<float>(), s));
         for (int64_t done = 0; done < k_eff; done += KMAX_FUSED) {
             const int kk = (int)std::min<int64_t>(KMAX_FUSED, k_eff - done);
@@ -281,7 +292,7 @@ static int stream_flat_search(vdb_rows* h, int metric, const float* q, int nq, i
             SelectOut o{d_out_d ? d_out_d + (int64_t)q0 * k : nullptr, d_out_i ? d_out_i + (int64_t)q0 * k : nullptr,
                         d_out_i32 ? d_out_i32 + (int64_t)q0 * k : nullptr, k, (int)done,
                         multi ? ws.lb_d.as<float>() : nullptr, multi ? ws.lb_k.as<int64_t>() : nullptr};
-            VDB_TRY(launch_select(ws.part_d.as<float>(), ws.part_i.as<int>(), nb, splits, kk, 1 << 30, nullptr, 0, o, s));
+            VDB_TRY(launch_select(ws.part_d.as<float>(), ws.part_i.as<int>(), nb, n_cand, kk, 1 << 30, nullptr, 0, o, s));
         }
     }
     return VDB_OK;
@@ -909,6 +920,7 @@ static int ivf_search_impl(vdb_ivf* h, const float* d_q, int nq, int k, int n_pr
     VDB_TRY(reserve_stream_plan(ws, h->n_lists, (int64_t)q_block * n_probe, (int64_t)q_block * (cand_stride / 256 + n_probe), &b));
     VDB_TRY(ws.cand.reserve((size_t)q_block * cand_stride * sizeof(float)));
     VDB_TRY(ws.cand_off.reserve((size_t)q_block * (n_probe + 1) * sizeof(int64_t)));
+    VDB_TRY(ws.tile_off.reserve((size_t)q_block * (n_probe + 1) * sizeof(int)));
     VDB_TRY(ws.list_cnt.reserve((size_t)h->n_lists * sizeof(int)));
     VDB_TRY(ws.cursor.reserve((size_t)h->n_lists * sizeof(int)));
     VDB_TRY(ws.slots.reserve((size_t)nq * k * sizeof(int)));
@@ -922,7 +934,7 @@ static int ivf_search_impl(vdb_ivf* h, const float* d_q, int nq, int k, int n_pr
         const int nb = std::min(q_block, nq - q0);
         const int* probes = ws.probes.as<int>() + (int64_t)q0 * n_probe;
         VDB_TRY(launch_ivf_plan(probes, nb, n_probe, h->list_off.as<int64_t>(), h->n_lists, group, cand_stride,
-                                ws.list_cnt.as<int>(), ws.cursor.as<int>(), ws.cand_off.as<int64_t>(), b, s));
+                                ws.list_cnt.as<int>(), ws.cursor.as<int>(), ws.cand_off.as<int64_t>(), ws.tile_off.as<int>(), b, s));
         StreamJob j{};
         j.data = m->r.data; j.ld = m->r.ld; j.dim = m->r.dim; j.plan = m->r.plan;
         j.op = op_of_metric(sm); j.post = post_of_metric(sm);
@@ -932,14 +944,16 @@ static int ivf_search_impl(vdb_ivf* h, const float* d_q, int nq, int k, int n_pr
         j.out = ws.cand.as<float>(); j.timed = true;
         VDB_TRY(launch_stream_sums(j, s));
 
-        const int splits = (int)std::max<int64_t>(1, std::min<int64_t>((avg_tiles + 7) / 8, (2 * ctx().num_cus + nb - 1) / nb));
-        VDB_TRY(ws.part_d.reserve((size_t)nb * splits * kmax * sizeof(float)));
-        VDB_TRY(ws.part_i.reserve((size_t)nb * splits * kmax * sizeof(int)));
+        const int splits = cand_splits(avg_tiles, nb);
+        const int n_cand = splits * topk_cand_lists_per_split();
+        VDB_TRY(ws.part_d.reserve((size_t)nb * n_cand * kmax * sizeof(float)));
+        VDB_TRY(ws.part_i.reserve((size_t)nb * n_cand * kmax * sizeof(int)));
         for (int64_t done = 0; done < k_eff; done += KMAX_FUSED) {
             const int kk = (int)std::min<int64_t>(KMAX_FUSED, k_eff - done);
             CandJob c{};
             c.cand = ws.cand.as<float>(); c.cand_stride = cand_stride; c.nq = nb; c.n = 0;
             c.probes = probes; c.n_probe = n_probe; c.n_lists = h->n_lists; c.list_off = h->list_off.as<int64_t>();
+            c.cand_off = ws.cand_off.as<int64_t>(); c.tile_off = ws.tile_off.as<int>();
             c.row_ids = h->row_ids.as<int>(); c.mask = d_mask;
             c.metric = sm; c.q_sq = ws.q_sq.as<float>() + q0; c.q_nrm = ws.q_nrm.as<float>() + q0;
             c.row_sq = m->r.sq; c.row_nrm = m->r.nrm;
@@ -948,7 +962,7 @@ static int ivf_search_impl(vdb_ivf* h, const float* d_q, int nq, int k, int n_pr
             VDB_TRY(launch_topk_cand(c, s));
             SelectOut o{d_out_d + (int64_t)q0 * k, nullptr, ws.slots.as<int>() + (int64_t)q0 * k, k, (int)done,
                         multi ? ws.lb_d.as<float>() : nullptr, multi ? ws.lb_k.as<int64_t>() : nullptr};
-            VDB_TRY(launch_select(ws.part_d.as<float>(), ws.part_i.as<int>(), nb, splits, kk, 1 << 30, nullptr, 0, o, s));
+            VDB_TRY(launch_select(ws.part_d.as<float>(), ws.part_i.as<int>(), nb, n_cand, kk, 1 << 30, nullptr, 0, o, s));
             VDB_TRY(launch_ivf_rows(ws.slots.as<int>() + (int64_t)q0 * k, nb, kk, k, (int)done, probes, n_probe, h->n_lists,
                                     ws.cand_off.as<int64_t>(), h->list_off.as<int64_t>(), h->row_ids.as<int>(),
                                     d_out_i + (int64_t)q0 * k, s));

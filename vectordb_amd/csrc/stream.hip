@@ -33,7 +33,7 @@ namespace vdb {
 static constexpr int S_NT = 256;                  // threads = rows per chunk
 static constexpr int S_CK = 32;                   // floats of every row per stage: one 128-byte line
 static constexpr int S_STAGE = S_NT * S_CK;       // floats per stage buffer (32 KiB)
-static constexpr int S_GLDS_PER_STAGE = 9;        // LDS-DMA instructions one wave issues per stage: 8 row pieces + 1 query piece
+static constexpr int STREAM_QS = 2;               // wave sets sharing one row chunk in the 8-query kernels
 
 // One LDS-DMA instruction: every lane fetches 16 bytes from its own global address; the
 // wave's 1 KiB lands at lds_dst (a wave-uniform LDS byte address) in lane order.  Written
@@ -120,104 +120,158 @@ __device__ __forceinline__ Item load_item(const StreamParams& p, int64_t item) {
     return it;
 }
 
-__device__ __forceinline__ void wait_loads(int stages_behind) {
+template <int PER_STAGE> __device__ __forceinline__ void wait_loads(int stages_behind) {
     // the wave's LDS-DMA loads retire in order: leaving `stages_behind` later stages
     // outstanding means the stage in front of them has landed
-    static_assert(S_GLDS_PER_STAGE == 9, "the immediates below are multiples of the per-stage count");
-    if (stages_behind >= 2) asm volatile("s_waitcnt vmcnt(18)" ::: "memory");
-    else if (stages_behind == 1) asm volatile("s_waitcnt vmcnt(9)" ::: "memory");
-    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    static_assert(PER_STAGE == 9 || PER_STAGE == 5 || PER_STAGE == 3, "add the immediates for this count");
+    if (stages_behind >= 2) {
+        if (PER_STAGE == 9) asm volatile("s_waitcnt vmcnt(18)" ::: "memory");
+        else if (PER_STAGE == 5) asm volatile("s_waitcnt vmcnt(10)" ::: "memory");
+        else asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+    } else if (stages_behind == 1) {
+        if (PER_STAGE == 9) asm volatile("s_waitcnt vmcnt(9)" ::: "memory");
+        else if (PER_STAGE == 5) asm volatile("s_waitcnt vmcnt(5)" ::: "memory");
+        else asm volatile("s_waitcnt vmcnt(3)" ::: "memory");
+    } else {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    }
 }
 
-template <int OP, int G>
-__global__ __launch_bounds__(S_NT) void stream_sums_kernel(const StreamParams p) {
+// G queries per item, shared out over QS sets of 4 waves: thread t sums row (t & 255) of
+// the chunk against the G/QS queries of set (t >> 8).  More than one set keeps two or
+// more waves on every SIMD, so one wave's scalar work and waits hide behind another's
+// arithmetic.
+template <int OP, int G, int QS>
+__global__ __launch_bounds__(S_NT * QS) void stream_sums_kernel(const StreamParams p) {
     extern __shared__ __align__(16) float smem[];
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int row = tid & (S_NT - 1);
     const int nbuf = p.nbuf;
-    constexpr int H = G >= 4 ? 4 : G;             // queries per unit of the arithmetic loop
-    constexpr int U = G / H;
+    constexpr int GT = G / QS;                    // queries per thread
+    constexpr int H = GT >= 4 ? 4 : GT;           // queries per unit of the arithmetic loop
+    constexpr int U = GT / H;
+    constexpr int NW = 4 * QS;                    // waves
+    constexpr int ROW_GLDS = 32 / NW;             // row LDS-DMA instructions per wave and stage
+    constexpr int PER_STAGE = ROW_GLDS + 1;
     constexpr int SLOT = S_STAGE + G * S_CK;      // floats per stage slot: 256 row pieces, then the G query pieces
+    const int g_first = __builtin_amdgcn_readfirstlane(tid >> 8) * GT;
     float* St = smem + nbuf * SLOT;               // [depth][G][256] pending partial sums (more than one leaf only)
 
     const int ksteps = (p.ld + S_CK - 1) / S_CK;
     const int64_t total_items = min(uload(p.seg_item_off + p.n_seg), p.items_cap);
     const int64_t first = blockIdx.x;
     if (first >= total_items) return;
-    const int64_t my_items = (total_items - first + gridDim.x - 1) / gridDim.x;
-    const int64_t n_stages = my_items * ksteps;
+    const int my_items = (int)((total_items - first + gridDim.x - 1) / gridDim.x);
+    const int n_stages = my_items * ksteps;
     const bool one_leaf = p.n_leaves == 1;
 
     // ---- producer: stage -> LDS.  Row r of the chunk sits at r*32 floats; its
     // 16-byte piece c is stored at piece position c ^ ((r >> 1) & 7), which makes
     // the one-row-per-thread 16-byte reads below conflict free.
-    int64_t pn = 0, p_item = first;
-    int p_ks = 0;
-    Item p_it = load_item(p, p_item);
+    int pn = 0, p_ks = 0, p_buf = 0;
+    int64_t p_item = first;
     const int piece = lane & 7;
-    // query pieces: the stage's 32 floats of each of the group's queries, 8 lanes per query.
-    // G == 8: wave w fetches queries 2w and 2w+1; G == 1: every wave fetches the same piece.
-    constexpr int QL = G == 8 ? 16 : 8;           // lanes per wave that fetch query pieces
-    const int qg0 = G == 8 ? wave * 2 : 0;       // first of this wave's (at most two) queries
+    // query pieces: the stage's 32 floats of each of the group's queries are G*8 pieces of
+    // 16 bytes; wave w fetches pieces [w*QL, (w+1)*QL) (piece s: query s >> 3, floats (s & 7)*4..)
+    constexpr int QL = (G * 8) / NW;              // lanes per wave that fetch query pieces: 2, 4, 8 or 16
+    static_assert(QL >= 1 && QL <= 16 && (QL & (QL - 1)) == 0, "query pieces must split evenly over the waves");
+    const int sidx = wave * QL + (lane & (QL - 1));
+    const int ga = (wave * QL) >> 3;              // the wave's pieces belong to at most two queries
+    const float* row_src[ROW_GLDS];               // this lane's row pieces of the item, at column 0
+    int row_c4[ROW_GLDS];                         // 4 * (piece of the row this lane fetches)
+    const float* q_src = p.q;
+    auto begin_item = [&]() {
+        const Item it = load_item(p, p_item);
+#pragma unroll
+        for (int i = 0; i < ROW_GLDS; ++i) {
+            const int r = wave * (8 * ROW_GLDS) + i * 8 + (lane >> 3);
+            row_src[i] = p.data + (it.row0 + min(r, it.rows - 1)) * p.ld;
+            row_c4[i] = (piece ^ ((r >> 1) & 7)) * 4;
+        }
+        const int id0 = uload(p.sq_qid + it.qbeg + min(ga, it.qcnt - 1));
+        const int id1 = uload(p.sq_qid + it.qbeg + min(ga + 1, it.qcnt - 1));
+        q_src = p.q + (int64_t)(((sidx >> 3) != ga) ? id1 : id0) * p.ldq + (sidx & 7) * 4;
+    };
+    begin_item();
     auto issue = [&]() {
-        const unsigned slot = (unsigned)(uintptr_t)(smem + (int)(pn % nbuf) * SLOT);
-        const unsigned base = __builtin_amdgcn_readfirstlane(slot + wave * 64 * S_CK * (unsigned)sizeof(float));
+        const unsigned slot = (unsigned)(uintptr_t)(smem + p_buf * SLOT);
+        const unsigned base = __builtin_amdgcn_readfirstlane(slot + wave * (8 * ROW_GLDS) * S_CK * (unsigned)sizeof(float));
+        const int col0 = p_ks * S_CK;
         if (lane < QL) {
-            const int id0 = uload(p.sq_qid + p_it.qbeg + min(qg0, p_it.qcnt - 1));
-            const int id1 = uload(p.sq_qid + p_it.qbeg + min(qg0 + 1, p_it.qcnt - 1));
-            const int id = (lane >> 3) ? id1 : id0;
-            const int col = p_ks * S_CK + piece * 4;
-            const float* src = (col < p.ld) ? p.q + (int64_t)id * p.ldq + col : p.zeros;
-            const unsigned qbase = __builtin_amdgcn_readfirstlane(
-                slot + (S_STAGE + (G == 8 ? wave * 2 * S_CK : 0)) * (unsigned)sizeof(float));
-            glds16(src, qbase);
+            const float* src = (col0 + (sidx & 7) * 4 < p.ld) ? q_src + col0 : p.zeros;
+            glds16(src, __builtin_amdgcn_readfirstlane(slot + (S_STAGE + wave * QL * 4) * (unsigned)sizeof(float)));
         }
 #pragma unroll
-        for (int i = 0; i < 8; ++i) {
-            const int r = wave * 64 + i * 8 + (lane >> 3);
-            const int64_t pos = p_it.row0 + min(r, p_it.rows - 1);
-            const int c = piece ^ ((r >> 1) & 7);
-            const int col = p_ks * S_CK + c * 4;
-            const float* src = (col < p.ld) ? p.data + pos * p.ld + col : p.zeros;
+        for (int i = 0; i < ROW_GLDS; ++i) {
+            const float* src = (col0 + row_c4[i] < p.ld) ? row_src[i] + col0 + row_c4[i] : p.zeros;
             glds16(src, base + i * 8 * S_CK * (unsigned)sizeof(float));
         }
         ++pn;
+        if (++p_buf == nbuf) p_buf = 0;
         if (++p_ks == ksteps) {
             p_ks = 0;
             p_item += gridDim.x;
-            if (pn < n_stages) p_it = load_item(p, p_item);
+            if (pn < n_stages) begin_item();
         }
     };
     for (int i = 0; i < nbuf - 1; ++i)
         if (pn < n_stages) issue();
 
     // ---- consumer.  Control flow (leaf boundaries, tails) depends on the dimension
-    // only, so it is uniform; inside a branch the G queries are straight-line code.
+    // only, so it is uniform; inside a branch the queries are straight-line code.
     // Query slots past the group's count repeat its last query and are not stored.
     int64_t c_item = first;
-    int c_ks = 0;
-    Item c_it = p_it;
-    f2 acc[G][4];
-    float res[G];
+    int c_ks = 0, c_buf = 0;
+    Item c_it{};
+    f2 acc[GT][4];
+    float res[GT];
     int leaf = 0, in_leaf = 0, sp = 0, L = 0;
-    const int sw = (tid >> 1) & 7;
+    const int sw = (row >> 1) & 7;
 
-    for (int64_t n = 0; n < n_stages; ++n) {
-        wait_loads((int)(pn - n - 1));
+    auto zero_acc = [&]() {
+#pragma unroll
+        for (int g = 0; g < GT; ++g) {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) acc[g][j] = f2{0.0f, 0.0f};
+        }
+    };
+    // a leaf is complete: res[] holds its sums
+    auto end_leaf = [&]() {
+        if (!one_leaf) {
+            // push, then fold pending partial sums right into left
+#pragma unroll
+            for (int g = 0; g < GT; ++g) St[(sp * G + g_first + g) * S_NT + row] = res[g];
+            ++sp;
+            for (int f = 0; f < p.folds[leaf]; ++f) {
+#pragma unroll
+                for (int g = 0; g < GT; ++g) {
+                    const float b = St[((sp - 1) * G + g_first + g) * S_NT + row];
+                    const float a = St[((sp - 2) * G + g_first + g) * S_NT + row];
+                    St[((sp - 2) * G + g_first + g) * S_NT + row] = s_comb<OP>(a, b);
+                }
+                --sp;
+            }
+        }
+        ++leaf;
+        in_leaf = 0;
+        L = (leaf < p.n_leaves) ? p.leaf_len[leaf] : 0;
+        zero_acc();
+    };
+
+    for (int n = 0; n < n_stages; ++n) {
+        wait_loads<PER_STAGE>(pn - n - 1);
         __builtin_amdgcn_s_barrier();
         if (pn < n_stages) { if (p.diag & 1) ++pn; else issue(); }
 
         if (c_ks == 0) {
             c_it = load_item(p, c_item);
-#pragma unroll
-            for (int g = 0; g < G; ++g) {
-#pragma unroll
-                for (int j = 0; j < 4; ++j) acc[g][j] = f2{0.0f, 0.0f};
-            }
+            zero_acc();
             leaf = 0; in_leaf = 0; sp = 0; L = p.leaf_len[0];
         }
 
-        const float* xb = smem + (int)(n % nbuf) * SLOT + tid * S_CK;
-        const float* qb = smem + (int)(n % nbuf) * SLOT + S_STAGE;
+        const float* xb = smem + c_buf * SLOT + row * S_CK;
+        const float* qb = smem + c_buf * SLOT + S_STAGE + g_first * S_CK;
+        if (++c_buf == nbuf) c_buf = 0;
         float4 xv[8];
 #pragma unroll
         for (int c = 0; c < 8; ++c) xv[c] = *reinterpret_cast<const float4*>(xb + ((c ^ sw) << 2));
@@ -234,69 +288,62 @@ __global__ __launch_bounds__(S_NT) void stream_sums_kernel(const StreamParams p)
         };
         load_q(0, 0);
 
+        const int col0 = c_ks * S_CK;
+        if (p.diag & 2) {
+        } else if (L - in_leaf >= S_CK) {
+            // the whole stage lies inside one leaf: four full groups of 8, no control flow
 #pragma unroll
-        for (int unit = 0; unit < (S_CK / 8) * U; ++unit) {
-            const int grp = unit / U, g0 = (unit % U) * H;
-            if (unit + 1 < (S_CK / 8) * U) load_q((unit + 1) & 1, unit + 1);
-            const int kpos = c_ks * S_CK + grp * 8;
-            if (kpos < p.dim && !(p.diag & 2)) {
+            for (int unit = 0; unit < (S_CK / 8) * U; ++unit) {
+                const int grp = unit / U, g0 = (unit % U) * H;
+                if (unit + 1 < (S_CK / 8) * U) load_q((unit + 1) & 1, unit + 1);
                 const f2 x2[4] = {f2{xv[2 * grp].x, xv[2 * grp].y}, f2{xv[2 * grp].z, xv[2 * grp].w},
                                   f2{xv[2 * grp + 1].x, xv[2 * grp + 1].y}, f2{xv[2 * grp + 1].z, xv[2 * grp + 1].w}};
-                const int cnt = min(8, L - in_leaf);
-                if (cnt == 8) {
-                    // 8 strided accumulators, zero at the start of a leaf (0 + t == t for these terms)
 #pragma unroll
-                    for (int h = 0; h < H; ++h) {
-                        const float4 qa = qv[unit & 1][h][0], qc = qv[unit & 1][h][1];
-                        const f2 q2[4] = {f2{qa.x, qa.y}, f2{qa.z, qa.w}, f2{qc.x, qc.y}, f2{qc.z, qc.w}};
+                for (int h = 0; h < H; ++h) {
+                    const float4 qa = qv[unit & 1][h][0], qc = qv[unit & 1][h][1];
+                    const f2 q2[4] = {f2{qa.x, qa.y}, f2{qa.z, qa.w}, f2{qc.x, qc.y}, f2{qc.z, qc.w}};
 #pragma unroll
-                        for (int j = 0; j < 4; ++j) acc[g0 + h][j] = s_accum2<OP>(acc[g0 + h][j], x2[j], q2[j]);
-                    }
-                    if (in_leaf + 8 == L) {
-#pragma unroll
-                        for (int h = 0; h < H; ++h) res[g0 + h] = s_tree2<OP>(acc[g0 + h]);
-                    }
-                } else {
-                    // sequential tail of the leaf (or a leaf shorter than 8)
-                    const float xs[8] = {x2[0].x, x2[0].y, x2[1].x, x2[1].y, x2[2].x, x2[2].y, x2[3].x, x2[3].y};
-#pragma unroll
-                    for (int h = 0; h < H; ++h) {
-                        const float4 qa = qv[unit & 1][h][0], qc = qv[unit & 1][h][1];
-                        const float qs[8] = {qa.x, qa.y, qa.z, qa.w, qc.x, qc.y, qc.z, qc.w};
-                        float r = in_leaf == 0 ? 0.0f : s_tree2<OP>(acc[g0 + h]);
-#pragma unroll
-                        for (int j = 0; j < 8; ++j)
-                            if (j < cnt) r = s_comb<OP>(r, s_term<OP>(xs[j], qs[j]));
-                        res[g0 + h] = r;
-                    }
+                    for (int j = 0; j < 4; ++j) acc[g0 + h][j] = s_accum2<OP>(acc[g0 + h][j], x2[j], q2[j]);
                 }
-                if (unit % U == U - 1) {
-                    in_leaf += cnt;
-                    if (in_leaf == L) {
-                        if (!one_leaf) {
-                            // leaf finished: push, then fold pending partial sums right into left
+                __builtin_amdgcn_sched_barrier(0);      // keep the query reads one unit ahead, not all at the top
+            }
+            in_leaf += S_CK;
+            if (in_leaf == L) {
 #pragma unroll
-                            for (int g = 0; g < G; ++g) St[(sp * G + g) * S_NT + tid] = res[g];
-                            ++sp;
-                            for (int f = 0; f < p.folds[leaf]; ++f) {
+                for (int g = 0; g < GT; ++g) res[g] = s_tree2<OP>(acc[g]);
+                end_leaf();
+            }
+        } else {
+            // a leaf ends inside the stage, or the dimension does: group by group (rare, kept simple)
 #pragma unroll
-                                for (int g = 0; g < G; ++g) {
-                                    const float b = St[((sp - 1) * G + g) * S_NT + tid];
-                                    const float a = St[((sp - 2) * G + g) * S_NT + tid];
-                                    St[((sp - 2) * G + g) * S_NT + tid] = s_comb<OP>(a, b);
-                                }
-                                --sp;
-                            }
+            for (int grp = 0; grp < S_CK / 8; ++grp) {
+                if (col0 + grp * 8 < p.dim) {
+                    const f2 x2[4] = {f2{xv[2 * grp].x, xv[2 * grp].y}, f2{xv[2 * grp].z, xv[2 * grp].w},
+                                      f2{xv[2 * grp + 1].x, xv[2 * grp + 1].y}, f2{xv[2 * grp + 1].z, xv[2 * grp + 1].w}};
+                    const float xs[8] = {x2[0].x, x2[0].y, x2[1].x, x2[1].y, x2[2].x, x2[2].y, x2[3].x, x2[3].y};
+                    const int cnt = min(8, L - in_leaf);
+#pragma unroll
+                    for (int g = 0; g < GT; ++g) {
+                        const float4 qa = *reinterpret_cast<const float4*>(qb + g * S_CK + grp * 8);
+                        const float4 qc = *reinterpret_cast<const float4*>(qb + g * S_CK + grp * 8 + 4);
+                        if (cnt == 8) {
+                            const f2 q2[4] = {f2{qa.x, qa.y}, f2{qa.z, qa.w}, f2{qc.x, qc.y}, f2{qc.z, qc.w}};
+#pragma unroll
+                            for (int j = 0; j < 4; ++j) acc[g][j] = s_accum2<OP>(acc[g][j], x2[j], q2[j]);
+                            res[g] = s_tree2<OP>(acc[g]);
+                        } else {
+                            // sequential tail of the leaf (or a leaf shorter than 8)
+                            const float qs[8] = {qa.x, qa.y, qa.z, qa.w, qc.x, qc.y, qc.z, qc.w};
+                            float r = in_leaf == 0 ? 0.0f : s_tree2<OP>(acc[g]);
+#pragma unroll
+                            for (int j = 0; j < 8; ++j)
+                                if (j < cnt) r = s_comb<OP>(r, s_term<OP>(xs[j], qs[j]));
+                            res[g] = r;
                         }
-                        ++leaf;
-                        in_leaf = 0;
-                        L = (leaf < p.n_leaves) ? p.leaf_len[leaf] : 0;
-#pragma unroll
-                        for (int g = 0; g < G; ++g) {
-#pragma unroll
-                            for (int j = 0; j < 4; ++j) acc[g][j] = f2{0.0f, 0.0f};
-                        }
+                        __builtin_amdgcn_sched_barrier(0);
                     }
+                    in_leaf += cnt;
+                    if (in_leaf == L) end_leaf();
                 }
             }
         }
@@ -304,15 +351,15 @@ __global__ __launch_bounds__(S_NT) void stream_sums_kernel(const StreamParams p)
         if (++c_ks == ksteps) {
             c_ks = 0;
             c_item += gridDim.x;
-            const int64_t chunk_off = c_it.out_rel + tid;
-            const bool live = tid < c_it.rows;
+            const int64_t chunk_off = c_it.out_rel + row;
+            const bool live = row < c_it.rows;
 #pragma unroll
-            for (int g = 0; g < G; ++g) {
-                if (g < c_it.qcnt) {
-                    float v = one_leaf ? res[g] : St[g * S_NT + tid];
+            for (int g = 0; g < GT; ++g) {
+                if (g_first + g < c_it.qcnt) {
+                    float v = one_leaf ? res[g] : St[(g_first + g) * S_NT + row];
                     if (p.post == POST_SQRT) v = sqrtf(v);
                     else if (p.post == POST_NEG) v = -v;
-                    const int64_t ob = uload(p.sq_out + c_it.qbeg + g);
+                    const int64_t ob = uload(p.sq_out + c_it.qbeg + g_first + g);
                     if (live) p.out[ob + chunk_off] = v;
                 }
             }
@@ -351,16 +398,16 @@ int launch_stream_sums(const StreamJob& j, hipStream_t s) {
     p.diag = diag;
     const int grid = ctx().num_cus;               // one block per CU (LDS-bound); blocks past the item count leave at once
     KernelTimer timer(s, j.timed);
-#define VDB_LAUNCH_STREAM(O, GG)                                                                \
+#define VDB_LAUNCH_STREAM(O, GG, QQ)                                                            \
     {                                                                                            \
-        auto kern = stream_sums_kernel<O, GG>;                                                   \
+        auto kern = stream_sums_kernel<O, GG, QQ>;                                               \
         VDB_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern),                         \
                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));      \
-        hipLaunchKernelGGL(kern, dim3(grid), dim3(S_NT), lds, s, p);                             \
+        hipLaunchKernelGGL(kern, dim3(grid), dim3(S_NT * QQ), lds, s, p);                        \
     }
 #define VDB_LAUNCH_STREAM_OP(O)                                                                  \
     case O:                                                                                      \
-        if (j.group == 1) VDB_LAUNCH_STREAM(O, 1) else VDB_LAUNCH_STREAM(O, 8)                    \
+        if (j.group == 1) VDB_LAUNCH_STREAM(O, 1, 1) else VDB_LAUNCH_STREAM(O, 8, STREAM_QS)      \
         break;
     switch (j.op) {
         VDB_LAUNCH_STREAM_OP(OP_DOT)
@@ -446,18 +493,23 @@ static int launch_build_items(const StreamPlanBufs& b, const int64_t* seg_row_of
 // no ranking) stands for an empty list.
 __global__ void ivf_plan_count_kernel(const int* __restrict__ probes, int nq, int n_probe, int n_lists,
                                       const int64_t* __restrict__ list_off, int* __restrict__ list_cnt,
-                                      int64_t* __restrict__ cand_off) {
+                                      int64_t* __restrict__ cand_off, int* __restrict__ tile_off) {
     const int q = blockIdx.x * blockDim.x + threadIdx.x;
     if (q >= nq) return;
     int64_t run = 0;
+    int tiles = 0;
     for (int pr = 0; pr < n_probe; ++pr) {
         const int l = probes[(int64_t)q * n_probe + pr];
         cand_off[(int64_t)q * (n_probe + 1) + pr] = run;
+        tile_off[(int64_t)q * (n_probe + 1) + pr] = tiles;
         if (l < 0 || l >= n_lists) continue;
-        run += list_off[l + 1] - list_off[l];
+        const int64_t len = list_off[l + 1] - list_off[l];
+        run += len;
+        tiles += (int)((len + LIST_NT - 1) / LIST_NT);
         atomicAdd(&list_cnt[l], 1);
     }
     cand_off[(int64_t)q * (n_probe + 1) + n_probe] = run;
+    tile_off[(int64_t)q * (n_probe + 1) + n_probe] = tiles;
 }
 
 // exclusive scans over the lists: query entries and items (single block)
@@ -518,11 +570,11 @@ __global__ void ivf_plan_fill_kernel(const int* __restrict__ probes, int nq, int
 }
 
 int launch_ivf_plan(const int* probes, int nq, int n_probe, const int64_t* list_off, int n_lists, int group,
-                    int64_t cand_stride, int* list_cnt, int* cursor, int64_t* cand_off, const StreamPlanBufs& b,
-                    hipStream_t s) {
+                    int64_t cand_stride, int* list_cnt, int* cursor, int64_t* cand_off, int* tile_off,
+                    const StreamPlanBufs& b, hipStream_t s) {
     VDB_HIP(hipMemsetAsync(list_cnt, 0, (size_t)n_lists * sizeof(int), s));
     hipLaunchKernelGGL(ivf_plan_count_kernel, dim3((nq + 255) / 256), dim3(256), 0, s, probes, nq, n_probe, n_lists,
-                       list_off, list_cnt, cand_off);
+                       list_off, list_cnt, cand_off, tile_off);
     hipLaunchKernelGGL(ivf_plan_scan_kernel, dim3(1), dim3(1024), 0, s, list_cnt, list_off, n_lists, group, b.seg_q_off,
                        b.seg_item_off, cursor);
     const int64_t total = (int64_t)nq * n_probe;
@@ -590,6 +642,7 @@ struct CandParams {
     int64_t n;                                   // flat: candidates per query (slot = stored row)
     const int* probes; int n_probe; int n_lists; // lists: probed lists of every query, or null
     const int64_t* list_off;
+    const int64_t* cand_off; const int* tile_off; // lists: [nq][n_probe+1] slots / 256-slot tiles before every probe
     const int* row_ids;                          // stored position -> row number (null = identity)
     const uint32_t* mask;                        // by row number
     Finish fin;
@@ -599,16 +652,22 @@ struct CandParams {
     float* part_d; int* part_i;                  // [nq][splits][k], idx = candidate slot
 };
 
+static constexpr int CAND_WAVES = LIST_NT / 64;   // candidate lists one block writes
+static constexpr int CAND_UNROLL = 4;       // tiles whose loads are in flight together
+static constexpr int RUN_CHUNK = 256;      // probed lists whose ranges are staged in LDS at a time
+
 __global__ __launch_bounds__(LIST_NT) void topk_cand_kernel(CandParams p) {
     extern __shared__ __align__(16) float smem[];
-    float* Ld = smem;
-    int* Li = reinterpret_cast<int*>(Ld + p.k * LIST_NT);
-    int* Red = Li + p.k * LIST_NT;
+    int64_t* R_pos0 = reinterpret_cast<int64_t*>(smem);         // first stored row of the run
+    int64_t* R_len = R_pos0 + RUN_CHUNK;                        // rows in the run
+    int* R_slot0 = reinterpret_cast<int*>(R_len + RUN_CHUNK);   // first candidate slot of the run
+    int* R_tile = R_slot0 + RUN_CHUNK;                          // [RUN_CHUNK + 1] tiles before the run
     const int tid = threadIdx.x;
     const int qi = blockIdx.x, split = blockIdx.y;
     const int k = p.k;
-    list_init(Ld, Li, k, tid);
-    float own_kth = INFINITY;
+    const int lane = tid & 63, wave = tid >> 6;
+    WaveTopK best;
+    best.init(k);
     const float q_sq = p.fin.q_sq ? p.fin.q_sq[qi] : 0.0f;
     const float q_nrm = p.fin.q_nrm ? p.fin.q_nrm[qi] : 0.0f;
     float lbd = -INFINITY;
@@ -616,48 +675,91 @@ __global__ __launch_bounds__(LIST_NT) void topk_cand_kernel(CandParams p) {
     if (p.lb_d) { lbd = p.lb_d[qi]; lbk = p.lb_k[qi]; }
     const float* cq = p.cand + (int64_t)qi * p.cand_stride;
 
+    // A query's candidates are runs of consecutive slots: one run per probed list (or
+    // one run holding every row).  Tiles of 256 slots are numbered through the runs and
+    // dealt to the splits round-robin.
     const int n_runs = p.probes ? p.n_probe : 1;
-    int64_t slot0 = 0;          // first slot of the run
-    int64_t tile0 = 0;          // tiles before the run
-    for (int run = 0; run < n_runs; ++run) {
-        int64_t pos0 = 0, len = p.n;
+    for (int c0 = 0; c0 < n_runs; c0 += RUN_CHUNK) {
+        const int nr = min(RUN_CHUNK, n_runs - c0);
+        __syncthreads();
         if (p.probes) {
-            const int l = p.probes[(int64_t)qi * p.n_probe + run];
-            len = 0;
-            if (l >= 0 && l < p.n_lists) { pos0 = p.list_off[l]; len = p.list_off[l + 1] - pos0; }
+            const int64_t qo = (int64_t)qi * (p.n_probe + 1) + c0;
+            for (int i = tid; i < nr; i += LIST_NT) {
+                const int l = p.probes[(int64_t)qi * p.n_probe + c0 + i];
+                const bool ok = l >= 0 && l < p.n_lists;
+                const int64_t pos0 = ok ? p.list_off[l] : 0;
+                R_pos0[i] = pos0;
+                R_len[i] = ok ? p.list_off[l + 1] - pos0 : 0;
+                R_slot0[i] = (int)p.cand_off[qo + i];
+            }
+            for (int i = tid; i <= nr; i += LIST_NT) R_tile[i] = p.tile_off[qo + i];
+        } else if (tid == 0) {
+            R_pos0[0] = 0; R_len[0] = p.n; R_slot0[0] = 0;
+            R_tile[0] = 0; R_tile[1] = (int)((p.n + LIST_NT - 1) / LIST_NT);
         }
-        const int64_t tiles = (len + LIST_NT - 1) / LIST_NT;
-        // tiles are dealt to the splits round-robin over the whole slice
-        int64_t t = (split - tile0 % p.splits + p.splits) % p.splits;
-        for (; t < tiles; t += p.splits) {
-            const int64_t r = t * LIST_NT + tid;
-            if (r >= len) continue;
-            const int64_t pos = pos0 + r;
-            const int64_t slot = slot0 + r;
-            const float d = finish_value(p.fin, cq[slot], q_sq, q_nrm, pos);
-            const int row = p.row_ids ? p.row_ids[pos] : (int)pos;
-            if (p.mask && !((p.mask[row >> 5] >> (row & 31)) & 1u)) continue;
-            if (p.use_radius && !(d <= p.radius)) continue;
-            const bool above = (d > lbd) || (d == lbd && slot > lbk);
-            if (above && d < own_kth) own_kth = list_insert(Ld + tid, Li + tid, k, d, (int)slot);
+        __syncthreads();
+        const int t_begin = R_tile[0], t_end = R_tile[nr];
+        int run = 0;
+        // CAND_UNROLL tiles per step: their loads are issued together, then the inserts run in tile order
+        for (int t = t_begin + (split - t_begin % p.splits + p.splits) % p.splits; t < t_end; t += p.splits * CAND_UNROLL) {
+            int64_t pos[CAND_UNROLL];
+            int slot[CAND_UNROLL];
+            bool ok[CAND_UNROLL];
+#pragma unroll
+            for (int u = 0; u < CAND_UNROLL; ++u) {
+                const int tu = t + u * p.splits;
+                ok[u] = tu < t_end;
+                pos[u] = 0; slot[u] = 0;
+                if (ok[u]) {
+                    while (R_tile[run + 1] <= tu) ++run;
+                    const int64_t r = (int64_t)(tu - R_tile[run]) * LIST_NT + tid;
+                    ok[u] = r < R_len[run];
+                    pos[u] = R_pos0[run] + r;
+                    slot[u] = R_slot0[run] + (int)r;
+                }
+            }
+            float raw[CAND_UNROLL];
+            int rown[CAND_UNROLL];
+#pragma unroll
+            for (int u = 0; u < CAND_UNROLL; ++u) {
+                raw[u] = ok[u] ? cq[slot[u]] : 0.0f;
+                rown[u] = (ok[u] && p.row_ids) ? p.row_ids[pos[u]] : (int)pos[u];
+            }
+            float d[CAND_UNROLL];
+#pragma unroll
+            for (int u = 0; u < CAND_UNROLL; ++u) d[u] = ok[u] ? finish_value(p.fin, raw[u], q_sq, q_nrm, pos[u]) : INFINITY;
+            if (p.mask) {
+#pragma unroll
+                for (int u = 0; u < CAND_UNROLL; ++u)
+                    if (ok[u]) ok[u] = (p.mask[rown[u] >> 5] >> (rown[u] & 31)) & 1u;
+            }
+#pragma unroll
+            for (int u = 0; u < CAND_UNROLL; ++u) {
+                bool want = ok[u];
+                if (p.use_radius && !(d[u] <= p.radius)) want = false;
+                if (!((d[u] > lbd) || (d[u] == lbd && slot[u] > lbk))) want = false;
+                best.offer(want, d[u], slot[u], lane);      // tiles in order, lanes in order: ascending slots
+            }
         }
-        slot0 += len;
-        tile0 += tiles;
     }
-    float* od = p.part_d + ((int64_t)qi * p.splits + split) * k;
-    int* oi = p.part_i + ((int64_t)qi * p.splits + split) * k;
-    block_reduce_lists(Ld, Li, k, tid, Red, od, oi);
+    // one candidate list per wave
+    const int64_t list = ((int64_t)qi * p.splits + split) * CAND_WAVES + wave;
+    best.store(p.part_d + list * k, p.part_i + list * k, lane);
 }
 
+int topk_cand_lists_per_split() { return CAND_WAVES; }
+
 int launch_topk_cand(const CandJob& j, hipStream_t s) {
-    VDB_REQUIRE(j.k >= 1 && j.k <= KMAX_FUSED, "candidate selection supports k <= %d, got %d", KMAX_FUSED, j.k);
+    VDB_REQUIRE(j.k >= 1 && j.k <= 64, "candidate selection supports k <= 64, got %d", j.k);
     CandParams p{};
     p.cand = j.cand; p.cand_stride = j.cand_stride; p.n = j.n; p.probes = j.probes; p.n_probe = j.n_probe; p.n_lists = j.n_lists;
     p.list_off = j.list_off; p.row_ids = j.row_ids; p.mask = j.mask;
     p.fin = Finish{j.metric, j.q_sq, j.q_nrm, j.row_sq, j.row_nrm};
     p.lb_d = j.lb_d; p.lb_k = j.lb_k; p.radius = j.radius; p.use_radius = j.use_radius;
     p.k = j.k; p.splits = j.splits; p.part_d = j.part_d; p.part_i = j.part_i;
-    const size_t lds = (size_t)j.k * LIST_NT * 8 + 12 * sizeof(int);
+    VDB_REQUIRE(j.probes == nullptr || (j.cand_off && j.tile_off), "list candidates need their slot and tile offsets");
+    p.cand_off = j.cand_off; p.tile_off = j.tile_off;
+    const size_t lds = (size_t)RUN_CHUNK * 24 + 8;
     VDB_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(topk_cand_kernel),
                                 hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     hipLaunchKernelGGL(topk_cand_kernel, dim3(j.nq, j.splits), dim3(LIST_NT), lds, s, p);

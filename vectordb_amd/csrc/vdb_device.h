@@ -32,20 +32,64 @@ __device__ __forceinline__ static void list_init(float* Ld, int* Li, int k, int 
     for (int i = 0; i < k; ++i) { Ld[i * LIST_NT + tid] = INFINITY; Li[i * LIST_NT + tid] = EMPTY_IDX; }
 }
 
+// --------------------------------------------------------------------------
+// Wave-wide selection: the wave's k best (distance, id) pairs live in registers,
+// lane j holding the j-th smallest (k <= 64; lanes >= k carry spill-over).  The
+// k-th pair is the acceptance bound, so after a warm-up almost every tile of
+// candidates is rejected with one compare and one ballot per wave.
+struct WaveTopK {
+    float e; int eid;            // this lane's element
+    float thr; int thr_id;       // the k-th element (wave-uniform)
+    int k;
+
+    __device__ __forceinline__ void init(int k_) { e = INFINITY; eid = EMPTY_IDX; thr = INFINITY; thr_id = EMPTY_IDX; k = k_; }
+
+    // insert one pair; v / vid must be wave-uniform.  Pairs equal to a stored one go behind it.
+    __device__ __forceinline__ void insert(float v, int vid, int lane) {
+        const bool gt = (e > v) || (e == v && eid > vid);
+        const float pe = __shfl_up(e, 1);
+        const int pid = __shfl_up(eid, 1);
+        const bool pgt = lane > 0 && ((pe > v) || (pe == v && pid > vid));
+        if (gt) { e = pgt ? pe : v; eid = pgt ? pid : vid; }
+        thr = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(e), k - 1));
+        thr_id = __builtin_amdgcn_readlane(eid, k - 1);
+    }
+
+    // offer every lane's candidate (want = this lane has one); lanes are taken in lane order
+    __device__ __forceinline__ void offer(bool want, float d, int id, int lane) {
+        unsigned long long m = __ballot(want && ((d < thr) || (d == thr && id < thr_id)));
+        while (m) {
+            const int l = __builtin_ctzll(m);
+            m &= m - 1;
+            const float v = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(d), l));
+            const int vid = __builtin_amdgcn_readlane(id, l);
+            if ((v < thr) || (v == thr && vid < thr_id)) insert(v, vid, lane);
+        }
+    }
+
+    // lanes 0..k-1 write the sorted list
+    __device__ __forceinline__ void store(float* od, int* oi, int lane) const {
+        if (lane < k) { od[lane] = e; oi[lane] = eid; }
+    }
+};
+
 // Reduce the 256 per-thread lists of a block to its k best under the
-// (distance, id) order: k rounds of "smallest list head".  red must hold 12
-// ints of LDS.  Thread 0 writes od[0..k), oi[0..k).  All threads must call.
-__device__ static void block_reduce_lists(const float* Ld, const int* Li, int k, int tid, int* red,
-                                          float* od, int* oi) {
-    float* red_d = reinterpret_cast<float*>(red);
-    int* red_i = red + 4;
-    int* red_t = red + 8;
+// (distance, id) order.  Every wave first merges its own 64 lists (k rounds of
+// "smallest list head", shuffles only), parks the result in its first column
+// of the list area, and after one barrier wave 0 merges the four wave lists.
+// k <= 64.  The lists are destroyed.  `red` is unused scratch kept for the
+// callers' LDS layout.  Thread 0..k-1 write od[0..k), oi[0..k).  All threads
+// must call.
+__device__ static void block_reduce_lists(float* Ld, int* Li, int k, int tid, int* red, float* od, int* oi) {
+    (void)red;
     const int lane = tid & 63, wave = tid >> 6;
     int head = 0;
+    float my_d = INFINITY;
+    int my_i = EMPTY_IDX;
     for (int round = 0; round < k; ++round) {
         float d = head < k ? Ld[head * LIST_NT + tid] : INFINITY;
         int id = head < k ? Li[head * LIST_NT + tid] : EMPTY_IDX;
-        int who = tid;
+        int who = lane;
 #pragma unroll
         for (int off = 32; off >= 1; off >>= 1) {
             const float d2 = __shfl_xor(d, off);
@@ -53,16 +97,33 @@ __device__ static void block_reduce_lists(const float* Ld, const int* Li, int k,
             const int w2 = __shfl_xor(who, off);
             if (d2 < d || (d2 == d && (i2 < id || (i2 == id && w2 < who)))) { d = d2; id = i2; who = w2; }
         }
-        if (lane == 0) { red_d[wave] = d; red_i[wave] = id; red_t[wave] = who; }
-        __syncthreads();
-        float bd = red_d[0]; int bi = red_i[0]; int bt = red_t[0];
-#pragma unroll
-        for (int w = 1; w < 4; ++w)
-            if (red_d[w] < bd || (red_d[w] == bd && red_i[w] < bi)) { bd = red_d[w]; bi = red_i[w]; bt = red_t[w]; }
-        if (tid == bt) ++head;
-        if (tid == 0) { od[round] = bd; oi[round] = bi; }
-        __syncthreads();
+        if (lane == who) ++head;
+        if (lane == round) { my_d = d; my_i = id; }
     }
+    __syncthreads();                    // every wave is done reading its lists
+    if (lane < k) { Ld[lane * LIST_NT + wave * 64] = my_d; Li[lane * LIST_NT + wave * 64] = my_i; }
+    __syncthreads();
+    if (wave != 0) return;
+    // lanes 0..3 walk the four wave lists
+    const int col = (lane & 3) * 64;
+    head = 0;
+    my_d = INFINITY; my_i = EMPTY_IDX;
+    for (int round = 0; round < k; ++round) {
+        float d = (lane < 4 && head < k) ? Ld[head * LIST_NT + col] : INFINITY;
+        int id = (lane < 4 && head < k) ? Li[head * LIST_NT + col] : EMPTY_IDX;
+        int who = lane;
+#pragma unroll
+        for (int off = 2; off >= 1; off >>= 1) {
+            const float d2 = __shfl_xor(d, off);
+            const int i2 = __shfl_xor(id, off);
+            const int w2 = __shfl_xor(who, off);
+            if (d2 < d || (d2 == d && (i2 < id || (i2 == id && w2 < who)))) { d = d2; id = i2; who = w2; }
+        }
+        d = __shfl(d, 0); id = __shfl(id, 0); who = __shfl(who, 0);
+        if (lane == who) ++head;
+        if (lane == round) { my_d = d; my_i = id; }
+    }
+    if (lane < k) { od[lane] = my_d; oi[lane] = my_i; }
 }
 
 }  // namespace vdb

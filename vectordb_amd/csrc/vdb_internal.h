@@ -196,16 +196,19 @@ struct StreamJob {
 int launch_stream_sums(const StreamJob& j, hipStream_t s);
 int launch_flat_plan(int64_t n, int nq, int group, int64_t out_stride, const StreamPlanBufs& b, hipStream_t s);
 int launch_ivf_plan(const int* probes, int nq, int n_probe, const int64_t* list_off, int n_lists, int group,
-                    int64_t cand_stride, int* list_cnt, int* cursor, int64_t* cand_off, const StreamPlanBufs& b,
-                    hipStream_t s);
+                    int64_t cand_stride, int* list_cnt, int* cursor, int64_t* cand_off, int* tile_off,
+                    const StreamPlanBufs& b, hipStream_t s);
 // in-place distance finish of a [nq][n] matrix of streamed sums (identity-form L2 and cosine only)
 int launch_finish_dist(int metric, const float* q_sq, const float* q_nrm, const float* row_sq, const float* row_nrm,
                        float* v, int nq, int64_t n, hipStream_t s);
-// per query: finish + filter + k best of its slice of the candidate buffer -> part lists [nq][splits][k]
+// per query: finish + filter + k best of its slice of the candidate buffer -> part lists
+// [nq][splits * topk_cand_lists_per_split()][k]
+int topk_cand_lists_per_split();
 struct CandJob {
     const float* cand; int64_t cand_stride; int nq;
     int64_t n;                                        // flat: candidates per query (slot = stored row)
     const int* probes; int n_probe; int n_lists; const int64_t* list_off;   // lists (probes == null: flat)
+    const int64_t* cand_off; const int* tile_off;     // lists: [nq][n_probe+1] from launch_ivf_plan
     const int* row_ids; const uint32_t* mask;
     int metric; const float* q_sq; const float* q_nrm; const float* row_sq; const float* row_nrm;
     const float* lb_d; const int64_t* lb_k; float radius; int use_radius;
