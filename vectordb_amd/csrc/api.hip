@@ -1197,10 +1197,11 @@ static int pq_search_impl(vdb_pq* h, const float* d_q, int nq, int k, const uint
     VDB_TRY(ws.lut.reserve((size_t)nq * h->m * h->ksub * sizeof(float)));
     VDB_TRY(launch_pq_lut(d_q, h->dim, nq, h->book.as<float>(), h->m, h->ksub, h->dsub, h->plan, ws.lut.as<float>(), s));
     const int64_t ntiles = (h->n + 255) / 256;
-    const int splits = (int)std::max<int64_t>(1, std::min<int64_t>(ntiles, (8 * ctx().num_cus + nq - 1) / nq));
+    const int splits = (int)std::max<int64_t>(1, std::min<int64_t>((ntiles + 15) / 16, (8 * ctx().num_cus + nq - 1) / nq));
+    const int n_cand = splits * pq_scan_lists_per_split();
     const int kmax = (int)std::min<int64_t>(KMAX_FUSED, k_eff);
-    VDB_TRY(ws.part_d.reserve((size_t)nq * splits * kmax * sizeof(float)));
-    VDB_TRY(ws.part_i.reserve((size_t)nq * splits * kmax * sizeof(int)));
+    VDB_TRY(ws.part_d.reserve((size_t)nq * n_cand * kmax * sizeof(float)));
+    VDB_TRY(ws.part_i.reserve((size_t)nq * n_cand * kmax * sizeof(int)));
     const bool multi = k_eff > KMAX_FUSED;
     if (multi) {
         VDB_TRY(ws.lb_d.reserve((size_t)nq * sizeof(float)));
@@ -1213,7 +1214,7 @@ static int pq_search_impl(vdb_pq* h, const float* d_q, int nq, int k, const uint
                                ws.part_d.as<float>(), ws.part_i.as<int>(), nullptr, s));
         SelectOut o{d_out_d, d_out_i, nullptr, k, (int)done,
                     multi ? ws.lb_d.as<float>() : nullptr, multi ? ws.lb_k.as<int64_t>() : nullptr};
-        VDB_TRY(launch_select(ws.part_d.as<float>(), ws.part_i.as<int>(), nq, splits, kk, 1 << 30, nullptr, 0, o, s));
+        VDB_TRY(launch_select(ws.part_d.as<float>(), ws.part_i.as<int>(), nq, n_cand, kk, 1 << 30, nullptr, 0, o, s));
     }
     return VDB_OK;
 }

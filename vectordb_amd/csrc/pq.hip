@@ -108,79 +108,132 @@ __global__ __launch_bounds__(256) void pq_encode_kernel(const float* __restrict_
 // ---------------------------------------------------------------- scan
 struct PqScanParams {
     const uint8_t* codes; int64_t n; int m; int ksub;
-    const float* lut;                // [nq][m][ksub]
+    const float* lut; int nq;        // [nq][m][ksub]
     const uint32_t* mask;
     const float* lb_d; const int64_t* lb_k;
     int k; int splits;
-    float* part_d; int* part_i;      // [nq][splits][k]
+    float* part_d; int* part_i;      // [nq][splits * PQ_WAVES][k]
     float* dist_out;                 // optional [nq][n]
 };
 
-template <int M>     // M > 0: compile-time number of sub-spaces (multiple of 4); 0: run-time
+static constexpr int PQ_UNROLL = 4;      // row tiles whose code loads are in flight together
+static constexpr int PQ_WAVES = 4;
+
+// M > 0: compile-time number of sub-spaces (multiple of 4); 0: run-time.
+// Q queries share one pass over the codes: their tables are interleaved in LDS,
+// T[(j * ksub + c) * Q + q], so one LDS read of Q floats serves all of them.
+template <int M, int Q>
 __global__ __launch_bounds__(256) void pq_scan_kernel(PqScanParams p) {
     extern __shared__ __align__(16) float sm[];
     const int m = M > 0 ? M : p.m;
-    float* T = sm;                                  // [m][ksub]
-    float* Ld = T + m * p.ksub;
-    int* Li = reinterpret_cast<int*>(Ld + p.k * LIST_NT);
-    int* Red = Li + p.k * LIST_NT;
-    const int tid = threadIdx.x;
-    const int split = blockIdx.x, qi = blockIdx.y;
+    float* T = sm;                                  // [m][ksub][Q]
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int split = blockIdx.x, q0 = blockIdx.y * Q;
+    const int qcnt = min(Q, p.nq - q0);
     const int k = p.k;
 
-    const float* lut = p.lut + (int64_t)qi * m * p.ksub;
-    for (int i = tid; i < m * p.ksub; i += 256) T[i] = lut[i];
-    list_init(Ld, Li, k, tid);
-    float own_kth = INFINITY;
-    float lbd = -INFINITY; int64_t lbk = -1;
-    if (p.lb_d) { lbd = p.lb_d[qi]; lbk = p.lb_k[qi]; }
+    for (int i = tid; i < m * p.ksub; i += 256) {
+#pragma unroll
+        for (int q = 0; q < Q; ++q) T[i * Q + q] = p.lut[(int64_t)(q0 + min(q, qcnt - 1)) * m * p.ksub + i];
+    }
+    WaveTopK best[Q];
+    float lbd[Q];
+    int64_t lbk[Q];
+#pragma unroll
+    for (int q = 0; q < Q; ++q) {
+        best[q].init(k > 0 ? k : 1);
+        lbd[q] = -INFINITY; lbk[q] = -1;
+        if (p.lb_d && q < qcnt) { lbd[q] = p.lb_d[q0 + q]; lbk[q] = p.lb_k[q0 + q]; }
+    }
     __syncthreads();
 
     const int64_t ntiles = (p.n + 255) / 256;
     const int64_t per = (ntiles + p.splits - 1) / p.splits;
     const int64_t t0 = split * per, t1 = min(t0 + per, ntiles);
-    for (int64_t t = t0; t < t1; ++t) {
-        const int64_t row = t * 256 + tid;
-        if (row >= p.n) continue;
-        float acc;
-        if (M > 0) {
-            uint32_t w[M > 0 ? M / 4 : 1];
-            if (M % 16 == 0) {
-                const uint4* src = reinterpret_cast<const uint4*>(p.codes + row * M);
+    for (int64_t tb = t0; tb < t1; tb += PQ_UNROLL) {
+        // ---- the rows' codes (and filter words), all tiles of the step first
+        uint32_t w[PQ_UNROLL][M > 0 ? M / 4 : 1];
+        uint32_t mw[PQ_UNROLL];
+        bool ok[PQ_UNROLL];
 #pragma unroll
-                for (int i = 0; i < M / 16; ++i) {
-                    const uint4 v = src[i];
-                    w[4 * i] = v.x; w[4 * i + 1] = v.y; w[4 * i + 2] = v.z; w[4 * i + 3] = v.w;
+        for (int u = 0; u < PQ_UNROLL; ++u) {
+            const int64_t row = (tb + u) * 256 + tid;
+            ok[u] = (tb + u) < t1 && row < p.n;
+            mw[u] = 0xffffffffu;
+            if (M > 0) {
+#pragma unroll
+                for (int i = 0; i < M / 4; ++i) w[u][i] = 0;
+                if (ok[u]) {
+                    if (M % 16 == 0) {
+                        const uint4* src = reinterpret_cast<const uint4*>(p.codes + row * M);
+#pragma unroll
+                        for (int i = 0; i < M / 16; ++i) {
+                            const uint4 v = src[i];
+                            w[u][4 * i] = v.x; w[u][4 * i + 1] = v.y; w[u][4 * i + 2] = v.z; w[u][4 * i + 3] = v.w;
+                        }
+                    } else if (M % 8 == 0) {
+                        const uint2* src = reinterpret_cast<const uint2*>(p.codes + row * M);
+#pragma unroll
+                        for (int i = 0; i < M / 8; ++i) { const uint2 v = src[i]; w[u][2 * i] = v.x; w[u][2 * i + 1] = v.y; }
+                    } else {
+                        const uint32_t* src = reinterpret_cast<const uint32_t*>(p.codes + row * M);
+#pragma unroll
+                        for (int i = 0; i < M / 4; ++i) w[u][i] = src[i];
+                    }
                 }
-            } else if (M % 8 == 0) {
-                const uint2* src = reinterpret_cast<const uint2*>(p.codes + row * M);
-#pragma unroll
-                for (int i = 0; i < M / 8; ++i) { const uint2 v = src[i]; w[2 * i] = v.x; w[2 * i + 1] = v.y; }
-            } else {
-                const uint32_t* src = reinterpret_cast<const uint32_t*>(p.codes + row * M);
-#pragma unroll
-                for (int i = 0; i < M / 4; ++i) w[i] = src[i];
             }
-            acc = T[w[0] & 0xff];
-#pragma unroll
-            for (int j = 1; j < M; ++j) acc = acc + T[j * p.ksub + ((w[j >> 2] >> (8 * (j & 3))) & 0xff)];
-        } else {
-            const uint8_t* src = p.codes + row * m;
-            acc = T[src[0]];
-            for (int j = 1; j < m; ++j) acc = acc + T[j * p.ksub + src[j]];
+            if (ok[u] && p.mask) mw[u] = p.mask[row >> 5];
         }
-        const float d = sqrtf(acc);
-        if (p.dist_out) p.dist_out[(int64_t)qi * p.n + row] = d;
-        if (k == 0) continue;
-        if (p.mask && !((p.mask[row >> 5] >> (row & 31)) & 1u)) continue;
-        const bool above = (d > lbd) || (d == lbd && row > lbk);
-        if (above && d < own_kth) own_kth = list_insert(Ld + tid, Li + tid, k, d, (int)row);
+        // ---- table sums in sub-space order, then the selection, tile by tile
+#pragma unroll
+        for (int u = 0; u < PQ_UNROLL; ++u) {
+            const int64_t row = (tb + u) * 256 + tid;
+            float acc[Q];
+            if (M > 0) {
+                const float* t0p = T + (w[u][0] & 0xff) * Q;
+#pragma unroll
+                for (int q = 0; q < Q; ++q) acc[q] = t0p[q];
+#pragma unroll
+                for (int j = 1; j < M; ++j) {
+                    const float* tp = T + (j * p.ksub + ((w[u][j >> 2] >> (8 * (j & 3))) & 0xff)) * Q;
+#pragma unroll
+                    for (int q = 0; q < Q; ++q) acc[q] = acc[q] + tp[q];
+                }
+            } else {
+                const uint8_t* src = p.codes + (ok[u] ? row : 0) * m;
+                const float* t0p = T + src[0] * Q;
+#pragma unroll
+                for (int q = 0; q < Q; ++q) acc[q] = t0p[q];
+                for (int j = 1; j < m; ++j) {
+                    const float* tp = T + (j * p.ksub + src[j]) * Q;
+#pragma unroll
+                    for (int q = 0; q < Q; ++q) acc[q] = acc[q] + tp[q];
+                }
+            }
+            const bool pass = ok[u] && ((mw[u] >> (row & 31)) & 1u);
+#pragma unroll
+            for (int q = 0; q < Q; ++q) {
+                const float d = sqrtf(acc[q]);
+                if (p.dist_out && ok[u] && q < qcnt) p.dist_out[(int64_t)(q0 + q) * p.n + row] = d;
+                if (k > 0) {
+                    const bool above = (d > lbd[q]) || (d == lbd[q] && row > lbk[q]);
+                    best[q].offer(pass && above, d, (int)row, lane);
+                }
+            }
+        }
     }
     if (k == 0) return;
-    float* od = p.part_d + ((int64_t)qi * p.splits + split) * k;
-    int* oi = p.part_i + ((int64_t)qi * p.splits + split) * k;
-    block_reduce_lists(Ld, Li, k, tid, Red, od, oi);
+    // one candidate list per wave
+#pragma unroll
+    for (int q = 0; q < Q; ++q) {
+        if (q < qcnt) {
+            const int64_t list = ((int64_t)(q0 + q) * p.splits + split) * PQ_WAVES + wave;
+            best[q].store(p.part_d + list * k, p.part_i + list * k, lane);
+        }
+    }
 }
+
+int pq_scan_lists_per_split() { return PQ_WAVES; }
 
 // ---------------------------------------------------------------- launchers
 int launch_pq_lut(const float* q, int ldq, int nq, const float* book, int m, int ksub, int dsub,
@@ -221,27 +274,40 @@ int launch_pq_encode(const float* x, int64_t n, int ldx, const float* book, int 
 int launch_pq_scan(const uint8_t* codes, int64_t n, int m, int ksub, const float* lut, int nq, int k,
                    const uint32_t* mask, const float* lb_d, const int64_t* lb_k, int splits,
                    float* part_d, int* part_i, float* dist_out, hipStream_t s) {
-    VDB_REQUIRE(k >= 0 && k <= KMAX_FUSED, "scan supports k <= %d, got %d", KMAX_FUSED, k);
-    PqScanParams p{codes, n, m, ksub, lut, mask, lb_d, lb_k, k, splits, part_d, part_i, dist_out};
-    const size_t lds = (size_t)m * ksub * sizeof(float) + (size_t)k * LIST_NT * 8 + 12 * sizeof(int);
-    VDB_REQUIRE(lds <= 160 * 1024, "%d sub-spaces x %d codewords with k=%d need %zu bytes of LDS", m, ksub, k, lds);
-    const dim3 grid(splits, nq);
+    VDB_REQUIRE(k >= 0 && k <= 64, "scan supports k <= 64, got %d", k);
+    VDB_REQUIRE(n < (int64_t)0x7fffffff, "at most 2^31-1 codes per device");
+    PqScanParams p{codes, n, m, ksub, lut, nq, mask, lb_d, lb_k, k, splits, part_d, part_i, dist_out};
+    const size_t table = (size_t)m * ksub * sizeof(float);
+    VDB_REQUIRE(table <= 160 * 1024, "%d sub-spaces x %d codewords need %zu bytes of LDS", m, ksub, table);
+    // queries per pass: as many tables as fit while two blocks still share a CU
+    int Q = 1;
+    if (nq >= 4 && 4 * table <= 80 * 1024) Q = 4;
+    else if (nq >= 2 && 2 * table <= 80 * 1024) Q = 2;
+    const bool fixed_m = m == 4 || m == 8 || m == 16 || m == 32 || m == 64;
+    if (!fixed_m) Q = 1;
+    const size_t lds = table * Q;
+    const dim3 grid(splits, (nq + Q - 1) / Q);
     KernelTimer timer(s);
-#define VDB_LAUNCH_PQ(MM)                                                                      \
+#define VDB_LAUNCH_PQ(MM, QQ)                                                                  \
     {                                                                                          \
-        auto kern = pq_scan_kernel<MM>;                                                        \
+        auto kern = pq_scan_kernel<MM, QQ>;                                                    \
         VDB_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern),                       \
                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));    \
         hipLaunchKernelGGL(kern, grid, dim3(256), lds, s, p);                                  \
     }
+#define VDB_LAUNCH_PQ_M(MM)                                                                    \
+    case MM:                                                                                   \
+        if (Q == 4) VDB_LAUNCH_PQ(MM, 4) else if (Q == 2) VDB_LAUNCH_PQ(MM, 2) else VDB_LAUNCH_PQ(MM, 1) \
+        break;
     switch (m) {
-        case 4: VDB_LAUNCH_PQ(4) break;
-        case 8: VDB_LAUNCH_PQ(8) break;
-        case 16: VDB_LAUNCH_PQ(16) break;
-        case 32: VDB_LAUNCH_PQ(32) break;
-        case 64: VDB_LAUNCH_PQ(64) break;
-        default: VDB_LAUNCH_PQ(0) break;
+        VDB_LAUNCH_PQ_M(4)
+        VDB_LAUNCH_PQ_M(8)
+        VDB_LAUNCH_PQ_M(16)
+        VDB_LAUNCH_PQ_M(32)
+        VDB_LAUNCH_PQ_M(64)
+        default: VDB_LAUNCH_PQ(0, 1) break;
     }
+#undef VDB_LAUNCH_PQ_M
 #undef VDB_LAUNCH_PQ
     VDB_HIP(hipGetLastError());
     return VDB_OK;

@@ -83,12 +83,116 @@ __global__ __launch_bounds__(64) void select_kernel(const float* __restrict__ d,
     if (lane == 0 && o.last_d) { o.last_d[q] = last_d; o.last_key[q] = last_key; }
 }
 
+// --------------------------------------------------------------------------
+// Merge of up to 256 ascending lists of k (int ids, order (distance, id)) by one
+// block: the lists are staged in LDS, every wave merges 64 of them (one list
+// per lane, k rounds of "smallest head"), then wave 0 merges the wave results.
+// FINAL = false: writes one list of k to out_d/out_i[(q * n_groups + group) * k].
+// FINAL = true : writes the results in SelectOut form.
+static constexpr int MERGE_LISTS = 256;
+
+template <bool FINAL>
+__global__ __launch_bounds__(256) void merge_lists_kernel(const float* __restrict__ d, const int* __restrict__ idx,
+                                                          int n_lists, int k, float* __restrict__ mid_d, int* __restrict__ mid_i,
+                                                          const int* __restrict__ idx_map, int64_t idx_offset, SelectOut o) {
+    extern __shared__ __align__(16) float sm[];
+    float* Sd = sm;                                            // [MERGE_LISTS + 4][k]
+    int* Si = reinterpret_cast<int*>(Sd + (MERGE_LISTS + 4) * k);
+    const int q = blockIdx.x, group = blockIdx.y, n_groups = gridDim.y;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int l0 = group * MERGE_LISTS;
+    const int nl = min(MERGE_LISTS, n_lists - l0);
+    const int64_t base = ((int64_t)q * n_lists + l0) * k;
+    for (int i = tid; i < MERGE_LISTS * k; i += 256) {
+        const bool in = i < nl * k;
+        Sd[i] = in ? d[base + i] : INFINITY;
+        Si[i] = in ? idx[base + i] : EMPTY_IDX;
+    }
+    __syncthreads();
+
+    auto merge64 = [&](int first_list, int count, int out_list) {
+        // lane l walks list first_list + l; the wave's k best go to list slot out_list
+        const int mine = first_list + lane;
+        int head = 0;
+        float cd = lane < count ? Sd[mine * k] : INFINITY;
+        int ci = lane < count ? Si[mine * k] : EMPTY_IDX;
+        float keep_d = INFINITY;
+        int keep_i = EMPTY_IDX;
+        for (int round = 0; round < k; ++round) {
+            float bd = cd; int bi = ci; int who = lane;
+#pragma unroll
+            for (int off = 32; off >= 1; off >>= 1) {
+                const float d2 = __shfl_xor(bd, off);
+                const int i2 = __shfl_xor(bi, off);
+                const int w2 = __shfl_xor(who, off);
+                if (d2 < bd || (d2 == bd && (i2 < bi || (i2 == bi && w2 < who)))) { bd = d2; bi = i2; who = w2; }
+            }
+            if (lane == who && lane < count) {
+                ++head;
+                cd = head < k ? Sd[mine * k + head] : INFINITY;
+                ci = head < k ? Si[mine * k + head] : EMPTY_IDX;
+            }
+            if (lane == round) { keep_d = bd; keep_i = bi; }
+        }
+        if (lane < k) { Sd[out_list * k + lane] = keep_d; Si[out_list * k + lane] = keep_i; }
+    };
+
+    merge64(wave * 64, max(0, min(64, nl - wave * 64)), MERGE_LISTS + wave);
+    __syncthreads();
+    if (wave != 0) return;
+    merge64(MERGE_LISTS, 4, MERGE_LISTS);          // result over slot MERGE_LISTS (read before it is written: per-round reads
+                                                   // touch heads only, and the store happens after the last round)
+    __builtin_amdgcn_wave_barrier();
+    if (lane < k) {
+        const float bd = Sd[MERGE_LISTS * k + lane];
+        const int bi = Si[MERGE_LISTS * k + lane];
+        if (!FINAL) {
+            mid_d[((int64_t)q * n_groups + group) * k + lane] = bd;
+            mid_i[((int64_t)q * n_groups + group) * k + lane] = bi;
+        } else {
+            const bool empty = bi == EMPTY_IDX;
+            const int64_t row = empty ? -1 : (idx_map ? (int64_t)idx_map[bi] : (int64_t)bi) + idx_offset;
+            const int64_t at = (int64_t)q * o.out_stride + o.out_off + lane;
+            if (o.out_d) o.out_d[at] = empty ? INFINITY : bd;
+            if (o.out_i) o.out_i[at] = row;
+            if (o.out_i32) o.out_i32[at] = (int)row;
+            if (lane == k - 1 && o.last_d) {
+                o.last_d[q] = empty ? INFINITY : bd;
+                o.last_key[q] = empty ? INT64_MAX : (int64_t)bi;
+            }
+        }
+    }
+}
+
+static DevBuf g_mid_d[2], g_mid_i[2];
+
 int launch_select(const float* part_d, const int* part_i, int nq, int n_cand, int k, int tie_group,
                   const int* idx_map, int64_t idx_offset, const SelectOut& o, hipStream_t s) {
     if (nq <= 0) return VDB_OK;
-    if (tie_group < 1) tie_group = 1;
-    hipLaunchKernelGGL(select_kernel<int>, dim3(nq), dim3(64), (size_t)n_cand * sizeof(int), s,
-                       part_d, part_i, (int64_t)n_cand * k, (int64_t)k, n_cand, k, tie_group, idx_map, idx_offset, o);
+    (void)tie_group;        // every caller orders equal distances by id alone
+    VDB_REQUIRE(k >= 1 && k <= 64, "selection merges lists of at most 64, got %d", k);
+    const size_t lds = (size_t)(MERGE_LISTS + 4) * k * 8;
+    VDB_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(merge_lists_kernel<false>),
+                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    VDB_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(merge_lists_kernel<true>),
+                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    const float* cur_d = part_d;
+    const int* cur_i = part_i;
+    int n = n_cand, level = 0;
+    while (n > MERGE_LISTS) {
+        const int groups = (n + MERGE_LISTS - 1) / MERGE_LISTS;
+        DevBuf& md = g_mid_d[level & 1];
+        DevBuf& mi = g_mid_i[level & 1];
+        VDB_TRY(md.reserve((size_t)nq * groups * k * sizeof(float)));
+        VDB_TRY(mi.reserve((size_t)nq * groups * k * sizeof(int)));
+        hipLaunchKernelGGL(merge_lists_kernel<false>, dim3(nq, groups), dim3(256), lds, s, cur_d, cur_i, n, k,
+                           md.as<float>(), mi.as<int>(), (const int*)nullptr, (int64_t)0, o);
+        cur_d = md.as<float>(); cur_i = mi.as<int>();
+        n = groups;
+        ++level;
+    }
+    hipLaunchKernelGGL(merge_lists_kernel<true>, dim3(nq, 1), dim3(256), lds, s, cur_d, cur_i, n, k,
+                       (float*)nullptr, (int*)nullptr, idx_map, idx_offset, o);
     VDB_HIP(hipGetLastError());
     return VDB_OK;
 }

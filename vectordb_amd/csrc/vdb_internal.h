@@ -241,6 +241,8 @@ int launch_pq_lut(const float* q, int ldq, int nq, const float* book, int m, int
                   const SumPlan& plan, float* lut, hipStream_t s);
 int launch_pq_encode(const float* x, int64_t n, int ldx, const float* book, int m, int ksub, int dsub,
                      const SumPlan& plan, uint8_t* codes, hipStream_t s);
+// candidate lists come out as [nq][splits * pq_scan_lists_per_split()][k]
+int pq_scan_lists_per_split();
 int launch_pq_scan(const uint8_t* codes, int64_t n, int m, int ksub, const float* lut, int nq, int k,
                    const uint32_t* mask, const float* lb_d, const int64_t* lb_k, int splits,
                    float* part_d, int* part_i, float* dist_out, hipStream_t s);
