@@ -123,12 +123,20 @@ __global__ __launch_bounds__(NT, 2) void flat_gemm_kernel(GemmParams p) {
 
     // blocks that work on the same slab of rows (one per query tile) get the
     // same blockIdx % 8, i.e. the same XCD and L2, and adjacent dispatch slots
-    const int per_group = 8 * p.n_qtiles;
-    const int grp = blockIdx.x / per_group;
-    const int rem = blockIdx.x - grp * per_group;
-    const int slab = grp * 8 + (rem & 7);
-    const int qt = rem >> 3;
-    if (slab >= p.n_slabs) return;
+    int slab, qt;
+    if (p.n_slabs >= 8) {
+        const int per_group = 8 * p.n_qtiles;
+        const int grp = blockIdx.x / per_group;
+        const int rem = blockIdx.x - grp * per_group;
+        slab = grp * 8 + (rem & 7);
+        qt = rem >> 3;
+        if (slab >= p.n_slabs) return;
+    } else {
+        // few slabs (a small row set, e.g. centroids): every block is live and the
+        // query tiles spread over all XCDs; the rows fit every L2 anyway
+        qt = blockIdx.x / p.n_slabs;
+        slab = blockIdx.x - qt * p.n_slabs;
+    }
     const int tile0 = slab * p.tiles_per_slab;
     const int tile1 = min(tile0 + p.tiles_per_slab, p.n_tiles);
 
@@ -385,7 +393,7 @@ template <bool TOPK>
 static int launch_gemm(int metric, GemmParams& p, hipStream_t s) {
     plan_grid(p.n_tiles, p.nq, ctx().num_cus, &p.n_qtiles, &p.n_slabs, &p.tiles_per_slab);
     const int groups = (p.n_slabs + 7) / 8;
-    const dim3 grid(groups * 8 * p.n_qtiles);
+    const dim3 grid(p.n_slabs >= 8 ? groups * 8 * p.n_qtiles : p.n_slabs * p.n_qtiles);
     static const int diag = getenv("VDB_DIAG") ? atoi(getenv("VDB_DIAG")) : 0;
     p.diag = diag;
     size_t lds = (size_t)(2 * TM * LW + TM) * sizeof(float) + (TOPK ? (size_t)p.k * NT * 8 : 0);
