@@ -168,7 +168,8 @@ def main():
                 od, orow = outputs(nq, 10)
                 mp = mask.data_ptr() if mask is not None else 0
                 wall, kern, launches = timed(lambda: pq.search_device(q.data_ptr(), nq, 10, od.data_ptr(), orow.data_ptr(), mask_ptr=mp), 10)
-                nbytes = nq * (n * m + (n // 8 if mask is not None else 0))
+                passes = (nq + 3) // 4          # four queries share one pass over the codes
+                nbytes = passes * (n * m + (n // 8 if mask is not None else 0))
                 emit("pq", workload=f"PQ m={m} nbits=8 ADC scan, {n} codes, batch {nq}, filter={sel}",
                      qps=round(nq / wall, 2), ms_per_batch=round(wall * 1e3, 4), kernel_ms=round(kern * 1e3, 4),
                      roofline={"bound": "hbm", "achieved": round(nbytes / kern / 1e9, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",

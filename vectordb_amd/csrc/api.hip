@@ -157,6 +157,28 @@ static bool is_dot_metric(int m) {
 static bool valid_metric(int m) { return m >= VDB_EUCLIDEAN && m <= VDB_EUCLIDEAN_SQ_DIRECT; }
 static const int GEMM_MIN_NQ = 4;     // below this the streaming scan reads the rows once per query and wins
 
+static int reserve_stream_plan(Workspace& ws, int n_seg, int64_t n_pairs, int64_t items_cap, StreamPlanBufs* b) {
+    VDB_TRY(ws.seg_row_off.reserve((size_t)(n_seg + 1) * sizeof(int64_t)));
+    VDB_TRY(ws.seg_q_off.reserve((size_t)(n_seg + 1) * sizeof(int)));
+    VDB_TRY(ws.seg_item_off.reserve((size_t)(n_seg + 1) * sizeof(int64_t)));
+    VDB_TRY(ws.sq_qid.reserve((size_t)std::max<int64_t>(n_pairs, 1) * sizeof(int)));
+    VDB_TRY(ws.sq_out.reserve((size_t)std::max<int64_t>(n_pairs, 1) * sizeof(int64_t)));
+    VDB_TRY(ws.items.reserve((size_t)std::max<int64_t>(items_cap, 1) * sizeof(StreamItem)));
+    b->items = ws.items.as<StreamItem>(); b->items_cap = items_cap;
+    b->seg_row_off = ws.seg_row_off.as<int64_t>(); b->seg_q_off = ws.seg_q_off.as<int>();
+    b->seg_item_off = ws.seg_item_off.as<int64_t>(); b->sq_qid = ws.sq_qid.as<int>(); b->sq_out = ws.sq_out.as<int64_t>();
+    return VDB_OK;
+}
+
+
+static int row_norms(Workspace& ws, const float* data, int ld, int dim, int64_t n, const SumPlan& plan,
+                     float* sq, float* nrm, hipStream_t s) {
+    if (n <= 0) return VDB_OK;
+    StreamPlanBufs b{};
+    VDB_TRY(reserve_stream_plan(ws, 1, 1, (n + 255) / 256, &b));
+    return launch_row_norms(data, ld, dim, n, plan, b, sq, nrm, s);
+}
+
 // queries -> padded device rows + their |q|^2, |q| in NumPy order
 static int prepare_queries(Workspace& ws, const float* d_q, int nq, int dim, int ld, const SumPlan& plan,
                            const float** q_out, hipStream_t s) {
@@ -170,7 +192,7 @@ static int prepare_queries(Workspace& ws, const float* d_q, int nq, int dim, int
     }
     VDB_TRY(ws.q_sq.reserve((size_t)nq * sizeof(float)));
     VDB_TRY(ws.q_nrm.reserve((size_t)nq * sizeof(float)));
-    VDB_TRY(launch_row_norms(*q_out, ld, dim, nq, plan, ws.q_sq.as<float>(), ws.q_nrm.as<float>(), s));
+    VDB_TRY(row_norms(ws, *q_out, ld, dim, nq, plan, ws.q_sq.as<float>(), ws.q_nrm.as<float>(), s));
     return VDB_OK;
 }
 
@@ -212,7 +234,7 @@ static int rows_append_dev_impl(vdb_rows* h, const float* d_rows, int64_t n, int
                            (const int*)nullptr, dst, r.ld);
         VDB_HIP(hipGetLastError());
     }
-    VDB_TRY(launch_row_norms(dst, r.ld, r.dim, n, r.plan, r.sq + r.n, r.nrm + r.n, s));
+    VDB_TRY(row_norms(h->ws, dst, r.ld, r.dim, n, r.plan, r.sq + r.n, r.nrm + r.n, s));
     r.n += n;
     return VDB_OK;
 }
@@ -229,19 +251,6 @@ static int cand_splits(int64_t tiles, int nq) {
     const int64_t by_chip = (4 * (int64_t)ctx().num_cus + nq - 1) / nq;
     const int64_t by_walk = (tiles + 63) / 64;
     return (int)std::max<int64_t>(1, std::min<int64_t>(tiles, std::max(by_chip, by_walk)));
-}
-
-static int reserve_stream_plan(Workspace& ws, int n_seg, int64_t n_pairs, int64_t items_cap, StreamPlanBufs* b) {
-    VDB_TRY(ws.seg_row_off.reserve((size_t)(n_seg + 1) * sizeof(int64_t)));
-    VDB_TRY(ws.seg_q_off.reserve((size_t)(n_seg + 1) * sizeof(int)));
-    VDB_TRY(ws.seg_item_off.reserve((size_t)(n_seg + 1) * sizeof(int64_t)));
-    VDB_TRY(ws.sq_qid.reserve((size_t)std::max<int64_t>(n_pairs, 1) * sizeof(int)));
-    VDB_TRY(ws.sq_out.reserve((size_t)std::max<int64_t>(n_pairs, 1) * sizeof(int64_t)));
-    VDB_TRY(ws.items.reserve((size_t)std::max<int64_t>(items_cap, 1) * sizeof(StreamItem)));
-    b->items = ws.items.as<StreamItem>(); b->items_cap = items_cap;
-    b->seg_row_off = ws.seg_row_off.as<int64_t>(); b->seg_q_off = ws.seg_q_off.as<int>();
-    b->seg_item_off = ws.seg_item_off.as<int64_t>(); b->sq_qid = ws.sq_qid.as<int>(); b->sq_out = ws.sq_out.as<int64_t>();
-    return VDB_OK;
 }
 
 static int stream_flat_sums(Workspace& ws, const Rows& r, int metric, const float* q, int nq, float* out, hipStream_t s) {
@@ -547,7 +556,7 @@ int vdb_rows_append(vdb_rows* h, const float* rows, int64_t n) {
     if (r.ld == r.dim) {
         float* dst = r.data + r.n * r.ld;
         VDB_HIP(hipMemcpyAsync(dst, rows, (size_t)n * r.dim * sizeof(float), hipMemcpyHostToDevice, s));
-        VDB_TRY(launch_row_norms(dst, r.ld, r.dim, n, r.plan, r.sq + r.n, r.nrm + r.n, s));
+        VDB_TRY(row_norms(h->ws, dst, r.ld, r.dim, n, r.plan, r.sq + r.n, r.nrm + r.n, s));
         r.n += n;
     } else {
         // stage in chunks, pad on the device
@@ -577,7 +586,7 @@ int vdb_rows_set(vdb_rows* h, int64_t row, const float* vec) {
     Rows& r = h->r;
     float* dst = r.data + row * r.ld;
     VDB_HIP(hipMemcpyAsync(dst, vec, (size_t)r.dim * sizeof(float), hipMemcpyHostToDevice, s));   // padding stays zero
-    VDB_TRY(launch_row_norms(dst, r.ld, r.dim, 1, r.plan, r.sq + row, r.nrm + row, s));
+    VDB_TRY(row_norms(h->ws, dst, r.ld, r.dim, 1, r.plan, r.sq + row, r.nrm + row, s));
     VDB_HIP(hipStreamSynchronize(s));
     return VDB_OK;
 }
@@ -667,27 +676,30 @@ int vdb_flat_range_search(vdb_rows* h, int metric, const float* query, float rad
     VDB_TRY(prepare_queries(ws, ws.stage.as<float>(), 1, r.dim, r.ld, r.plan, &q, s));
     const int kk = KMAX_FUSED;
     const int64_t ntiles = (r.n + 255) / 256;
-    const int splits = (int)std::max<int64_t>(1, std::min<int64_t>(ntiles, 8 * ctx().num_cus));
-    VDB_TRY(ws.part_d.reserve((size_t)splits * kk * sizeof(float)));
-    VDB_TRY(ws.part_i.reserve((size_t)splits * kk * sizeof(int)));
+    const int splits = cand_splits(ntiles, 1);
+    const int n_cand = splits * topk_cand_lists_per_split();
+    VDB_TRY(ws.part_d.reserve((size_t)n_cand * kk * sizeof(float)));
+    VDB_TRY(ws.part_i.reserve((size_t)n_cand * kk * sizeof(int)));
     VDB_TRY(ws.lb_d.reserve(sizeof(float)));
     VDB_TRY(ws.lb_k.reserve(sizeof(int64_t)));
     VDB_TRY(ws.out_d.reserve(kk * sizeof(float)));
     VDB_TRY(ws.out_i.reserve(kk * sizeof(int64_t)));
+    // the rows are streamed once; every round of 32 results re-reads only the candidate buffer
+    VDB_TRY(ws.cand.reserve((size_t)r.n * sizeof(float)));
+    VDB_TRY(stream_flat_sums(ws, r, metric, q, 1, ws.cand.as<float>(), s));
     float hd[KMAX_FUSED];
     int64_t hi[KMAX_FUSED];
     bool first = true;
     while (*count < cap) {
-        ScanJob j{};
-        j.data = r.data; j.ld = r.ld; j.dim = r.dim; j.row_sq = r.sq; j.row_nrm = r.nrm; j.plan = r.plan;
-        j.metric = metric; j.q = q; j.ldq = r.ld; j.nq = 1; j.q_sq = ws.q_sq.as<float>(); j.q_nrm = ws.q_nrm.as<float>();
-        j.n = r.n; j.mask = d_mask; j.k = kk; j.splits = splits;
-        j.lb_d = first ? nullptr : ws.lb_d.as<float>(); j.lb_k = first ? nullptr : ws.lb_k.as<int64_t>();
-        j.part_d = ws.part_d.as<float>(); j.part_i = ws.part_i.as<int>();
-        j.radius = radius; j.use_radius = 1;
-        VDB_TRY(launch_scan(j, s));
+        CandJob c{};
+        c.cand = ws.cand.as<float>(); c.cand_stride = r.n; c.nq = 1; c.n = r.n; c.mask = d_mask;
+        c.metric = metric; c.q_sq = ws.q_sq.as<float>(); c.q_nrm = ws.q_nrm.as<float>(); c.row_sq = r.sq; c.row_nrm = r.nrm;
+        c.lb_d = first ? nullptr : ws.lb_d.as<float>(); c.lb_k = first ? nullptr : ws.lb_k.as<int64_t>();
+        c.radius = radius; c.use_radius = 1;
+        c.k = kk; c.splits = splits; c.part_d = ws.part_d.as<float>(); c.part_i = ws.part_i.as<int>();
+        VDB_TRY(launch_topk_cand(c, s));
         SelectOut o{ws.out_d.as<float>(), ws.out_i.as<int64_t>(), nullptr, kk, 0, ws.lb_d.as<float>(), ws.lb_k.as<int64_t>()};
-        VDB_TRY(launch_select(ws.part_d.as<float>(), ws.part_i.as<int>(), 1, splits, kk, 1 << 30, nullptr, 0, o, s));
+        VDB_TRY(launch_select(ws.part_d.as<float>(), ws.part_i.as<int>(), 1, n_cand, kk, 1 << 30, nullptr, 0, o, s));
         VDB_HIP(hipMemcpyAsync(hd, ws.out_d.p, kk * sizeof(float), hipMemcpyDeviceToHost, s));
         VDB_HIP(hipMemcpyAsync(hi, ws.out_i.p, kk * sizeof(int64_t), hipMemcpyDeviceToHost, s));
         VDB_HIP(hipStreamSynchronize(s));
@@ -846,7 +858,7 @@ int vdb_ivf_build_lists(vdb_ivf* h, const float* rows, int64_t n, const int64_t*
             hipLaunchKernelGGL(pad_rows_kernel, dim3(grid_for(n * m->r.ld)), dim3(256), 0, s, raw.as<float>(), (int64_t)h->dim,
                                h->dim, n, h->row_ids.as<int>(), m->r.data, m->r.ld);
             VDB_HIP(hipGetLastError());
-            VDB_TRY(launch_row_norms(m->r.data, m->r.ld, m->r.dim, n, m->r.plan, m->r.sq, m->r.nrm, s));
+            VDB_TRY(row_norms(m->ws, m->r.data, m->r.ld, m->r.dim, n, m->r.plan, m->r.sq, m->r.nrm, s));
             VDB_HIP(hipStreamSynchronize(s));
             return VDB_OK;
         };
@@ -906,7 +918,10 @@ static int ivf_search_impl(vdb_ivf* h, const float* d_q, int nq, int k, int n_pr
     const int64_t cand_stride = round_up64(std::max<int64_t>(h->probe_bound(n_probe), 1), 64);
     VDB_REQUIRE(cand_stride < (int64_t)0x7fffffff, "n_probe=%d lists can hold more than 2^31 rows", n_probe);
     const int q_block = (int)std::max<int64_t>(1, std::min<int64_t>(nq, CAND_BUDGET / (cand_stride * (int64_t)sizeof(float))));
-    const int group = nq == 1 ? 1 : 8;
+    static const int env_group = getenv("VDB_STREAM_GROUP") ? atoi(getenv("VDB_STREAM_GROUP")) : 0;
+    // 16 queries per row chunk once a list is probed by ~8 queries or more on average
+    const int64_t per_list = (int64_t)nq * n_probe / std::max(1, h->n_lists);
+    const int group = nq == 1 ? 1 : (env_group > 0 ? env_group : (per_list >= 6 ? 16 : 8));
 
     VDB_TRY(ws.probes.reserve((size_t)nq * n_probe * sizeof(int)));
     VDB_TRY(ws.probe_d.reserve((size_t)nq * n_probe * sizeof(float)));

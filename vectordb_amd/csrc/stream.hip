@@ -296,14 +296,16 @@ __global__ __launch_bounds__(S_NT * QS) void stream_sums_kernel(const StreamPara
             for (int unit = 0; unit < (S_CK / 8) * U; ++unit) {
                 const int grp = unit / U, g0 = (unit % U) * H;
                 if (unit + 1 < (S_CK / 8) * U) load_q((unit + 1) & 1, unit + 1);
-                const f2 x2[4] = {f2{xv[2 * grp].x, xv[2 * grp].y}, f2{xv[2 * grp].z, xv[2 * grp].w},
-                                  f2{xv[2 * grp + 1].x, xv[2 * grp + 1].y}, f2{xv[2 * grp + 1].z, xv[2 * grp + 1].w}};
+                if (g_first + g0 < c_it.qcnt) {         // units whose queries are all padding do no arithmetic
+                    const f2 x2[4] = {f2{xv[2 * grp].x, xv[2 * grp].y}, f2{xv[2 * grp].z, xv[2 * grp].w},
+                                      f2{xv[2 * grp + 1].x, xv[2 * grp + 1].y}, f2{xv[2 * grp + 1].z, xv[2 * grp + 1].w}};
 #pragma unroll
-                for (int h = 0; h < H; ++h) {
-                    const float4 qa = qv[unit & 1][h][0], qc = qv[unit & 1][h][1];
-                    const f2 q2[4] = {f2{qa.x, qa.y}, f2{qa.z, qa.w}, f2{qc.x, qc.y}, f2{qc.z, qc.w}};
+                    for (int h = 0; h < H; ++h) {
+                        const float4 qa = qv[unit & 1][h][0], qc = qv[unit & 1][h][1];
+                        const f2 q2[4] = {f2{qa.x, qa.y}, f2{qa.z, qa.w}, f2{qc.x, qc.y}, f2{qc.z, qc.w}};
 #pragma unroll
-                    for (int j = 0; j < 4; ++j) acc[g0 + h][j] = s_accum2<OP>(acc[g0 + h][j], x2[j], q2[j]);
+                        for (int j = 0; j < 4; ++j) acc[g0 + h][j] = s_accum2<OP>(acc[g0 + h][j], x2[j], q2[j]);
+                    }
                 }
                 __builtin_amdgcn_sched_barrier(0);      // keep the query reads one unit ahead, not all at the top
             }
@@ -379,7 +381,7 @@ static int stream_depth(const SumPlan& plan) {
 }
 
 int launch_stream_sums(const StreamJob& j, hipStream_t s) {
-    VDB_REQUIRE(j.group == 1 || j.group == 8, "query group must be 1 or 8");
+    VDB_REQUIRE(j.group == 1 || j.group == 8 || j.group == 16, "query group must be 1, 8 or 16");
     VDB_REQUIRE(j.ld % 4 == 0 && j.ld >= j.dim, "stored rows must be padded to a multiple of 4 floats");
     StreamParams p{};
     p.data = j.data; p.ld = j.ld; p.dim = j.dim; p.post = j.post;
@@ -392,11 +394,17 @@ int launch_stream_sums(const StreamJob& j, hipStream_t s) {
     const size_t budget = 160 * 1024;
     const size_t slot = (size_t)(S_STAGE + j.group * S_CK) * sizeof(float);
     VDB_REQUIRE(stack + 2 * slot <= budget, "dimension %d is too large for the streaming scan", j.dim);
-    p.nbuf = (int)std::min<size_t>(4, (budget - stack) / slot);
+    // one query: bandwidth-bound, one block per CU with up to four stages in flight.
+    // eight queries: arithmetic-bound, two independent blocks per CU (two stage buffers each),
+    // so that one block's loads, waits and barriers hide behind the other's arithmetic.
+    static const int env_nbuf = getenv("VDB_STREAM_NBUF") ? atoi(getenv("VDB_STREAM_NBUF")) : 0;
+    const int want_nbuf = env_nbuf > 0 ? env_nbuf : (j.group == 1 ? 4 : 2);
+    p.nbuf = (int)std::max<size_t>(2, std::min<size_t>(want_nbuf, (budget - stack) / slot));
     const size_t lds = (size_t)p.nbuf * slot + stack;
+    const int blocks_per_cu = (int)std::max<size_t>(1, std::min<size_t>(2, budget / lds));
     static const int diag = getenv("VDB_STREAM_DIAG") ? atoi(getenv("VDB_STREAM_DIAG")) : 0;
     p.diag = diag;
-    const int grid = ctx().num_cus;               // one block per CU (LDS-bound); blocks past the item count leave at once
+    const int grid = ctx().num_cus * blocks_per_cu;   // blocks past the item count leave at once
     KernelTimer timer(s, j.timed);
 #define VDB_LAUNCH_STREAM(O, GG, QQ)                                                            \
     {                                                                                            \
@@ -407,13 +415,19 @@ int launch_stream_sums(const StreamJob& j, hipStream_t s) {
     }
 #define VDB_LAUNCH_STREAM_OP(O)                                                                  \
     case O:                                                                                      \
-        if (j.group == 1) VDB_LAUNCH_STREAM(O, 1, 1) else VDB_LAUNCH_STREAM(O, 8, STREAM_QS)      \
+        if (j.group == 1) VDB_LAUNCH_STREAM(O, 1, 1)                                              \
+        else if (j.group == 8) VDB_LAUNCH_STREAM(O, 8, STREAM_QS)                                 \
+        else VDB_LAUNCH_STREAM(O, 16, STREAM_QS)                                                  \
         break;
     switch (j.op) {
         VDB_LAUNCH_STREAM_OP(OP_DOT)
         VDB_LAUNCH_STREAM_OP(OP_SQDIFF)
         VDB_LAUNCH_STREAM_OP(OP_ABSDIFF)
         VDB_LAUNCH_STREAM_OP(OP_MAXABS)
+        case OP_SQ:
+            VDB_REQUIRE(j.group == 1, "squared norms run one row set at a time");
+            VDB_LAUNCH_STREAM(OP_SQ, 1, 1)
+            break;
         default: VDB_REQUIRE(false, "unknown streaming op %d", j.op);
     }
 #undef VDB_LAUNCH_STREAM_OP
@@ -793,6 +807,32 @@ int launch_ivf_rows(const int* slots, int nq, int k, int out_stride, int out_off
     if (nq <= 0 || k <= 0) return VDB_OK;
     hipLaunchKernelGGL(ivf_rows_kernel, dim3((nq * k + 255) / 256), dim3(256), 0, s, slots, nq, k, out_stride, out_off,
                        probes, n_probe, n_lists, cand_off, list_off, row_ids, out_rows);
+    VDB_HIP(hipGetLastError());
+    return VDB_OK;
+}
+
+// --------------------------------------------------------------------------
+// row norms in NumPy order: sq[i] = np.sum(row_i**2), nrm[i] = sqrt(sq[i])
+// (distance/metrics.py:456,470)
+__global__ void sqrt_kernel(const float* __restrict__ sq, float* __restrict__ nrm, int64_t n) {
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x)
+        nrm[i] = sqrtf(sq[i]);
+}
+
+int launch_row_norms(const float* data, int ld, int dim, int64_t n, const SumPlan& plan, const StreamPlanBufs& b,
+                     float* sq, float* nrm, hipStream_t s) {
+    if (n <= 0) return VDB_OK;
+    VDB_REQUIRE(b.items_cap >= (n + S_NT - 1) / S_NT, "item table too small for %lld rows", (long long)n);
+    VDB_TRY(launch_flat_plan(n, 1, 1, n, b, s));
+    StreamJob j{};
+    j.data = data; j.ld = ld; j.dim = dim; j.plan = plan; j.op = OP_SQ; j.post = POST_NONE;
+    j.q = data; j.ldq = 0;                       // the query operand is unused: any readable row
+    j.group = 1; j.n_seg = 1;
+    j.seg_row_off = b.seg_row_off; j.seg_q_off = b.seg_q_off; j.seg_item_off = b.seg_item_off;
+    j.sq_qid = b.sq_qid; j.sq_out = b.sq_out; j.items = b.items; j.items_cap = b.items_cap;
+    j.out = sq; j.timed = false;
+    VDB_TRY(launch_stream_sums(j, s));
+    hipLaunchKernelGGL(sqrt_kernel, dim3((unsigned)std::min<int64_t>((n + 255) / 256, 4096)), dim3(256), 0, s, sq, nrm, n);
     VDB_HIP(hipGetLastError());
     return VDB_OK;
 }

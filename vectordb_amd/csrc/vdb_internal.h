@@ -106,10 +106,6 @@ struct Rows {
 // ---------------------------------------------------------------- kernel launchers (device pointers)
 enum { KMAX_FUSED = 32 };   // largest k the fused selection keeps per thread in LDS
 
-// row norms in NumPy order: sq[i] = np.sum(row_i**2), nrm[i] = sqrt(sq[i])
-int launch_row_norms(const float* data, int ld, int dim, int64_t n, const SumPlan& plan,
-                     float* sq, float* nrm, hipStream_t s);
-
 // copy n rows of `dim` floats (source leading dimension src_ld) into padded rows of dst_ld floats
 int launch_pad_rows(const float* src, int64_t src_ld, int dim, int64_t n, float* dst, int dst_ld, hipStream_t s);
 
@@ -127,32 +123,6 @@ int launch_flat_gemm_topk(const Rows& r, int metric, const float* q, const float
 // MFMA path, full distance matrix out[nq][n]
 int launch_flat_gemm_dist(const Rows& r, int metric, const float* q, const float* q_sq, const float* q_nrm,
                           int nq, float* out, hipStream_t s);
-
-// streaming path (one thread per row, row tile staged through LDS)
-struct ScanJob {
-    const float* data; int ld; int dim;
-    const float* row_sq; const float* row_nrm;
-    SumPlan plan;
-    int metric;
-    // queries
-    const float* q; int ldq; int nq;
-    const float* q_sq; const float* q_nrm;
-    // rows: either a flat range [0, n) ...
-    int64_t n;
-    // ... or inverted lists: list_off[n_lists+1], probes[nq][n_probe]
-    const int64_t* list_off; const int* probes; int n_probe;
-    const int* row_ids;           // row number of every stored position (lists) or null (= position)
-    const uint32_t* mask;         // indexed by row number
-    const float* lb_d; const int64_t* lb_k;   // exclusive lower bound (distance, tie key) per query, or null
-    int k;
-    int splits;                   // blocks per (query[, probe])
-    // outputs
-    float* part_d; int* part_i;   // [nq][n_cand][k] candidate lists (idx = scan position or row)
-    float* dist_out;              // full distances [nq][n] (flat range only) or null
-    float radius; int use_radius; // keep only rows with distance <= radius
-};
-int scan_num_cand(const ScanJob& j, int* n_cand);
-int launch_scan(const ScanJob& j, hipStream_t s);
 
 // streaming pipeline: pairwise-ordered sums for (row chunk, query group) items -> candidate buffer
 enum ScanOp { OP_DOT = 0, OP_SQDIFF = 1, OP_ABSDIFF = 2, OP_MAXABS = 3, OP_SQ = 4 };
@@ -194,6 +164,9 @@ struct StreamJob {
     bool timed;
 };
 int launch_stream_sums(const StreamJob& j, hipStream_t s);
+// row norms in NumPy order: sq[i] = np.sum(row_i**2), nrm[i] = sqrt(sq[i]); b needs ceil(n/256) items
+int launch_row_norms(const float* data, int ld, int dim, int64_t n, const SumPlan& plan, const StreamPlanBufs& b,
+                     float* sq, float* nrm, hipStream_t s);
 int launch_flat_plan(int64_t n, int nq, int group, int64_t out_stride, const StreamPlanBufs& b, hipStream_t s);
 int launch_ivf_plan(const int* probes, int nq, int n_probe, const int64_t* list_off, int n_lists, int group,
                     int64_t cand_stride, int* list_cnt, int* cursor, int64_t* cand_off, int* tile_off,
