@@ -1,0 +1,214 @@
+"""The hot path at the sizes BASELINE.json quotes, checked through properties that
+do not need a full CPU run per query, plus full CPU checks on a few queries:
+
+  * every returned distance equals the oracle's distance for that row (bit-exact on the
+    pinned paths, 1e-4 relative on the dot-product paths);
+  * results are sorted, row numbers are distinct and in range, filters are respected;
+  * completeness: for a few queries the oracle scans everything (or the probed lists) and
+    must pick the same rows;
+  * the batched kernels and the single-query kernels agree;
+  * running a search twice gives the same bits.
+
+Inputs are generated on the GPU (seeded) and copied back for the oracle.
+"""
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import ref_numpy as R
+from conftest import same_ids_or_near_ties
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def nat(native):
+    from vectordb_amd import _native
+    return _native
+
+
+def randn(n, d, seed):
+    g = torch.Generator(device="cuda")
+    g.manual_seed(seed)
+    return torch.randn((n, d), device="cuda", dtype=torch.float32, generator=g)
+
+
+def search_dev(fn, q, k):
+    nq = q.shape[0]
+    od = torch.empty((nq, k), device="cuda", dtype=torch.float32)
+    orow = torch.empty((nq, k), device="cuda", dtype=torch.int64)
+    fn(q.data_ptr(), nq, k, od.data_ptr(), orow.data_ptr())
+    torch.cuda.synchronize()
+    return od.cpu().numpy(), orow.cpu().numpy()
+
+
+def topk_big(d, k):
+    """The oracle's stable top-k (ties to the lower row) without sorting all of a 100M-entry array."""
+    thr = np.partition(d, k - 1)[k - 1]
+    idx = np.flatnonzero(d <= thr)
+    return idx[np.lexsort((idx, d[idx]))][:k]
+
+
+def check_shape_properties(dist, rows, n):
+    assert np.all(np.diff(dist, axis=1) >= 0), "distances must ascend"
+    assert rows.min() >= 0 and rows.max() < n
+    for r in rows:
+        assert len(set(r.tolist())) == len(r), "row numbers must be distinct"
+
+
+# ---------------------------------------------------------------- Flat cosine 1M x 384, batch 1024 (configs[1])
+def test_flat_cosine_1m_batch_1024(nat):
+    n, d, nq, k = 1_000_000, 384, 1024, 10
+    x = randn(n, d, 42)
+    q = randn(nq, d, 123)
+    store = nat.RowStore(d)
+    store.append_device(x.data_ptr(), n, d, 0)
+    fn = lambda qp, m, kk, dp, rp: store.search_device(qp, m, kk, nat.COSINE, dp, rp)
+    dist, rows = search_dev(fn, q, k)
+    dist2, rows2 = search_dev(fn, q, k)
+    assert np.array_equal(rows, rows2) and np.array_equal(dist, dist2), "same call, same bits"
+    check_shape_properties(dist, rows, n)
+
+    xh, qh = x.cpu().numpy(), q.cpu().numpy()
+    # every returned distance against the oracle's value for that row (1e-4 relative, BLAS vs MFMA order)
+    for qi in range(0, nq, 37):
+        ref = R.query_distances(qh[qi], xh[rows[qi]], "cosine")
+        np.testing.assert_allclose(dist[qi], ref, rtol=1e-4, atol=2e-6)
+    # completeness: full oracle scan for a few queries
+    for qi in (0, 511, 1023):
+        ref_all = R.query_distances(qh[qi], xh, "cosine")
+        ref_rows = R.topk_stable(ref_all, k)
+        assert same_ids_or_near_ties(rows[qi], ref_rows, lambda r: ref_all[r], float(ref_all[ref_rows[-1]]),
+                                     rtol=1e-4, atol=2e-6)
+    # the single-query streaming kernel agrees with the batched matrix-core kernel
+    for qi in (3, 700):
+        d1, r1 = search_dev(fn, q[qi:qi + 1].contiguous(), k)
+        ref_all = R.query_distances(qh[qi], xh, "cosine")
+        assert same_ids_or_near_ties(r1[0], rows[qi], lambda r: ref_all[r], float(np.sort(ref_all)[k - 1]),
+                                     rtol=1e-4, atol=2e-6)
+        np.testing.assert_allclose(d1[0], dist[qi], rtol=1e-4, atol=2e-6)
+    store.close()
+
+
+# ---------------------------------------------------------------- Manhattan 1M x 128 (configs[4] side check), bit-exact
+def test_flat_manhattan_1m(nat):
+    n, d, k = 1_000_000, 128, 10
+    x = randn(n, d, 7)
+    q = randn(9, d, 8)
+    store = nat.RowStore(d)
+    store.append_device(x.data_ptr(), n, d, 0)
+    fn = lambda qp, m, kk, dp, rp: store.search_device(qp, m, kk, nat.MANHATTAN, dp, rp)
+    dist, rows = search_dev(fn, q, k)                     # 9 queries: the 8-query kernel with a ragged second group
+    check_shape_properties(dist, rows, n)
+    xh, qh = x.cpu().numpy(), q.cpu().numpy()
+    for qi in range(9):
+        ref_all = R.query_distances(qh[qi], xh, "manhattan")
+        ref_rows = R.topk_stable(ref_all, k)
+        assert np.array_equal(rows[qi], ref_rows)
+        assert np.array_equal(dist[qi], ref_all[ref_rows])
+    d1, r1 = search_dev(fn, q[4:5].contiguous(), k)       # one query: the single-query kernel
+    assert np.array_equal(r1[0], rows[4]) and np.array_equal(d1[0], dist[4])
+    store.close()
+
+
+# ---------------------------------------------------------------- IVF nlist=4096 nprobe=32 over 10M x 128 (configs[3])
+def test_ivf_10m_nprobe_32(nat):
+    n, d, nlist, nprobe, k, nq = 10_000_000, 128, 4096, 32, 10, 256
+    x = randn(n, d, 11)
+    xh = x.cpu().numpy()
+    del x
+    torch.cuda.empty_cache()
+    rng = np.random.default_rng(5)
+    cent = xh[rng.choice(n, nlist, replace=False)].copy()
+    assign, _ = nat.assign(xh, cent, nat.EUCLIDEAN)
+    # the same assignment from the oracle on a sample (identity-form batch assignment, ivf.py:352-404)
+    sample = rng.choice(n, 2000, replace=False)
+    assert np.array_equal(assign[sample], R.ivf_assign_batch(xh[sample], cent, "euclidean"))
+    lists = nat.IvfLists(d, nat.EUCLIDEAN)
+    lists.set_centroids(cent)
+    lists.build(xh, assign)
+    order = np.argsort(assign, kind="stable")
+    bounds = np.searchsorted(assign[order], np.arange(nlist + 1))
+    members = [order[bounds[l]:bounds[l + 1]] for l in range(nlist)]
+
+    q = randn(nq, d, 12)
+    qh = q.cpu().numpy()
+    fn = lambda qp, m, kk, dp, rp: lists.search_device(qp, m, kk, nprobe, dp, rp)
+    dist, rows = search_dev(fn, q, k)
+    check_shape_properties(dist, rows, n)
+    # returned distances: bit-exact direct form
+    for qi in range(0, nq, 5):
+        ref = R.rows_scalar_metric(qh[qi], xh[rows[qi]], "euclidean").astype(np.float32)
+        assert np.array_equal(dist[qi], ref)
+    # completeness and probe order: the oracle's search over the same lists
+    for qi in (0, 100, 255):
+        ref_rows, ref_d = R.ivf_search(qh[qi], xh, cent, members, k, nprobe, "euclidean")
+        assert np.array_equal(rows[qi], ref_rows)
+        assert np.array_equal(dist[qi], ref_d.astype(np.float32))
+    # single-query path == batched list-major path
+    for qi in (7, 200):
+        d1, r1 = search_dev(fn, q[qi:qi + 1].contiguous(), k)
+        assert np.array_equal(r1[0], rows[qi]) and np.array_equal(d1[0], dist[qi])
+    # a filter that keeps 1 row in 16
+    keep = (np.arange(n) % 16) == 3
+    words = nat.pack_mask(keep)
+    dm, rm = lists.search(qh[:4], k, nprobe, mask_words=words)
+    assert np.all(keep[rm[rm >= 0]])
+    ref_rows, ref_d = R.ivf_search(qh[1], xh, cent, members, k, nprobe, "euclidean", mask=keep)
+    assert np.array_equal(rm[1][:len(ref_rows)], ref_rows)
+    lists.close()
+
+
+# ---------------------------------------------------------------- PQ m=16 nbits=8 over 100M codes with a filter (configs[4])
+def test_pq_100m_codes_with_filter(nat):
+    n, m, d, k = 100_000_000, 16, 128, 10
+    rng = np.random.default_rng(3)
+    book = rng.standard_normal((m, 256, d // m), dtype=np.float32)
+    pq = nat.PqCodes(d, m, 256)
+    pq.set_codebook(book)
+    g = torch.Generator(device="cuda")
+    g.manual_seed(99)
+    chunk = 10_000_000
+    host_codes = np.empty((n, m), np.uint8)
+    for s in range(0, n, chunk):
+        c = torch.randint(0, 256, (chunk, m), device="cuda", dtype=torch.uint8, generator=g)
+        pq.append_codes_device(c.data_ptr(), chunk, 0)
+        torch.cuda.synchronize()
+        host_codes[s:s + chunk] = c.cpu().numpy()
+    del c
+    assert len(pq) == n
+    q = randn(8, d, 17)
+    qh = q.cpu().numpy()
+    keep_t = (torch.rand(n, device="cuda", generator=g) < 0.01)
+    keep = keep_t.cpu().numpy()
+    words_t = torch.from_numpy(nat.pack_mask(keep).view(np.int32)).cuda()
+
+    fn = lambda qp, nn, kk, dp, rp: pq.search_device(qp, nn, kk, dp, rp)
+    fn_mask = lambda qp, nn, kk, dp, rp: pq.search_device(qp, nn, kk, dp, rp, mask_ptr=words_t.data_ptr())
+    dist, rows = search_dev(fn, q, k)
+    dmask, rmask = search_dev(fn_mask, q, k)
+    check_shape_properties(dist, rows, n)
+    check_shape_properties(dmask, rmask, n)
+    assert np.all(keep[rmask]), "filtered rows must not be returned"
+    # returned distances: bit-exact ADC
+    for qi in range(8):
+        lut = R.pq_lut(qh[qi], book)
+        assert np.array_equal(pq.lut(qh[qi]), lut)
+        assert np.array_equal(dist[qi], R.pq_adc(host_codes[rows[qi]], lut))
+        assert np.array_equal(dmask[qi], R.pq_adc(host_codes[rmask[qi]], lut))
+    # completeness: the oracle over all 100M codes for one query, with and without the filter
+    lut = R.pq_lut(qh[2], book)
+    acc = lut[0, host_codes[:, 0]].copy()
+    for j in range(1, m):
+        acc += lut[j, host_codes[:, j]]          # in-place: same fp32 additions, no 400 MB temporaries
+    dall = np.sqrt(acc)
+    ref_rows = topk_big(dall, k)
+    assert np.array_equal(rows[2], ref_rows)
+    kept = np.flatnonzero(keep)
+    ref_rows_m = kept[topk_big(dall[kept], k)]
+    assert np.array_equal(rmask[2], ref_rows_m)
+    # single query == batch
+    d1, r1 = search_dev(fn, q[5:6].contiguous(), k)
+    assert np.array_equal(r1[0], rows[5]) and np.array_equal(d1[0], dist[5])
+    pq.close()
