@@ -164,6 +164,57 @@ __global__ __launch_bounds__(256) void merge_lists_kernel(const float* __restric
     }
 }
 
+// A handful of lists per query (e.g. the two half-wave lists of a nearest-centroid
+// assignment over a million rows): one thread merges them.
+static constexpr int FEW_LISTS = 8;
+
+__global__ __launch_bounds__(256) void merge_few_kernel(const float* __restrict__ d, const int* __restrict__ idx, int nq,
+                                                        int n_lists, int k, const int* __restrict__ idx_map,
+                                                        int64_t idx_offset, SelectOut o) {
+    const int q = blockIdx.x * blockDim.x + threadIdx.x;
+    if (q >= nq) return;
+    const float* dq = d + (int64_t)q * n_lists * k;
+    const int* iq = idx + (int64_t)q * n_lists * k;
+    int head[FEW_LISTS];
+    float cd[FEW_LISTS];
+    int ci[FEW_LISTS];
+#pragma unroll
+    for (int l = 0; l < FEW_LISTS; ++l) {
+        head[l] = 0;
+        cd[l] = l < n_lists ? dq[l * k] : INFINITY;
+        ci[l] = l < n_lists ? iq[l * k] : EMPTY_IDX;
+    }
+    float bd = INFINITY;
+    int bi = EMPTY_IDX;
+    for (int round = 0; round < k; ++round) {
+        int bl = 0;
+        bd = cd[0]; bi = ci[0];
+#pragma unroll
+        for (int l = 1; l < FEW_LISTS; ++l)
+            if (cd[l] < bd || (cd[l] == bd && ci[l] < bi)) { bd = cd[l]; bi = ci[l]; bl = l; }
+#pragma unroll
+        for (int l = 0; l < FEW_LISTS; ++l) {
+            if (l == bl) {
+                ++head[l];
+                const bool more = l < n_lists && head[l] < k;
+                cd[l] = more ? dq[l * k + head[l]] : INFINITY;
+                ci[l] = more ? iq[l * k + head[l]] : EMPTY_IDX;
+            }
+        }
+        const bool empty = bi == EMPTY_IDX;
+        const int64_t row = empty ? -1 : (idx_map ? (int64_t)idx_map[bi] : (int64_t)bi) + idx_offset;
+        const int64_t at = (int64_t)q * o.out_stride + o.out_off + round;
+        if (o.out_d) o.out_d[at] = empty ? INFINITY : bd;
+        if (o.out_i) o.out_i[at] = row;
+        if (o.out_i32) o.out_i32[at] = (int)row;
+    }
+    if (o.last_d) {
+        const bool empty = bi == EMPTY_IDX;
+        o.last_d[q] = empty ? INFINITY : bd;
+        o.last_key[q] = empty ? INT64_MAX : (int64_t)bi;
+    }
+}
+
 static DevBuf g_mid_d[2], g_mid_i[2];
 
 int launch_select(const float* part_d, const int* part_i, int nq, int n_cand, int k, int tie_group,
@@ -171,6 +222,12 @@ int launch_select(const float* part_d, const int* part_i, int nq, int n_cand, in
     if (nq <= 0) return VDB_OK;
     (void)tie_group;        // every caller orders equal distances by id alone
     VDB_REQUIRE(k >= 1 && k <= 64, "selection merges lists of at most 64, got %d", k);
+    if (n_cand <= FEW_LISTS) {
+        hipLaunchKernelGGL(merge_few_kernel, dim3((nq + 255) / 256), dim3(256), 0, s, part_d, part_i, nq, n_cand, k,
+                           idx_map, idx_offset, o);
+        VDB_HIP(hipGetLastError());
+        return VDB_OK;
+    }
     const size_t lds = (size_t)(MERGE_LISTS + 4) * k * 8;
     VDB_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(merge_lists_kernel<false>),
                                 hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
