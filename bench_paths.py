@@ -3,7 +3,7 @@
 headline bench): bandwidth-bound scans and build steps at BASELINE.json sizes,
 each rated against the HBM roofline with its algorithmic bytes.
 
-    python bench_paths.py [--only flat1,l1,ivf,pq,assign,encode] [--scale 1.0]
+    python bench_paths.py [--only flat1,l1,c3,ivf,pq,assign,encode] [--scale 1.0]
 
 Prints one JSON line per path.  Inputs are synthetic standard-normal (or
 uniform random codes) and resident in HBM before timing.
@@ -47,7 +47,7 @@ def emit(name, **kw):
 
 def main():
     ap = argparse.ArgumentParser()
-    ap.add_argument("--only", default="flat1,l1,ivf,pq,assign,encode")
+    ap.add_argument("--only", default="flat1,l1,c3,ivf,pq,assign,encode")
     ap.add_argument("--scale", type=float, default=1.0, help="scale the row counts (1.0 = BASELINE sizes)")
     args = ap.parse_args()
     only = set(args.only.split(","))
@@ -82,6 +82,31 @@ def main():
              qps=round(1 / wall, 1), ms_per_query=round(wall * 1e3, 4), kernel_ms=round(kern * 1e3, 4),
              roofline={"bound": "hbm", "achieved": round(nbytes / kern / 1e9, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                        "frac": round(nbytes / kern / 1e9 / HBM_PEAK_GBS, 4), "bytes_per_launch": nbytes})
+        store.close()
+        torch.cuda.empty_cache()
+
+    # ---- one GPU's shard of Flat dot-product 10M x 768 over 8 GPUs: 1.25M rows, batch 1024 (MFMA) and batch 1 (HBM)
+    if "c3" in only:
+        n, d = int(1_250_000 * args.scale), 768
+        rows = randn(n, d, 42)
+        store = N.RowStore(d)
+        store.append_device(rows.data_ptr(), n, d, stream)
+        torch.cuda.synchronize()
+        del rows
+        for nq in (1024, 1):
+            q = randn(nq, d, 123)
+            od, orow = outputs(nq, 10)
+            wall, kern, launches = timed(lambda: store.search_device(q.data_ptr(), nq, 10, N.DOT, od.data_ptr(), orow.data_ptr()), 10)
+            if nq == 1:
+                nbytes = n * d * 4
+                roof = {"bound": "hbm", "achieved": round(nbytes / kern / 1e9, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                        "frac": round(nbytes / kern / 1e9 / HBM_PEAK_GBS, 4), "bytes_per_launch": nbytes}
+            else:
+                flop = 2.0 * nq * n * d
+                roof = {"bound": "mfma", "achieved": round(flop / kern / 1e12, 2), "peak": MFMA_F32_PEAK, "unit": "TFLOP/s",
+                        "frac": round(flop / kern / 1e12 / MFMA_F32_PEAK, 4), "flop_per_launch": flop}
+            emit("c3", workload=f"Flat dot {n}x{d} fp32 (one of 8 shards of 10M), batch {nq}, k=10",
+                 qps=round(nq / wall, 1), ms_per_batch=round(wall * 1e3, 4), kernel_ms=round(kern * 1e3, 4), roofline=roof)
         store.close()
         torch.cuda.empty_cache()
 

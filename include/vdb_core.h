@@ -152,6 +152,13 @@ int vdb_ivf_search(vdb_ivf* h, const float* queries, int nq, int k, int n_probe,
                    const uint32_t* mask, float* out_dist, int64_t* out_row);
 int vdb_ivf_search_dev(vdb_ivf* h, const float* d_queries, int nq, int k, int n_probe,
                        const uint32_t* d_mask, float* d_out_dist, int64_t* d_out_row, void* stream);
+/* The same search, plus for every result its place in the reference's visiting
+ * order (ivf.py:619-628): order = probe rank << 32 | position in the list, -1 for
+ * an unfilled slot.  Equal distances are ordered by it; a shard that holds only
+ * some of the lists reports keys that compare correctly with other shards'. */
+int vdb_ivf_search_ordered_dev(vdb_ivf* h, const float* d_queries, int nq, int k, int n_probe,
+                               const uint32_t* d_mask, float* d_out_dist, int64_t* d_out_row,
+                               int64_t* d_out_order, void* stream);
 /* probe selection alone (ivf.py:611-614): n_probe nearest lists per query, ascending */
 int vdb_ivf_probe(vdb_ivf* h, const float* queries, int nq, int n_probe, int32_t* out_lists, float* out_dist);
 /* bytes one search of this batch reads from the lists (sum of probed list lengths * dim * 4), for roofline accounting */
@@ -187,6 +194,10 @@ int vdb_pq_search_dev(vdb_pq* h, const float* d_queries, int nq, int k,
  * Layout of the inputs: [n_lists][nq][k].  Device pointers. */
 int vdb_topk_merge_dev(const float* d_dist, const int64_t* d_row, int n_lists, int nq, int k,
                        float* d_out_dist, int64_t* d_out_row, void* stream);
+/* Same, ordered by (distance, key) with the rows carried along: the merge of
+ * IVF shards, key = the visiting order of vdb_ivf_search_ordered_dev. */
+int vdb_topk_merge_keyed_dev(const float* d_dist, const int64_t* d_key, const int64_t* d_row, int n_lists, int nq, int k,
+                             float* d_out_dist, int64_t* d_out_row, void* stream);
 
 #ifdef __cplusplus
 }

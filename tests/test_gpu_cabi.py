@@ -526,3 +526,87 @@ def test_sharded_merge_equals_single_store(nat, shards):
             for i in range(len(q)):
                 assert set(orow[i]) == set(sr[i])
             np.testing.assert_allclose(od, sd, rtol=1e-6, atol=1e-6)
+
+
+@pytest.mark.parametrize("shards", [2, 5])
+def test_sharded_ivf_lists_equal_single_index(nat, shards):
+    """Inverted lists spread over G logical shards (balanced greedy), every shard
+    searched through the C ABI with all centroids but only its own lists, merged by
+    (distance, visiting order): rows, order and distances equal the unsharded index."""
+    import torch
+    from vectordb_amd.sharded import HipIvfBackend, ShardedIVF, assign_lists_balanced, local_ivf_layout
+    rng = np.random.RandomState(31 + shards)
+    x = rng.randn(6000, 24).astype(np.float32)
+    x[4100] = x[77]                        # equal distances
+    x[5000] = x[77]
+    cent = x[rng.choice(len(x), 40, replace=False)].copy()
+    assign = R.ivf_assign_batch(x, cent, "euclidean").astype(np.int32)
+    q = rng.randn(19, 24).astype(np.float32)
+    q[0] = x[77]
+    k, n_probe = 12, 9
+    dev = torch.device("cuda", 0)
+    tq = torch.from_numpy(q).to(dev)
+    owner = assign_lists_balanced(np.bincount(assign, minlength=len(cent)), shards)
+    gd = torch.empty((shards, len(q), k), device=dev, dtype=torch.float32)
+    gr = torch.empty((shards, len(q), k), device=dev, dtype=torch.int64)
+    go = torch.empty((shards, len(q), k), device=dev, dtype=torch.int64)
+    backends = []
+    for r in range(shards):
+        rows_g, list_rows_l, offs = local_ivf_layout(assign, len(cent), owner, r)
+        be = HipIvfBackend(24, nat.EUCLIDEAN, cent, x[rows_g], list_rows_l, offs, rows_g)
+        be.local_search(tq, k, n_probe, gd[r], gr[r], go[r])
+        backends.append(be)
+    od = torch.empty((len(q), k), device=dev, dtype=torch.float32)
+    orow = torch.empty((len(q), k), device=dev, dtype=torch.int64)
+    backends[0].merge(gd, go, gr, k, od, orow)
+    torch.cuda.synchronize()
+    single = nat.IvfLists(24, nat.EUCLIDEAN)
+    single.set_centroids(cent)
+    single.build(x, assign)
+    sd, sr = single.search(q, k, n_probe)
+    np.testing.assert_array_equal(orow.cpu().numpy(), sr)
+    np.testing.assert_array_equal(od.cpu().numpy(), sd)
+    members = [np.flatnonzero(assign == l).astype(np.int64) for l in range(len(cent))]
+    ref_r, ref_d = R.ivf_search(q[0], x, cent, members, k, n_probe, "euclidean")
+    np.testing.assert_array_equal(sr[0], ref_r)
+    # ShardedIVF with one shard is the plain index
+    d1, r1 = ShardedIVF(backends[0], 0, 1).search(tq, k, n_probe)
+    assert d1.shape == (len(q), k)
+    single.close()
+    for be in backends:
+        be.lists.close()
+
+
+def test_sharded_pq_blocks_equal_single_index(nat):
+    """PQ codes in contiguous row blocks, one block per logical shard, merged by (distance, global row)."""
+    import torch
+    from vectordb_amd.sharded import HipPqBackend, ShardedFlat, shard_range
+    rng = np.random.RandomState(8)
+    m, d, n, k, shards = 8, 32, 9001, 10, 3
+    book = rng.randn(m, 256, d // m).astype(np.float32)
+    codes = rng.randint(0, 256, size=(n, m)).astype(np.uint8)
+    codes[7000] = codes[5]                 # equal distances across shards
+    q = rng.randn(6, d).astype(np.float32)
+    dev = torch.device("cuda", 0)
+    tq = torch.from_numpy(q).to(dev)
+    gd = torch.empty((shards, len(q), k), device=dev, dtype=torch.float32)
+    gr = torch.empty((shards, len(q), k), device=dev, dtype=torch.int64)
+    bes = []
+    for r in range(shards):
+        lo, hi = shard_range(n, shards, r)
+        be = HipPqBackend(d, m, 256, book)
+        be.add_device(torch.from_numpy(codes[lo:hi]).to(dev))
+        dl, rl = ShardedFlat(be, hi - lo, 0, 1).search(tq, k)
+        gd[r] = dl
+        gr[r] = rl + (rl >= 0).to(torch.int64) * lo
+        bes.append(be)
+    od = torch.empty((len(q), k), device=dev, dtype=torch.float32)
+    orow = torch.empty((len(q), k), device=dev, dtype=torch.int64)
+    bes[0].merge(gd, gr, k, od, orow)
+    torch.cuda.synchronize()
+    for i in range(len(q)):
+        ref_r, ref_d = R.pq_search(q[i], book, codes, k)
+        np.testing.assert_array_equal(orow[i].cpu().numpy(), ref_r)
+        np.testing.assert_array_equal(od[i].cpu().numpy(), ref_d)
+    for be in bes:
+        be.codes.close()

@@ -73,6 +73,8 @@ SIGNATURES = {
     "vdb_ivf_search": (C.c_int, [C.c_void_p, c_float_p, C.c_int, C.c_int, C.c_int, c_u32_p, c_float_p, c_i64_p]),
     "vdb_ivf_search_dev": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p,
                                      C.c_void_p, C.c_void_p]),
+    "vdb_ivf_search_ordered_dev": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p,
+                                             C.c_void_p, C.c_void_p, C.c_void_p]),
     "vdb_ivf_probe": (C.c_int, [C.c_void_p, c_float_p, C.c_int, C.c_int, c_i32_p, c_float_p]),
     "vdb_ivf_last_scan_rows": (C.c_int, [C.c_void_p, c_i64_p]),
     "vdb_pq_encode": (C.c_int, [c_float_p, C.c_int64, c_float_p, C.c_int, C.c_int, C.c_int, c_u8_p]),
@@ -91,6 +93,8 @@ SIGNATURES = {
                                     C.c_void_p]),
     "vdb_topk_merge_dev": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p,
                                      C.c_void_p]),
+    "vdb_topk_merge_keyed_dev": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p,
+                                           C.c_void_p, C.c_void_p]),
 }
 
 _lib: Optional[C.CDLL] = None
@@ -371,7 +375,12 @@ class IvfLists:
         return dist, rows
 
     def search_device(self, q_ptr: int, nq: int, k: int, n_probe: int, out_dist_ptr: int, out_row_ptr: int,
-                      mask_ptr: int = 0, stream: int = 0) -> None:
+                      mask_ptr: int = 0, stream: int = 0, out_order_ptr: int = 0) -> None:
+        if out_order_ptr:
+            check(self.lib.vdb_ivf_search_ordered_dev(self.h, C.c_void_p(q_ptr), nq, k, n_probe, C.c_void_p(mask_ptr or None),
+                                                      C.c_void_p(out_dist_ptr), C.c_void_p(out_row_ptr),
+                                                      C.c_void_p(out_order_ptr), C.c_void_p(stream or None)))
+            return
         check(self.lib.vdb_ivf_search_dev(self.h, C.c_void_p(q_ptr), nq, k, n_probe, C.c_void_p(mask_ptr or None),
                                           C.c_void_p(out_dist_ptr), C.c_void_p(out_row_ptr), C.c_void_p(stream or None)))
 
@@ -470,3 +479,10 @@ def topk_merge_device(dist_ptr: int, row_ptr: int, n_lists: int, nq: int, k: int
     init()
     check(load().vdb_topk_merge_dev(C.c_void_p(dist_ptr), C.c_void_p(row_ptr), n_lists, nq, k,
                                     C.c_void_p(out_dist_ptr), C.c_void_p(out_row_ptr), C.c_void_p(stream or None)))
+
+
+def topk_merge_keyed_device(dist_ptr: int, key_ptr: int, row_ptr: int, n_lists: int, nq: int, k: int,
+                            out_dist_ptr: int, out_row_ptr: int, stream: int = 0) -> None:
+    init()
+    check(load().vdb_topk_merge_keyed_dev(C.c_void_p(dist_ptr), C.c_void_p(key_ptr), C.c_void_p(row_ptr), n_lists, nq, k,
+                                          C.c_void_p(out_dist_ptr), C.c_void_p(out_row_ptr), C.c_void_p(stream or None)))

@@ -900,7 +900,7 @@ static int ivf_probe_impl(vdb_ivf* h, const float* q_pad_unused, const float* d_
 }
 
 static int ivf_search_impl(vdb_ivf* h, const float* d_q, int nq, int k, int n_probe, const uint32_t* d_mask,
-                           float* d_out_d, int64_t* d_out_i, hipStream_t s) {
+                           float* d_out_d, int64_t* d_out_i, int64_t* d_out_order, hipStream_t s) {
     VDB_REQUIRE(h->n_lists >= 1, "index is not trained");
     VDB_REQUIRE(nq >= 0 && k >= 1 && n_probe >= 1, "need nq >= 0, k >= 1, n_probe >= 1");
     if (nq == 0) return VDB_OK;
@@ -908,6 +908,7 @@ static int ivf_search_impl(vdb_ivf* h, const float* d_q, int nq, int k, int n_pr
     vdb_rows* m = h->members;
     Workspace& ws = h->ws;
     VDB_TRY(fill_results(d_out_d, d_out_i, (int64_t)nq * k, s));
+    if (d_out_order) VDB_TRY(fill_results(nullptr, d_out_order, (int64_t)nq * k, s));
     if (m->r.n == 0) return VDB_OK;
 
     const int64_t k_eff = std::min<int64_t>(k, m->r.n);
@@ -980,7 +981,7 @@ static int ivf_search_impl(vdb_ivf* h, const float* d_q, int nq, int k, int n_pr
             VDB_TRY(launch_select(ws.part_d.as<float>(), ws.part_i.as<int>(), nb, n_cand, kk, 1 << 30, nullptr, 0, o, s));
             VDB_TRY(launch_ivf_rows(ws.slots.as<int>() + (int64_t)q0 * k, nb, kk, k, (int)done, probes, n_probe, h->n_lists,
                                     ws.cand_off.as<int64_t>(), h->list_off.as<int64_t>(), h->row_ids.as<int>(),
-                                    d_out_i + (int64_t)q0 * k, s));
+                                    d_out_i + (int64_t)q0 * k, d_out_order ? d_out_order + (int64_t)q0 * k : nullptr, s));
         }
     }
     return VDB_OK;
@@ -990,7 +991,14 @@ int vdb_ivf_search_dev(vdb_ivf* h, const float* d_queries, int nq, int k, int n_
                        float* d_out_dist, int64_t* d_out_row, void* stream) {
     VDB_REQUIRE(h && (d_queries || nq == 0), "null argument");
     std::lock_guard<std::mutex> g(ctx().mu);
-    return ivf_search_impl(h, d_queries, nq, k, n_probe, d_mask, d_out_dist, d_out_row, pick_stream(stream));
+    return ivf_search_impl(h, d_queries, nq, k, n_probe, d_mask, d_out_dist, d_out_row, nullptr, pick_stream(stream));
+}
+
+int vdb_ivf_search_ordered_dev(vdb_ivf* h, const float* d_queries, int nq, int k, int n_probe, const uint32_t* d_mask,
+                               float* d_out_dist, int64_t* d_out_row, int64_t* d_out_order, void* stream) {
+    VDB_REQUIRE(h && (d_queries || nq == 0) && d_out_order, "null argument");
+    std::lock_guard<std::mutex> g(ctx().mu);
+    return ivf_search_impl(h, d_queries, nq, k, n_probe, d_mask, d_out_dist, d_out_row, d_out_order, pick_stream(stream));
 }
 
 int vdb_ivf_search(vdb_ivf* h, const float* queries, int nq, int k, int n_probe, const uint32_t* mask,
@@ -1003,7 +1011,7 @@ int vdb_ivf_search(vdb_ivf* h, const float* queries, int nq, int k, int n_probe,
     VDB_TRY(upload_mask(h->ws, mask, h->members->r.n, &d_mask, s));
     return with_host_io(h->members->ws, queries, nq, h->dim, k, out_dist, out_row, s,
                         [&](const float* dq, float* dd, int64_t* di) {
-                            return ivf_search_impl(h, dq, nq, k, n_probe, d_mask, dd, di, s);
+                            return ivf_search_impl(h, dq, nq, k, n_probe, d_mask, dd, di, nullptr, s);
                         });
 }
 
@@ -1260,7 +1268,15 @@ int vdb_topk_merge_dev(const float* d_dist, const int64_t* d_row, int n_lists, i
     VDB_TRY(ensure_init());
     VDB_REQUIRE(d_dist && d_row && d_out_dist && d_out_row && n_lists >= 1 && nq >= 0 && k >= 1,
                 "bad arguments to vdb_topk_merge_dev");
-    return launch_select_i64(d_dist, d_row, n_lists, nq, k, d_out_dist, d_out_row, pick_stream(stream));
+    return launch_select_i64(d_dist, d_row, nullptr, n_lists, nq, k, d_out_dist, d_out_row, pick_stream(stream));
+}
+
+int vdb_topk_merge_keyed_dev(const float* d_dist, const int64_t* d_key, const int64_t* d_row, int n_lists, int nq, int k,
+                             float* d_out_dist, int64_t* d_out_row, void* stream) {
+    VDB_TRY(ensure_init());
+    VDB_REQUIRE(d_dist && d_key && d_row && d_out_dist && d_out_row && n_lists >= 1 && nq >= 0 && k >= 1,
+                "bad arguments to vdb_topk_merge_keyed_dev");
+    return launch_select_i64(d_dist, d_key, d_row, n_lists, nq, k, d_out_dist, d_out_row, pick_stream(stream));
 }
 
 }  // extern "C"

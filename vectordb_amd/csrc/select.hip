@@ -27,7 +27,7 @@ template <class IdxT>
 __global__ __launch_bounds__(64) void select_kernel(const float* __restrict__ d, const IdxT* __restrict__ idx,
                                                     int64_t q_stride, int64_t l_stride, int n_lists, int k,
                                                     int tie_group, const int* __restrict__ idx_map, int64_t idx_offset,
-                                                    SelectOut o) {
+                                                    const int64_t* __restrict__ payload, SelectOut o) {
     extern __shared__ int heads[];
     const int q = blockIdx.x;
     const int lane = threadIdx.x;
@@ -35,6 +35,7 @@ __global__ __launch_bounds__(64) void select_kernel(const float* __restrict__ d,
     __syncthreads();
     const float* dq = d + (int64_t)q * q_stride;
     const IdxT* iq = idx + (int64_t)q * q_stride;
+    const int64_t* pq = payload ? payload + (int64_t)q * q_stride : nullptr;
 
     float last_d = INFINITY;
     int64_t last_key = INT64_MAX;
@@ -65,7 +66,7 @@ __global__ __launch_bounds__(64) void select_kernel(const float* __restrict__ d,
             float dist = INFINITY;
             if (bl != 0x7fffffff) {
                 heads[bl] += 1;
-                row = (idx_map ? (int64_t)idx_map[bidx] : bidx) + idx_offset;
+                row = pq ? pq[(int64_t)bl * l_stride + heads[bl] - 1] : (idx_map ? (int64_t)idx_map[bidx] : bidx) + idx_offset;
                 dist = bd;
                 last_d = bd;
                 last_key = bkey;
@@ -255,12 +256,12 @@ int launch_select(const float* part_d, const int* part_i, int nq, int n_cand, in
 }
 
 // lists laid out [n_lists][nq][k] (the shape an all-gather of per-shard results produces)
-int launch_select_i64(const float* d, const int64_t* i, int n_lists, int nq, int k,
+int launch_select_i64(const float* d, const int64_t* i, const int64_t* payload, int n_lists, int nq, int k,
                       float* out_d, int64_t* out_i, hipStream_t s) {
     if (nq <= 0) return VDB_OK;
     SelectOut o{out_d, out_i, nullptr, k, 0, nullptr, nullptr};
     hipLaunchKernelGGL(select_kernel<int64_t>, dim3(nq), dim3(64), (size_t)n_lists * sizeof(int), s,
-                       d, i, (int64_t)k, (int64_t)nq * k, n_lists, k, 1, (const int*)nullptr, (int64_t)0, o);
+                       d, i, (int64_t)k, (int64_t)nq * k, n_lists, k, 1, (const int*)nullptr, (int64_t)0, payload, o);
     VDB_HIP(hipGetLastError());
     return VDB_OK;
 }

@@ -785,13 +785,13 @@ int launch_topk_cand(const CandJob& j, hipStream_t s) {
 __global__ void ivf_rows_kernel(const int* __restrict__ slots, int nq, int k, int out_stride, int out_off,
                                 const int* __restrict__ probes, int n_probe, int n_lists, const int64_t* __restrict__ cand_off,
                                 const int64_t* __restrict__ list_off, const int* __restrict__ row_ids,
-                                int64_t* __restrict__ out_rows) {
+                                int64_t* __restrict__ out_rows, int64_t* __restrict__ out_order) {
     const int t = blockIdx.x * blockDim.x + threadIdx.x;
     if (t >= nq * k) return;
     const int q = t / k, r = t - q * k;
     const int64_t at = (int64_t)q * out_stride + out_off + r;
     const int slot = slots[at];
-    if (slot < 0) { out_rows[at] = -1; return; }
+    if (slot < 0) { out_rows[at] = -1; if (out_order) out_order[at] = -1; return; }
     const int64_t* co = cand_off + (int64_t)q * (n_probe + 1);
     int lo = 0, hi = n_probe;                   // co[lo] <= slot < co[hi]
     while (hi - lo > 1) {
@@ -800,13 +800,16 @@ __global__ void ivf_rows_kernel(const int* __restrict__ slots, int nq, int k, in
     }
     const int l = probes[(int64_t)q * n_probe + lo];
     out_rows[at] = (l >= 0 && l < n_lists) ? (int64_t)row_ids[list_off[l] + (slot - co[lo])] : -1;
+    // visiting order of the reference's scan (ivf.py:619-628): probe rank, then position in the list
+    if (out_order) out_order[at] = ((int64_t)lo << 32) | (int64_t)(slot - co[lo]);
 }
 
 int launch_ivf_rows(const int* slots, int nq, int k, int out_stride, int out_off, const int* probes, int n_probe, int n_lists,
-                    const int64_t* cand_off, const int64_t* list_off, const int* row_ids, int64_t* out_rows, hipStream_t s) {
+                    const int64_t* cand_off, const int64_t* list_off, const int* row_ids, int64_t* out_rows,
+                    int64_t* out_order, hipStream_t s) {
     if (nq <= 0 || k <= 0) return VDB_OK;
     hipLaunchKernelGGL(ivf_rows_kernel, dim3((nq * k + 255) / 256), dim3(256), 0, s, slots, nq, k, out_stride, out_off,
-                       probes, n_probe, n_lists, cand_off, list_off, row_ids, out_rows);
+                       probes, n_probe, n_lists, cand_off, list_off, row_ids, out_rows, out_order);
     VDB_HIP(hipGetLastError());
     return VDB_OK;
 }

@@ -189,7 +189,8 @@ struct CandJob {
 };
 int launch_topk_cand(const CandJob& j, hipStream_t s);
 int launch_ivf_rows(const int* slots, int nq, int k, int out_stride, int out_off, const int* probes, int n_probe, int n_lists,
-                    const int64_t* cand_off, const int64_t* list_off, const int* row_ids, int64_t* out_rows, hipStream_t s);
+                    const int64_t* cand_off, const int64_t* list_off, const int* row_ids, int64_t* out_rows,
+                    int64_t* out_order, hipStream_t s);
 
 // final selection: per query, the k best of n_cand ascending candidate lists of k,
 // layout [nq][n_cand][k], under the (distance, tie key) order with
@@ -202,8 +203,9 @@ struct SelectOut {
 };
 int launch_select(const float* part_d, const int* part_i, int nq, int n_cand, int k, int tie_group,
                   const int* idx_map, int64_t idx_offset, const SelectOut& o, hipStream_t s);
-// lists laid out [n_lists][nq][k] with int64 rows (negative = empty)
-int launch_select_i64(const float* d, const int64_t* i, int n_lists, int nq, int k,
+// lists laid out [n_lists][nq][k] with int64 ids (negative = empty), ordered by (distance, id);
+// with a payload of the same layout the payload of every selected entry is written instead of its id
+int launch_select_i64(const float* d, const int64_t* i, const int64_t* payload, int n_lists, int nq, int k,
                       float* out_d, int64_t* out_i, hipStream_t s);
 
 // sort every row of a [nq][n] matrix (n <= 16384) ascending by (value, index); writes the first k of each

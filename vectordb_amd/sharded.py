@@ -1,9 +1,15 @@
-"""Row-sharded search across the GPUs of one node: one process per GPU.
+"""Sharded search across the GPUs of one node: one process per GPU.
 
 The reference is single-process (nothing in it shards), so this module has no
 counterpart there; it keeps the single-GPU contract: the merged result equals
-what one GPU holding all rows would return, including the tie rule (equal
-distances go to the lower global row number).
+what one GPU holding everything would return, including the tie rule (Flat and
+PQ: equal distances go to the lower global row number; IVF: to the candidate
+the reference's scan visits first).
+
+Flat rows and PQ codes shard in contiguous row blocks (ShardedFlat with a
+HipFlatBackend or HipPqBackend).  IVF shards by whole inverted lists, balanced
+greedily on list length, with the centroids replicated (ShardedIVF).  K-means
+training all-reduces the per-cluster sums and counts (kmeans_update_allreduce).
 
 Partition: rank r owns the contiguous global rows [r*N//G, (r+1)*N//G).  Every
 query goes to every rank; each rank returns its local k best with GLOBAL row
@@ -52,6 +58,26 @@ class HipFlatBackend:
                                   stream=torch.cuda.current_stream().cuda_stream)
 
 
+class HipPqBackend:
+    """Local ADC search over this rank's block of PQ codes, merge on the GPU."""
+
+    def __init__(self, dim: int, m: int, ksub: int, codebook):
+        from . import _native
+        self._n = _native
+        self.codes = _native.PqCodes(dim, m, ksub)
+        self.codes.set_codebook(codebook)
+
+    def add_device(self, codes: torch.Tensor) -> None:
+        assert codes.is_cuda and codes.dtype == torch.uint8 and codes.is_contiguous()
+        self.codes.append_codes_device(codes.data_ptr(), codes.shape[0], torch.cuda.current_stream().cuda_stream)
+
+    def local_search(self, queries: torch.Tensor, k: int, out_dist: torch.Tensor, out_rows: torch.Tensor) -> None:
+        self.codes.search_device(queries.data_ptr(), queries.shape[0], k, out_dist.data_ptr(), out_rows.data_ptr(),
+                                 stream=torch.cuda.current_stream().cuda_stream)
+
+    merge = HipFlatBackend.merge
+
+
 class ShardedFlat:
     """Flat search over rows sharded across the ranks of a process group."""
 
@@ -84,3 +110,102 @@ class ShardedFlat:
         dist.all_gather_into_tensor(gr.view(self.world * nq, k), lr, group=self.group)
         self.backend.merge(gd, gr, k, od, orow)
         return od, orow
+
+
+# --------------------------------------------------------------------------- IVF
+def assign_lists_balanced(list_lengths, world: int):
+    """Owner rank of every inverted list: longest list first, each to the rank with
+    the fewest rows so far (ties to the lower rank).  Deterministic, so every rank
+    computes the same map."""
+    import numpy as np
+    lengths = np.asarray(list_lengths, dtype=np.int64)
+    owner = np.empty(len(lengths), dtype=np.int32)
+    load = np.zeros(world, dtype=np.int64)
+    for l in np.argsort(-lengths, kind="stable"):
+        r = int(np.argmin(load))
+        owner[l] = r
+        load[r] += lengths[l]
+    return owner
+
+
+def local_ivf_layout(list_of_row, n_lists: int, owner, rank: int):
+    """For this rank: the global rows it stores (ascending), and the CSR layout of its
+    lists over those rows (`list_rows` in local numbering, `list_offsets`); lists of
+    other ranks are empty.  Positions inside a list are the same as on a single GPU."""
+    import numpy as np
+    list_of_row = np.asarray(list_of_row)
+    mine = np.flatnonzero(owner[list_of_row] == rank)                  # global rows, ascending
+    order = mine[np.argsort(list_of_row[mine], kind="stable")]        # grouped by list, insertion order inside
+    counts = np.bincount(list_of_row[mine], minlength=n_lists).astype(np.int64)
+    offsets = np.zeros(n_lists + 1, dtype=np.int64)
+    np.cumsum(counts, out=offsets[1:])
+    local_of_global = np.full(len(list_of_row), -1, dtype=np.int64)
+    local_of_global[mine] = np.arange(len(mine))
+    return mine, local_of_global[order], offsets
+
+
+class HipIvfBackend:
+    """This rank's inverted lists behind the C ABI (all centroids, own lists only)."""
+
+    def __init__(self, dim: int, metric: int, centroids, rows_local, list_rows_local, list_offsets, global_rows):
+        from . import _native
+        self._n = _native
+        self.lists = _native.IvfLists(dim, metric)
+        self.lists.set_centroids(centroids)
+        self.lists.build_lists(rows_local, list_rows_local, list_offsets)
+        self.global_rows = torch.as_tensor(global_rows, dtype=torch.int64, device="cuda")
+
+    def local_search(self, queries, k, n_probe, out_dist, out_rows, out_order) -> None:
+        self.lists.search_device(queries.data_ptr(), queries.shape[0], k, n_probe, out_dist.data_ptr(), out_rows.data_ptr(),
+                                 stream=torch.cuda.current_stream().cuda_stream, out_order_ptr=out_order.data_ptr())
+        valid = out_rows >= 0
+        out_rows.copy_(torch.where(valid, self.global_rows[out_rows.clamp(min=0)], out_rows))
+
+    def merge(self, all_dist, all_order, all_rows, k, out_dist, out_rows) -> None:
+        world, nq = all_dist.shape[0], all_dist.shape[1]
+        self._n.topk_merge_keyed_device(all_dist.data_ptr(), all_order.data_ptr(), all_rows.data_ptr(), world, nq, k,
+                                        out_dist.data_ptr(), out_rows.data_ptr(),
+                                        stream=torch.cuda.current_stream().cuda_stream)
+
+
+class ShardedIVF:
+    """IVF search with the inverted lists spread over the ranks of a process group.
+    Every rank ranks all centroids (they are replicated), scans the probed lists it
+    owns, and the per-rank results are merged by (distance, visiting order)."""
+
+    def __init__(self, backend, rank: int = 0, world: int = 1, group=None):
+        self.backend, self.rank, self.world, self.group = backend, rank, world, group
+
+    def search(self, queries: torch.Tensor, k: int, n_probe: int):
+        nq, dev = queries.shape[0], queries.device
+        ld = torch.empty((nq, k), device=dev, dtype=torch.float32)
+        lr = torch.empty((nq, k), device=dev, dtype=torch.int64)
+        lo = torch.empty((nq, k), device=dev, dtype=torch.int64)
+        self.backend.local_search(queries, k, n_probe, ld, lr, lo)
+        if self.world == 1:
+            return ld, lr
+        gd = torch.empty((self.world, nq, k), device=dev, dtype=torch.float32)
+        gr = torch.empty((self.world, nq, k), device=dev, dtype=torch.int64)
+        go = torch.empty((self.world, nq, k), device=dev, dtype=torch.int64)
+        dist.all_gather_into_tensor(gd.view(self.world * nq, k), ld, group=self.group)
+        dist.all_gather_into_tensor(gr.view(self.world * nq, k), lr, group=self.group)
+        dist.all_gather_into_tensor(go.view(self.world * nq, k), lo, group=self.group)
+        od = torch.empty((nq, k), device=dev, dtype=torch.float32)
+        orow = torch.empty((nq, k), device=dev, dtype=torch.int64)
+        self.backend.merge(gd, go, gr, k, od, orow)
+        return od, orow
+
+
+# --------------------------------------------------------------------------- k-means
+def kmeans_update_allreduce(sums: torch.Tensor, counts: torch.Tensor, old_centroids: torch.Tensor, group=None):
+    """One Lloyd update over sharded training rows: all-reduce the per-cluster fp64
+    sums [k][d] and counts [k] that every rank accumulated over its own rows, then
+    mean; a cluster nobody feeds keeps its centroid (the caller reseeds it the way
+    index/ivf.py:192-196 does).  Returns (centroids fp32, global counts)."""
+    if dist.is_initialized() and dist.get_world_size(group) > 1:
+        dist.all_reduce(sums, group=group)
+        dist.all_reduce(counts, group=group)
+    fed = counts > 0
+    new = old_centroids.clone()
+    new[fed] = (sums[fed] / counts[fed].unsqueeze(1).to(sums.dtype)).to(old_centroids.dtype)
+    return new, counts
