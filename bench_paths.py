@@ -3,7 +3,7 @@
 headline bench): bandwidth-bound scans and build steps at BASELINE.json sizes,
 each rated against the HBM roofline with its algorithmic bytes.
 
-    python bench_paths.py [--only flat1,l1,c3,ivf,pq,assign,encode] [--scale 1.0]
+    python bench_paths.py [--only flat1,l1,c3,bf16,ivf,pq,assign,encode] [--scale 1.0]
 
 Prints one JSON line per path.  Inputs are synthetic standard-normal (or
 uniform random codes) and resident in HBM before timing.
@@ -22,6 +22,7 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 HBM_PEAK_GBS = 8000.0
 MFMA_F32_PEAK = 157.3
+MFMA_BF16_PEAK = 2500.0
 
 
 def timed(fn, steps, warmup=2):
@@ -47,7 +48,7 @@ def emit(name, **kw):
 
 def main():
     ap = argparse.ArgumentParser()
-    ap.add_argument("--only", default="flat1,l1,c3,ivf,pq,assign,encode")
+    ap.add_argument("--only", default="flat1,l1,c3,bf16,ivf,pq,assign,encode")
     ap.add_argument("--scale", type=float, default=1.0, help="scale the row counts (1.0 = BASELINE sizes)")
     args = ap.parse_args()
     only = set(args.only.split(","))
@@ -109,6 +110,32 @@ def main():
                  qps=round(nq / wall, 1), ms_per_batch=round(wall * 1e3, 4), kernel_ms=round(kern * 1e3, 4), roofline=roof)
         store.close()
         torch.cuda.empty_cache()
+
+    # ---- bf16 storage: configs[1] shape (cosine 1M x 384) and one configs[2] shard (dot 1.25M x 768), batch 1024
+    if "bf16" in only:
+        for metric, mname, n, d in ((N.COSINE, "cosine", int(1_000_000 * args.scale), 384), (N.DOT, "dot", int(1_250_000 * args.scale), 768)):
+            rows = randn(n, d, 42)
+            store = N.RowStore(d, storage="bf16")
+            store.append_device(rows.data_ptr(), n, d, stream)
+            ref = N.RowStore(d)
+            ref.append_device(rows.data_ptr(), n, d, stream)
+            torch.cuda.synchronize()
+            del rows
+            nq = 1024
+            q = randn(nq, d, 123)
+            od, orow = outputs(nq, 10)
+            rd, rrow = outputs(nq, 10)
+            ref.search_device(q.data_ptr(), nq, 10, metric, rd.data_ptr(), rrow.data_ptr())
+            wall, kern, launches = timed(lambda: store.search_device(q.data_ptr(), nq, 10, metric, od.data_ptr(), orow.data_ptr()), 10)
+            a, b = orow.cpu().numpy(), rrow.cpu().numpy()
+            recall = float(np.mean([len(set(a[i]) & set(b[i])) / 10.0 for i in range(nq)]))
+            flop = 2.0 * nq * n * d
+            emit("bf16", workload=f"Flat {mname} {n}x{d} bf16 storage, batch {nq}, k=10", qps=round(nq / wall, 1),
+                 ms_per_batch=round(wall * 1e3, 4), kernel_ms=round(kern * 1e3, 4), recall_at_10_vs_fp32=round(recall, 4),
+                 roofline={"bound": "mfma", "achieved": round(flop / kern / 1e12, 2), "peak": MFMA_BF16_PEAK, "unit": "TFLOP/s",
+                           "frac": round(flop / kern / 1e12 / MFMA_BF16_PEAK, 4), "flop_per_launch": flop})
+            store.close(); ref.close()
+            torch.cuda.empty_cache()
 
     # ---- nearest-centroid assignment: n x 4096 x 128 (MFMA)
     if "assign" in only:

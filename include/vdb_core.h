@@ -91,6 +91,14 @@ int vdb_profile_read(float* kernel_ms, int* launches);
  * the reference recomputes on every search. */
 typedef struct vdb_rows vdb_rows;
 int vdb_rows_create(vdb_rows** out, int dim);
+/* Same with a storage type.  VDB_STORE_BF16 keeps the rows (and rounds the queries) in
+ * bfloat16, round-to-nearest-even, multiplies them on the bf16 matrix cores with fp32
+ * accumulation, and takes the norm terms of the rounded values; it serves the
+ * euclidean, euclidean_squared, cosine and dot metrics.  No counterpart in the
+ * reference, which is fp32 throughout: results are those of the fp32 path on rounded
+ * inputs (tolerance and recall: tests/test_gpu_cabi.py::test_flat_bf16_storage). */
+enum vdb_storage { VDB_STORE_F32 = 0, VDB_STORE_BF16 = 1 };
+int vdb_rows_create_typed(vdb_rows** out, int dim, int storage);
 int vdb_rows_destroy(vdb_rows* h);
 int vdb_rows_append(vdb_rows* h, const float* rows, int64_t n);           /* flat.py:261 */
 int vdb_rows_append_dev(vdb_rows* h, const float* d_rows, int64_t n, int64_t ld, void* stream);

@@ -487,3 +487,24 @@ def test_pq_train_quality():
     small = PQIndex(dimension=32, n_subvectors=8, n_bits=8, seed=1)
     small.train(x[:100])
     assert not small._codebook[:, 100:].any()                            # zero padding beyond the trained codewords
+
+
+def test_flat_index_bf16_storage_kwarg():
+    """FlatIndex(storage="bf16"): same interface, device rows in bfloat16."""
+    from vectordb_amd.index import FlatIndex
+    rng = np.random.RandomState(3)
+    x = rng.randn(3000, 48).astype(np.float32)
+    ids = [f"v{i}" for i in range(len(x))]
+    exact = FlatIndex(48, metric="cosine")
+    half = FlatIndex(48, metric="cosine", storage="bf16")
+    exact.add_batch(ids, x)
+    half.add_batch(ids, x)
+    hits = 0
+    for qi in range(20):
+        a = [r.id for r in exact.search(x[qi] + 0.05 * rng.randn(48).astype(np.float32), k=10)]
+        b = [r.id for r in half.search(x[qi] + 0.05 * rng.randn(48).astype(np.float32), k=10)]
+        assert b[0] == f"v{qi}" and a[0] == f"v{qi}"
+        hits += 1
+    assert hits == 20
+    with pytest.raises(ValueError):
+        FlatIndex(48, storage="fp8")

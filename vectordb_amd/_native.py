@@ -49,6 +49,7 @@ SIGNATURES = {
     "vdb_profile_enable": (C.c_int, [C.c_int]),
     "vdb_profile_read": (C.c_int, [c_float_p, C.POINTER(C.c_int)]),
     "vdb_rows_create": (C.c_int, [C.POINTER(C.c_void_p), C.c_int]),
+    "vdb_rows_create_typed": (C.c_int, [C.POINTER(C.c_void_p), C.c_int, C.c_int]),
     "vdb_rows_destroy": (C.c_int, [C.c_void_p]),
     "vdb_rows_append": (C.c_int, [C.c_void_p, c_float_p, C.c_int64]),
     "vdb_rows_append_dev": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_int64, C.c_void_p]),
@@ -213,15 +214,21 @@ def u32ptr(a: Optional[np.ndarray]):
     return None if a is None else a.ctypes.data_as(c_u32_p)
 
 
-class RowStore:
-    """Owner of a vdb_rows handle (resident fp32 matrix + norms)."""
+STORAGE = {"f32": 0, "bf16": 1}
 
-    def __init__(self, dim: int):
+
+class RowStore:
+    """Owner of a vdb_rows handle (resident row matrix + norms); storage "f32" or "bf16"."""
+
+    def __init__(self, dim: int, storage: str = "f32"):
         init()
         self.lib = load()
         self.dim = int(dim)
+        if storage not in STORAGE:
+            raise ValueError(f"storage must be one of {sorted(STORAGE)}, got {storage!r}")
+        self.storage = storage
         self.h = C.c_void_p()
-        check(self.lib.vdb_rows_create(C.byref(self.h), self.dim))
+        check(self.lib.vdb_rows_create_typed(C.byref(self.h), self.dim, STORAGE[storage]))
 
     def close(self):
         if getattr(self, "h", None) is not None and self.h:

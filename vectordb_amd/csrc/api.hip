@@ -115,6 +115,26 @@ __global__ void pad_rows_kernel(const float* __restrict__ src, int64_t src_ld, i
     }
 }
 
+// fp32 rows -> bf16 rows (round to nearest even), plus the rounded values back in fp32 so
+// that the norm terms describe exactly what the matrix cores multiply
+__global__ void round_bf16_kernel(const float* __restrict__ src, int64_t src_ld, int dim, int64_t n,
+                                  uint16_t* __restrict__ dst16, int ld16, float* __restrict__ dst32, int ld32) {
+    const int w = max(ld16, ld32);
+    const int64_t total = n * w;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t r = i / w;
+        const int c = (int)(i - r * w);
+        uint32_t b = 0;
+        if (c < dim) {
+            const uint32_t x = __float_as_uint(src[r * src_ld + c]);
+            b = ((x & 0x7fffffffu) > 0x7f800000u) ? ((x >> 16) | 0x40u)        // NaN stays NaN
+                                                  : ((x + 0x7fffu + ((x >> 16) & 1u)) >> 16);
+        }
+        if (c < ld16) dst16[r * ld16 + c] = (uint16_t)b;
+        if (c < ld32) dst32[r * ld32 + c] = __uint_as_float(b << 16);
+    }
+}
+
 __global__ void fill_results_kernel(float* d, int64_t* i, int64_t total) {
     for (int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; t < total; t += (int64_t)gridDim.x * blockDim.x) {
         if (d) d[t] = INFINITY;
@@ -142,10 +162,10 @@ static int fill_results(float* d, int64_t* i, int64_t total, hipStream_t s) {
 // ============================================================== workspaces
 struct Workspace {
     DevBuf q_buf, q_sq, q_nrm, part_d, part_i, lb_d, lb_k, thr_d, thr_k, mask, out_d, out_i, dist, probes, probe_d, lut, stage;
-    DevBuf cand, seg_row_off, seg_q_off, seg_item_off, sq_qid, sq_out, cand_off, tile_off, list_cnt, cursor, slots, items;
+    DevBuf round32, q16, cand, seg_row_off, seg_q_off, seg_item_off, sq_qid, sq_out, cand_off, tile_off, list_cnt, cursor, slots, items;
     void release() {
         DevBuf* all[] = {&q_buf, &q_sq, &q_nrm, &part_d, &part_i, &lb_d, &lb_k, &thr_d, &thr_k, &mask, &out_d, &out_i, &dist,
-                         &probes, &probe_d, &lut, &stage, &cand, &seg_row_off, &seg_q_off, &seg_item_off, &sq_qid, &sq_out,
+                         &probes, &probe_d, &lut, &stage, &round32, &q16, &cand, &seg_row_off, &seg_q_off, &seg_item_off, &sq_qid, &sq_out,
                          &cand_off, &tile_off, &list_cnt, &cursor, &slots, &items};
         for (DevBuf* b : all) b->release();
     }
@@ -203,7 +223,7 @@ using namespace vdb;
 // ============================================================== row store
 struct vdb_rows {
     Rows r;
-    DevBuf data, sq, nrm;
+    DevBuf data, data16, sq, nrm;
     Workspace ws;
 };
 
@@ -212,11 +232,15 @@ static int rows_reserve(vdb_rows* h, int64_t n_total, hipStream_t s) {
     if (n_total <= r.cap) return VDB_OK;
     int64_t cap = std::max<int64_t>(n_total, r.cap + r.cap / 2);
     cap = std::max<int64_t>(cap, 1024);
-    VDB_TRY(h->data.reserve_keep((size_t)cap * r.ld * sizeof(float), (size_t)r.n * r.ld * sizeof(float), s));
+    if (r.bf16)
+        VDB_TRY(h->data16.reserve_keep((size_t)cap * r.ld16 * 2, (size_t)r.n * r.ld16 * 2, s));
+    else
+        VDB_TRY(h->data.reserve_keep((size_t)cap * r.ld * sizeof(float), (size_t)r.n * r.ld * sizeof(float), s));
     VDB_TRY(h->sq.reserve_keep((size_t)cap * sizeof(float), (size_t)r.n * sizeof(float), s));
     VDB_TRY(h->nrm.reserve_keep((size_t)cap * sizeof(float), (size_t)r.n * sizeof(float), s));
     r.cap = cap;
     r.data = h->data.as<float>();
+    r.data16 = h->data16.as<uint16_t>();
     r.sq = h->sq.as<float>();
     r.nrm = h->nrm.as<float>();
     return VDB_OK;
@@ -226,6 +250,20 @@ static int rows_append_dev_impl(vdb_rows* h, const float* d_rows, int64_t n, int
     Rows& r = h->r;
     if (n <= 0) return VDB_OK;
     VDB_TRY(rows_reserve(h, r.n + n, s));
+    if (r.bf16) {
+        // in chunks: round, store bf16, norms of the rounded values
+        const int64_t chunk = std::max<int64_t>(1024, (int64_t)(256 << 20) / (r.ld * (int64_t)sizeof(float)));
+        for (int64_t o = 0; o < n; o += chunk) {
+            const int64_t c = std::min(chunk, n - o);
+            VDB_TRY(h->ws.round32.reserve((size_t)c * r.ld * sizeof(float)));
+            hipLaunchKernelGGL(round_bf16_kernel, dim3(grid_for(c * r.ld16)), dim3(256), 0, s, d_rows + o * src_ld, src_ld, r.dim,
+                               c, r.data16 + (r.n + o) * r.ld16, r.ld16, h->ws.round32.as<float>(), r.ld);
+            VDB_HIP(hipGetLastError());
+            VDB_TRY(row_norms(h->ws, h->ws.round32.as<float>(), r.ld, r.dim, c, r.plan, r.sq + r.n + o, r.nrm + r.n + o, s));
+        }
+        r.n += n;
+        return VDB_OK;
+    }
     float* dst = r.data + r.n * r.ld;
     if (src_ld == r.ld && r.ld == r.dim) {
         VDB_HIP(hipMemcpyAsync(dst, d_rows, (size_t)n * r.ld * sizeof(float), hipMemcpyDeviceToDevice, s));
@@ -239,6 +277,20 @@ static int rows_append_dev_impl(vdb_rows* h, const float* d_rows, int64_t n, int
     return VDB_OK;
 }
 
+
+// bf16 storage: queries rounded to bf16 (what the matrix cores multiply) + norms of the rounded values
+static int prepare_queries_bf16(Workspace& ws, const Rows& r, const float* d_q, int nq, const void** q_out, hipStream_t s) {
+    VDB_TRY(ws.round32.reserve((size_t)nq * r.ld * sizeof(float)));
+    VDB_TRY(ws.q16.reserve((size_t)nq * r.ld16 * 2));
+    hipLaunchKernelGGL(round_bf16_kernel, dim3(grid_for((int64_t)nq * r.ld16)), dim3(256), 0, s, d_q, (int64_t)r.dim, r.dim,
+                       (int64_t)nq, ws.q16.as<uint16_t>(), r.ld16, ws.round32.as<float>(), r.ld);
+    VDB_HIP(hipGetLastError());
+    VDB_TRY(ws.q_sq.reserve((size_t)nq * sizeof(float)));
+    VDB_TRY(ws.q_nrm.reserve((size_t)nq * sizeof(float)));
+    VDB_TRY(row_norms(ws, ws.round32.as<float>(), r.ld, r.dim, nq, r.plan, ws.q_sq.as<float>(), ws.q_nrm.as<float>(), s));
+    *q_out = ws.q16.p;
+    return VDB_OK;
+}
 
 // ---- streaming scan of all rows for a block of queries: candidate buffer [nq][n] of streamed sums
 static const int64_t CAND_BUDGET = (int64_t)1 << 30;      // bytes of candidate buffer per pass
@@ -322,10 +374,17 @@ static int flat_search_impl(vdb_rows* h, int metric, const float* d_q, int nq, i
     }
     if (r.n == 0) return VDB_OK;
 
-    const float* q = nullptr;
-    VDB_TRY(prepare_queries(ws, d_q, nq, r.dim, r.ld, r.plan, &q, s));
-    const bool gemm = is_dot_metric(metric) && nq >= GEMM_MIN_NQ;
-    if (!gemm) return stream_flat_search(h, metric, q, nq, k, k_eff, d_mask, d_out_d, d_out_i, d_out_i32, s);
+    const void* q = nullptr;
+    if (r.bf16) {
+        VDB_REQUIRE(is_dot_metric(metric), "bf16 storage serves euclidean, euclidean_squared, cosine and dot (metric %d asked)", metric);
+        VDB_TRY(prepare_queries_bf16(ws, r, d_q, nq, &q, s));
+    } else {
+        const float* qf = nullptr;
+        VDB_TRY(prepare_queries(ws, d_q, nq, r.dim, r.ld, r.plan, &qf, s));
+        const bool gemm = is_dot_metric(metric) && nq >= GEMM_MIN_NQ;
+        if (!gemm) return stream_flat_search(h, metric, qf, nq, k, k_eff, d_mask, d_out_d, d_out_i, d_out_i32, s);
+        q = qf;
+    }
 
     int n_cand = 0, sample_tiles = 0, sample_stride = 1, n_cand_sample = 0;
     VDB_TRY(flat_gemm_num_cand(r.n, nq, k, &n_cand));
@@ -373,6 +432,12 @@ static int flat_distances_impl(vdb_rows* h, int metric, const float* d_q, int nq
     Workspace& ws = h->ws;
     VDB_REQUIRE(valid_metric(metric), "unknown metric code %d", metric);
     if (nq <= 0 || r.n == 0) return VDB_OK;
+    if (r.bf16) {
+        VDB_REQUIRE(is_dot_metric(metric), "bf16 storage serves euclidean, euclidean_squared, cosine and dot (metric %d asked)", metric);
+        const void* q16 = nullptr;
+        VDB_TRY(prepare_queries_bf16(ws, r, d_q, nq, &q16, s));
+        return launch_flat_gemm_dist(r, metric, q16, ws.q_sq.as<float>(), ws.q_nrm.as<float>(), nq, d_out, s);
+    }
     const float* q = nullptr;
     VDB_TRY(prepare_queries(ws, d_q, nq, r.dim, r.ld, r.plan, &q, s));
     if (is_dot_metric(metric) && nq >= GEMM_MIN_NQ)
@@ -525,13 +590,18 @@ int vdb_synchronize(void) {
 }
 
 // ============================================================== rows
-int vdb_rows_create(vdb_rows** out, int dim) {
+int vdb_rows_create(vdb_rows** out, int dim) { return vdb_rows_create_typed(out, dim, VDB_STORE_F32); }
+
+int vdb_rows_create_typed(vdb_rows** out, int dim, int storage) {
     VDB_TRY(ensure_init());
     VDB_REQUIRE(out != nullptr, "null output handle");
     VDB_REQUIRE(dim >= 1 && dim <= 8192, "dimension must be in 1..8192, got %d", dim);
+    VDB_REQUIRE(storage == VDB_STORE_F32 || storage == VDB_STORE_BF16, "unknown storage type %d", storage);
     vdb_rows* h = new vdb_rows();
     h->r.dim = dim;
     h->r.ld = round_up(dim, 4);
+    h->r.bf16 = storage == VDB_STORE_BF16;
+    h->r.ld16 = round_up(dim, 8);
     VDB_TRY(make_sum_plan(dim, &h->r.plan));
     *out = h;
     return VDB_OK;
@@ -541,7 +611,7 @@ int vdb_rows_destroy(vdb_rows* h) {
     if (!h) return VDB_OK;
     std::lock_guard<std::mutex> g(ctx().mu);
     (void)hipStreamSynchronize(ctx().stream);
-    h->data.release(); h->sq.release(); h->nrm.release(); h->ws.release();
+    h->data.release(); h->data16.release(); h->sq.release(); h->nrm.release(); h->ws.release();
     delete h;
     return VDB_OK;
 }
@@ -553,7 +623,7 @@ int vdb_rows_append(vdb_rows* h, const float* rows, int64_t n) {
     hipStream_t s = ctx().stream;
     Rows& r = h->r;
     VDB_TRY(rows_reserve(h, r.n + n, s));
-    if (r.ld == r.dim) {
+    if (r.ld == r.dim && !r.bf16) {
         float* dst = r.data + r.n * r.ld;
         VDB_HIP(hipMemcpyAsync(dst, rows, (size_t)n * r.dim * sizeof(float), hipMemcpyHostToDevice, s));
         VDB_TRY(row_norms(h->ws, dst, r.ld, r.dim, n, r.plan, r.sq + r.n, r.nrm + r.n, s));
@@ -584,6 +654,17 @@ int vdb_rows_set(vdb_rows* h, int64_t row, const float* vec) {
     std::lock_guard<std::mutex> g(ctx().mu);
     hipStream_t s = ctx().stream;
     Rows& r = h->r;
+    if (r.bf16) {
+        VDB_TRY(h->ws.stage.reserve((size_t)r.dim * sizeof(float)));
+        VDB_TRY(h->ws.round32.reserve((size_t)r.ld * sizeof(float)));
+        VDB_HIP(hipMemcpyAsync(h->ws.stage.p, vec, (size_t)r.dim * sizeof(float), hipMemcpyHostToDevice, s));
+        hipLaunchKernelGGL(round_bf16_kernel, dim3(1), dim3(256), 0, s, h->ws.stage.as<float>(), (int64_t)r.dim, r.dim, (int64_t)1,
+                           r.data16 + row * r.ld16, r.ld16, h->ws.round32.as<float>(), r.ld);
+        VDB_HIP(hipGetLastError());
+        VDB_TRY(row_norms(h->ws, h->ws.round32.as<float>(), r.ld, r.dim, 1, r.plan, r.sq + row, r.nrm + row, s));
+        VDB_HIP(hipStreamSynchronize(s));
+        return VDB_OK;
+    }
     float* dst = r.data + row * r.ld;
     VDB_HIP(hipMemcpyAsync(dst, vec, (size_t)r.dim * sizeof(float), hipMemcpyHostToDevice, s));   // padding stays zero
     VDB_TRY(row_norms(h->ws, dst, r.ld, r.dim, 1, r.plan, r.sq + row, r.nrm + row, s));
@@ -667,6 +748,7 @@ int vdb_flat_range_search(vdb_rows* h, int metric, const float* query, float rad
     Rows& r = h->r;
     Workspace& ws = h->ws;
     *count = 0;
+    VDB_REQUIRE(!r.bf16, "range search needs fp32 storage");
     if (r.n == 0 || cap <= 0) return VDB_OK;
     const uint32_t* d_mask = nullptr;
     VDB_TRY(upload_mask(ws, mask, r.n, &d_mask, s));

@@ -30,17 +30,18 @@
 namespace vdb {
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef short bf16x8 __attribute__((ext_vector_type(8)));
 
 static constexpr int TM = 128;      // database rows per tile
 static constexpr int TQ = 128;      // queries per tile
-static constexpr int TK = 32;       // K step
-static constexpr int LW = TK + 4;   // padded LDS row width in floats
+static constexpr int TKB = 128;     // bytes of every row per K step: 32 fp32 or 64 bf16
+static constexpr int LW = 36;       // padded LDS row width in dwords (128 B of data + 16 B)
 static constexpr int NT = LIST_NT;  // threads per block
 
 struct GemmParams {
-    const float* rows; int64_t n; int ld;
+    const void* rows; int64_t n; int ld_bytes;     // row pitch in bytes (multiple of 16); fp32 or bf16 elements
     const float* row_sq; const float* row_nrm;
-    const float* q; int nq;
+    const void* q; int nq;                         // same element type and pitch as the rows
     const float* q_sq; const float* q_nrm;
     const uint32_t* mask;
     const float* lb_d; const int64_t* lb_k;
@@ -106,7 +107,9 @@ __device__ __forceinline__ float pick16(const f32x16& a, int e) {
 
 // SAMPLE only gives the strided warm-up pass a kernel name of its own, so that
 // profiles list it separately from the full pass.
-template <int METRIC, bool TOPK, bool SAMPLE>
+// BF16: rows and queries are bf16 (v_mfma_f32_32x32x16_bf16, fp32 accumulation); the LDS image,
+// the staging and the fragment addresses are the same bytes as for fp32.
+template <int METRIC, bool TOPK, bool SAMPLE, bool BF16>
 __global__ __launch_bounds__(NT, 2) void flat_gemm_kernel(GemmParams p) {
     extern __shared__ __align__(16) float smem[];
     float* As = smem;                   // [TM][LW]  database rows
@@ -161,35 +164,37 @@ __global__ __launch_bounds__(NT, 2) void flat_gemm_kernel(GemmParams p) {
     }
     float bound = filter_bound<METRIC>(thr, q_term);
 
-    const int ksteps = (p.ld + TK - 1) / TK;
+    const int ksteps = (p.ld_bytes + TKB - 1) / TKB;
     const int srow = tid >> 3;          // staging: row within a 32-row pass
-    const int skc = (tid & 7) * 4;      // staging: float offset inside the K step
+    const int skc = (tid & 7) * 4;      // staging: dword offset inside the K step (16-byte pieces)
     const int64_t q_base = (int64_t)qt * TQ;
 
     // staging addresses: a wave-uniform base (tile, K step) plus a 32-bit per-thread
     // offset (row inside the tile, float4 inside the K step), so a K step costs
     // eight loads and no per-thread address arithmetic
-    const bool k_tail = (p.ld % TK) != 0;
+    const bool k_tail = (p.ld_bytes % TKB) != 0;
+    const int ldw = p.ld_bytes >> 2;    // row pitch in dwords
     uint32_t offb[4], offa[4];
 #pragma unroll
     for (int ps = 0; ps < 4; ++ps) {
         const int64_t gq = min(q_base + ps * 32 + srow, (int64_t)p.nq - 1) - q_base;
-        offb[ps] = (uint32_t)(gq * p.ld + skc);
-        offa[ps] = (uint32_t)((ps * 32 + srow) * p.ld + skc);
+        offb[ps] = (uint32_t)(gq * ldw + skc);
+        offa[ps] = (uint32_t)((ps * 32 + srow) * ldw + skc);
     }
-    const float* qbase_ptr = p.q + q_base * p.ld;
+    const float* rows_w = reinterpret_cast<const float*>(p.rows);      // dword views of the operands
+    const float* qbase_ptr = reinterpret_cast<const float*>(p.q) + q_base * ldw;
     float4 ra[4], rb[4];
     auto issue_loads = [&](int tile, int ks) {
         const int64_t rbase = (int64_t)tile * p.tile_stride * TM;
-        const float* abase = p.rows + rbase * p.ld + ks * TK;
-        const float* bbase = qbase_ptr + ks * TK;
+        const float* abase = rows_w + rbase * ldw + ks * (TKB / 4);
+        const float* bbase = qbase_ptr + ks * (TKB / 4);
         if (rbase + TM > p.n) {             // last tile: rows past the end re-read the last row (masked out later)
 #pragma unroll
             for (int ps = 0; ps < 4; ++ps)
-                offa[ps] = (uint32_t)(min((int64_t)(ps * 32 + srow), p.n - 1 - rbase) * p.ld + skc);
+                offa[ps] = (uint32_t)(min((int64_t)(ps * 32 + srow), p.n - 1 - rbase) * ldw + skc);
         }
         if (k_tail && ks == ksteps - 1) {
-            const bool kin = ks * TK + skc < p.ld;
+            const bool kin = ks * (TKB / 4) + skc < ldw;
 #pragma unroll
             for (int ps = 0; ps < 4; ++ps) {
                 ra[ps] = kin ? *reinterpret_cast<const float4*>(abase + offa[ps]) : make_float4(0, 0, 0, 0);
@@ -253,10 +258,16 @@ __global__ __launch_bounds__(NT, 2) void flat_gemm_kernel(GemmParams p) {
             for (int ch = 0; ch < 4; ++ch) {
 #pragma unroll
                 for (int s = 0; s < 4; ++s) {
-                    acc[s] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[ch][s].x, bf[ch].x, acc[s], 0, 0, 0);
-                    acc[s] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[ch][s].y, bf[ch].y, acc[s], 0, 0, 0);
-                    acc[s] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[ch][s].z, bf[ch].z, acc[s], 0, 0, 0);
-                    acc[s] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[ch][s].w, bf[ch].w, acc[s], 0, 0, 0);
+                    if (BF16) {
+                        // the 16 bytes are 8 consecutive bf16 of the K step: k = 16*ch + 8*half + 0..7
+                        acc[s] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, af[ch][s]),
+                                                                         __builtin_bit_cast(bf16x8, bf[ch]), acc[s], 0, 0, 0);
+                    } else {
+                        acc[s] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[ch][s].x, bf[ch].x, acc[s], 0, 0, 0);
+                        acc[s] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[ch][s].y, bf[ch].y, acc[s], 0, 0, 0);
+                        acc[s] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[ch][s].z, bf[ch].z, acc[s], 0, 0, 0);
+                        acc[s] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[ch][s].w, bf[ch].w, acc[s], 0, 0, 0);
+                    }
                 }
             }
         }
@@ -389,7 +400,7 @@ int flat_gemm_sample_plan(int64_t n, int* sample_tiles, int* tile_stride) {
     return VDB_OK;
 }
 
-template <bool TOPK>
+template <bool TOPK, bool BF16>
 static int launch_gemm(int metric, GemmParams& p, hipStream_t s) {
     plan_grid(p.n_tiles, p.nq, ctx().num_cus, &p.n_qtiles, &p.n_slabs, &p.tiles_per_slab);
     const int groups = (p.n_slabs + 7) / 8;
@@ -401,7 +412,7 @@ static int launch_gemm(int metric, GemmParams& p, hipStream_t s) {
     KernelTimer timer(s, p.tile_stride == 1);
 #define VDB_LAUNCH_GEMM(M)                                                                     \
     case M: {                                                                                  \
-        auto kern = (TOPK && p.tile_stride != 1) ? flat_gemm_kernel<M, TOPK, TOPK> : flat_gemm_kernel<M, TOPK, false>; \
+        auto kern = (TOPK && p.tile_stride != 1) ? flat_gemm_kernel<M, TOPK, TOPK, BF16> : flat_gemm_kernel<M, TOPK, false, BF16>; \
         VDB_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern),                       \
                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));    \
         hipLaunchKernelGGL(kern, grid, dim3(NT), lds, s, p);                                   \
@@ -421,32 +432,34 @@ static int launch_gemm(int metric, GemmParams& p, hipStream_t s) {
     return VDB_OK;
 }
 
-int launch_flat_gemm_topk(const Rows& r, int metric, const float* q, const float* q_sq, const float* q_nrm,
+int launch_flat_gemm_topk(const Rows& r, int metric, const void* q, const float* q_sq, const float* q_nrm,
                           int nq, int k, const uint32_t* mask, const float* lb_d, const int64_t* lb_k,
                           const float* thr_init, int sample_tiles, int tile_stride,
                           float* part_d, int* part_i, int n_cand, hipStream_t s) {
     VDB_REQUIRE(k >= 1 && k <= KMAX_FUSED, "fused selection supports 1 <= k <= %d, got %d", KMAX_FUSED, k);
     VDB_REQUIRE(r.n >= 1 && nq >= 1, "empty search");
     GemmParams p{};
-    p.rows = r.data; p.n = r.n; p.ld = r.ld; p.row_sq = r.sq; p.row_nrm = r.nrm;
+    p.rows = r.bf16 ? (const void*)r.data16 : (const void*)r.data; p.n = r.n;
+    p.ld_bytes = r.bf16 ? r.ld16 * 2 : r.ld * 4; p.row_sq = r.sq; p.row_nrm = r.nrm;
     p.q = q; p.nq = nq; p.q_sq = q_sq; p.q_nrm = q_nrm;
     p.mask = mask; p.lb_d = lb_d; p.lb_k = lb_k; p.thr_init = thr_init; p.k = k;
     p.n_tiles = sample_tiles > 0 ? sample_tiles : (int)((r.n + TM - 1) / TM);
     p.tile_stride = sample_tiles > 0 ? tile_stride : 1;
     p.part_d = part_d; p.part_i = part_i; p.n_cand = n_cand; p.dist_out = nullptr;
-    return launch_gemm<true>(metric, p, s);
+    return r.bf16 ? launch_gemm<true, true>(metric, p, s) : launch_gemm<true, false>(metric, p, s);
 }
 
-int launch_flat_gemm_dist(const Rows& r, int metric, const float* q, const float* q_sq, const float* q_nrm,
+int launch_flat_gemm_dist(const Rows& r, int metric, const void* q, const float* q_sq, const float* q_nrm,
                           int nq, float* out, hipStream_t s) {
     VDB_REQUIRE(r.n >= 1 && nq >= 1, "empty distance computation");
     GemmParams p{};
-    p.rows = r.data; p.n = r.n; p.ld = r.ld; p.row_sq = r.sq; p.row_nrm = r.nrm;
+    p.rows = r.bf16 ? (const void*)r.data16 : (const void*)r.data; p.n = r.n;
+    p.ld_bytes = r.bf16 ? r.ld16 * 2 : r.ld * 4; p.row_sq = r.sq; p.row_nrm = r.nrm;
     p.q = q; p.nq = nq; p.q_sq = q_sq; p.q_nrm = q_nrm;
     p.k = 0; p.dist_out = out;
     p.n_tiles = (int)((r.n + TM - 1) / TM);
     p.tile_stride = 1;
-    return launch_gemm<false>(metric, p, s);
+    return r.bf16 ? launch_gemm<false, true>(metric, p, s) : launch_gemm<false, false>(metric, p, s);
 }
 
 }  // namespace vdb

@@ -97,7 +97,10 @@ struct Rows {
     int ld = 0;             // floats per stored row: dim rounded up to 4, zero padded
     int64_t n = 0;
     int64_t cap = 0;
-    float* data = nullptr;  // [cap][ld]
+    float* data = nullptr;  // [cap][ld]   (fp32 storage)
+    bool bf16 = false;      // bf16 storage: data16 holds the rows, data is unused
+    int ld16 = 0;           // bf16 elements per stored row: dim rounded up to 8, zero padded
+    uint16_t* data16 = nullptr;   // [cap][ld16]
     float* sq = nullptr;    // [cap]  np.sum(row**2)
     float* nrm = nullptr;   // [cap]  sqrt(sq)
     SumPlan plan;
@@ -116,12 +119,12 @@ int flat_gemm_num_cand_tiles(int n_tiles, int nq, int* n_cand);
 // strided row sample used to warm-start the selection threshold: number of
 // 128-row tiles to visit (0 = not worth it) and the stride between them
 int flat_gemm_sample_plan(int64_t n, int* sample_tiles, int* tile_stride);
-int launch_flat_gemm_topk(const Rows& r, int metric, const float* q, const float* q_sq, const float* q_nrm,
+int launch_flat_gemm_topk(const Rows& r, int metric, const void* q, const float* q_sq, const float* q_nrm,
                           int nq, int k, const uint32_t* mask, const float* lb_d, const int64_t* lb_k,
                           const float* thr_init, int sample_tiles, int tile_stride,
                           float* part_d, int* part_i, int n_cand, hipStream_t s);
 // MFMA path, full distance matrix out[nq][n]
-int launch_flat_gemm_dist(const Rows& r, int metric, const float* q, const float* q_sq, const float* q_nrm,
+int launch_flat_gemm_dist(const Rows& r, int metric, const void* q, const float* q_sq, const float* q_nrm,
                           int nq, float* out, hipStream_t s);
 
 // streaming pipeline: pairwise-ordered sums for (row chunk, query group) items -> candidate buffer

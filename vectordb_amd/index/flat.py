@@ -35,8 +35,14 @@ class FlatIndex(BaseIndex):
     """Exact k-NN over every stored row (index/flat.py:69-956)."""
 
     def __init__(self, dimension: int, metric: str = "euclidean", normalize: bool = False, use_matrix: bool = True,
-                 initial_capacity: int = 1000, **kwargs):
+                 initial_capacity: int = 1000, storage: str = "f32", **kwargs):
+        """`storage` is not a reference argument: "bf16" keeps the device copy of the rows in
+        bfloat16 (euclidean, euclidean_squared, cosine, dot only; distances are those of inputs
+        rounded to bf16).  The host copy returned by get()/include_vectors stays fp32."""
         super().__init__(dimension, metric, **kwargs)
+        if storage not in N.STORAGE:
+            raise ValueError(f"storage must be one of {sorted(N.STORAGE)}, got {storage!r}")
+        self._storage = storage
         self.config = FlatIndexConfig(dimension=dimension, metric=metric, normalize=normalize, use_matrix=use_matrix,
                                       initial_capacity=initial_capacity)
         self._ids: List[str] = []
@@ -62,7 +68,7 @@ class FlatIndex(BaseIndex):
     # ------------------------------------------------------------ device mirror
     def _device(self) -> N.RowStore:
         if self._store is None:
-            self._store = N.RowStore(self._dimension)
+            self._store = N.RowStore(self._dimension, storage=self._storage)
             self._synced = 0
         if self._synced < self._size:
             self._store.append(self._vectors[self._synced:self._size])
