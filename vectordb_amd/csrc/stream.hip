@@ -35,16 +35,6 @@ static constexpr int S_CK = 32;                   // floats of every row per sta
 static constexpr int S_STAGE = S_NT * S_CK;       // floats per stage buffer (32 KiB)
 static constexpr int STREAM_QS = 2;               // wave sets sharing one row chunk in the 8-query kernels
 
-// One LDS-DMA instruction: every lane fetches 16 bytes from its own global address; the
-// wave's 1 KiB lands at lds_dst (a wave-uniform LDS byte address) in lane order.  Written
-// as asm so that the compiler neither counts it nor drains it before later LDS reads;
-// completion is awaited with wait_loads() below.
-__device__ __forceinline__ void glds16(const float* gsrc, unsigned lds_dst) {
-    unsigned keep;
-    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
-                 : "=&s"(keep) : "v"(gsrc), "s"(lds_dst) : "memory");
-}
-
 // uniform (scalar-cache) load: the address must be the same in every lane
 template <class T> __device__ __forceinline__ T uload(const T* p) {
     return *reinterpret_cast<const __attribute__((address_space(4))) T*>(reinterpret_cast<uintptr_t>(p));

@@ -10,6 +10,16 @@ namespace vdb {
 static constexpr int LIST_NT = 256;         // threads per block of every kernel that keeps lists
 static constexpr int EMPTY_IDX = 0x7fffffff;
 
+// One LDS-DMA instruction: every lane fetches 16 bytes from its own global address; the
+// wave's 1 KiB lands at lds_dst (a wave-uniform LDS byte address) in lane order.  Written
+// as asm so that the compiler neither counts it nor drains it before later LDS reads;
+// completion is awaited with wait_loads() below.
+__device__ __forceinline__ void glds16(const void* gsrc, unsigned lds_dst) {
+    unsigned keep;
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
+                 : "=&s"(keep) : "v"(gsrc), "s"(lds_dst) : "memory");
+}
+
 // Insert (v, id) into the calling thread's ascending list (consecutive
 // positions are LIST_NT floats apart).  A thread sees ids in ascending order,
 // so an equal distance is placed behind the entries already present.
