@@ -195,6 +195,27 @@ int vdb_pq_search(vdb_pq* h, const float* queries, int nq, int k,
 int vdb_pq_search_dev(vdb_pq* h, const float* d_queries, int nq, int k,
                       const uint32_t* d_mask, float* d_out_dist, int64_t* d_out_row, void* stream);
 
+/* ---- IVF-PQ (HybridIndex, index/hybrid.py:41-536) ----------------------------
+ * Coarse k-means centroids + a PQ codebook trained on residuals.  Rows live as
+ * m-byte codes in inverted lists.  Search (hybrid.py:276-352): coarse ranking by
+ * the identity-form squared distance, then per probed list the table of the
+ * residual query and the ADC scan (fp32 sum in sub-space order, sqrt), results
+ * ascending with ties in visiting order (probe rank, then position in the list). */
+typedef struct vdb_ivfpq vdb_ivfpq;
+int vdb_ivfpq_create(vdb_ivfpq** out, int dim, int m, int ksub);
+int vdb_ivfpq_destroy(vdb_ivfpq* h);
+/* trained quantizers (hybrid.py:146,165); empties the lists */
+int vdb_ivfpq_set_quantizers(vdb_ivfpq* h, const float* centroids, int n_lists, const float* codebook);
+/* rows -> (list, code): nearest coarse centroid (hybrid.py:205-210), residual, PQ code (:212-224) */
+int vdb_ivfpq_encode(vdb_ivfpq* h, const float* rows, int64_t n, int32_t* out_list, uint8_t* out_codes);
+/* lists in scan order: codes[n][m] by row number, the row numbers of every list
+ * concatenated, n_lists+1 offsets (hybrid.py:262 appends, :405-409 removes in place) */
+int vdb_ivfpq_build(vdb_ivfpq* h, const uint8_t* codes, int64_t n, const int64_t* list_rows, const int64_t* list_offsets);
+int vdb_ivfpq_search(vdb_ivfpq* h, const float* queries, int nq, int k, int n_probe,
+                     const uint32_t* mask, float* out_dist, int64_t* out_row);
+int vdb_ivfpq_search_dev(vdb_ivfpq* h, const float* d_queries, int nq, int k, int n_probe,
+                         const uint32_t* d_mask, float* d_out_dist, int64_t* d_out_row, void* stream);
+
 /* ---- cross-shard merge ------------------------------------------------------
  * No counterpart in the reference (it is single-process).  After an
  * all-gather of every shard's (distance, global row) lists: n_lists lists of k

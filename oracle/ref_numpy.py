@@ -426,6 +426,87 @@ def pq_search(query: np.ndarray, codebook: np.ndarray, codes: np.ndarray, k: int
 
 
 # ---------------------------------------------------------------------------
+# f1: HybridIndex (IVF-PQ)                   index/hybrid.py:41-536
+# ---------------------------------------------------------------------------
+
+def hybrid_assign_coarse(x: np.ndarray, centroids: np.ndarray) -> np.ndarray:
+    """hybrid.py:205-210 -- argmin of |x|^2 + |c|^2 - 2 x.c (no clamp, no sqrt; BLAS)."""
+    xs = np.sum(x ** 2, axis=1, keepdims=True)
+    cs = np.sum(centroids ** 2, axis=1, keepdims=True)
+    return np.argmin(xs + cs.T - 2 * x @ centroids.T, axis=1)
+
+
+def hybrid_train_subquantizer(sub: np.ndarray, ksub: int, n_iter: int, rng: np.random.RandomState) -> np.ndarray:
+    """hybrid.py:177-203 -- random initial rows, Lloyd with identity-form assignment,
+    sequential accumulation, empty clusters become zero rows (counts clamped to 1)."""
+    n = len(sub)
+    k = min(ksub, n)
+    cent = sub[rng.choice(n, k, replace=False)].copy()
+    for _ in range(n_iter):
+        xs = np.sum(sub ** 2, axis=1, keepdims=True)
+        cs = np.sum(cent ** 2, axis=1, keepdims=True)
+        assign = np.argmin(xs + cs.T - 2 * sub @ cent.T, axis=1)
+        new = np.zeros_like(cent)
+        counts = np.zeros(k)
+        for i, c in enumerate(assign):
+            new[c] += sub[i]
+            counts[c] += 1
+        cent = new / np.maximum(counts, 1)[:, None]
+    if k < ksub:
+        full = np.zeros((ksub, sub.shape[1]), dtype=np.float32)
+        full[:k] = cent
+        cent = full
+    return cent
+
+
+def hybrid_train(x: np.ndarray, n_clusters: int, m: int, n_bits: int = 8, n_iter: int = 20,
+                 seed: Optional[int] = None) -> Tuple[np.ndarray, np.ndarray]:
+    """HybridIndex.train (hybrid.py:126-175).  The coarse k-means has its own
+    RandomState(seed) (ivf.py:121); the sub-quantizers draw from a second
+    RandomState(seed) created in __init__ (hybrid.py:111)."""
+    cent = kmeans_fit(x, min(n_clusters, len(x)), n_iter=n_iter, seed=seed)
+    assign = hybrid_assign_coarse(x, cent)
+    res = x - cent[assign]
+    rng = np.random.RandomState(seed)
+    ds = x.shape[1] // m
+    book = np.zeros((m, 2 ** n_bits, ds), dtype=np.float32)
+    for j in range(m):
+        book[j] = hybrid_train_subquantizer(res[:, j * ds:(j + 1) * ds], 2 ** n_bits, n_iter, rng)
+    return cent, book
+
+
+def hybrid_encode(x: np.ndarray, centroids: np.ndarray, codebook: np.ndarray) -> Tuple[np.ndarray, np.ndarray]:
+    """hybrid.py:266-270 -- coarse list, residual, PQ code (direct form, first minimum)."""
+    lists = hybrid_assign_coarse(x, centroids)
+    return lists, pq_encode(x - centroids[lists], codebook)
+
+
+def hybrid_search(query: np.ndarray, centroids: np.ndarray, codebook: np.ndarray, codes: np.ndarray,
+                  members: List[np.ndarray], k: int, n_probe: int,
+                  mask: Optional[np.ndarray] = None) -> Tuple[np.ndarray, np.ndarray]:
+    """HybridIndex.search (hybrid.py:276-352).  `members[l]` lists the row numbers of
+    list l in scan order; `codes[row]` is the row's PQ code.  Returns (row numbers,
+    fp32 distances), ties in visiting order."""
+    cs = np.sum(centroids ** 2, axis=1)
+    coarse = np.sum(query ** 2) + cs - 2 * (query @ centroids.T)
+    probes = np.argsort(coarse)[:n_probe]
+    rows, dist = [], []
+    for l in probes:
+        lut = pq_lut(query - centroids[l], codebook)
+        mem = members[l]
+        if mask is not None:
+            mem = mem[mask[mem]]
+        if len(mem):
+            rows.append(mem)
+            dist.append(pq_adc(codes[mem], lut))
+    if not rows:
+        return np.zeros(0, dtype=np.int64), np.zeros(0, dtype=np.float32)
+    rows, dist = np.concatenate(rows), np.concatenate(dist)
+    order = np.argsort(dist, kind="stable")[:k]
+    return rows[order], dist[order]
+
+
+# ---------------------------------------------------------------------------
 # NumPy's fp32 pairwise summation, spelled out (documentation of the order the
 # HIP kernels reproduce for row norms, direct-form distances and PQ tables)
 # ---------------------------------------------------------------------------

@@ -32,6 +32,7 @@ from vectordb.distance.registry import get_metric_fn            # noqa: E402
 from vectordb.index.flat import FlatIndex                       # noqa: E402
 from vectordb.index.ivf import IVFIndex, KMeans                 # noqa: E402
 from vectordb.index.pq import PQIndex                           # noqa: E402
+from vectordb.index.hybrid import HybridIndex                   # noqa: E402
 from vectordb.core.collection import Collection                 # noqa: E402
 
 
@@ -295,6 +296,48 @@ def gen_pq():
     save("pq.npz", **out)
 
 
+def gen_hybrid():
+    """HybridIndex (IVF-PQ): trained quantizers, the (list, code) of every row, searches at two
+    probe counts with and without a filter, and a removal that keeps list order."""
+    out = {}
+    rng = np.random.RandomState(77)
+    x = rng.randn(1500, 32).astype(np.float32)
+    q = rng.randn(5, 32).astype(np.float32)
+    out["x"], out["q"] = x, q
+    ids = ids_of(len(x))
+    meta = [{"cat": int(i % 3)} for i in range(len(x))]
+    out["mask"] = np.array([m["cat"] == 1 for m in meta])
+    idx = HybridIndex(dimension=32, n_clusters=16, n_probe=4, n_subvectors=4, n_bits=8, seed=11)
+    idx.config.n_iter = 5                         # the default 20 only makes the fixture slower to produce
+    idx.train(x)
+    out["n_iter"] = np.array(5)
+    out["centroids"], out["codebook"] = idx._coarse_centroids, idx._pq_codebook
+    idx.add_batch(ids, x, meta)
+    lists = np.array([idx._id_to_cluster[i] for i in ids], dtype=np.int64)
+    codes = np.zeros((len(x), 4), dtype=np.uint8)
+    for l, entries in idx._inverted_lists.items():
+        for id_, c, _ in entries:
+            codes[int(id_[1:])] = c
+    out["lists"], out["codes"] = lists, codes
+    for tag, n_probe in (("p4", 4), ("p16", 16)):
+        rows = np.full((len(q), 10), -1, dtype=np.int64)
+        dist = np.full((len(q), 10), np.inf, dtype=np.float32)
+        frows = np.full((len(q), 10), -1, dtype=np.int64)
+        fdist = np.full((len(q), 10), np.inf, dtype=np.float32)
+        for i in range(len(q)):
+            res = idx.search(q[i], k=10, n_probe=n_probe)
+            rows[i, :len(res)], dist[i, :len(res)] = rows_of(res), [r.distance for r in res]
+            res = idx.search(q[i], k=10, n_probe=n_probe, filter_fn=lambda _id, m: m["cat"] == 1)
+            frows[i, :len(res)], fdist[i, :len(res)] = rows_of(res), [r.distance for r in res]
+        out[f"rows_{tag}"], out[f"dist_{tag}"], out[f"filter_rows_{tag}"], out[f"filter_dist_{tag}"] = rows, dist, frows, fdist
+    for i in (3, 500, 501, 1499):
+        idx.remove(ids[i])
+    out["removed"] = np.array([3, 500, 501, 1499])
+    res = idx.search(q[0], k=10, n_probe=16)
+    out["rows_after_remove"], out["dist_after_remove"] = rows_of(res), np.array([r.distance for r in res], dtype=np.float32)
+    save("hybrid.npz", **out)
+
+
 if __name__ == "__main__":
     gen_metrics()
     gen_flat_config1()
@@ -303,3 +346,4 @@ if __name__ == "__main__":
     gen_kmeans()
     gen_ivf()
     gen_pq()
+    gen_hybrid()

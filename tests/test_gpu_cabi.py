@@ -667,3 +667,77 @@ def test_flat_bf16_storage(nat, metric):
     with pytest.raises(ValueError):
         store.search(q[:1], 5, nat.MANHATTAN)
     store.close()
+
+
+# ------------------------------------------------------------------ IVF-PQ (HybridIndex)
+def test_ivfpq_golden(nat):
+    """The reference's own HybridIndex outputs: list and code of every row, searches at two probe
+    counts with and without a filter, bit-exact distances and order; coarse assignment goes through
+    BLAS in the reference, so a row may sit in another list only on a rounding-level tie."""
+    g = load_golden("hybrid.npz")
+    x, q, cent, book = g["x"], g["q"], g["centroids"], g["codebook"]
+    h = nat.IvfPqLists(32, 4, 256)
+    h.set_quantizers(cent, book)
+    lists, codes = h.encode(x)
+    moved = np.flatnonzero(lists != g["lists"])
+    assert len(moved) <= 2
+    for r in moved:
+        d = np.sum((x[r] - cent) ** 2, axis=1)
+        assert abs(d[lists[r]] - d[g["lists"][r]]) <= 1e-4 * d[g["lists"][r]]
+    same = lists == g["lists"]
+    assert np.array_equal(codes[same], g["codes"][same])           # direct-form residual codes: exact
+    n_lists = len(cent)
+    order = np.argsort(g["lists"], kind="stable")
+    offs = np.searchsorted(g["lists"][order], np.arange(n_lists + 1))
+    h.build(g["codes"], order, offs)
+    words = nat.pack_mask(g["mask"])
+    for tag, n_probe in (("p4", 4), ("p16", 16)):
+        dist, rows = h.search(q, 10, n_probe)
+        np.testing.assert_array_equal(rows, g[f"rows_{tag}"])
+        np.testing.assert_array_equal(dist, g[f"dist_{tag}"])
+        dist, rows = h.search(q, 10, n_probe, mask_words=words)
+        np.testing.assert_array_equal(rows, g[f"filter_rows_{tag}"])
+        np.testing.assert_array_equal(dist, g[f"filter_dist_{tag}"])
+    # removal keeps list order (hybrid.py:405-409): rebuild the lists without the removed rows
+    keep = np.ones(len(x), dtype=bool)
+    keep[g["removed"]] = False
+    order2 = order[keep[order]]
+    offs2 = np.searchsorted(g["lists"][order2], np.arange(n_lists + 1))
+    compact = np.full(len(x), -1, dtype=np.int64)
+    compact[np.flatnonzero(keep)] = np.arange(int(keep.sum()))
+    h.build(g["codes"][keep], compact[order2], offs2)
+    dist, rows = h.search(q[:1], 10, 16)
+    np.testing.assert_array_equal(np.flatnonzero(keep)[rows[0]], g["rows_after_remove"])
+    np.testing.assert_array_equal(dist[0], g["dist_after_remove"])
+    h.close()
+
+
+def test_ivfpq_vs_oracle_batch(nat):
+    """A batch large enough for the matrix-core coarse ranking, k beyond one selection pass, m = 8."""
+    rng = np.random.RandomState(21)
+    n, d, m, n_lists = 20000, 64, 8, 64
+    x = rng.randn(n, d).astype(np.float32)
+    q = rng.randn(40, d).astype(np.float32)
+    cent = x[rng.choice(n, n_lists, replace=False)].copy()
+    book = (0.5 * rng.randn(m, 256, d // m)).astype(np.float32)
+    h = nat.IvfPqLists(d, m, 256)
+    h.set_quantizers(cent, book)
+    lists, codes = h.encode(x)
+    ref_lists, ref_codes = R.hybrid_encode(x, cent, book)
+    same = lists == ref_lists
+    assert same.mean() > 0.999
+    assert np.array_equal(codes[same], ref_codes[same])
+    order = np.argsort(lists, kind="stable")
+    offs = np.searchsorted(lists[order], np.arange(n_lists + 1))
+    h.build(codes, order, offs)
+    members = [order[offs[l]:offs[l + 1]] for l in range(n_lists)]
+    dist, rows = h.search(q, 50, 6)
+    for i in range(len(q)):
+        ref_rows, ref_dist = R.hybrid_search(q[i], cent, book, codes, members, 50, 6)
+        # the coarse ranking is a BLAS product in the reference: compare only when the probed sets agree
+        cs = np.sum(cent ** 2, axis=1)
+        coarse = np.sort(np.sum(q[i] ** 2) + cs - 2 * (q[i] @ cent.T))
+        if coarse[6] - coarse[5] > 1e-3:
+            np.testing.assert_array_equal(rows[i], ref_rows)
+            np.testing.assert_array_equal(dist[i], ref_dist)
+    h.close()

@@ -280,3 +280,37 @@ def test_pq_train_golden():
     small = R.pq_train(g["x"][:100], 8, 8, 20, seed=1)
     close(small, g["small_codebook"], rtol=1e-5, atol=1e-5)
     assert not small[:, 100:].any()          # zero padding beyond the 100 trained codewords
+
+
+# ------------------------------------------------------------------ HybridIndex (IVF-PQ)
+def _hybrid_members(lists, n_lists, removed=()):
+    keep = np.ones(len(lists), dtype=bool)
+    keep[list(removed)] = False
+    return [np.flatnonzero((lists == l) & keep).astype(np.int64) for l in range(n_lists)]
+
+
+def test_hybrid_train_encode_match_reference():
+    g = load_golden("hybrid.npz")
+    x = g["x"]
+    cent, book = R.hybrid_train(x, 16, 4, n_bits=8, n_iter=int(g["n_iter"]), seed=11)
+    np.testing.assert_allclose(cent, g["centroids"], rtol=1e-5, atol=1e-6)
+    np.testing.assert_allclose(book, g["codebook"], rtol=1e-4, atol=1e-5)
+    lists, codes = R.hybrid_encode(x, g["centroids"], g["codebook"])
+    assert np.array_equal(lists, g["lists"])
+    assert np.array_equal(codes, g["codes"])
+
+
+def test_hybrid_search_matches_reference():
+    g = load_golden("hybrid.npz")
+    members = _hybrid_members(g["lists"], len(g["centroids"]))
+    for tag, n_probe in (("p4", 4), ("p16", 16)):
+        for i, q in enumerate(g["q"]):
+            rows, dist = R.hybrid_search(q, g["centroids"], g["codebook"], g["codes"], members, 10, n_probe)
+            assert np.array_equal(rows, g[f"rows_{tag}"][i][:len(rows)])
+            assert np.array_equal(dist, g[f"dist_{tag}"][i][:len(rows)])
+            rows, dist = R.hybrid_search(q, g["centroids"], g["codebook"], g["codes"], members, 10, n_probe, mask=g["mask"])
+            assert np.array_equal(rows, g[f"filter_rows_{tag}"][i][:len(rows)])
+            assert np.array_equal(dist, g[f"filter_dist_{tag}"][i][:len(rows)])
+    members = _hybrid_members(g["lists"], len(g["centroids"]), removed=g["removed"])
+    rows, dist = R.hybrid_search(g["q"][0], g["centroids"], g["codebook"], g["codes"], members, 10, 16)
+    assert np.array_equal(rows, g["rows_after_remove"]) and np.array_equal(dist, g["dist_after_remove"])

@@ -92,6 +92,14 @@ SIGNATURES = {
     "vdb_pq_search": (C.c_int, [C.c_void_p, c_float_p, C.c_int, C.c_int, c_u32_p, c_float_p, c_i64_p]),
     "vdb_pq_search_dev": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p,
                                     C.c_void_p]),
+    "vdb_ivfpq_create": (C.c_int, [C.POINTER(C.c_void_p), C.c_int, C.c_int, C.c_int]),
+    "vdb_ivfpq_destroy": (C.c_int, [C.c_void_p]),
+    "vdb_ivfpq_set_quantizers": (C.c_int, [C.c_void_p, c_float_p, C.c_int, c_float_p]),
+    "vdb_ivfpq_encode": (C.c_int, [C.c_void_p, c_float_p, C.c_int64, c_i32_p, c_u8_p]),
+    "vdb_ivfpq_build": (C.c_int, [C.c_void_p, c_u8_p, C.c_int64, c_i64_p, c_i64_p]),
+    "vdb_ivfpq_search": (C.c_int, [C.c_void_p, c_float_p, C.c_int, C.c_int, C.c_int, c_u32_p, c_float_p, c_i64_p]),
+    "vdb_ivfpq_search_dev": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p,
+                                       C.c_void_p, C.c_void_p]),
     "vdb_topk_merge_dev": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p,
                                      C.c_void_p]),
     "vdb_topk_merge_keyed_dev": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p,
@@ -479,6 +487,65 @@ class PqCodes:
                       mask_ptr: int = 0, stream: int = 0) -> None:
         check(self.lib.vdb_pq_search_dev(self.h, C.c_void_p(q_ptr), nq, k, C.c_void_p(mask_ptr or None),
                                          C.c_void_p(out_dist_ptr), C.c_void_p(out_row_ptr), C.c_void_p(stream or None)))
+
+
+class IvfPqLists:
+    """Owner of a vdb_ivfpq handle (coarse centroids, residual codebook, codes in inverted lists)."""
+
+    def __init__(self, dim: int, m: int, ksub: int):
+        init()
+        self.lib = load()
+        self.dim, self.m, self.ksub = int(dim), int(m), int(ksub)
+        self.h = C.c_void_p()
+        check(self.lib.vdb_ivfpq_create(C.byref(self.h), self.dim, self.m, self.ksub))
+
+    def close(self):
+        if getattr(self, "h", None) is not None and self.h:
+            self.lib.vdb_ivfpq_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def set_quantizers(self, centroids: np.ndarray, codebook: np.ndarray) -> None:
+        c, b = f32(centroids), f32(codebook)
+        if b.shape != (self.m, self.ksub, self.dim // self.m):
+            raise ValueError(f"codebook shape {b.shape} != {(self.m, self.ksub, self.dim // self.m)}")
+        check(self.lib.vdb_ivfpq_set_quantizers(self.h, fptr(c), len(c), fptr(b)))
+
+    def encode(self, rows: np.ndarray):
+        rows = f32(rows).reshape(-1, self.dim)
+        lists = np.empty(len(rows), np.int32)
+        codes = np.empty((len(rows), self.m), np.uint8)
+        check(self.lib.vdb_ivfpq_encode(self.h, fptr(rows), len(rows), lists.ctypes.data_as(c_i32_p),
+                                        codes.ctypes.data_as(c_u8_p)))
+        return lists, codes
+
+    def build(self, codes: np.ndarray, list_rows: np.ndarray, list_offsets: np.ndarray) -> None:
+        c = np.ascontiguousarray(codes, dtype=np.uint8).reshape(-1, self.m)
+        lr = np.ascontiguousarray(list_rows, dtype=np.int64)
+        lo = np.ascontiguousarray(list_offsets, dtype=np.int64)
+        check(self.lib.vdb_ivfpq_build(self.h, c.ctypes.data_as(c_u8_p), len(c), lr.ctypes.data_as(c_i64_p),
+                                       lo.ctypes.data_as(c_i64_p)))
+
+    def search(self, queries: np.ndarray, k: int, n_probe: int, mask_words=None):
+        q = f32(queries)
+        if q.ndim == 1:
+            q = q[None, :]
+        nq = q.shape[0]
+        dist = np.empty((nq, k), np.float32)
+        rows = np.empty((nq, k), np.int64)
+        check(self.lib.vdb_ivfpq_search(self.h, fptr(q), nq, k, n_probe, u32ptr(mask_words), fptr(dist),
+                                        rows.ctypes.data_as(c_i64_p)))
+        return dist, rows
+
+    def search_device(self, q_ptr: int, nq: int, k: int, n_probe: int, out_dist_ptr: int, out_row_ptr: int,
+                      mask_ptr: int = 0, stream: int = 0) -> None:
+        check(self.lib.vdb_ivfpq_search_dev(self.h, C.c_void_p(q_ptr), nq, k, n_probe, C.c_void_p(mask_ptr or None),
+                                            C.c_void_p(out_dist_ptr), C.c_void_p(out_row_ptr), C.c_void_p(stream or None)))
 
 
 def topk_merge_device(dist_ptr: int, row_ptr: int, n_lists: int, nq: int, k: int,

@@ -1344,6 +1344,238 @@ int vdb_pq_search(vdb_pq* h, const float* queries, int nq, int k, const uint32_t
                         });
 }
 
+// ============================================================== IVF-PQ (index/hybrid.py)
+struct vdb_ivfpq {
+    int dim = 0, m = 0, ksub = 0, dsub = 0;
+    SumPlan plan;                       // over one sub-vector
+    vdb_rows* centroids = nullptr;      // coarse centroids
+    DevBuf book;                        // float [m][ksub][dsub]
+    DevBuf codes;                       // uint8 [n][m] in list order
+    DevBuf list_off;                    // int64 [n_lists + 1]
+    DevBuf row_ids;                     // int   [n]
+    std::vector<int64_t> h_list_off, len_desc;
+    int n_lists = 0;
+    int64_t n = 0;
+    bool ready = false;
+    Workspace ws, io;
+    int64_t probe_bound(int n_probe) {
+        if (len_desc.size() != (size_t)n_lists) {
+            len_desc.resize(n_lists);
+            for (int l = 0; l < n_lists; ++l) len_desc[l] = h_list_off[l + 1] - h_list_off[l];
+            std::sort(len_desc.begin(), len_desc.end(), std::greater<int64_t>());
+        }
+        int64_t t = 0;
+        for (int i = 0; i < std::min(n_probe, n_lists); ++i) t += len_desc[i];
+        return t;
+    }
+};
+
+int vdb_ivfpq_create(vdb_ivfpq** out, int dim, int m, int ksub) {
+    VDB_TRY(ensure_init());
+    VDB_REQUIRE(out != nullptr, "null output handle");
+    VDB_REQUIRE(dim >= 1 && m >= 1 && dim % m == 0, "dimension %d must be divisible by the number of sub-spaces %d", dim, m);
+    VDB_REQUIRE(ksub >= 1 && ksub <= 256, "codewords per sub-space must be in 1..256, got %d", ksub);
+    vdb_ivfpq* h = new vdb_ivfpq();
+    h->dim = dim; h->m = m; h->ksub = ksub; h->dsub = dim / m;
+    int st = make_sum_plan(h->dsub, &h->plan);
+    if (st == VDB_OK) st = vdb_rows_create(&h->centroids, dim);
+    if (st != VDB_OK) { delete h; return st; }
+    *out = h;
+    return VDB_OK;
+}
+
+int vdb_ivfpq_destroy(vdb_ivfpq* h) {
+    if (!h) return VDB_OK;
+    vdb_rows_destroy(h->centroids);
+    std::lock_guard<std::mutex> g(ctx().mu);
+    (void)hipStreamSynchronize(ctx().stream);
+    h->book.release(); h->codes.release(); h->list_off.release(); h->row_ids.release(); h->ws.release(); h->io.release();
+    delete h;
+    return VDB_OK;
+}
+
+int vdb_ivfpq_set_quantizers(vdb_ivfpq* h, const float* centroids, int n_lists, const float* codebook) {
+    VDB_REQUIRE(h && centroids && codebook && n_lists >= 1, "bad arguments to vdb_ivfpq_set_quantizers");
+    VDB_TRY(vdb_rows_truncate(h->centroids, 0));
+    VDB_TRY(vdb_rows_append(h->centroids, centroids, n_lists));
+    std::lock_guard<std::mutex> g(ctx().mu);
+    hipStream_t s = ctx().stream;
+    const size_t bytes = (size_t)h->m * h->ksub * h->dsub * sizeof(float);
+    VDB_TRY(h->book.reserve(bytes));
+    VDB_HIP(hipMemcpyAsync(h->book.p, codebook, bytes, hipMemcpyHostToDevice, s));
+    VDB_HIP(hipStreamSynchronize(s));
+    h->n_lists = n_lists;
+    h->h_list_off.assign(n_lists + 1, 0);
+    h->len_desc.clear();
+    h->n = 0;
+    h->ready = true;
+    return VDB_OK;
+}
+
+int vdb_ivfpq_encode(vdb_ivfpq* h, const float* rows, int64_t n, int32_t* out_list, uint8_t* out_codes) {
+    VDB_REQUIRE(h && h->ready && (rows || n == 0) && n >= 0 && out_list && out_codes, "bad arguments to vdb_ivfpq_encode");
+    if (n == 0) return VDB_OK;
+    std::lock_guard<std::mutex> g(ctx().mu);
+    hipStream_t s = ctx().stream;
+    Workspace& ws = h->ws;
+    vdb_rows* c = h->centroids;
+    DevBuf i32, res, codes;
+    auto body = [&]() -> int {
+        const int64_t chunk = std::max<int64_t>(1024, (int64_t)(128 << 20) / (h->dim * (int64_t)sizeof(float)));
+        for (int64_t o = 0; o < n; o += chunk) {
+            const int nb = (int)std::min(chunk, n - o);
+            VDB_TRY(ws.stage.reserve((size_t)nb * h->dim * sizeof(float)));
+            VDB_TRY(ws.out_d.reserve((size_t)nb * sizeof(float)));
+            VDB_TRY(i32.reserve((size_t)nb * sizeof(int)));
+            VDB_TRY(res.reserve((size_t)nb * h->dim * sizeof(float)));
+            VDB_TRY(codes.reserve((size_t)nb * h->m));
+            VDB_HIP(hipMemcpyAsync(ws.stage.p, rows + o * h->dim, (size_t)nb * h->dim * sizeof(float), hipMemcpyHostToDevice, s));
+            // nearest coarse centroid in the identity-form squared distance (hybrid.py:205-210)
+            VDB_TRY(flat_search_impl(c, VDB_EUCLIDEAN_SQ, ws.stage.as<float>(), nb, 1, nullptr, ws.out_d.as<float>(), nullptr,
+                                     i32.as<int>(), s));
+            VDB_TRY(launch_residual(ws.stage.as<float>(), h->dim, c->r.data, c->r.ld, i32.as<int>(), h->dim, nb, res.as<float>(), s));
+            VDB_TRY(launch_pq_encode(res.as<float>(), nb, h->dim, h->book.as<float>(), h->m, h->ksub, h->dsub, h->plan,
+                                     codes.as<uint8_t>(), s));
+            VDB_HIP(hipMemcpyAsync(out_list + o, i32.p, (size_t)nb * sizeof(int), hipMemcpyDeviceToHost, s));
+            VDB_HIP(hipMemcpyAsync(out_codes + o * h->m, codes.p, (size_t)nb * h->m, hipMemcpyDeviceToHost, s));
+            VDB_HIP(hipStreamSynchronize(s));
+        }
+        return VDB_OK;
+    };
+    const int st = body();
+    i32.release(); res.release(); codes.release();
+    return st;
+}
+
+int vdb_ivfpq_build(vdb_ivfpq* h, const uint8_t* codes, int64_t n, const int64_t* list_rows, const int64_t* list_offsets) {
+    VDB_REQUIRE(h && h->ready, "quantizers must be set before the lists are built");
+    VDB_REQUIRE(n >= 0 && (n == 0 || (codes && list_rows)) && list_offsets, "bad arguments to vdb_ivfpq_build");
+    VDB_REQUIRE(list_offsets[0] == 0 && list_offsets[h->n_lists] == n, "list offsets do not cover %lld rows", (long long)n);
+    VDB_REQUIRE(n < (int64_t)0x7fffffff, "at most 2^31-1 rows per device");
+    std::vector<int> perm((size_t)n);
+    std::vector<uint8_t> ordered((size_t)n * h->m);
+    for (int l = 0; l < h->n_lists; ++l)
+        VDB_REQUIRE(list_offsets[l] <= list_offsets[l + 1], "list offsets must be non-decreasing");
+    for (int64_t i = 0; i < n; ++i) {
+        VDB_REQUIRE(list_rows[i] >= 0 && list_rows[i] < n, "row number %lld out of range", (long long)list_rows[i]);
+        perm[(size_t)i] = (int)list_rows[i];
+        memcpy(&ordered[(size_t)i * h->m], codes + list_rows[i] * h->m, h->m);
+    }
+    std::lock_guard<std::mutex> g(ctx().mu);
+    hipStream_t s = ctx().stream;
+    h->h_list_off.assign(list_offsets, list_offsets + h->n_lists + 1);
+    h->len_desc.clear();
+    VDB_TRY(h->list_off.reserve((size_t)(h->n_lists + 1) * sizeof(int64_t)));
+    VDB_HIP(hipMemcpyAsync(h->list_off.p, list_offsets, (size_t)(h->n_lists + 1) * sizeof(int64_t), hipMemcpyHostToDevice, s));
+    if (n > 0) {
+        VDB_TRY(h->row_ids.reserve((size_t)n * sizeof(int)));
+        VDB_TRY(h->codes.reserve((size_t)n * h->m));
+        VDB_HIP(hipMemcpyAsync(h->row_ids.p, perm.data(), (size_t)n * sizeof(int), hipMemcpyHostToDevice, s));
+        VDB_HIP(hipMemcpyAsync(h->codes.p, ordered.data(), (size_t)n * h->m, hipMemcpyHostToDevice, s));
+    }
+    VDB_HIP(hipStreamSynchronize(s));
+    h->n = n;
+    return VDB_OK;
+}
+
+static int ivfpq_search_impl(vdb_ivfpq* h, const float* d_q, int nq, int k, int n_probe, const uint32_t* d_mask,
+                             float* d_out_d, int64_t* d_out_i, hipStream_t s) {
+    VDB_REQUIRE(h->ready, "index is not trained");
+    VDB_REQUIRE(nq >= 0 && k >= 1 && n_probe >= 1, "need nq >= 0, k >= 1, n_probe >= 1");
+    if (nq == 0) return VDB_OK;
+    n_probe = std::min(n_probe, h->n_lists);
+    Workspace& ws = h->ws;
+    VDB_TRY(fill_results(d_out_d, d_out_i, (int64_t)nq * k, s));
+    if (h->n == 0) return VDB_OK;
+    const int64_t k_eff = std::min<int64_t>(k, h->n);
+    const int kmax = (int)std::min<int64_t>(KMAX_FUSED, k_eff);
+    const bool multi = k_eff > KMAX_FUSED;
+    const int64_t cand_stride = round_up64(std::max<int64_t>(h->probe_bound(n_probe), 1), 64);
+    VDB_REQUIRE(cand_stride < (int64_t)0x7fffffff, "n_probe=%d lists can hold more than 2^31 rows", n_probe);
+    const int q_block = (int)std::max<int64_t>(1, std::min<int64_t>(nq, CAND_BUDGET / (cand_stride * (int64_t)sizeof(float))));
+
+    // coarse ranking: identity-form squared distances to the centroids (hybrid.py:296-300)
+    VDB_TRY(ws.probes.reserve((size_t)nq * n_probe * sizeof(int)));
+    VDB_TRY(ws.probe_d.reserve((size_t)nq * n_probe * sizeof(float)));
+    if (n_probe <= KMAX_FUSED) {
+        VDB_TRY(flat_search_impl(h->centroids, VDB_EUCLIDEAN_SQ, d_q, nq, n_probe, nullptr, ws.probe_d.as<float>(), nullptr,
+                                 ws.probes.as<int>(), s));
+    } else {
+        VDB_REQUIRE(h->n_lists <= 16384, "n_probe > %d needs n_lists <= 16384", KMAX_FUSED);
+        VDB_TRY(ws.dist.reserve((size_t)nq * h->n_lists * sizeof(float)));
+        VDB_TRY(flat_distances_impl(h->centroids, VDB_EUCLIDEAN_SQ, d_q, nq, ws.dist.as<float>(), s));
+        VDB_TRY(launch_row_sort_topk(ws.dist.as<float>(), nq, h->n_lists, n_probe, ws.probe_d.as<float>(), ws.probes.as<int>(), s));
+    }
+
+    StreamPlanBufs b{};
+    VDB_TRY(reserve_stream_plan(ws, h->n_lists, (int64_t)q_block * n_probe, 1, &b));   // only the slot offsets of the plan are used
+    VDB_TRY(ws.cand.reserve((size_t)q_block * cand_stride * sizeof(float)));
+    VDB_TRY(ws.cand_off.reserve((size_t)q_block * (n_probe + 1) * sizeof(int64_t)));
+    VDB_TRY(ws.tile_off.reserve((size_t)q_block * (n_probe + 1) * sizeof(int)));
+    VDB_TRY(ws.list_cnt.reserve((size_t)h->n_lists * sizeof(int)));
+    VDB_TRY(ws.cursor.reserve((size_t)h->n_lists * sizeof(int)));
+    VDB_TRY(ws.slots.reserve((size_t)nq * k * sizeof(int)));
+    if (multi) {
+        VDB_TRY(ws.lb_d.reserve((size_t)q_block * sizeof(float)));
+        VDB_TRY(ws.lb_k.reserve((size_t)q_block * sizeof(int64_t)));
+    }
+    const int64_t avg_tiles = std::max<int64_t>(1, ((int64_t)n_probe * (h->n / std::max(1, h->n_lists)) + 255) / 256);
+    for (int q0 = 0; q0 < nq; q0 += q_block) {
+        const int nb = std::min(q_block, nq - q0);
+        const int* probes = ws.probes.as<int>() + (int64_t)q0 * n_probe;
+        VDB_TRY(launch_ivf_plan(probes, nb, n_probe, h->list_off.as<int64_t>(), h->n_lists, 8, cand_stride,
+                                ws.list_cnt.as<int>(), ws.cursor.as<int>(), ws.cand_off.as<int64_t>(), ws.tile_off.as<int>(), b, s));
+        VDB_TRY(launch_ivfpq_scan(d_q + (int64_t)q0 * h->dim, h->dim, h->dim, nb, h->centroids->r.data, h->centroids->r.ld,
+                                  h->book.as<float>(), h->m, h->ksub, h->dsub, h->plan, h->codes.as<uint8_t>(),
+                                  h->list_off.as<int64_t>(), h->n_lists, probes, n_probe, ws.cand_off.as<int64_t>(),
+                                  cand_stride, ws.cand.as<float>(), s));
+        const int splits = cand_splits(avg_tiles, nb);
+        const int n_cand = splits * topk_cand_lists_per_split();
+        VDB_TRY(ws.part_d.reserve((size_t)nb * n_cand * kmax * sizeof(float)));
+        VDB_TRY(ws.part_i.reserve((size_t)nb * n_cand * kmax * sizeof(int)));
+        for (int64_t done = 0; done < k_eff; done += KMAX_FUSED) {
+            const int kk = (int)std::min<int64_t>(KMAX_FUSED, k_eff - done);
+            CandJob c{};
+            c.cand = ws.cand.as<float>(); c.cand_stride = cand_stride; c.nq = nb; c.n = 0;
+            c.probes = probes; c.n_probe = n_probe; c.n_lists = h->n_lists; c.list_off = h->list_off.as<int64_t>();
+            c.cand_off = ws.cand_off.as<int64_t>(); c.tile_off = ws.tile_off.as<int>();
+            c.row_ids = h->row_ids.as<int>(); c.mask = d_mask;
+            c.metric = VDB_MANHATTAN;                 // the slots already hold final distances
+            c.lb_d = done > 0 ? ws.lb_d.as<float>() : nullptr; c.lb_k = done > 0 ? ws.lb_k.as<int64_t>() : nullptr;
+            c.k = kk; c.splits = splits; c.part_d = ws.part_d.as<float>(); c.part_i = ws.part_i.as<int>();
+            VDB_TRY(launch_topk_cand(c, s));
+            SelectOut o{d_out_d + (int64_t)q0 * k, nullptr, ws.slots.as<int>() + (int64_t)q0 * k, k, (int)done,
+                        multi ? ws.lb_d.as<float>() : nullptr, multi ? ws.lb_k.as<int64_t>() : nullptr};
+            VDB_TRY(launch_select(ws.part_d.as<float>(), ws.part_i.as<int>(), nb, n_cand, kk, 1 << 30, nullptr, 0, o, s));
+            VDB_TRY(launch_ivf_rows(ws.slots.as<int>() + (int64_t)q0 * k, nb, kk, k, (int)done, probes, n_probe, h->n_lists,
+                                    ws.cand_off.as<int64_t>(), h->list_off.as<int64_t>(), h->row_ids.as<int>(),
+                                    d_out_i + (int64_t)q0 * k, nullptr, s));
+        }
+    }
+    return VDB_OK;
+}
+
+int vdb_ivfpq_search_dev(vdb_ivfpq* h, const float* d_queries, int nq, int k, int n_probe, const uint32_t* d_mask,
+                         float* d_out_dist, int64_t* d_out_row, void* stream) {
+    VDB_REQUIRE(h && (d_queries || nq == 0), "null argument");
+    std::lock_guard<std::mutex> g(ctx().mu);
+    return ivfpq_search_impl(h, d_queries, nq, k, n_probe, d_mask, d_out_dist, d_out_row, pick_stream(stream));
+}
+
+int vdb_ivfpq_search(vdb_ivfpq* h, const float* queries, int nq, int k, int n_probe, const uint32_t* mask,
+                     float* out_dist, int64_t* out_row) {
+    VDB_REQUIRE(h && (queries || nq == 0), "null argument");
+    VDB_REQUIRE(k >= 1, "k must be >= 1, got %d", k);
+    std::lock_guard<std::mutex> g(ctx().mu);
+    hipStream_t s = ctx().stream;
+    const uint32_t* d_mask = nullptr;
+    VDB_TRY(upload_mask(h->ws, mask, h->n, &d_mask, s));
+    return with_host_io(h->io, queries, nq, h->dim, k, out_dist, out_row, s,
+                        [&](const float* dq, float* dd, int64_t* di) {
+                            return ivfpq_search_impl(h, dq, nq, k, n_probe, d_mask, dd, di, s);
+                        });
+}
+
 // ============================================================== cross-shard merge
 int vdb_topk_merge_dev(const float* d_dist, const int64_t* d_row, int n_lists, int nq, int k,
                        float* d_out_dist, int64_t* d_out_row, void* stream) {

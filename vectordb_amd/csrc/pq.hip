@@ -235,6 +235,85 @@ __global__ __launch_bounds__(256) void pq_scan_kernel(PqScanParams p) {
 
 int pq_scan_lists_per_split() { return PQ_WAVES; }
 
+// ---------------------------------------------------------------- IVF-PQ (index/hybrid.py)
+// residual of every row against its coarse centroid (hybrid.py:151,269), element-wise fp32
+__global__ void residual_kernel(const float* __restrict__ x, int64_t ldx, const float* __restrict__ cent, int ldc,
+                                const int* __restrict__ list, int dim, int64_t n, float* __restrict__ out) {
+    const int64_t total = n * dim;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t r = i / dim;
+        const int c = (int)(i - r * dim);
+        out[i] = x[r * ldx + c] - cent[(int64_t)list[r] * ldc + c];
+    }
+}
+
+int launch_residual(const float* x, int64_t ldx, const float* cent, int ldc, const int* list, int dim, int64_t n,
+                    float* out, hipStream_t s) {
+    if (n <= 0) return VDB_OK;
+    hipLaunchKernelGGL(residual_kernel, dim3((unsigned)std::min<int64_t>((n * dim + 255) / 256, 16384)), dim3(256), 0, s,
+                       x, ldx, cent, ldc, list, dim, n, out);
+    VDB_HIP(hipGetLastError());
+    return VDB_OK;
+}
+
+// One block per (query, probed list): the table of the residual query q - centroid
+// (hybrid.py:303-318) is built in LDS in NumPy order, then the list's codes are
+// scanned one row per thread: fp32 sum in sub-space order, sqrt (hybrid.py:320-326).
+// Distances go to the query's candidate slots in visiting order.
+struct IvfPqScanParams {
+    const float* q; int ldq; int dim;
+    const float* cent; int ldc;
+    const float* book; int m; int ksub; int dsub; SumPlan plan;
+    const uint8_t* codes;                       // [n][m] in list order
+    const int64_t* list_off; int n_lists;
+    const int* probes; int n_probe;
+    const int64_t* cand_off; int64_t cand_stride;
+    float* cand;
+};
+
+__global__ __launch_bounds__(256) void ivfpq_scan_kernel(IvfPqScanParams p) {
+    extern __shared__ __align__(16) float sm[];
+    float* T = sm;                               // [m][ksub]
+    float* qres = T + p.m * p.ksub;              // [dim]
+    const int tid = threadIdx.x;
+    const int unit = blockIdx.x;
+    const int qi = unit / p.n_probe, pr = unit - qi * p.n_probe;
+    const int l = p.probes[unit];
+    if (l < 0 || l >= p.n_lists) return;
+    const int64_t pos0 = p.list_off[l];
+    const int64_t len = p.list_off[l + 1] - pos0;
+    if (len == 0) return;
+    for (int i = tid; i < p.dim; i += 256) qres[i] = p.q[(int64_t)qi * p.ldq + i] - p.cent[(int64_t)l * p.ldc + i];
+    __syncthreads();
+    for (int c = tid; c < p.ksub; c += 256)
+        for (int j = 0; j < p.m; ++j)
+            T[j * p.ksub + c] = np_sum_sqdiff(p.book + ((int64_t)j * p.ksub + c) * p.dsub, qres + j * p.dsub, p.dsub, p.plan);
+    __syncthreads();
+    float* out = p.cand + (int64_t)qi * p.cand_stride + p.cand_off[(int64_t)qi * (p.n_probe + 1) + pr];
+    for (int64_t r = tid; r < len; r += 256) {
+        const uint8_t* code = p.codes + (pos0 + r) * p.m;
+        float acc = T[code[0]];
+        for (int j = 1; j < p.m; ++j) acc = acc + T[j * p.ksub + code[j]];
+        out[r] = sqrtf(acc);
+    }
+}
+
+int launch_ivfpq_scan(const float* q, int ldq, int dim, int nq, const float* cent, int ldc, const float* book, int m, int ksub,
+                      int dsub, const SumPlan& plan, const uint8_t* codes, const int64_t* list_off, int n_lists,
+                      const int* probes, int n_probe, const int64_t* cand_off, int64_t cand_stride, float* cand, hipStream_t s) {
+    if (nq <= 0) return VDB_OK;
+    IvfPqScanParams p{q, ldq, dim, cent, ldc, book, m, ksub, dsub, plan, codes, list_off, n_lists, probes, n_probe,
+                      cand_off, cand_stride, cand};
+    const size_t lds = ((size_t)m * ksub + dim) * sizeof(float);
+    VDB_REQUIRE(lds <= 160 * 1024, "%d sub-spaces x %d codewords need %zu bytes of LDS", m, ksub, lds);
+    VDB_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(ivfpq_scan_kernel),
+                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    KernelTimer timer(s);
+    hipLaunchKernelGGL(ivfpq_scan_kernel, dim3((unsigned)((int64_t)nq * n_probe)), dim3(256), lds, s, p);
+    VDB_HIP(hipGetLastError());
+    return VDB_OK;
+}
+
 // ---------------------------------------------------------------- launchers
 int launch_pq_lut(const float* q, int ldq, int nq, const float* book, int m, int ksub, int dsub,
                   const SumPlan& plan, float* lut, hipStream_t s) {

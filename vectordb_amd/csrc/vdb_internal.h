@@ -224,6 +224,12 @@ int pq_scan_lists_per_split();
 int launch_pq_scan(const uint8_t* codes, int64_t n, int m, int ksub, const float* lut, int nq, int k,
                    const uint32_t* mask, const float* lb_d, const int64_t* lb_k, int splits,
                    float* part_d, int* part_i, float* dist_out, hipStream_t s);
+// IVF-PQ (index/hybrid.py): residuals, and the per-(query, probe) table + list scan into candidate slots
+int launch_residual(const float* x, int64_t ldx, const float* cent, int ldc, const int* list, int dim, int64_t n,
+                    float* out, hipStream_t s);
+int launch_ivfpq_scan(const float* q, int ldq, int dim, int nq, const float* cent, int ldc, const float* book, int m, int ksub,
+                      int dsub, const SumPlan& plan, const uint8_t* codes, const int64_t* list_off, int n_lists,
+                      const int* probes, int n_probe, const int64_t* cand_off, int64_t cand_stride, float* cand, hipStream_t s);
 // k-means
 int launch_kmeans_accumulate(const float* x, int64_t n, int dim, int ldx, const int* assign, int n_clusters,
                              double* sums, unsigned long long* counts, hipStream_t s);
