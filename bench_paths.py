@@ -3,7 +3,7 @@
 headline bench): bandwidth-bound scans and build steps at BASELINE.json sizes,
 each rated against the HBM roofline with its algorithmic bytes.
 
-    python bench_paths.py [--only flat1,l1,c3,bf16,ivf,pq,assign,encode] [--scale 1.0]
+    python bench_paths.py [--only flat1,l1,c3,bf16,ivf,ivfpq,pq,assign,encode] [--scale 1.0]
 
 Prints one JSON line per path.  Inputs are synthetic standard-normal (or
 uniform random codes) and resident in HBM before timing.
@@ -48,7 +48,7 @@ def emit(name, **kw):
 
 def main():
     ap = argparse.ArgumentParser()
-    ap.add_argument("--only", default="flat1,l1,c3,bf16,ivf,pq,assign,encode")
+    ap.add_argument("--only", default="flat1,l1,c3,bf16,ivf,ivfpq,pq,assign,encode")
     ap.add_argument("--scale", type=float, default=1.0, help="scale the row counts (1.0 = BASELINE sizes)")
     args = ap.parse_args()
     only = set(args.only.split(","))
@@ -193,6 +193,40 @@ def main():
                            "note": "algorithmic bytes / whole-batch wall time (probe + scan + select)"})
         lists.close()
         del x
+        torch.cuda.empty_cache()
+
+    # ---- IVF-PQ (HybridIndex): nlist=4096 nprobe=32 over 10M x 128 rows stored as 16-byte codes
+    if "ivfpq" in only:
+        n, d, m, nlist, nprobe = int(10_000_000 * args.scale), 128, 16, 4096, 32
+        rng = np.random.default_rng(42)
+        x = rng.standard_normal((n, d), dtype=np.float32)
+        sample = x[rng.choice(n, min(n, 64 * nlist), replace=False)]
+        cent = sample[rng.choice(len(sample), nlist, replace=False)].copy()
+        for _ in range(4):
+            a, _d = N.assign(sample, cent, N.EUCLIDEAN_SQ)
+            sums, counts = N.kmeans_accumulate(sample, a, nlist)
+            nz = counts > 0
+            cent[nz] = (sums[nz] / counts[nz, None]).astype(np.float32)
+        book = (0.3 * rng.standard_normal((m, 256, d // m))).astype(np.float32)      # untrained codebook: the scan cost is the same
+        h = N.IvfPqLists(d, m, 256)
+        h.set_quantizers(cent, book)
+        t0 = time.perf_counter()
+        lists, codes = h.encode(x)
+        t_encode = time.perf_counter() - t0
+        del x
+        order = np.argsort(lists, kind="stable")
+        offs = np.searchsorted(lists[order], np.arange(nlist + 1))
+        t0 = time.perf_counter()
+        h.build(codes, order, offs)
+        t_build = time.perf_counter() - t0
+        for nq in (1, 1024):
+            q = randn(nq, d, 123)
+            od, orow = outputs(nq, 10)
+            wall, kern, launches = timed(lambda: h.search_device(q.data_ptr(), nq, 10, nprobe, od.data_ptr(), orow.data_ptr()), 10)
+            emit("ivfpq", workload=f"IVF-PQ nlist={nlist} nprobe={nprobe} m={m}, {n}x{d}, batch {nq}, k=10",
+                 qps=round(nq / wall, 1), ms_per_batch=round(wall * 1e3, 4), kernel_ms_avg=round(kern * 1e3, 4),
+                 kernels_per_batch=launches, encode_rows_per_s=round(n / t_encode, 1), build_s=round(t_build, 2))
+        h.close()
         torch.cuda.empty_cache()
 
     # ---- PQ m=16 nbits=8 ADC scan over 100M codes with a filter bitmask

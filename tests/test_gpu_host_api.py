@@ -508,3 +508,67 @@ def test_flat_index_bf16_storage_kwarg():
     assert hits == 20
     with pytest.raises(ValueError):
         FlatIndex(48, storage="fp8")
+
+
+# ================================================================= HybridIndex (IVF-PQ)
+def test_hybrid_index_matches_reference_outputs():
+    """With the reference's trained quantizers: list, code and search results of the reference's own
+    HybridIndex (tests/golden/hybrid.npz), through the index class; then removal, to_dict/from_dict."""
+    from vectordb_amd.index import HybridIndex, IndexType, create_index
+    g = load_golden("hybrid.npz")
+    x, q = g["x"], g["q"]
+    ids = [f"v{i}" for i in range(len(x))]
+    meta = [{"cat": int(i % 3)} for i in range(len(x))]
+    idx = create_index("ivf_pq", 32, n_clusters=16, n_probe=4, n_subvectors=4, n_bits=8, seed=11)
+    assert isinstance(idx, HybridIndex) and idx.index_type == IndexType.IVF_PQ
+    with pytest.raises(RuntimeError):
+        idx.add("a", x[0])
+    idx._set_quantizers(g["centroids"], g["codebook"])
+    assert idx.add_batch(ids, x, meta) == len(x)
+    with pytest.raises(ValueError):
+        idx.add("v3", x[3])
+    got_lists = np.array([idx._id_to_cluster[i] for i in ids])
+    assert (got_lists != g["lists"]).sum() <= 2
+    for tag, n_probe in (("p4", 4), ("p16", 16)):
+        batch = idx.search_batch(q, k=10, n_probe=n_probe)
+        for i in range(len(q)):
+            res = idx.search(q[i], k=10, n_probe=n_probe)
+            assert [int(r.id[1:]) for r in res] == g[f"rows_{tag}"][i].tolist()
+            assert [r.distance for r in res] == g[f"dist_{tag}"][i].tolist()
+            assert [r.id for r in batch[i]] == [r.id for r in res]
+            res = idx.search(q[i], k=10, n_probe=n_probe, filter_fn=lambda _id, m: m["cat"] == 1)
+            n = int((g[f"filter_rows_{tag}"][i] >= 0).sum())
+            assert [int(r.id[1:]) for r in res] == g[f"filter_rows_{tag}"][i][:n].tolist()
+    assert idx.search(q[0], k=3)[0].score == pytest.approx(1.0 / (1.0 + g["dist_p4"][0][0]))
+    for r in g["removed"]:
+        assert idx.remove(ids[r])
+    assert not idx.remove("v3") and len(idx) == len(x) - 4
+    res = idx.search(q[0], k=10, n_probe=16)
+    assert [int(r.id[1:]) for r in res] == g["rows_after_remove"].tolist()
+    back = HybridIndex.from_dict(idx.to_dict())
+    res2 = back.search(q[0], k=10, n_probe=16)
+    assert [r.id for r in res2] == [r.id for r in res] and [r.distance for r in res2] == [r.distance for r in res]
+    vec, md = back.get("v7")
+    assert vec.shape == (32,) and md == {"cat": 1}
+    assert back.stats().index_type == "ivf_pq" and back.stats().extra["compression_ratio"] > 1
+
+
+def test_hybrid_index_training_on_device():
+    """train() on the device: the coarse centroids follow the reference's (same k-means++ draws; fp64
+    sums instead of sequential fp32), the residual codebook quantises as well as the reference's."""
+    from vectordb_amd.index import HybridIndex
+    g = load_golden("hybrid.npz")
+    x = g["x"]
+    idx = HybridIndex(32, n_clusters=16, n_probe=4, n_subvectors=4, n_bits=8, seed=11)
+    idx.config.n_iter = int(g["n_iter"])
+    idx.train(x)
+    np.testing.assert_allclose(idx._coarse_centroids, g["centroids"], rtol=1e-3, atol=1e-3)
+
+    def quant_error(cent, book):
+        lists, codes = R.hybrid_encode(x, cent, book)
+        rec = cent[lists] + np.concatenate([book[j][codes[:, j]] for j in range(4)], axis=1)
+        return float(np.mean(np.sum((x - rec) ** 2, axis=1)))
+    assert quant_error(idx._coarse_centroids, idx._pq_codebook) <= 1.02 * quant_error(g["centroids"], g["codebook"])
+    idx.add_batch([f"v{i}" for i in range(len(x))], x)
+    hits = sum(idx.search(x[i], k=5, n_probe=16)[0].id == f"v{i}" for i in range(0, 200, 10))
+    assert hits >= 14          # PQ distances are approximate: the row itself is usually, not always, first
