@@ -162,11 +162,13 @@ static int fill_results(float* d, int64_t* i, int64_t total, hipStream_t s) {
 // ============================================================== workspaces
 struct Workspace {
     DevBuf q_buf, q_sq, q_nrm, part_d, part_i, lb_d, lb_k, thr_d, thr_k, mask, out_d, out_i, dist, probes, probe_d, lut, stage;
+    DevBuf queue, queue_cnt, flag;
     DevBuf round32, q16, cand, seg_row_off, seg_q_off, seg_item_off, sq_qid, sq_out, cand_off, tile_off, list_cnt, cursor, slots, items;
     void release() {
         DevBuf* all[] = {&q_buf, &q_sq, &q_nrm, &part_d, &part_i, &lb_d, &lb_k, &thr_d, &thr_k, &mask, &out_d, &out_i, &dist,
                          &probes, &probe_d, &lut, &stage, &round32, &q16, &cand, &seg_row_off, &seg_q_off, &seg_item_off, &sq_qid, &sq_out,
-                         &cand_off, &tile_off, &list_cnt, &cursor, &slots, &items};
+                         &cand_off, &tile_off, &list_cnt, &cursor, &slots, &items,
+                         &queue, &queue_cnt, &flag};
         for (DevBuf* b : all) b->release();
     }
 };
@@ -175,6 +177,7 @@ static bool is_dot_metric(int m) {
     return m == VDB_EUCLIDEAN || m == VDB_EUCLIDEAN_SQ || m == VDB_COSINE || m == VDB_DOT;
 }
 static bool valid_metric(int m) { return m >= VDB_EUCLIDEAN && m <= VDB_EUCLIDEAN_SQ_DIRECT; }
+static const int QUEUE_Q_BLOCK = 1024;  // queries per launch of the candidate-queue kernel (bounds its workspace)
 static const int GEMM_MIN_NQ = 4;     // below this the streaming scan reads the rows once per query and wins
 
 static int reserve_stream_plan(Workspace& ws, int n_seg, int64_t n_pairs, int64_t items_cap, StreamPlanBufs* b) {
@@ -413,15 +416,40 @@ static int flat_search_impl(vdb_rows* h, int metric, const float* d_q, int nq, i
         thr_init = ws.thr_d.as<float>();
     }
 
+    // With a bound in hand and a single pass (k <= KMAX_FUSED) the survivors are queued and selected
+    // directly; the list kernel below then runs only if a queue overflowed (a device-side flag, no
+    // host round trip).
+    static const bool no_queue = getenv("VDB_NO_QUEUE") != nullptr;
+    const int* run_if = nullptr;
+    if (thr_init && !multi && !no_queue) {
+        VDB_TRY(ws.flag.reserve(sizeof(int)));
+        VDB_HIP(hipMemsetAsync(ws.flag.p, 0, sizeof(int), s));
+        const char* qb = reinterpret_cast<const char*>(q);
+        const size_t q_pitch = r.bf16 ? (size_t)r.ld16 * 2 : (size_t)r.ld * 4;
+        for (int q0 = 0; q0 < nq; q0 += QUEUE_Q_BLOCK) {
+            const int nb = std::min(QUEUE_Q_BLOCK, nq - q0);
+            int n_slabs = 0, cap = 0;
+            VDB_TRY(flat_queue_plan(r.n, nb, kmax, sample_stride, &n_slabs, &cap));
+            VDB_TRY(ws.queue.reserve((size_t)nb * n_slabs * cap * 8));
+            VDB_TRY(ws.queue_cnt.reserve((size_t)nb * n_slabs * sizeof(int)));
+            VDB_TRY(launch_flat_queue(r, metric, qb + (size_t)q0 * q_pitch, ws.q_sq.as<float>() + q0, ws.q_nrm.as<float>() + q0,
+                                      nb, kmax, d_mask, thr_init + q0, n_slabs, cap, ws.queue.p, ws.queue_cnt.as<int>(),
+                                      ws.flag.as<int>(), d_out_d ? d_out_d + (int64_t)q0 * k : nullptr,
+                                      d_out_i ? d_out_i + (int64_t)q0 * k : nullptr,
+                                      d_out_i32 ? d_out_i32 + (int64_t)q0 * k : nullptr, s));
+        }
+        run_if = ws.flag.as<int>();
+    }
+
     for (int64_t done = 0; done < k_eff; done += KMAX_FUSED) {
         const int kk = (int)std::min<int64_t>(KMAX_FUSED, k_eff - done);
         const float* lb_d = (done > 0) ? ws.lb_d.as<float>() : nullptr;
         const int64_t* lb_k = (done > 0) ? ws.lb_k.as<int64_t>() : nullptr;
         VDB_TRY(launch_flat_gemm_topk(r, metric, q, ws.q_sq.as<float>(), ws.q_nrm.as<float>(), nq, kk, d_mask,
                                       lb_d, lb_k, done == 0 ? thr_init : nullptr, 0, 1,
-                                      ws.part_d.as<float>(), ws.part_i.as<int>(), n_cand, s));
+                                      ws.part_d.as<float>(), ws.part_i.as<int>(), n_cand, s, run_if));
         SelectOut o{d_out_d, d_out_i, d_out_i32, k, (int)done,
-                    multi ? ws.lb_d.as<float>() : nullptr, multi ? ws.lb_k.as<int64_t>() : nullptr};
+                    multi ? ws.lb_d.as<float>() : nullptr, multi ? ws.lb_k.as<int64_t>() : nullptr, run_if};
         VDB_TRY(launch_select(ws.part_d.as<float>(), ws.part_i.as<int>(), nq, n_cand, kk, 1 << 30, nullptr, 0, o, s));
     }
     return VDB_OK;

@@ -24,19 +24,9 @@
 // tile and all 128 database rows of the current tile (4 accumulators of
 // 32x32).  K is walked in steps of 32 staged through LDS (row stride 36
 // floats: conflict-free ds_read_b128 fragment reads).
-#include "vdb_internal.h"
-#include "vdb_device.h"
+#include "flat_math.h"
 
 namespace vdb {
-
-typedef float f32x16 __attribute__((ext_vector_type(16)));
-typedef short bf16x8 __attribute__((ext_vector_type(8)));
-
-static constexpr int TM = 128;      // database rows per tile
-static constexpr int TQ = 128;      // queries per tile
-static constexpr int TKB = 128;     // bytes of every row per K step: 32 fp32 or 64 bf16
-static constexpr int LW = 36;       // padded LDS row width in dwords (128 B of data + 16 B)
-static constexpr int NT = LIST_NT;  // threads per block
 
 struct GemmParams {
     const void* rows; int64_t n; int ld_bytes;     // row pitch in bytes (multiple of 16); fp32 or bf16 elements
@@ -52,58 +42,10 @@ struct GemmParams {
     int n_slabs, tiles_per_slab, n_qtiles;
     float* part_d; int* part_i; int n_cand;
     float* dist_out;
+    const int* run_if;              // optional device flag: the launch does nothing while it is zero
     int diag;                       // timing experiments only (env VDB_DIAG, results are wrong when set): 1 no epilogue,
                                     // 2 no exact/insert stage, 4 no row terms, 8 no staging loads, 16 no LDS staging, 32 one block per CU
 };
-
-// ---- final distance value from the dot product, per metric ---------------
-template <int METRIC>
-__device__ __forceinline__ float finish(float dot, float row_term, float q_term) {
-    if (METRIC == VDB_DOT) {
-        return -dot;
-    } else if (METRIC == VDB_COSINE) {
-        // q_term = |q| (or +inf for a zero query -> similarity 0 -> distance 1);
-        // row_term = |c| with the <1e-8 -> 1 substitution already applied
-        float sim = dot / (q_term * row_term);
-        sim = fminf(fmaxf(sim, -1.0f), 1.0f);
-        return 1.0f - sim;
-    } else {
-        // (|q|^2 + |c|^2) - 2*dot : 2*dot is exact, so one fma rounds like the
-        // reference's separate multiply and subtract
-        float sq = fmaxf(__fmaf_rn(-2.0f, dot, q_term + row_term), 0.0f);
-        return METRIC == VDB_EUCLIDEAN ? sqrtf(sq) : sq;
-    }
-}
-
-// ---- conservative filter: never rejects a value whose exact distance is <= thr
-template <int METRIC>
-__device__ __forceinline__ float filter_bound(float thr, float q_term) {
-    if (METRIC == VDB_DOT) return -thr;                                     // pass: dot >= bound
-    if (METRIC == VDB_EUCLIDEAN_SQ) return thr;                             // pass: raw <= bound
-    if (METRIC == VDB_EUCLIDEAN) return thr * thr * 1.000001f;              // sqrt_rn(x) <= thr  =>  x <= thr^2 (1 + 2^-22)
-    // cosine, pass: dot >= bound * |c|.  1 - clip(dot/(|q||c|)) <= thr implies
-    // dot/(|q||c|) >= 1 - thr - 5e-7 after every rounding on both sides.
-    if (q_term == INFINITY) return (1.0f <= thr) ? -INFINITY : INFINITY;    // zero query: every distance is exactly 1
-    if (thr >= 2.0f) return -INFINITY;
-    return ((1.0f - thr) - 3e-6f) * q_term;
-}
-
-template <int METRIC>
-__device__ __forceinline__ bool filter_pass(float dot, float row_term, float q_term, float bound) {
-    if (METRIC == VDB_DOT) return dot >= bound;
-    if (METRIC == VDB_COSINE) return dot >= bound * row_term;
-    return __fmaf_rn(-2.0f, dot, q_term + row_term) <= bound;
-}
-
-// element e (lane-varying) of a 16-register accumulator: binary tree of selects
-__device__ __forceinline__ float pick16(const f32x16& a, int e) {
-    const bool b0 = e & 1, b1 = e & 2, b2 = e & 4, b3 = e & 8;
-    const float p0 = b0 ? a[1] : a[0], p1 = b0 ? a[3] : a[2], p2 = b0 ? a[5] : a[4], p3 = b0 ? a[7] : a[6];
-    const float p4 = b0 ? a[9] : a[8], p5 = b0 ? a[11] : a[10], p6 = b0 ? a[13] : a[12], p7 = b0 ? a[15] : a[14];
-    const float q0 = b1 ? p1 : p0, q1 = b1 ? p3 : p2, q2 = b1 ? p5 : p4, q3 = b1 ? p7 : p6;
-    const float r0 = b2 ? q1 : q0, r1 = b2 ? q3 : q2;
-    return b3 ? r1 : r0;
-}
 
 // SAMPLE only gives the strided warm-up pass a kernel name of its own, so that
 // profiles list it separately from the full pass.
@@ -118,6 +60,7 @@ __global__ __launch_bounds__(NT, 2) void flat_gemm_kernel(GemmParams p) {
     float* Ld = Rs + TM;                // [k][NT]   per-thread best distances
     int* Li = reinterpret_cast<int*>(Ld + (TOPK ? p.k : 0) * NT);
 
+    if (p.run_if && *p.run_if == 0) return;
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int wave = tid >> 6;
@@ -367,14 +310,6 @@ __global__ __launch_bounds__(NT, 2) void flat_gemm_kernel(GemmParams p) {
 }
 
 // --------------------------------------------------------------------------
-static void plan_grid(int n_tiles, int nq, int num_cus, int* n_qtiles, int* n_slabs, int* tiles_per_slab) {
-    *n_qtiles = (nq + TQ - 1) / TQ;
-    int want = (2 * num_cus + *n_qtiles - 1) / *n_qtiles;      // ~2 blocks per CU in total
-    if (want < 1) want = 1;
-    if (want > n_tiles) want = n_tiles;
-    *tiles_per_slab = (n_tiles + want - 1) / want;
-    *n_slabs = (n_tiles + *tiles_per_slab - 1) / *tiles_per_slab;
-}
 
 int flat_gemm_num_cand(int64_t n, int nq, int k, int* n_cand) {
     int nqt, ns, tps;
@@ -409,7 +344,7 @@ static int launch_gemm(int metric, GemmParams& p, hipStream_t s) {
     p.diag = diag;
     size_t lds = (size_t)(2 * TM * LW + TM) * sizeof(float) + (TOPK ? (size_t)p.k * NT * 8 : 0);
     if (diag & 32) lds = 100 * 1024;       // one block per CU
-    KernelTimer timer(s, p.tile_stride == 1);
+    KernelTimer timer(s, p.tile_stride == 1 && p.run_if == nullptr);
 #define VDB_LAUNCH_GEMM(M)                                                                     \
     case M: {                                                                                  \
         auto kern = (TOPK && p.tile_stride != 1) ? flat_gemm_kernel<M, TOPK, TOPK, BF16> : flat_gemm_kernel<M, TOPK, false, BF16>; \
@@ -435,7 +370,7 @@ static int launch_gemm(int metric, GemmParams& p, hipStream_t s) {
 int launch_flat_gemm_topk(const Rows& r, int metric, const void* q, const float* q_sq, const float* q_nrm,
                           int nq, int k, const uint32_t* mask, const float* lb_d, const int64_t* lb_k,
                           const float* thr_init, int sample_tiles, int tile_stride,
-                          float* part_d, int* part_i, int n_cand, hipStream_t s) {
+                          float* part_d, int* part_i, int n_cand, hipStream_t s, const int* run_if) {
     VDB_REQUIRE(k >= 1 && k <= KMAX_FUSED, "fused selection supports 1 <= k <= %d, got %d", KMAX_FUSED, k);
     VDB_REQUIRE(r.n >= 1 && nq >= 1, "empty search");
     GemmParams p{};
@@ -445,7 +380,7 @@ int launch_flat_gemm_topk(const Rows& r, int metric, const void* q, const float*
     p.mask = mask; p.lb_d = lb_d; p.lb_k = lb_k; p.thr_init = thr_init; p.k = k;
     p.n_tiles = sample_tiles > 0 ? sample_tiles : (int)((r.n + TM - 1) / TM);
     p.tile_stride = sample_tiles > 0 ? tile_stride : 1;
-    p.part_d = part_d; p.part_i = part_i; p.n_cand = n_cand; p.dist_out = nullptr;
+    p.part_d = part_d; p.part_i = part_i; p.n_cand = n_cand; p.dist_out = nullptr; p.run_if = run_if;
     return r.bf16 ? launch_gemm<true, true>(metric, p, s) : launch_gemm<true, false>(metric, p, s);
 }
 

@@ -1,0 +1,438 @@
+// Batched distance + top-k for the Flat index on the matrix cores, candidate-queue form.
+//
+// Same contraction as flat_gemm.hip (128 queries x 128 database rows per tile,
+// v_mfma_f32_32x32x2_f32 or v_mfma_f32_32x32x16_bf16, distances as in
+// distance/metrics.py:453-484), for searches that already hold a per-query upper
+// bound of the k-th best distance (the k-th best over a strided sample of the
+// rows).  With that bound almost no value survives the conservative filter, so
+// the kernel keeps no sorted lists: a survivor's raw dot product and row number
+// are appended to a small queue per (query, slab of rows) and the exact distance,
+// the ordering and the final k best (index/flat.py:354-362) are left to
+// queue_select_kernel.  The LDS that the lists would take holds a second staging
+// buffer instead: one barrier per K step, the next step's rows are written to LDS
+// and the step after that is fetched while the current one is multiplied.
+//
+// A queue that overflows is reported through a flag; the caller then repeats the
+// search with the list kernel, so the result never depends on the queue size.
+#include "flat_math.h"
+
+namespace vdb {
+
+struct QueueParams {
+    const void* rows; int64_t n; int ld_bytes;     // row pitch in bytes (multiple of 16); fp32 or bf16 elements
+    const float* row_sq; const float* row_nrm;
+    const void* q; int nq;                         // same element type and pitch as the rows
+    const float* q_sq; const float* q_nrm;
+    const uint32_t* mask;
+    const float* thr;                              // per query: an upper bound of its k-th best distance
+    int n_tiles, n_slabs, tiles_per_slab, n_qtiles;
+    int cap;                                       // queue slots per (query, slab)
+    float2* queue;                                 // [nq][n_slabs][cap]  (dot product, row number bits)
+    int* counts;                                   // [nq][n_slabs]       survivors seen (may exceed cap)
+};
+
+template <int METRIC, bool BF16>
+__global__ __launch_bounds__(NT, 2) void flat_queue_kernel(QueueParams p) {
+    extern __shared__ __align__(16) float smem[];
+    float* As = smem;                                   // [2][TM][LW]  database rows, two stages
+    float* Bs = As + 2 * TM * LW;                       // [2][TQ][LW]  queries, two stages
+    float* Rs = Bs + 2 * TQ * LW;                       // [2][TM]      per-row term (|c|^2 or |c|), by tile parity
+    int* Cnt = reinterpret_cast<int*>(Rs + 2 * TM);     // [TQ]         survivors per query of this block
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = tid >> 6;
+    const int half = lane >> 5;
+    const int col = lane & 31;
+
+    // blocks that work on the same slab of rows (one per query tile) get the
+    // same blockIdx % 8, i.e. the same XCD and L2, and adjacent dispatch slots
+    int slab, qt;
+    if (p.n_slabs >= 8) {
+        const int per_group = 8 * p.n_qtiles;
+        const int grp = blockIdx.x / per_group;
+        const int rem = blockIdx.x - grp * per_group;
+        slab = grp * 8 + (rem & 7);
+        qt = rem >> 3;
+        if (slab >= p.n_slabs) return;
+    } else {
+        qt = blockIdx.x / p.n_slabs;
+        slab = blockIdx.x - qt * p.n_slabs;
+    }
+    const int tile0 = slab * p.tiles_per_slab;
+    const int tile1 = min(tile0 + p.tiles_per_slab, p.n_tiles);
+
+    const int my_q = qt * TQ + wave * 32 + col;
+    const bool q_ok = my_q < p.nq;
+    const int my_q_ld = min(my_q, p.nq - 1);
+    float q_term = 0.0f;
+    if (METRIC == VDB_COSINE) {
+        q_term = p.q_nrm[my_q_ld];
+        if (q_term < 1e-8f) q_term = INFINITY;      // metrics.py:472-473: all ones
+    } else if (METRIC != VDB_DOT) {
+        q_term = p.q_sq[my_q_ld];
+    }
+    // lanes past the last query must never pass the filter
+    float bound = filter_bound<METRIC>(p.thr[my_q_ld], q_term);
+    if (!q_ok) bound = (METRIC == VDB_DOT || METRIC == VDB_COSINE) ? INFINITY : -INFINITY;
+    float2* my_queue = p.queue + ((int64_t)my_q_ld * p.n_slabs + slab) * p.cap;
+    if (tid < TQ) Cnt[tid] = 0;
+
+    const int ksteps = (p.ld_bytes + TKB - 1) / TKB;
+    const int srow = tid >> 3;          // staging: row within a 32-row pass
+    const int skc = (tid & 7) * 4;      // staging: dword offset inside the K step (16-byte pieces)
+    const int64_t q_base = (int64_t)qt * TQ;
+    const bool k_tail = (p.ld_bytes % TKB) != 0;
+    const int ldw = p.ld_bytes >> 2;    // row pitch in dwords
+    uint32_t offb[4], offa[4];
+#pragma unroll
+    for (int ps = 0; ps < 4; ++ps) {
+        const int64_t gq = min(q_base + ps * 32 + srow, (int64_t)p.nq - 1) - q_base;
+        offb[ps] = (uint32_t)(gq * ldw + skc);
+        offa[ps] = (uint32_t)((ps * 32 + srow) * ldw + skc);
+    }
+    const float* rows_w = reinterpret_cast<const float*>(p.rows);
+    const float* qbase_ptr = reinterpret_cast<const float*>(p.q) + q_base * ldw;
+    float4 ra[4], rb[4];
+    float rterm = 0.0f;
+
+    // fetch K step `ks` of tile `tile` (rows and queries) into registers
+    auto issue_loads = [&](int tile, int ks) {
+        const int64_t rbase = (int64_t)tile * TM;
+        const float* abase = rows_w + rbase * ldw + ks * (TKB / 4);
+        const float* bbase = qbase_ptr + ks * (TKB / 4);
+        if (rbase + TM > p.n) {             // last tile: rows past the end re-read the last row (masked out later)
+#pragma unroll
+            for (int ps = 0; ps < 4; ++ps)
+                offa[ps] = (uint32_t)(min((int64_t)(ps * 32 + srow), p.n - 1 - rbase) * ldw + skc);
+        }
+        if (k_tail && ks == ksteps - 1) {
+            const bool kin = ks * (TKB / 4) + skc < ldw;
+#pragma unroll
+            for (int ps = 0; ps < 4; ++ps) {
+                ra[ps] = kin ? *reinterpret_cast<const float4*>(abase + offa[ps]) : make_float4(0, 0, 0, 0);
+                rb[ps] = kin ? *reinterpret_cast<const float4*>(bbase + offb[ps]) : make_float4(0, 0, 0, 0);
+            }
+        } else {
+#pragma unroll
+            for (int ps = 0; ps < 4; ++ps) {
+                ra[ps] = *reinterpret_cast<const float4*>(abase + offa[ps]);
+                rb[ps] = *reinterpret_cast<const float4*>(bbase + offb[ps]);
+            }
+        }
+        if (METRIC != VDB_DOT && ks == 0 && tid < TM) {
+            const int64_t gr = min(rbase + tid, p.n - 1);
+            rterm = (METRIC == VDB_COSINE) ? p.row_nrm[gr] : p.row_sq[gr];
+        }
+    };
+    // registers -> LDS stage `buf`
+    auto stage_write = [&](int buf, int tile, int ks) {
+        float* a = As + buf * (TM * LW);
+        float* b = Bs + buf * (TQ * LW);
+#pragma unroll
+        for (int ps = 0; ps < 4; ++ps) {
+            const int r = ps * 32 + srow;
+            *reinterpret_cast<float4*>(a + r * LW + skc) = ra[ps];
+            *reinterpret_cast<float4*>(b + r * LW + skc) = rb[ps];
+        }
+        if (METRIC != VDB_DOT && ks == 0 && tid < TM) {
+            float t = rterm;
+            if (METRIC == VDB_COSINE && t < 1e-8f) t = 1.0f;        // metrics.py:476
+            Rs[(tile & 1) * TM + tid] = t;
+        }
+    };
+
+    f32x16 acc[4];
+#pragma unroll
+    for (int s = 0; s < 4; ++s)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) acc[s][e] = 0.0f;
+
+    // survivors of one finished tile -> queue
+    auto epilogue = [&](int tile) {
+        const int64_t rbase = (int64_t)tile * TM;
+        const float* rs = Rs + (tile & 1) * TM;
+        const bool masked = (rbase + TM > p.n) || p.mask != nullptr;
+#pragma unroll
+        for (int s = 0; s < 4; ++s) {
+            float v[16];
+            if (METRIC == VDB_DOT) {
+#pragma unroll
+                for (int e = 0; e < 16; ++e) v[e] = acc[s][e];
+            } else {
+#pragma unroll
+                for (int g = 0; g < 4; ++g) {
+                    const float4 t = *reinterpret_cast<const float4*>(rs + s * 32 + 8 * g + 4 * half);
+                    const float rts[4] = {t.x, t.y, t.z, t.w};
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) {
+                        // cosine: dot - bound*|c| >= 0 ; L2: (|q|^2+|c|^2) - 2 dot <= bound   (one rounding each)
+                        v[g * 4 + j] = (METRIC == VDB_COSINE) ? __fmaf_rn(-bound, rts[j], acc[s][g * 4 + j])
+                                                              : __fmaf_rn(-2.0f, acc[s][g * 4 + j], q_term + rts[j]);
+                    }
+                }
+            }
+            const bool want_max = (METRIC == VDB_DOT || METRIC == VDB_COSINE);
+            float m = v[0];
+#pragma unroll
+            for (int e = 1; e < 16; ++e) m = want_max ? fmaxf(m, v[e]) : fminf(m, v[e]);
+            const float lim = (METRIC == VDB_COSINE) ? 0.0f : bound;
+            const bool any = want_max ? (m >= lim) : (m <= lim);
+            if (any) {
+                uint32_t hits = 0;
+#pragma unroll
+                for (int e = 0; e < 16; ++e) {
+                    const bool pass = want_max ? (v[e] >= lim) : (v[e] <= lim);
+                    hits |= pass ? (1u << e) : 0u;
+                }
+                if (masked) {
+                    uint32_t bits = 0xffffffffu;
+                    const int64_t r0 = rbase + s * 32;
+                    if (p.mask) bits = (r0 < p.n) ? p.mask[r0 >> 5] : 0u;
+                    const int64_t left = p.n - r0;
+                    if (left < 32) bits = left <= 0 ? 0u : (bits & ((1u << left) - 1u));
+                    bits >>= (4 * half);
+                    // value e = 4g + j of this lane is row 8g + 4*half + j of the 32-row sub-tile
+                    hits &= (bits & 0xFu) | ((bits >> 4) & 0xF0u) | ((bits >> 8) & 0xF00u) | ((bits >> 12) & 0xF000u);
+                }
+                while (hits) {
+                    const int e = __ffs(hits) - 1;
+                    hits &= hits - 1;
+                    const int off = 8 * (e >> 2) + (e & 3) + 4 * half;
+                    const float dot = pick16(acc[s], e);
+                    const int row = (int)(rbase + s * 32 + off);
+                    const int slot = atomicAdd(&Cnt[wave * 32 + col], 1);
+                    if (slot < p.cap) my_queue[slot] = make_float2(dot, __int_as_float(row));
+                }
+            }
+        }
+    };
+
+    const int n_steps = (tile1 - tile0) * ksteps;
+    // cursors: c = step being multiplied, w = the step after it (written to LDS meanwhile),
+    // l = the step after that (fetched meanwhile)
+    int ct = tile0, ck = 0;
+    int wt = ct, wk = ck + 1;
+    if (wk == ksteps) { wk = 0; ++wt; }
+    int lt = wt, lk = wk + 1;
+    if (lk == ksteps) { lk = 0; ++lt; }
+
+    if (n_steps > 0) {
+        issue_loads(ct, ck);
+        stage_write(0, ct, ck);
+        if (n_steps > 1) issue_loads(wt, wk);
+    }
+    __syncthreads();
+
+    for (int st = 0; st < n_steps; ++st) {
+        const int b = st & 1;
+        const float* bq = Bs + b * (TQ * LW) + (wave * 32 + col) * LW + half * 4;
+        const float* ar = As + b * (TM * LW) + col * LW + half * 4;
+        float4 bf0[2], af0[2][4], bf1[2], af1[2][4];
+#pragma unroll
+        for (int c2 = 0; c2 < 2; ++c2) {
+            bf0[c2] = *reinterpret_cast<const float4*>(bq + c2 * 8);
+#pragma unroll
+            for (int s = 0; s < 4; ++s) af0[c2][s] = *reinterpret_cast<const float4*>(ar + s * 32 * LW + c2 * 8);
+        }
+#pragma unroll
+        for (int c2 = 0; c2 < 2; ++c2) {
+            bf1[c2] = *reinterpret_cast<const float4*>(bq + (2 + c2) * 8);
+#pragma unroll
+            for (int s = 0; s < 4; ++s) af1[c2][s] = *reinterpret_cast<const float4*>(ar + s * 32 * LW + (2 + c2) * 8);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int c2 = 0; c2 < 2; ++c2) {
+#pragma unroll
+            for (int s = 0; s < 4; ++s) {
+                if (BF16) {
+                    acc[s] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, af0[c2][s]),
+                                                                     __builtin_bit_cast(bf16x8, bf0[c2]), acc[s], 0, 0, 0);
+                } else {
+                    acc[s] = __builtin_amdgcn_mfma_f32_32x32x2f32(af0[c2][s].x, bf0[c2].x, acc[s], 0, 0, 0);
+                    acc[s] = __builtin_amdgcn_mfma_f32_32x32x2f32(af0[c2][s].y, bf0[c2].y, acc[s], 0, 0, 0);
+                    acc[s] = __builtin_amdgcn_mfma_f32_32x32x2f32(af0[c2][s].z, bf0[c2].z, acc[s], 0, 0, 0);
+                    acc[s] = __builtin_amdgcn_mfma_f32_32x32x2f32(af0[c2][s].w, bf0[c2].w, acc[s], 0, 0, 0);
+                }
+            }
+        }
+        // the next step's operands have had a whole step to arrive: park them in the other
+        // stage and start fetching the step after, all behind the matrix instructions above
+        if (st + 1 < n_steps) {
+            stage_write(1 - b, wt, wk);
+            if (st + 2 < n_steps) issue_loads(lt, lk);
+        }
+#pragma unroll
+        for (int c2 = 0; c2 < 2; ++c2) {
+#pragma unroll
+            for (int s = 0; s < 4; ++s) {
+                if (BF16) {
+                    acc[s] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, af1[c2][s]),
+                                                                     __builtin_bit_cast(bf16x8, bf1[c2]), acc[s], 0, 0, 0);
+                } else {
+                    acc[s] = __builtin_amdgcn_mfma_f32_32x32x2f32(af1[c2][s].x, bf1[c2].x, acc[s], 0, 0, 0);
+                    acc[s] = __builtin_amdgcn_mfma_f32_32x32x2f32(af1[c2][s].y, bf1[c2].y, acc[s], 0, 0, 0);
+                    acc[s] = __builtin_amdgcn_mfma_f32_32x32x2f32(af1[c2][s].z, bf1[c2].z, acc[s], 0, 0, 0);
+                    acc[s] = __builtin_amdgcn_mfma_f32_32x32x2f32(af1[c2][s].w, bf1[c2].w, acc[s], 0, 0, 0);
+                }
+            }
+        }
+        if (ck == ksteps - 1) {
+            epilogue(ct);
+#pragma unroll
+            for (int s = 0; s < 4; ++s)
+#pragma unroll
+                for (int e = 0; e < 16; ++e) acc[s][e] = 0.0f;
+        }
+        __syncthreads();
+        ct = wt; ck = wk;
+        wt = lt; wk = lk;
+        if (++lk == ksteps) { lk = 0; ++lt; }
+    }
+
+    if (tid < TQ && q_base + tid < p.nq) p.counts[(q_base + tid) * p.n_slabs + slab] = Cnt[tid];
+}
+
+// --------------------------------------------------------------------------
+// Per query: exact distances of the queued survivors (the same arithmetic as
+// finish<>() in the list kernel), the k best under the (distance, row) order.
+struct QueueSelectParams {
+    const float2* queue; const int* counts; int n_slabs, cap;
+    const float* row_sq; const float* row_nrm; const float* q_sq; const float* q_nrm;
+    int nq, k;
+    float* out_d; int64_t* out_i; int* out_i32;
+    int* overflow;                  // set to 1 when a queue held more survivors than it has slots
+};
+
+template <int METRIC>
+__global__ __launch_bounds__(256) void queue_select_kernel(QueueSelectParams p) {
+    const int lane = threadIdx.x & 63;
+    const int q = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (q >= p.nq) return;
+    float q_term = 0.0f;
+    if (METRIC == VDB_COSINE) {
+        q_term = p.q_nrm[q];
+        if (q_term < 1e-8f) q_term = INFINITY;
+    } else if (METRIC != VDB_DOT) {
+        q_term = p.q_sq[q];
+    }
+    WaveTopK top;
+    top.init(p.k);
+    bool over = false;
+    for (int s0 = 0; s0 < p.n_slabs; s0 += 64) {
+        // lane l walks the queue of slab s0 + l
+        const int s = s0 + lane;
+        int c = 0;
+        if (s < p.n_slabs) {
+            c = p.counts[(int64_t)q * p.n_slabs + s];
+            if (c > p.cap) { over = true; c = p.cap; }
+        }
+        int cmax = c;
+#pragma unroll
+        for (int off = 32; off >= 1; off >>= 1) cmax = max(cmax, __shfl_xor(cmax, off));
+        const float2* e = p.queue + ((int64_t)q * p.n_slabs + min(s, p.n_slabs - 1)) * p.cap;
+        for (int j0 = 0; j0 < cmax; j0 += 4) {
+            float2 v[4];
+            float rt[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) v[u] = (j0 + u < c) ? e[j0 + u] : make_float2(0.0f, 0.0f);
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                rt[u] = 1.0f;
+                if (METRIC != VDB_DOT && j0 + u < c) {
+                    const int row = __float_as_int(v[u].y);
+                    rt[u] = (METRIC == VDB_COSINE) ? p.row_nrm[row] : p.row_sq[row];
+                    if (METRIC == VDB_COSINE && rt[u] < 1e-8f) rt[u] = 1.0f;
+                }
+            }
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const float d = finish<METRIC>(v[u].x, rt[u], q_term);
+                top.offer(j0 + u < c, d, __float_as_int(v[u].y), lane);
+            }
+        }
+    }
+    if (over) *p.overflow = 1;
+    if (lane < p.k) {
+        const bool empty = top.eid == EMPTY_IDX;
+        const int64_t at = (int64_t)q * p.k + lane;
+        const int64_t row = empty ? -1 : (int64_t)top.eid;
+        if (p.out_d) p.out_d[at] = empty ? INFINITY : top.e;
+        if (p.out_i) p.out_i[at] = row;
+        if (p.out_i32) p.out_i32[at] = (int)row;
+    }
+}
+
+// --------------------------------------------------------------------------
+int flat_queue_plan(int64_t n, int nq, int k, int sample_stride, int* n_slabs, int* cap) {
+    int nqt, tps;
+    plan_grid((int)((n + TM - 1) / TM), nq, ctx().num_cus, &nqt, n_slabs, &tps);
+    // survivors per query: about sample_stride * k in expectation (the bound is the k-th best of
+    // one row in sample_stride); four times that plus a constant, spread over the slabs
+    const int64_t total = 4LL * sample_stride * k + 1024;
+    int c = (int)((total + *n_slabs - 1) / *n_slabs);
+    c = std::max(32, (c + 7) / 8 * 8);
+    *cap = c;
+    return VDB_OK;
+}
+
+template <bool BF16>
+static int launch_queue(int metric, QueueParams& p, hipStream_t s) {
+    const int groups = (p.n_slabs + 7) / 8;
+    const dim3 grid(p.n_slabs >= 8 ? groups * 8 * p.n_qtiles : p.n_slabs * p.n_qtiles);
+    const size_t lds = (size_t)(2 * TM * LW + 2 * TQ * LW + 2 * TM + TQ) * sizeof(float);
+    KernelTimer timer(s, true);
+#define VDB_LAUNCH_QUEUE(M)                                                                    \
+    case M: {                                                                                  \
+        auto kern = flat_queue_kernel<M, BF16>;                                                \
+        VDB_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern),                       \
+                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));    \
+        hipLaunchKernelGGL(kern, grid, dim3(NT), lds, s, p);                                   \
+        break;                                                                                 \
+    }
+    switch (metric) {
+        VDB_LAUNCH_QUEUE(VDB_EUCLIDEAN)
+        VDB_LAUNCH_QUEUE(VDB_EUCLIDEAN_SQ)
+        VDB_LAUNCH_QUEUE(VDB_COSINE)
+        VDB_LAUNCH_QUEUE(VDB_DOT)
+        default:
+            set_error("metric %d has no matrix-core path", metric);
+            return VDB_ERR_INVALID;
+    }
+#undef VDB_LAUNCH_QUEUE
+    VDB_HIP(hipGetLastError());
+    return VDB_OK;
+}
+
+int launch_flat_queue(const Rows& r, int metric, const void* q, const float* q_sq, const float* q_nrm, int nq, int k,
+                      const uint32_t* mask, const float* thr, int n_slabs, int cap, void* queue, int* counts,
+                      int* overflow, float* out_d, int64_t* out_i, int* out_i32, hipStream_t s) {
+    VDB_REQUIRE(k >= 1 && k <= 64, "queue selection supports 1 <= k <= 64, got %d", k);
+    VDB_REQUIRE(r.n >= 1 && r.n < (1LL << 31) && nq >= 1 && thr != nullptr, "bad queue search arguments");
+    QueueParams p{};
+    p.rows = r.bf16 ? (const void*)r.data16 : (const void*)r.data; p.n = r.n;
+    p.ld_bytes = r.bf16 ? r.ld16 * 2 : r.ld * 4; p.row_sq = r.sq; p.row_nrm = r.nrm;
+    p.q = q; p.nq = nq; p.q_sq = q_sq; p.q_nrm = q_nrm; p.mask = mask; p.thr = thr;
+    p.n_tiles = (int)((r.n + TM - 1) / TM);
+    plan_grid(p.n_tiles, nq, ctx().num_cus, &p.n_qtiles, &p.n_slabs, &p.tiles_per_slab);
+    VDB_REQUIRE(p.n_slabs == n_slabs, "queue plan mismatch (%d slabs planned, %d now)", n_slabs, p.n_slabs);
+    p.cap = cap; p.queue = reinterpret_cast<float2*>(queue); p.counts = counts;
+    VDB_TRY(r.bf16 ? launch_queue<true>(metric, p, s) : launch_queue<false>(metric, p, s));
+
+    QueueSelectParams sp{};
+    sp.queue = p.queue; sp.counts = counts; sp.n_slabs = n_slabs; sp.cap = cap;
+    sp.row_sq = r.sq; sp.row_nrm = r.nrm; sp.q_sq = q_sq; sp.q_nrm = q_nrm; sp.nq = nq; sp.k = k;
+    sp.out_d = out_d; sp.out_i = out_i; sp.out_i32 = out_i32; sp.overflow = overflow;
+    const dim3 sgrid((nq + 3) / 4);
+    switch (metric) {
+        case VDB_EUCLIDEAN: hipLaunchKernelGGL(queue_select_kernel<VDB_EUCLIDEAN>, sgrid, dim3(256), 0, s, sp); break;
+        case VDB_EUCLIDEAN_SQ: hipLaunchKernelGGL(queue_select_kernel<VDB_EUCLIDEAN_SQ>, sgrid, dim3(256), 0, s, sp); break;
+        case VDB_COSINE: hipLaunchKernelGGL(queue_select_kernel<VDB_COSINE>, sgrid, dim3(256), 0, s, sp); break;
+        default: hipLaunchKernelGGL(queue_select_kernel<VDB_DOT>, sgrid, dim3(256), 0, s, sp); break;
+    }
+    VDB_HIP(hipGetLastError());
+    return VDB_OK;
+}
+
+}  // namespace vdb

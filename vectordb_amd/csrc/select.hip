@@ -96,6 +96,7 @@ template <bool FINAL>
 __global__ __launch_bounds__(256) void merge_lists_kernel(const float* __restrict__ d, const int* __restrict__ idx,
                                                           int n_lists, int k, float* __restrict__ mid_d, int* __restrict__ mid_i,
                                                           const int* __restrict__ idx_map, int64_t idx_offset, SelectOut o) {
+    if (o.run_if && *o.run_if == 0) return;
     extern __shared__ __align__(16) float sm[];
     float* Sd = sm;                                            // [MERGE_LISTS + 4][k]
     int* Si = reinterpret_cast<int*>(Sd + (MERGE_LISTS + 4) * k);
@@ -173,7 +174,7 @@ __global__ __launch_bounds__(256) void merge_few_kernel(const float* __restrict_
                                                         int n_lists, int k, const int* __restrict__ idx_map,
                                                         int64_t idx_offset, SelectOut o) {
     const int q = blockIdx.x * blockDim.x + threadIdx.x;
-    if (q >= nq) return;
+    if (q >= nq || (o.run_if && *o.run_if == 0)) return;
     const float* dq = d + (int64_t)q * n_lists * k;
     const int* iq = idx + (int64_t)q * n_lists * k;
     int head[FEW_LISTS];
@@ -259,7 +260,7 @@ int launch_select(const float* part_d, const int* part_i, int nq, int n_cand, in
 int launch_select_i64(const float* d, const int64_t* i, const int64_t* payload, int n_lists, int nq, int k,
                       float* out_d, int64_t* out_i, hipStream_t s) {
     if (nq <= 0) return VDB_OK;
-    SelectOut o{out_d, out_i, nullptr, k, 0, nullptr, nullptr};
+    SelectOut o{out_d, out_i, nullptr, k, 0, nullptr, nullptr, nullptr};
     hipLaunchKernelGGL(select_kernel<int64_t>, dim3(nq), dim3(64), (size_t)n_lists * sizeof(int), s,
                        d, i, (int64_t)k, (int64_t)nq * k, n_lists, k, 1, (const int*)nullptr, (int64_t)0, payload, o);
     VDB_HIP(hipGetLastError());

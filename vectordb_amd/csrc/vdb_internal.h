@@ -122,7 +122,15 @@ int flat_gemm_sample_plan(int64_t n, int* sample_tiles, int* tile_stride);
 int launch_flat_gemm_topk(const Rows& r, int metric, const void* q, const float* q_sq, const float* q_nrm,
                           int nq, int k, const uint32_t* mask, const float* lb_d, const int64_t* lb_k,
                           const float* thr_init, int sample_tiles, int tile_stride,
-                          float* part_d, int* part_i, int n_cand, hipStream_t s);
+                          float* part_d, int* part_i, int n_cand, hipStream_t s, const int* run_if = nullptr);
+// MFMA path with a known per-query bound of the k-th best distance (`thr`): survivors of the
+// bound go to queues of `cap` entries per (query, slab) and the k best of them come out directly.
+// `*overflow` is set to 1 when a queue was too small (the caller then repeats the search with
+// launch_flat_gemm_topk(..., run_if = overflow)); it must be zero on entry.
+int flat_queue_plan(int64_t n, int nq, int k, int sample_stride, int* n_slabs, int* cap);
+int launch_flat_queue(const Rows& r, int metric, const void* q, const float* q_sq, const float* q_nrm, int nq, int k,
+                      const uint32_t* mask, const float* thr, int n_slabs, int cap, void* queue, int* counts,
+                      int* overflow, float* out_d, int64_t* out_i, int* out_i32, hipStream_t s);
 // MFMA path, full distance matrix out[nq][n]
 int launch_flat_gemm_dist(const Rows& r, int metric, const void* q, const float* q_sq, const float* q_nrm,
                           int nq, float* out, hipStream_t s);
@@ -203,6 +211,7 @@ struct SelectOut {
     float* out_d; int64_t* out_i; int* out_i32;   // any of the index outputs may be null
     int out_stride; int out_off;                  // result r of query q goes to [q*out_stride + out_off + r]
     float* last_d; int64_t* last_key;             // (distance, tie key) of the last result, for a follow-up pass
+    const int* run_if;                            // optional device flag: the launch does nothing while it is zero
 };
 int launch_select(const float* part_d, const int* part_i, int nq, int n_cand, int k, int tie_group,
                   const int* idx_map, int64_t idx_offset, const SelectOut& o, hipStream_t s);
