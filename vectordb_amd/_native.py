@@ -16,7 +16,8 @@ from typing import Optional
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "_lib", "libvdbcore.so")
+# VDB_LIB_PATH selects another build of the same library (kernel experiments)
+LIB_PATH = os.environ.get("VDB_LIB_PATH") or os.path.join(_HERE, "_lib", "libvdbcore.so")
 
 VDB_OK, VDB_ERR_INVALID, VDB_ERR_HIP, VDB_ERR_STATE, VDB_ERR_NOMEM = 0, -1, -2, -3, -4
 

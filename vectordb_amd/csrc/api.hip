@@ -234,7 +234,7 @@ static int rows_reserve(vdb_rows* h, int64_t n_total, hipStream_t s) {
     Rows& r = h->r;
     if (n_total <= r.cap) return VDB_OK;
     int64_t cap = std::max<int64_t>(n_total, r.cap + r.cap / 2);
-    cap = round_up64(std::max<int64_t>(cap, 1024), 4);      // kernels fetch the norm terms four rows at a time
+    cap = round_up64(std::max<int64_t>(cap, 1024), 128);    // whole 128-row tiles stay readable past the last row
     if (r.bf16)
         VDB_TRY(h->data16.reserve_keep((size_t)cap * r.ld16 * 2, (size_t)r.n * r.ld16 * 2, s));
     else

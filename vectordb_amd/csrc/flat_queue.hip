@@ -16,6 +16,8 @@
 // search with the list kernel, so the result never depends on the queue size.
 #include "flat_math.h"
 
+#include <type_traits>
+
 namespace vdb {
 
 struct QueueParams {
@@ -30,6 +32,70 @@ struct QueueParams {
     float2* queue;                                 // [nq][n_slabs][cap]  (dot product, row number bits)
     int* counts;                                   // [nq][n_slabs]       survivors seen (may exceed cap)
 };
+
+// Survivors of one finished 128 x 128 tile -> queue.  `acc[s]` holds the dot products of this
+// lane's query with rows rbase + 32 s + 8 g + 4 half + j (value index 4 g + j); `rs` the row terms
+// of the tile.  A packed test per accumulator (one fma per value, a max/min tree, one compare)
+// decides whether any of its 16 values can pass; only then are the values looked at one by one.
+template <int METRIC>
+__device__ __forceinline__ void queue_epilogue(const f32x16 (&acc)[4], const float* rs, int64_t rbase, int64_t n,
+                                               const uint32_t* mask, int half, float bound, float q_term, int* cnt,
+                                               float2* my_queue, int cap) {
+    const bool masked = (rbase + TM > n) || mask != nullptr;
+#pragma unroll
+    for (int s = 0; s < 4; ++s) {
+        float v[16];
+        if (METRIC == VDB_DOT) {
+#pragma unroll
+            for (int e = 0; e < 16; ++e) v[e] = acc[s][e];
+        } else {
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                const float4 t = *reinterpret_cast<const float4*>(rs + s * 32 + 8 * g + 4 * half);
+                const float rts[4] = {t.x, t.y, t.z, t.w};
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    // cosine: dot - bound*|c| >= 0 ; L2: (|q|^2+|c|^2) - 2 dot <= bound   (one rounding each)
+                    v[g * 4 + j] = (METRIC == VDB_COSINE) ? __fmaf_rn(-bound, rts[j], acc[s][g * 4 + j])
+                                                          : __fmaf_rn(-2.0f, acc[s][g * 4 + j], q_term + rts[j]);
+                }
+            }
+        }
+        const bool want_max = (METRIC == VDB_DOT || METRIC == VDB_COSINE);
+        float m = v[0];
+#pragma unroll
+        for (int e = 1; e < 16; ++e) m = want_max ? fmaxf(m, v[e]) : fminf(m, v[e]);
+        const float lim = (METRIC == VDB_COSINE) ? 0.0f : bound;
+        const bool any = want_max ? (m >= lim) : (m <= lim);
+        if (any) {
+            uint32_t hits = 0;
+#pragma unroll
+            for (int e = 0; e < 16; ++e) {
+                const bool pass = want_max ? (v[e] >= lim) : (v[e] <= lim);
+                hits |= pass ? (1u << e) : 0u;
+            }
+            if (masked) {
+                uint32_t bits = 0xffffffffu;
+                const int64_t r0 = rbase + s * 32;
+                if (mask) bits = (r0 < n) ? mask[r0 >> 5] : 0u;
+                const int64_t left = n - r0;
+                if (left < 32) bits = left <= 0 ? 0u : (bits & ((1u << left) - 1u));
+                bits >>= (4 * half);
+                // value e = 4g + j of this lane is row 8g + 4*half + j of the 32-row sub-tile
+                hits &= (bits & 0xFu) | ((bits >> 4) & 0xF0u) | ((bits >> 8) & 0xF00u) | ((bits >> 12) & 0xF000u);
+            }
+            while (hits) {
+                const int e = __ffs(hits) - 1;
+                hits &= hits - 1;
+                const int off = 8 * (e >> 2) + (e & 3) + 4 * half;
+                const float dot = pick16(acc[s], e);
+                const int row = (int)(rbase + s * 32 + off);
+                const int slot = atomicAdd(cnt, 1);
+                if (slot < cap) my_queue[slot] = make_float2(dot, __int_as_float(row));
+            }
+        }
+    }
+}
 
 template <int METRIC, bool BF16>
 __global__ __launch_bounds__(NT, 2) void flat_queue_kernel(QueueParams p) {
@@ -148,64 +214,9 @@ __global__ __launch_bounds__(NT, 2) void flat_queue_kernel(QueueParams p) {
 #pragma unroll
         for (int e = 0; e < 16; ++e) acc[s][e] = 0.0f;
 
-    // survivors of one finished tile -> queue
     auto epilogue = [&](int tile) {
-        const int64_t rbase = (int64_t)tile * TM;
-        const float* rs = Rs + (tile & 1) * TM;
-        const bool masked = (rbase + TM > p.n) || p.mask != nullptr;
-#pragma unroll
-        for (int s = 0; s < 4; ++s) {
-            float v[16];
-            if (METRIC == VDB_DOT) {
-#pragma unroll
-                for (int e = 0; e < 16; ++e) v[e] = acc[s][e];
-            } else {
-#pragma unroll
-                for (int g = 0; g < 4; ++g) {
-                    const float4 t = *reinterpret_cast<const float4*>(rs + s * 32 + 8 * g + 4 * half);
-                    const float rts[4] = {t.x, t.y, t.z, t.w};
-#pragma unroll
-                    for (int j = 0; j < 4; ++j) {
-                        // cosine: dot - bound*|c| >= 0 ; L2: (|q|^2+|c|^2) - 2 dot <= bound   (one rounding each)
-                        v[g * 4 + j] = (METRIC == VDB_COSINE) ? __fmaf_rn(-bound, rts[j], acc[s][g * 4 + j])
-                                                              : __fmaf_rn(-2.0f, acc[s][g * 4 + j], q_term + rts[j]);
-                    }
-                }
-            }
-            const bool want_max = (METRIC == VDB_DOT || METRIC == VDB_COSINE);
-            float m = v[0];
-#pragma unroll
-            for (int e = 1; e < 16; ++e) m = want_max ? fmaxf(m, v[e]) : fminf(m, v[e]);
-            const float lim = (METRIC == VDB_COSINE) ? 0.0f : bound;
-            const bool any = want_max ? (m >= lim) : (m <= lim);
-            if (any) {
-                uint32_t hits = 0;
-#pragma unroll
-                for (int e = 0; e < 16; ++e) {
-                    const bool pass = want_max ? (v[e] >= lim) : (v[e] <= lim);
-                    hits |= pass ? (1u << e) : 0u;
-                }
-                if (masked) {
-                    uint32_t bits = 0xffffffffu;
-                    const int64_t r0 = rbase + s * 32;
-                    if (p.mask) bits = (r0 < p.n) ? p.mask[r0 >> 5] : 0u;
-                    const int64_t left = p.n - r0;
-                    if (left < 32) bits = left <= 0 ? 0u : (bits & ((1u << left) - 1u));
-                    bits >>= (4 * half);
-                    // value e = 4g + j of this lane is row 8g + 4*half + j of the 32-row sub-tile
-                    hits &= (bits & 0xFu) | ((bits >> 4) & 0xF0u) | ((bits >> 8) & 0xF00u) | ((bits >> 12) & 0xF000u);
-                }
-                while (hits) {
-                    const int e = __ffs(hits) - 1;
-                    hits &= hits - 1;
-                    const int off = 8 * (e >> 2) + (e & 3) + 4 * half;
-                    const float dot = pick16(acc[s], e);
-                    const int row = (int)(rbase + s * 32 + off);
-                    const int slot = atomicAdd(&Cnt[wave * 32 + col], 1);
-                    if (slot < p.cap) my_queue[slot] = make_float2(dot, __int_as_float(row));
-                }
-            }
-        }
+        queue_epilogue<METRIC>(acc, Rs + (tile & 1) * TM, (int64_t)tile * TM, p.n, p.mask, half, bound, q_term,
+                               &Cnt[wave * 32 + col], my_queue, p.cap);
     };
 
     const int n_steps = (tile1 - tile0) * ksteps;
@@ -295,6 +306,205 @@ __global__ __launch_bounds__(NT, 2) void flat_queue_kernel(QueueParams p) {
 }
 
 // --------------------------------------------------------------------------
+// The same kernel for the common shape: row pitch a multiple of 128 bytes and a row store
+// whose capacity covers whole tiles (rows past n are read and masked out, never clamped).
+// A step then has no branch and no vector ALU work: its fragment reads, the 8 LDS writes of
+// the next step's operands and the 8 global loads of the step after are spread, in program
+// order, between this wave's own matrix instructions.  (Vector ALU and LDS/VMEM issue of a
+// wave crawls while the other block's wave on the same SIMD runs dependent matrix
+// instructions back to back, so nothing is left for a separate phase to do.)
+#ifndef VDB_QFAST_INDEP
+#define VDB_QFAST_INDEP 0       // 1: consecutive matrix instructions go to different accumulators
+#endif
+#define VDB_FENCE() __builtin_amdgcn_sched_barrier(0)
+
+template <int METRIC, bool BF16>
+__global__ __launch_bounds__(NT, 2) void flat_queue_fast_kernel(QueueParams p) {
+    extern __shared__ __align__(16) float smem[];
+    float* As = smem;                                   // [2][TM][LW]
+    float* Bs = As + 2 * TM * LW;                       // [2][TQ][LW]
+    float* Rs = Bs + 2 * TQ * LW;                       // [2][TM]
+    int* Cnt = reinterpret_cast<int*>(Rs + 2 * TM);     // [TQ]
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = tid >> 6;
+    const int half = lane >> 5;
+    const int col = lane & 31;
+
+    int slab, qt;
+    if (p.n_slabs >= 8) {
+        const int per_group = 8 * p.n_qtiles;
+        const int grp = blockIdx.x / per_group;
+        const int rem = blockIdx.x - grp * per_group;
+        slab = grp * 8 + (rem & 7);
+        qt = rem >> 3;
+        if (slab >= p.n_slabs) return;
+    } else {
+        qt = blockIdx.x / p.n_slabs;
+        slab = blockIdx.x - qt * p.n_slabs;
+    }
+    const int tile0 = slab * p.tiles_per_slab;
+    const int tile1 = min(tile0 + p.tiles_per_slab, p.n_tiles);
+
+    const int my_q = qt * TQ + wave * 32 + col;
+    const bool q_ok = my_q < p.nq;
+    const int my_q_ld = min(my_q, p.nq - 1);
+    float q_term = 0.0f;
+    if (METRIC == VDB_COSINE) {
+        q_term = p.q_nrm[my_q_ld];
+        if (q_term < 1e-8f) q_term = INFINITY;
+    } else if (METRIC != VDB_DOT) {
+        q_term = p.q_sq[my_q_ld];
+    }
+    float bound = filter_bound<METRIC>(p.thr[my_q_ld], q_term);
+    if (!q_ok) bound = (METRIC == VDB_DOT || METRIC == VDB_COSINE) ? INFINITY : -INFINITY;
+    float2* my_queue = p.queue + ((int64_t)my_q_ld * p.n_slabs + slab) * p.cap;
+    int* my_cnt = &Cnt[wave * 32 + col];
+    if (tid < TQ) Cnt[tid] = 0;
+
+    const int ksteps = p.ld_bytes / TKB;
+    const int srow = tid >> 3;
+    const int skc = (tid & 7) * 4;
+    const int64_t q_base = (int64_t)qt * TQ;
+    const int ldw = p.ld_bytes >> 2;
+    uint32_t offb[4], offa[4];
+#pragma unroll
+    for (int ps = 0; ps < 4; ++ps) {
+        const int64_t gq = min(q_base + ps * 32 + srow, (int64_t)p.nq - 1) - q_base;
+        offb[ps] = (uint32_t)(gq * ldw + skc) * 4u;                 // byte offsets from a wave-uniform base
+        offa[ps] = (uint32_t)((ps * 32 + srow) * ldw + skc) * 4u;
+    }
+    const char* rows_w = reinterpret_cast<const char*>(p.rows);
+    const char* qbase_ptr = reinterpret_cast<const char*>(p.q) + q_base * p.ld_bytes;
+    const float* row_term = (METRIC == VDB_COSINE) ? p.row_nrm : p.row_sq;
+    float* wr_a = As + srow * LW + skc;                 // this thread's staging slots (stage 0, pass 0)
+    float* wr_b = Bs + srow * LW + skc;
+    const float* rd_a = As + col * LW + half * 4;       // this lane's fragment rows (stage 0)
+    const float* rd_b = Bs + (wave * 32 + col) * LW + half * 4;
+    float4 ra0, ra1, ra2, ra3, rb0, rb1, rb2, rb3;          // the operands in flight (plain variables: they must stay in registers)
+
+    f32x16 acc[4];
+#pragma unroll
+    for (int s = 0; s < 4; ++s)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) acc[s][e] = 0.0f;
+
+    const int n_steps = (tile1 - tile0) * ksteps;
+    int ck = 0, ct = tile0;                             // the step being multiplied
+    // uniform bases of the step to fetch next (two steps ahead of the one being multiplied)
+    int lk = 0, lt = tile0;
+#define VDB_LOAD_STEP()                                                                     \
+    do {                                                                                    \
+        const char* abase = rows_w + (int64_t)min(lt, tile1 - 1) * TM * p.ld_bytes + lk * TKB; \
+        const char* bbase = qbase_ptr + lk * TKB;                                           \
+        ra0 = *reinterpret_cast<const float4*>(abase + offa[0]); rb0 = *reinterpret_cast<const float4*>(bbase + offb[0]); \
+        ra1 = *reinterpret_cast<const float4*>(abase + offa[1]); rb1 = *reinterpret_cast<const float4*>(bbase + offb[1]); \
+        ra2 = *reinterpret_cast<const float4*>(abase + offa[2]); rb2 = *reinterpret_cast<const float4*>(bbase + offb[2]); \
+        ra3 = *reinterpret_cast<const float4*>(abase + offa[3]); rb3 = *reinterpret_cast<const float4*>(bbase + offb[3]); \
+        if (++lk == ksteps) { lk = 0; ++lt; }                                               \
+    } while (0)
+
+    // prologue: step 0 into stage 0, step 1 on its way, row terms of the first tile
+    if (n_steps > 0) {
+        VDB_LOAD_STEP();
+        *reinterpret_cast<float4*>(wr_a + 0 * 32 * LW) = ra0; *reinterpret_cast<float4*>(wr_b + 0 * 32 * LW) = rb0;
+        *reinterpret_cast<float4*>(wr_a + 1 * 32 * LW) = ra1; *reinterpret_cast<float4*>(wr_b + 1 * 32 * LW) = rb1;
+        *reinterpret_cast<float4*>(wr_a + 2 * 32 * LW) = ra2; *reinterpret_cast<float4*>(wr_b + 2 * 32 * LW) = rb2;
+        *reinterpret_cast<float4*>(wr_a + 3 * 32 * LW) = ra3; *reinterpret_cast<float4*>(wr_b + 3 * 32 * LW) = rb3;
+        if (METRIC != VDB_DOT && tid < TM) {
+            float t = row_term[(int64_t)tile0 * TM + tid];
+            if (METRIC == VDB_COSINE && t < 1e-8f) t = 1.0f;
+            Rs[(tile0 & 1) * TM + tid] = t;
+        }
+        VDB_LOAD_STEP();
+    }
+    __syncthreads();
+
+#define VDB_MFMA4(CH, S)                                                                                           \
+    do {                                                                                                           \
+        if (BF16) {                                                                                                \
+            acc[S] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, af[CH][S]),                \
+                                                             __builtin_bit_cast(bf16x8, bf[CH]), acc[S], 0, 0, 0); \
+        } else {                                                                                                   \
+            acc[S] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[CH][S].x, bf[CH].x, acc[S], 0, 0, 0);                 \
+            acc[S] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[CH][S].y, bf[CH].y, acc[S], 0, 0, 0);                 \
+            acc[S] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[CH][S].z, bf[CH].z, acc[S], 0, 0, 0);                 \
+            acc[S] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[CH][S].w, bf[CH].w, acc[S], 0, 0, 0);                 \
+        }                                                                                                          \
+    } while (0)
+#define VDB_RD_A(CH, S) af[CH][S] = *reinterpret_cast<const float4*>(ra_ + (S) * 32 * LW + (CH) * 8)
+#define VDB_RD_B(CH) bf[CH] = *reinterpret_cast<const float4*>(rb_ + (CH) * 8)
+#define VDB_WR_A(PS) *reinterpret_cast<float4*>(wa_ + (PS) * 32 * LW) = ra##PS
+#define VDB_WR_B(PS) *reinterpret_cast<float4*>(wb_ + (PS) * 32 * LW) = rb##PS
+
+    // two steps per trip so that the stage in use is a literal: every LDS address is base + immediate
+    for (int st = 0; st < n_steps; st += 2) {
+#pragma unroll
+      for (int B_ = 0; B_ < 2; ++B_) {
+        if (st + B_ >= n_steps) break;
+        const float* ra_ = rd_a + B_ * (TM * LW);
+        const float* rb_ = rd_b + B_ * (TQ * LW);
+        float* wa_ = wr_a + (1 - B_) * (TM * LW);
+        float* wb_ = wr_b + (1 - B_) * (TQ * LW);
+        float4 bf[4], af[4][4];
+        VDB_RD_B(0); VDB_RD_A(0, 0); VDB_RD_A(0, 1); VDB_RD_A(0, 2); VDB_RD_A(0, 3);
+        VDB_FENCE();
+        VDB_MFMA4(0, 0); VDB_RD_B(1); VDB_RD_A(1, 0); VDB_FENCE();
+        VDB_MFMA4(0, 1); VDB_RD_A(1, 1); VDB_RD_A(1, 2); VDB_FENCE();
+        VDB_MFMA4(0, 2); VDB_RD_A(1, 3); VDB_RD_B(2); VDB_FENCE();
+        VDB_MFMA4(0, 3); VDB_RD_A(2, 0); VDB_RD_A(2, 1); VDB_FENCE();
+        VDB_MFMA4(1, 0); VDB_RD_A(2, 2); VDB_RD_A(2, 3); VDB_FENCE();
+        VDB_MFMA4(1, 1); VDB_RD_B(3); VDB_RD_A(3, 0); VDB_FENCE();
+        VDB_MFMA4(1, 2); VDB_RD_A(3, 1); VDB_RD_A(3, 2); VDB_FENCE();
+        VDB_MFMA4(1, 3); VDB_RD_A(3, 3); VDB_FENCE();
+        // (the last two steps of a block park and fetch a step nobody multiplies: the last tile again)
+        VDB_MFMA4(2, 0); VDB_WR_A(0); VDB_WR_B(0); VDB_FENCE();
+        VDB_MFMA4(2, 1); VDB_WR_A(1); VDB_WR_B(1); VDB_FENCE();
+        VDB_MFMA4(2, 2); VDB_WR_A(2); VDB_WR_B(2); VDB_FENCE();
+        VDB_MFMA4(2, 3); VDB_WR_A(3); VDB_WR_B(3); VDB_FENCE();
+        {
+            const char* abase = rows_w + (int64_t)min(lt, tile1 - 1) * TM * p.ld_bytes + lk * TKB;
+            const char* bbase = qbase_ptr + lk * TKB;
+            VDB_MFMA4(3, 0); ra0 = *reinterpret_cast<const float4*>(abase + offa[0]); rb0 = *reinterpret_cast<const float4*>(bbase + offb[0]); VDB_FENCE();
+            VDB_MFMA4(3, 1); ra1 = *reinterpret_cast<const float4*>(abase + offa[1]); rb1 = *reinterpret_cast<const float4*>(bbase + offb[1]); VDB_FENCE();
+            VDB_MFMA4(3, 2); ra2 = *reinterpret_cast<const float4*>(abase + offa[2]); rb2 = *reinterpret_cast<const float4*>(bbase + offb[2]); VDB_FENCE();
+            VDB_MFMA4(3, 3); ra3 = *reinterpret_cast<const float4*>(abase + offa[3]); rb3 = *reinterpret_cast<const float4*>(bbase + offb[3]); VDB_FENCE();
+            if (++lk == ksteps) { lk = 0; ++lt; }
+        }
+        if (ck == ksteps - 1) {
+            // row terms of the next tile travel while this tile's survivors are picked
+            float nxt = 1.0f;
+            const bool has_next = ct + 1 < tile1;
+            if (METRIC != VDB_DOT && has_next && tid < TM) nxt = row_term[(int64_t)(ct + 1) * TM + tid];
+            queue_epilogue<METRIC>(acc, Rs + (ct & 1) * TM, (int64_t)ct * TM, p.n, p.mask, half, bound, q_term,
+                                   my_cnt, my_queue, p.cap);
+            if (METRIC != VDB_DOT && has_next && tid < TM) {
+                if (METRIC == VDB_COSINE && nxt < 1e-8f) nxt = 1.0f;
+                Rs[((ct + 1) & 1) * TM + tid] = nxt;
+            }
+#pragma unroll
+            for (int s = 0; s < 4; ++s)
+#pragma unroll
+                for (int e = 0; e < 16; ++e) acc[s][e] = 0.0f;
+            ck = 0; ++ct;
+        } else {
+            ++ck;
+        }
+        __syncthreads();
+      }
+    }
+#undef VDB_LOAD_STEP
+#undef VDB_MFMA4
+#undef VDB_RD_A
+#undef VDB_RD_B
+#undef VDB_WR_A
+#undef VDB_WR_B
+
+    if (tid < TQ && q_base + tid < p.nq) p.counts[(q_base + tid) * p.n_slabs + slab] = Cnt[tid];
+}
+
+// --------------------------------------------------------------------------
 // Per query: exact distances of the queued survivors (the same arithmetic as
 // finish<>() in the list kernel), the k best under the (distance, row) order.
 struct QueueSelectParams {
@@ -378,14 +588,14 @@ int flat_queue_plan(int64_t n, int nq, int k, int sample_stride, int* n_slabs, i
 }
 
 template <bool BF16>
-static int launch_queue(int metric, QueueParams& p, hipStream_t s) {
+static int launch_queue(int metric, QueueParams& p, bool fast, hipStream_t s) {
     const int groups = (p.n_slabs + 7) / 8;
     const dim3 grid(p.n_slabs >= 8 ? groups * 8 * p.n_qtiles : p.n_slabs * p.n_qtiles);
     const size_t lds = (size_t)(2 * TM * LW + 2 * TQ * LW + 2 * TM + TQ) * sizeof(float);
     KernelTimer timer(s, true);
 #define VDB_LAUNCH_QUEUE(M)                                                                    \
     case M: {                                                                                  \
-        auto kern = flat_queue_kernel<M, BF16>;                                                \
+        auto kern = fast ? flat_queue_fast_kernel<M, BF16> : flat_queue_kernel<M, BF16>;       \
         VDB_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern),                       \
                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));    \
         hipLaunchKernelGGL(kern, grid, dim3(NT), lds, s, p);                                   \
@@ -418,7 +628,10 @@ int launch_flat_queue(const Rows& r, int metric, const void* q, const float* q_s
     plan_grid(p.n_tiles, nq, ctx().num_cus, &p.n_qtiles, &p.n_slabs, &p.tiles_per_slab);
     VDB_REQUIRE(p.n_slabs == n_slabs, "queue plan mismatch (%d slabs planned, %d now)", n_slabs, p.n_slabs);
     p.cap = cap; p.queue = reinterpret_cast<float2*>(queue); p.counts = counts;
-    VDB_TRY(r.bf16 ? launch_queue<true>(metric, p, s) : launch_queue<false>(metric, p, s));
+    // whole tiles readable and no partial K step: the branch-free kernel
+    static const bool no_fast = getenv("VDB_NO_QFAST") != nullptr;
+    const bool fast = !no_fast && p.ld_bytes % TKB == 0 && r.cap >= (int64_t)p.n_tiles * TM;
+    VDB_TRY(r.bf16 ? launch_queue<true>(metric, p, fast, s) : launch_queue<false>(metric, p, fast, s));
 
     QueueSelectParams sp{};
     sp.queue = p.queue; sp.counts = counts; sp.n_slabs = n_slabs; sp.cap = cap;
