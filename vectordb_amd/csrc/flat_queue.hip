@@ -466,6 +466,10 @@ __global__ __launch_bounds__(NT, 2) void flat_queue_fast_kernel(QueueParams p) {
         {
             const char* abase = rows_w + (int64_t)min(lt, tile1 - 1) * TM * p.ld_bytes + lk * TKB;
             const char* bbase = qbase_ptr + lk * TKB;
+            // keep the per-thread offsets 32 bits wide here, so that every load is "uniform base +
+            // 32-bit lane offset" in one instruction and no vector ALU work is left in the step
+#pragma unroll
+            for (int ps = 0; ps < 4; ++ps) { asm("" : "+v"(offa[ps])); asm("" : "+v"(offb[ps])); }
             VDB_MFMA4(3, 0); ra0 = *reinterpret_cast<const float4*>(abase + offa[0]); rb0 = *reinterpret_cast<const float4*>(bbase + offb[0]); VDB_FENCE();
             VDB_MFMA4(3, 1); ra1 = *reinterpret_cast<const float4*>(abase + offa[1]); rb1 = *reinterpret_cast<const float4*>(bbase + offb[1]); VDB_FENCE();
             VDB_MFMA4(3, 2); ra2 = *reinterpret_cast<const float4*>(abase + offa[2]); rb2 = *reinterpret_cast<const float4*>(bbase + offb[2]); VDB_FENCE();
