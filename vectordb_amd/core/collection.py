@@ -129,10 +129,24 @@ class MetadataFilter:
 
 
 class Collection:
-    """core/collection.py:302-828 (search path)."""
+    """core/collection.py:302-828 (search path).
+
+    ``index_type`` (with ``index_params`` or plain keyword arguments such as
+    ``n_clusters=...``) routes searches through one of the index classes instead
+    of the exact scan.  The reference documents this argument
+    (docs/indexing_guide.md:32-36,66-73; examples/semantic_search.py:75-81) but its
+    ``Collection.__init__`` (core/collection.py:326-334) does not accept it.  An
+    index that needs training is trained on the rows present at the first search
+    after it was (re)built; later writes are applied to it one by one."""
 
     def __init__(self, name: str, dimension: int, metric: str = "euclidean", normalize: bool = False,
-                 max_vectors: Optional[int] = None, enable_metadata_index: bool = True):
+                 max_vectors: Optional[int] = None, enable_metadata_index: bool = True,
+                 index_type: Optional[str] = None, index_params: Optional[Dict[str, Any]] = None, **index_kwargs):
+        self.index_type = index_type.lower() if index_type else None
+        if self.index_type is None and (index_params or index_kwargs):
+            raise TypeError("index parameters given without index_type")
+        self._index_params = {**(index_params or {}), **index_kwargs}
+        self._index = None
         self.name = name
         self.dimension = dimension
         self.metric = metric
@@ -162,10 +176,18 @@ class Collection:
             raise VectorExistsError(f"Vector with ID '{id}' already exists")
         if id not in self._vectors and self.max_vectors and len(self._vectors) >= self.max_vectors:
             raise ValueError(f"Collection at maximum capacity ({self.max_vectors})")
+        existed = id in self._vectors
         self._vectors[id] = vector
         self._metadata[id] = dict(metadata or {})
         self._matrix_dirty = True
         self._updated_at = time.time()
+        if self._index is not None:
+            try:
+                if existed:
+                    self._index.remove(id)
+                self._index.add(id, vector, self._metadata[id])
+            except Exception:
+                self._drop_index()
         return id
 
     def add_batch(self, vectors: List[Dict[str, Any]], overwrite: bool = False, on_error: str = "raise") -> Dict[str, Any]:
@@ -194,13 +216,56 @@ class Collection:
             return False
         del self._vectors[id], self._metadata[id]
         self._matrix_dirty = True
+        if self._index is not None:
+            try:
+                self._index.remove(id)
+            except Exception:
+                self._drop_index()
         return True
 
     def clear(self) -> int:
         n = len(self._vectors)
         self._vectors.clear(); self._metadata.clear()
         self._matrix_dirty = True
+        self._drop_index()
         return n
+
+    # ------------------------------------------------------------ optional index
+    def _drop_index(self) -> None:
+        self._index = None
+
+    def _ensure_index(self):
+        """Build (and, where needed, train) the index over the rows present now."""
+        if self._index is not None:
+            return self._index
+        from ..index import create_index
+        ix = create_index(self.index_type, self.dimension, metric=self.metric, **self._index_params)
+        ids = list(self._vectors.keys())
+        if ids:
+            mat = np.stack([self._vectors[i] for i in ids]).astype(np.float32)
+            trained = ix.is_trained() if callable(ix.is_trained) else ix.is_trained
+            if not trained:
+                ix.train(mat)
+            ix.add_batch(ids, mat, [self._metadata[i] for i in ids])
+        self._index = ix
+        return ix
+
+    def _index_results(self, found, include_vector: bool, include_metadata: bool) -> List[SearchResult]:
+        out = []
+        dmax = np.float32(found[-1].distance) if found else np.float32(1.0)
+        for r in found:
+            d = np.float32(r.distance)
+            score = 1.0 - (d / (dmax + 1e-8)) if dmax > 0 else 1.0             # core/collection.py:762-771
+            out.append(SearchResult(id=r.id, distance=float(d), score=float(score),
+                                    vector=self._vectors[r.id].copy() if include_vector else None,
+                                    metadata=self._metadata[r.id].copy() if include_metadata else {}))
+        return out
+
+    def _filter_fn(self, filter: Optional[Dict[str, Any]]):
+        if not (filter and self.enable_metadata_index):
+            return None
+        pred = MetadataFilter(filter)
+        return lambda id, metadata: pred(metadata or {})
 
     # ------------------------------------------------------------ search
     def _ensure_matrix(self) -> None:
@@ -252,6 +317,9 @@ class Collection:
             query = _normalize_vector(query)
         if k <= 0:
             return []
+        if self.index_type is not None:
+            found = self._ensure_index().search(query, k, filter_fn=self._filter_fn(filter))
+            return self._index_results(found, include_vector, include_metadata)
         found = self._search_device(query[None, :], k, filter)
         if found is None:
             return []
@@ -267,6 +335,9 @@ class Collection:
         qs = np.stack([_validate_vector(q, self.dimension) for q in queries])
         if self.normalize:
             qs = np.stack([_normalize_vector(q) for q in qs])
+        if self.index_type is not None:
+            per_query = self._ensure_index().search_batch(qs, k, filter_fn=self._filter_fn(filter))
+            return [self._index_results(f, include_vector, True) for f in per_query]
         found = self._search_device(qs, k, filter)
         if found is None:
             return [[] for _ in range(len(qs))]

@@ -8,9 +8,11 @@ from .flat import FlatIndex, FlatIndexConfig                                    
 from .ivf import IVFIndex, IVFConfig, KMeans                                                     # noqa: F401
 from .pq import PQIndex, PQConfig                                                                # noqa: F401
 from .hybrid import HybridIndex, HybridConfig                                                    # noqa: F401
+from .io import save_index, load_index                                                           # noqa: F401
 
 __all__ = ["BaseIndex", "IndexConfig", "IndexStats", "SearchResult", "IndexType", "FlatIndex", "FlatIndexConfig",
-           "IVFIndex", "IVFConfig", "KMeans", "PQIndex", "PQConfig", "HybridIndex", "HybridConfig", "create_index"]
+           "IVFIndex", "IVFConfig", "KMeans", "PQIndex", "PQConfig", "HybridIndex", "HybridConfig", "create_index",
+           "save_index", "load_index"]
 
 
 def create_index(index_type: str, dimension: int, metric: str = "euclidean", **kwargs) -> BaseIndex:
