@@ -34,11 +34,11 @@ with open(f"profiles/{tag}_bench_pmc.csv", "w", newline="") as f:
 import json
 vals = {}
 for r in csv.DictReader(open(f"profiles/{tag}_bench_pmc.csv")):
-    if "flat_gemm_kernel" in r["kernel"] and "true, false" in r["kernel"] and r["counter"] in ("FETCH_SIZE", "WRITE_SIZE"):
+    if "flat_queue_fast_kernel" in r["kernel"] and r["counter"] in ("FETCH_SIZE", "WRITE_SIZE"):
         vals[r["counter"]] = float(r["mean_per_dispatch"])
 if len(vals) == 2:
     traffic = 2 * vals["FETCH_SIZE"] * 1024 + vals["WRITE_SIZE"] * 1024
-    json.dump({"kernel": "flat_gemm_kernel<cosine> full pass", "tag": tag, "fetch_size_kib": vals["FETCH_SIZE"],
+    json.dump({"kernel": "flat_queue_fast_kernel<cosine> (full pass)", "tag": tag, "fetch_size_kib": vals["FETCH_SIZE"],
                "write_size_kib": vals["WRITE_SIZE"], "hbm_bytes_per_launch": traffic,
                "note": "2*FETCH_SIZE + WRITE_SIZE, separate --pmc passes of `bench.py --steps 3 --warmup 1`"},
               open("profiles/bench_traffic.json", "w"), indent=1)
