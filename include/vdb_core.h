@@ -116,6 +116,13 @@ int vdb_flat_search(vdb_rows* h, int metric, const float* queries, int nq, int k
 int vdb_flat_search_dev(vdb_rows* h, int metric, const float* d_queries, int nq, int k,
                         const uint32_t* d_mask, float* d_out_dist, int64_t* d_out_row, void* stream);
 
+/* Diagnostics of the last vdb_flat_search* call on this handle (no counterpart in the reference;
+ * the analogue of IVFIndex's distance_computations counter, index/ivf.py:626,838):
+ * *used_queue = 1 when the batch ran the candidate-queue kernel behind a sampled bound,
+ * *overflowed = 1 when a queue was too small and the list kernel repeated the search.
+ * Waits for the handle's stream. */
+int vdb_flat_search_stats(vdb_rows* h, int* used_queue, int* overflowed);
+
 /* query_distances (distance/metrics.py:431-493), pairwise_* (:272-424),
  * GPUDistanceCalculator.compute (distance/gpu.py:74-134): the full nq x n
  * distance matrix, out[i*n + j] = distance(query i, row j). */

@@ -1,0 +1,137 @@
+"""The candidate-queue form of the batched Flat search (vdb_flat_search on row sets large
+enough for a sampled bound): parity with the CPU oracle to the same bars as the list form
+(distances 1e-4 relative, ids equal up to rows tied at the k-th place), on both kernels
+(row pitch a multiple of 128 bytes or not), with a filter mask, ragged ends, k = 1 and
+k = 32, bf16 storage, and on data built so that the queues overflow and the list kernel
+has to repeat the search."""
+
+import numpy as np
+import pytest
+
+from oracle import ref_numpy as R
+from conftest import same_ids_or_near_ties
+from test_gpu_cabi import check_search, assert_close, ids_atol, RTOL, _bf16_round
+
+pytestmark = pytest.mark.gpu
+
+N_MIN = 2048 * 128          # smallest row count that gets a sample pass
+
+
+@pytest.fixture(scope="module")
+def nat(native):
+    from vectordb_amd import _native
+    return _native
+
+
+def search_and_stats(nat, x, q, k, metric, mask=None, storage=None):
+    store = nat.RowStore(x.shape[1], storage=storage or "f32")
+    store.append(x)
+    dist, rows = store.search(q, k, nat.METRIC_CODES[metric], nat.pack_mask(mask))
+    stats = store.search_stats()
+    store.close()
+    return dist, rows, stats
+
+
+@pytest.mark.parametrize("metric", ["euclidean", "euclidean_squared", "cosine", "dot"])
+@pytest.mark.parametrize("d,n_extra", [(32, 0), (32, 77), (100, 5), (48, 128)])
+def test_queue_search_matches_oracle(nat, metric, d, n_extra):
+    """d = 32: 128-byte pitch (branch-free kernel); d = 100, 48: other pitches (generic kernel)."""
+    rng = np.random.default_rng(d * 7 + n_extra)
+    n = N_MIN + n_extra
+    x = rng.standard_normal((n, d), dtype=np.float32)
+    q = rng.standard_normal((130, d), dtype=np.float32)         # two query tiles, the second ragged
+    _, _, stats = search_and_stats(nat, x, q[:5], 10, metric)
+    assert stats == (True, False)
+    check_search(nat, x, q[:40], 10, metric)
+    dist, rows = check_search(nat, x, q[:3], 1, metric)
+    check_search(nat, x, q[100:130], 32, metric)                # rows of the second tile only through a full batch:
+    d_all, r_all, _ = search_and_stats(nat, x, q, 10, metric)
+    d_part, r_part, _ = search_and_stats(nat, x, q[124:130], 10, metric)     # the same dot products in another tiling
+    np.testing.assert_array_equal(r_all[124:130], r_part)
+    np.testing.assert_array_equal(d_all[124:130], d_part)
+
+
+def test_queue_search_with_mask_and_few_survivors(nat):
+    rng = np.random.default_rng(3)
+    n, d = N_MIN + 1000, 64
+    x = rng.standard_normal((n, d), dtype=np.float32)
+    q = rng.standard_normal((16, d), dtype=np.float32)
+    for keep in (0.5, 0.01, 20.0 / n):
+        mask = rng.random(n) < keep
+        mask[-3:] = True                                         # rows of the ragged last tile stay eligible
+        check_search(nat, x, q, 10, "cosine", mask=mask)
+        check_search(nat, x, q[:4], 10, "euclidean", mask=mask)
+    mask = np.zeros(n, dtype=bool)
+    mask[[5, n - 1]] = True                                      # fewer passing rows than k
+    dist, rows, stats = search_and_stats(nat, x, q[:4], 10, "dot", mask=mask)
+    assert stats[0]
+    assert (np.sort(rows[:, :2], axis=1) == [5, n - 1]).all() and (rows[:, 2:] == -1).all()
+
+
+def test_queue_ties_go_to_lowest_row(nat):
+    """Duplicated rows: equal distances come out in ascending row order (the stable order of
+    core/collection.py:757 and the argsort tie rule of index/flat.py:354-362)."""
+    rng = np.random.default_rng(11)
+    n, d = N_MIN, 32
+    x = rng.standard_normal((n, d), dtype=np.float32)
+    q = rng.standard_normal((4, d), dtype=np.float32)
+    for i in range(4):
+        near = (q[i] + 0.01 * rng.standard_normal(d)).astype(np.float32)
+        x[[1000 + i, 70000 + i, 200000 + i, n - 1 - i]] = near   # four copies, four different slabs
+    dist, rows, stats = search_and_stats(nat, x, q, 6, "euclidean")
+    assert stats == (True, False)
+    for i in range(4):
+        assert list(rows[i, :4]) == [1000 + i, 70000 + i, 200000 + i, n - 1 - i]
+        assert dist[i, 0] == dist[i, 1] == dist[i, 2] == dist[i, 3]
+
+
+@pytest.mark.parametrize("metric", ["euclidean", "cosine", "dot"])
+def test_queue_overflow_falls_back_to_lists(nat, metric):
+    """The sampled tiles (every 16th) hold only far rows, all others hold rows close to the
+    queries: the sampled bound lets almost every row through, the queues overflow, the flag
+    is raised on the device and the list kernel repeats the search.  Results stay exact."""
+    rng = np.random.default_rng(5)
+    n, d = N_MIN, 32
+    centre = rng.standard_normal(d).astype(np.float32)
+    x = (centre + 0.05 * rng.standard_normal((n, d))).astype(np.float32)
+    tiles = np.arange(n) // 128
+    far = tiles % 16 == 0
+    x[far] = (-centre + 3.0 * rng.standard_normal((int(far.sum()), d))).astype(np.float32)
+    q = (centre + 0.05 * rng.standard_normal((12, d))).astype(np.float32)
+    dist, rows, stats = search_and_stats(nat, x, q, 10, metric)
+    assert stats == (True, True)
+    for i in range(len(q)):
+        ref_rows, ref_dist = R.flat_search(q[i], x, 10, metric)
+        full = R.query_distances(q[i], x, metric)
+        atol = ids_atol(metric, q[i], x, float(ref_dist[-1]))
+        assert same_ids_or_near_ties(rows[i], ref_rows, lambda r: full[r], float(ref_dist[-1]), rtol=RTOL, atol=atol)
+        assert_close(metric, dist[i], ref_dist, q[i], x)
+    # the next search on the same handle starts from a clean flag
+    store = nat.RowStore(d)
+    store.append(x)
+    store.search(q, 10, nat.METRIC_CODES[metric])
+    assert store.search_stats() == (True, True)
+    y = rng.standard_normal((n, d), dtype=np.float32)
+    store.truncate(0)
+    store.append(y)
+    store.search(q, 10, nat.METRIC_CODES[metric])
+    assert store.search_stats() == (True, False)
+    store.close()
+
+
+def test_queue_search_bf16_storage(nat):
+    """bf16 rows: the fp32 bars hold against the oracle on the rounded inputs."""
+    rng = np.random.default_rng(9)
+    n, d = N_MIN + 50, 64
+    x = rng.standard_normal((n, d), dtype=np.float32)
+    q = rng.standard_normal((20, d), dtype=np.float32)
+    xr, qr = _bf16_round(x), _bf16_round(q)
+    for metric in ("cosine", "dot", "euclidean"):
+        dist, rows, stats = search_and_stats(nat, x, q, 10, metric, storage="bf16")
+        assert stats == (True, False)
+        for i in range(len(q)):
+            ref_rows, ref_dist = R.flat_search(qr[i], xr, 10, metric)
+            full = R.query_distances(qr[i], xr, metric)
+            atol = ids_atol(metric, qr[i], xr, float(ref_dist[-1]))
+            assert same_ids_or_near_ties(rows[i], ref_rows, lambda r: full[r], float(ref_dist[-1]), rtol=RTOL, atol=atol)
+            assert_close(metric, dist[i], ref_dist, qr[i], xr)

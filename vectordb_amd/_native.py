@@ -58,6 +58,7 @@ SIGNATURES = {
     "vdb_rows_truncate": (C.c_int, [C.c_void_p, C.c_int64]),
     "vdb_rows_size": (C.c_int, [C.c_void_p, c_i64_p]),
     "vdb_rows_norms": (C.c_int, [C.c_void_p, c_float_p, c_float_p]),
+    "vdb_flat_search_stats": (C.c_int, [C.c_void_p, C.POINTER(C.c_int), C.POINTER(C.c_int)]),
     "vdb_flat_search": (C.c_int, [C.c_void_p, C.c_int, c_float_p, C.c_int, C.c_int, c_u32_p, c_float_p, c_i64_p]),
     "vdb_flat_search_dev": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p,
                                       C.c_void_p, C.c_void_p]),
@@ -287,6 +288,12 @@ class RowStore:
         check(self.lib.vdb_flat_search(self.h, metric, fptr(q), nq, k, u32ptr(mask_words), fptr(dist),
                                        rows.ctypes.data_as(c_i64_p)))
         return dist, rows
+
+    def search_stats(self):
+        """(used_queue, overflowed) of the last search on this store."""
+        a, b = C.c_int(0), C.c_int(0)
+        check(self.lib.vdb_flat_search_stats(self.h, C.byref(a), C.byref(b)))
+        return bool(a.value), bool(b.value)
 
     def search_device(self, q_ptr: int, nq: int, k: int, metric: int, out_dist_ptr: int, out_row_ptr: int,
                       mask_ptr: int = 0, stream: int = 0) -> None:

@@ -228,6 +228,8 @@ struct vdb_rows {
     Rows r;
     DevBuf data, data16, sq, nrm;
     Workspace ws;
+    bool last_used_queue = false;       // diagnostics of the last flat search
+    hipStream_t last_stream = nullptr;
 };
 
 static int rows_reserve(vdb_rows* h, int64_t n_total, hipStream_t s) {
@@ -367,6 +369,8 @@ static int flat_search_impl(vdb_rows* h, int metric, const float* d_q, int nq, i
                             float* d_out_d, int64_t* d_out_i, int* d_out_i32, hipStream_t s) {
     Rows& r = h->r;
     Workspace& ws = h->ws;
+    h->last_used_queue = false;
+    h->last_stream = s;
     VDB_REQUIRE(valid_metric(metric), "unknown metric code %d", metric);
     VDB_REQUIRE(nq >= 0 && k >= 1, "need nq >= 0 and k >= 1 (got nq=%d, k=%d)", nq, k);
     if (nq == 0) return VDB_OK;
@@ -422,6 +426,7 @@ static int flat_search_impl(vdb_rows* h, int metric, const float* d_q, int nq, i
     static const bool no_queue = getenv("VDB_NO_QUEUE") != nullptr;
     const int* run_if = nullptr;
     if (thr_init && !multi && !no_queue) {
+        h->last_used_queue = true;
         VDB_TRY(ws.flag.reserve(sizeof(int)));
         VDB_HIP(hipMemsetAsync(ws.flag.p, 0, sizeof(int), s));
         const char* qb = reinterpret_cast<const char*>(q);
@@ -744,6 +749,19 @@ int vdb_flat_search(vdb_rows* h, int metric, const float* queries, int nq, int k
                         [&](const float* dq, float* dd, int64_t* di) {
                             return flat_search_impl(h, metric, dq, nq, k, d_mask, dd, di, nullptr, s);
                         });
+}
+
+int vdb_flat_search_stats(vdb_rows* h, int* used_queue, int* overflowed) {
+    VDB_REQUIRE(h && used_queue && overflowed, "null argument");
+    std::lock_guard<std::mutex> g(ctx().mu);
+    *used_queue = h->last_used_queue ? 1 : 0;
+    *overflowed = 0;
+    if (h->last_used_queue && h->ws.flag.p) {
+        hipStream_t s = h->last_stream ? h->last_stream : ctx().stream;
+        VDB_HIP(hipMemcpyAsync(overflowed, h->ws.flag.p, sizeof(int), hipMemcpyDeviceToHost, s));
+        VDB_HIP(hipStreamSynchronize(s));
+    }
+    return VDB_OK;
 }
 
 int vdb_flat_distances_dev(vdb_rows* h, int metric, const float* d_queries, int nq, float* d_out, void* stream) {
