@@ -14,7 +14,7 @@ from test_gpu_cabi import check_search, assert_close, ids_atol, RTOL, _bf16_roun
 
 pytestmark = pytest.mark.gpu
 
-N_MIN = 2048 * 128          # smallest row count that gets a sample pass
+N_MIN = 512 * 128           # smallest row count that gets a sample pass
 
 
 @pytest.fixture(scope="module")
@@ -77,11 +77,11 @@ def test_queue_ties_go_to_lowest_row(nat):
     q = rng.standard_normal((4, d), dtype=np.float32)
     for i in range(4):
         near = (q[i] + 0.01 * rng.standard_normal(d)).astype(np.float32)
-        x[[1000 + i, 70000 + i, 200000 + i, n - 1 - i]] = near   # four copies, four different slabs
+        x[[1000 + i, 20000 + i, 50000 + i, n - 1 - i]] = near   # four copies, four different slabs
     dist, rows, stats = search_and_stats(nat, x, q, 6, "euclidean")
     assert stats == (True, False)
     for i in range(4):
-        assert list(rows[i, :4]) == [1000 + i, 70000 + i, 200000 + i, n - 1 - i]
+        assert list(rows[i, :4]) == [1000 + i, 20000 + i, 50000 + i, n - 1 - i]
         assert dist[i, 0] == dist[i, 1] == dist[i, 2] == dist[i, 3]
 
 

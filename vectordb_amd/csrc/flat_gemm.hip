@@ -326,10 +326,13 @@ int flat_gemm_num_cand_tiles(int n_tiles, int nq, int* n_cand) {
 }
 
 int flat_gemm_sample_plan(int64_t n, int* sample_tiles, int* tile_stride) {
-    // a strided sample of ~1/64 of the tiles (at least 128 of them) once the set is large
+    // a strided sample of ~1/64 of the tiles (at least 32 of them) once the set has 512 tiles:
+    // the sample pass then costs a few percent of the full pass, and the bound it yields lets
+    // the full pass run as the candidate-queue kernel
     const int n_tiles = (int)((n + TM - 1) / TM);
-    if (n_tiles < 2048) { *sample_tiles = 0; *tile_stride = 1; return VDB_OK; }
-    int want = std::max(128, n_tiles / 64);
+    static const int min_tiles = getenv("VDB_SAMPLE_MIN_TILES") ? atoi(getenv("VDB_SAMPLE_MIN_TILES")) : 512;
+    if (n_tiles < min_tiles) { *sample_tiles = 0; *tile_stride = 1; return VDB_OK; }
+    int want = std::max(32, n_tiles / 64);
     *tile_stride = n_tiles / want;
     *sample_tiles = want;
     return VDB_OK;
