@@ -236,7 +236,7 @@ static int rows_reserve(vdb_rows* h, int64_t n_total, hipStream_t s) {
     Rows& r = h->r;
     if (n_total <= r.cap) return VDB_OK;
     int64_t cap = std::max<int64_t>(n_total, r.cap + r.cap / 2);
-    cap = round_up64(std::max<int64_t>(cap, 1024), 128);    // whole 128-row tiles stay readable past the last row
+    cap = round_up64(std::max<int64_t>(cap, 1024), 256);    // whole 256-row tiles stay readable past the last row
     if (r.bf16)
         VDB_TRY(h->data16.reserve_keep((size_t)cap * r.ld16 * 2, (size_t)r.n * r.ld16 * 2, s));
     else
@@ -434,7 +434,7 @@ static int flat_search_impl(vdb_rows* h, int metric, const float* d_q, int nq, i
         for (int q0 = 0; q0 < nq; q0 += QUEUE_Q_BLOCK) {
             const int nb = std::min(QUEUE_Q_BLOCK, nq - q0);
             int n_slabs = 0, cap = 0;
-            VDB_TRY(flat_queue_plan(r.n, nb, kmax, sample_stride, &n_slabs, &cap));
+            VDB_TRY(flat_queue_plan(r, nb, kmax, sample_stride, &n_slabs, &cap));
             VDB_TRY(ws.queue.reserve((size_t)nb * n_slabs * cap * 8));
             VDB_TRY(ws.queue_cnt.reserve((size_t)nb * n_slabs * sizeof(int)));
             VDB_TRY(launch_flat_queue(r, metric, qb + (size_t)q0 * q_pitch, ws.q_sq.as<float>() + q0, ws.q_nrm.as<float>() + q0,

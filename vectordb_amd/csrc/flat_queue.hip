@@ -14,88 +14,11 @@
 //
 // A queue that overflows is reported through a flag; the caller then repeats the
 // search with the list kernel, so the result never depends on the queue size.
-#include "flat_math.h"
+#include "flat_queue.h"
 
 #include <type_traits>
 
 namespace vdb {
-
-struct QueueParams {
-    const void* rows; int64_t n; int ld_bytes;     // row pitch in bytes (multiple of 16); fp32 or bf16 elements
-    const float* row_sq; const float* row_nrm;
-    const void* q; int nq;                         // same element type and pitch as the rows
-    const float* q_sq; const float* q_nrm;
-    const uint32_t* mask;
-    const float* thr;                              // per query: an upper bound of its k-th best distance
-    int n_tiles, n_slabs, tiles_per_slab, n_qtiles;
-    int cap;                                       // queue slots per (query, slab)
-    float2* queue;                                 // [nq][n_slabs][cap]  (dot product, row number bits)
-    int* counts;                                   // [nq][n_slabs]       survivors seen (may exceed cap)
-};
-
-// Survivors of one finished 128 x 128 tile -> queue.  `acc[s]` holds the dot products of this
-// lane's query with rows rbase + 32 s + 8 g + 4 half + j (value index 4 g + j); `rs` the row terms
-// of the tile.  A packed test per accumulator (one fma per value, a max/min tree, one compare)
-// decides whether any of its 16 values can pass; only then are the values looked at one by one.
-template <int METRIC>
-__device__ __forceinline__ void queue_epilogue(const f32x16 (&acc)[4], const float* rs, int64_t rbase, int64_t n,
-                                               const uint32_t* mask, int half, float bound, float q_term, int* cnt,
-                                               float2* my_queue, int cap) {
-    const bool masked = (rbase + TM > n) || mask != nullptr;
-#pragma unroll
-    for (int s = 0; s < 4; ++s) {
-        float v[16];
-        if (METRIC == VDB_DOT) {
-#pragma unroll
-            for (int e = 0; e < 16; ++e) v[e] = acc[s][e];
-        } else {
-#pragma unroll
-            for (int g = 0; g < 4; ++g) {
-                const float4 t = *reinterpret_cast<const float4*>(rs + s * 32 + 8 * g + 4 * half);
-                const float rts[4] = {t.x, t.y, t.z, t.w};
-#pragma unroll
-                for (int j = 0; j < 4; ++j) {
-                    // cosine: dot - bound*|c| >= 0 ; L2: (|q|^2+|c|^2) - 2 dot <= bound   (one rounding each)
-                    v[g * 4 + j] = (METRIC == VDB_COSINE) ? __fmaf_rn(-bound, rts[j], acc[s][g * 4 + j])
-                                                          : __fmaf_rn(-2.0f, acc[s][g * 4 + j], q_term + rts[j]);
-                }
-            }
-        }
-        const bool want_max = (METRIC == VDB_DOT || METRIC == VDB_COSINE);
-        float m = v[0];
-#pragma unroll
-        for (int e = 1; e < 16; ++e) m = want_max ? fmaxf(m, v[e]) : fminf(m, v[e]);
-        const float lim = (METRIC == VDB_COSINE) ? 0.0f : bound;
-        const bool any = want_max ? (m >= lim) : (m <= lim);
-        if (any) {
-            uint32_t hits = 0;
-#pragma unroll
-            for (int e = 0; e < 16; ++e) {
-                const bool pass = want_max ? (v[e] >= lim) : (v[e] <= lim);
-                hits |= pass ? (1u << e) : 0u;
-            }
-            if (masked) {
-                uint32_t bits = 0xffffffffu;
-                const int64_t r0 = rbase + s * 32;
-                if (mask) bits = (r0 < n) ? mask[r0 >> 5] : 0u;
-                const int64_t left = n - r0;
-                if (left < 32) bits = left <= 0 ? 0u : (bits & ((1u << left) - 1u));
-                bits >>= (4 * half);
-                // value e = 4g + j of this lane is row 8g + 4*half + j of the 32-row sub-tile
-                hits &= (bits & 0xFu) | ((bits >> 4) & 0xF0u) | ((bits >> 8) & 0xF00u) | ((bits >> 12) & 0xF000u);
-            }
-            while (hits) {
-                const int e = __ffs(hits) - 1;
-                hits &= hits - 1;
-                const int off = 8 * (e >> 2) + (e & 3) + 4 * half;
-                const float dot = pick16(acc[s], e);
-                const int row = (int)(rbase + s * 32 + off);
-                const int slot = atomicAdd(cnt, 1);
-                if (slot < cap) my_queue[slot] = make_float2(dot, __int_as_float(row));
-            }
-        }
-    }
-}
 
 template <int METRIC, bool BF16>
 __global__ __launch_bounds__(NT, 2) void flat_queue_kernel(QueueParams p) {
@@ -579,9 +502,10 @@ __global__ __launch_bounds__(256) void queue_select_kernel(QueueSelectParams p) 
 }
 
 // --------------------------------------------------------------------------
-int flat_queue_plan(int64_t n, int nq, int k, int sample_stride, int* n_slabs, int* cap) {
+int flat_queue_plan(const Rows& r, int nq, int k, int sample_stride, int* n_slabs, int* cap) {
     int nqt, tps;
-    plan_grid((int)((n + TM - 1) / TM), nq, ctx().num_cus, &nqt, n_slabs, &tps);
+    if (queue_use_wide(r)) plan_grid_wide((int)((r.n + WM - 1) / WM), nq, ctx().num_cus, &nqt, n_slabs, &tps);
+    else plan_grid((int)((r.n + TM - 1) / TM), nq, ctx().num_cus, &nqt, n_slabs, &tps);
     // survivors per query: about sample_stride * k in expectation (the bound is the k-th best of
     // one row in sample_stride); four times that plus a constant, spread over the slabs
     const int64_t total = 4LL * sample_stride * k + 1024;
@@ -628,14 +552,21 @@ int launch_flat_queue(const Rows& r, int metric, const void* q, const float* q_s
     p.rows = r.bf16 ? (const void*)r.data16 : (const void*)r.data; p.n = r.n;
     p.ld_bytes = r.bf16 ? r.ld16 * 2 : r.ld * 4; p.row_sq = r.sq; p.row_nrm = r.nrm;
     p.q = q; p.nq = nq; p.q_sq = q_sq; p.q_nrm = q_nrm; p.mask = mask; p.thr = thr;
-    p.n_tiles = (int)((r.n + TM - 1) / TM);
-    plan_grid(p.n_tiles, nq, ctx().num_cus, &p.n_qtiles, &p.n_slabs, &p.tiles_per_slab);
+    const bool wide = queue_use_wide(r);
+    if (wide) {
+        p.n_tiles = (int)((r.n + WM - 1) / WM);
+        plan_grid_wide(p.n_tiles, nq, ctx().num_cus, &p.n_qtiles, &p.n_slabs, &p.tiles_per_slab);
+    } else {
+        p.n_tiles = (int)((r.n + TM - 1) / TM);
+        plan_grid(p.n_tiles, nq, ctx().num_cus, &p.n_qtiles, &p.n_slabs, &p.tiles_per_slab);
+    }
     VDB_REQUIRE(p.n_slabs == n_slabs, "queue plan mismatch (%d slabs planned, %d now)", n_slabs, p.n_slabs);
     p.cap = cap; p.queue = reinterpret_cast<float2*>(queue); p.counts = counts;
     // whole tiles readable and no partial K step: the branch-free kernel
     static const bool no_fast = getenv("VDB_NO_QFAST") != nullptr;
     const bool fast = !no_fast && p.ld_bytes % TKB == 0 && r.cap >= (int64_t)p.n_tiles * TM;
-    VDB_TRY(r.bf16 ? launch_queue<true>(metric, p, fast, s) : launch_queue<false>(metric, p, fast, s));
+    if (wide) VDB_TRY(launch_queue_wide(metric, p, s));
+    else VDB_TRY(r.bf16 ? launch_queue<true>(metric, p, fast, s) : launch_queue<false>(metric, p, fast, s));
 
     QueueSelectParams sp{};
     sp.queue = p.queue; sp.counts = counts; sp.n_slabs = n_slabs; sp.cap = cap;

@@ -1,0 +1,292 @@
+// Candidate-queue kernel on 256 x 256 tiles, for bf16 rows.
+//
+// With v_mfma_f32_32x32x16_bf16 a 128 x 128 tile finishes a 128-byte K step in a
+// quarter of the fp32 time while it stages the same 32 KB per step: the kernel of
+// flat_queue.hip is then bound by the bytes it moves (L2 -> LDS, LDS -> registers),
+// not by the matrix cores.  Here a block of 8 waves owns 256 database rows x 256
+// queries: a K step stages 64 KB for four times the matrix work (half the bytes per
+// flop), a wave multiplies 128 rows x 64 queries (8 accumulators, 6 fragment reads
+// per 8 matrix instructions instead of 5 per 4).  One block per CU (147 KB of LDS for
+// two stages), so both waves of a SIMD belong to it and meet every barrier together:
+// the step's barrier sits before its last quarter of matrix instructions, and the
+// first fragments of the coming step are fetched behind it.
+//
+// Everything else — the conservative filter, the queues, queue_select_kernel, the
+// overflow flag and the list-kernel fallback — is shared with flat_queue.hip
+// (distance/metrics.py:453-484, index/flat.py:354-362).
+#include "flat_queue.h"
+
+namespace vdb {
+
+#define VDB_FENCE() __builtin_amdgcn_sched_barrier(0)
+
+template <int METRIC, bool BF16>
+__global__ __launch_bounds__(WNT, 1) void flat_queue_wide_kernel(QueueParams p) {
+    extern __shared__ __align__(16) float smem[];
+    float* As = smem;                                   // [2][WM][LW]  database rows, two stages
+    float* Bs = As + 2 * WM * LW;                       // [2][WQ][LW]  queries, two stages
+    float* Rs = Bs + 2 * WQ * LW;                       // [2][WM]      per-row term, by tile parity
+    int* Cnt = reinterpret_cast<int*>(Rs + 2 * WM);     // [WQ]         survivors per query of this block
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = tid >> 6;
+    const int half = lane >> 5;
+    const int col = lane & 31;
+    const int wr = wave >> 2;                           // which 128 rows of the tile
+    const int wq = wave & 3;                            // which 64 queries of the tile
+
+    // blocks that share a slab of rows (one per query tile) get the same blockIdx % 8: one XCD, one L2
+    int slab, qt;
+    if (p.n_slabs >= 8) {
+        const int per_group = 8 * p.n_qtiles;
+        const int grp = blockIdx.x / per_group;
+        const int rem = blockIdx.x - grp * per_group;
+        slab = grp * 8 + (rem & 7);
+        qt = rem >> 3;
+        if (slab >= p.n_slabs) return;
+    } else {
+        qt = blockIdx.x / p.n_slabs;
+        slab = blockIdx.x - qt * p.n_slabs;
+    }
+    const int tile0 = slab * p.tiles_per_slab;
+    const int tile1 = min(tile0 + p.tiles_per_slab, p.n_tiles);
+
+    // a lane owns two queries: column `col` of each of its wave's two 32-query groups
+    float q_term[2], bound[2];
+    float2* my_queue[2];
+    int* my_cnt[2];
+#pragma unroll
+    for (int qd = 0; qd < 2; ++qd) {
+        const int ql = wq * 64 + qd * 32 + col;
+        const int my_q = qt * WQ + ql;
+        const int my_q_ld = min(my_q, p.nq - 1);
+        q_term[qd] = 0.0f;
+        if (METRIC == VDB_COSINE) {
+            q_term[qd] = p.q_nrm[my_q_ld];
+            if (q_term[qd] < 1e-8f) q_term[qd] = INFINITY;       // metrics.py:472-473: all ones
+        } else if (METRIC != VDB_DOT) {
+            q_term[qd] = p.q_sq[my_q_ld];
+        }
+        bound[qd] = filter_bound<METRIC>(p.thr[my_q_ld], q_term[qd]);
+        if (my_q >= p.nq) bound[qd] = (METRIC == VDB_DOT || METRIC == VDB_COSINE) ? INFINITY : -INFINITY;
+        my_queue[qd] = p.queue + ((int64_t)my_q_ld * p.n_slabs + slab) * p.cap;
+        my_cnt[qd] = &Cnt[ql];
+    }
+    if (tid < WQ) Cnt[tid] = 0;
+
+    const int ksteps = p.ld_bytes / TKB;
+    const int srow = tid >> 3;          // staging: row within a 64-row pass
+    const int skc = (tid & 7) * 4;      // staging: dword offset inside the K step (16-byte pieces)
+    const int64_t q_base = (int64_t)qt * WQ;
+    const int ldw = p.ld_bytes >> 2;
+    uint32_t offb[4], offa[4];          // byte offsets from a wave-uniform base
+#pragma unroll
+    for (int ps = 0; ps < 4; ++ps) {
+        const int64_t gq = min(q_base + ps * 64 + srow, (int64_t)p.nq - 1) - q_base;
+        offb[ps] = (uint32_t)(gq * ldw + skc) * 4u;
+        offa[ps] = (uint32_t)((ps * 64 + srow) * ldw + skc) * 4u;
+    }
+    const char* rows_w = reinterpret_cast<const char*>(p.rows);
+    const char* qbase_ptr = reinterpret_cast<const char*>(p.q) + q_base * p.ld_bytes;
+    const float* row_term = (METRIC == VDB_COSINE) ? p.row_nrm : p.row_sq;
+    float* wr_a = As + srow * LW + skc;                           // this thread's staging slots (stage 0, pass 0)
+    float* wr_b = Bs + srow * LW + skc;
+    const float* rd_a = As + (wr * 128 + col) * LW + half * 4;    // this lane's fragment rows (stage 0)
+    const float* rd_b = Bs + (wq * 64 + col) * LW + half * 4;
+    float4 ra0, ra1, ra2, ra3, rb0, rb1, rb2, rb3;                // the operands in flight
+
+    f32x16 acc[2][4];                                             // [query group][32-row sub-tile]
+#pragma unroll
+    for (int qd = 0; qd < 2; ++qd)
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) acc[qd][r][e] = 0.0f;
+
+    const int n_steps = (tile1 - tile0) * ksteps;
+    int ck = 0, ct = tile0;             // the step being multiplied
+    int lk = 0, lt = tile0;             // the step to fetch next
+#define VDB_LOAD_STEP()                                                                        \
+    do {                                                                                       \
+        const char* abase = rows_w + (int64_t)min(lt, tile1 - 1) * WM * p.ld_bytes + lk * TKB; \
+        const char* bbase = qbase_ptr + lk * TKB;                                              \
+        ra0 = *reinterpret_cast<const float4*>(abase + offa[0]); rb0 = *reinterpret_cast<const float4*>(bbase + offb[0]); \
+        ra1 = *reinterpret_cast<const float4*>(abase + offa[1]); rb1 = *reinterpret_cast<const float4*>(bbase + offb[1]); \
+        ra2 = *reinterpret_cast<const float4*>(abase + offa[2]); rb2 = *reinterpret_cast<const float4*>(bbase + offb[2]); \
+        ra3 = *reinterpret_cast<const float4*>(abase + offa[3]); rb3 = *reinterpret_cast<const float4*>(bbase + offb[3]); \
+        if (++lk == ksteps) { lk = 0; ++lt; }                                                  \
+    } while (0)
+
+    if (n_steps > 0) {
+        VDB_LOAD_STEP();
+        *reinterpret_cast<float4*>(wr_a + 0 * 64 * LW) = ra0; *reinterpret_cast<float4*>(wr_b + 0 * 64 * LW) = rb0;
+        *reinterpret_cast<float4*>(wr_a + 1 * 64 * LW) = ra1; *reinterpret_cast<float4*>(wr_b + 1 * 64 * LW) = rb1;
+        *reinterpret_cast<float4*>(wr_a + 2 * 64 * LW) = ra2; *reinterpret_cast<float4*>(wr_b + 2 * 64 * LW) = rb2;
+        *reinterpret_cast<float4*>(wr_a + 3 * 64 * LW) = ra3; *reinterpret_cast<float4*>(wr_b + 3 * 64 * LW) = rb3;
+        if (METRIC != VDB_DOT && tid < WM) {
+            float t = row_term[(int64_t)tile0 * WM + tid];
+            if (METRIC == VDB_COSINE && t < 1e-8f) t = 1.0f;        // metrics.py:476
+            Rs[(tile0 & 1) * WM + tid] = t;
+        }
+        VDB_LOAD_STEP();
+    }
+    __syncthreads();
+
+    // fragment sets: X holds the K chunk being multiplied, Y the next one
+    float4 xa0, xa1, xa2, xa3, xb0, xb1, ya0, ya1, ya2, ya3, yb0, yb1;
+    xb0 = *reinterpret_cast<const float4*>(rd_b); xb1 = *reinterpret_cast<const float4*>(rd_b + 32 * LW);
+    xa0 = *reinterpret_cast<const float4*>(rd_a); xa1 = *reinterpret_cast<const float4*>(rd_a + 32 * LW);
+    xa2 = *reinterpret_cast<const float4*>(rd_a + 64 * LW); xa3 = *reinterpret_cast<const float4*>(rd_a + 96 * LW);
+
+#define VDB_MM(A, B, QD, R)                                                                                       \
+    do {                                                                                                          \
+        if (BF16) {                                                                                               \
+            acc[QD][R] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, A),                   \
+                                                                 __builtin_bit_cast(bf16x8, B), acc[QD][R], 0, 0, 0); \
+        } else {                                                                                                  \
+            acc[QD][R] = __builtin_amdgcn_mfma_f32_32x32x2f32(A.x, B.x, acc[QD][R], 0, 0, 0);                     \
+            acc[QD][R] = __builtin_amdgcn_mfma_f32_32x32x2f32(A.y, B.y, acc[QD][R], 0, 0, 0);                     \
+            acc[QD][R] = __builtin_amdgcn_mfma_f32_32x32x2f32(A.z, B.z, acc[QD][R], 0, 0, 0);                     \
+            acc[QD][R] = __builtin_amdgcn_mfma_f32_32x32x2f32(A.w, B.w, acc[QD][R], 0, 0, 0);                     \
+        }                                                                                                         \
+    } while (0)
+    // fragment reads of K chunk CH from the stage at (PA, PB)
+#define VDB_RA(DST, PA, CH, R) DST = *reinterpret_cast<const float4*>(PA + (R) * 32 * LW + (CH) * 8)
+#define VDB_RB(DST, PB, CH, QD) DST = *reinterpret_cast<const float4*>(PB + (QD) * 32 * LW + (CH) * 8)
+
+    for (int st = 0; st < n_steps; st += 2) {
+#pragma unroll
+      for (int B_ = 0; B_ < 2; ++B_) {          // two steps per trip: the stage in use is a literal
+        if (st + B_ >= n_steps) break;
+        const float* pa = rd_a + B_ * (WM * LW);
+        const float* pb = rd_b + B_ * (WQ * LW);
+        const float* na = rd_a + (1 - B_) * (WM * LW);      // the coming step's stage
+        const float* nb = rd_b + (1 - B_) * (WQ * LW);
+        float* wa_ = wr_a + (1 - B_) * (WM * LW);
+        float* wb_ = wr_b + (1 - B_) * (WQ * LW);
+
+        // chunk 0 (set X) while chunk 1 travels into set Y
+        VDB_MM(xa0, xb0, 0, 0); VDB_RB(yb0, pb, 1, 0); VDB_FENCE();
+        VDB_MM(xa0, xb1, 1, 0); VDB_RB(yb1, pb, 1, 1); VDB_FENCE();
+        VDB_MM(xa1, xb0, 0, 1); VDB_RA(ya0, pa, 1, 0); VDB_FENCE();
+        VDB_MM(xa1, xb1, 1, 1); VDB_RA(ya1, pa, 1, 1); VDB_FENCE();
+        VDB_MM(xa2, xb0, 0, 2); VDB_RA(ya2, pa, 1, 2); VDB_FENCE();
+        VDB_MM(xa2, xb1, 1, 2); VDB_RA(ya3, pa, 1, 3); VDB_FENCE();
+        VDB_MM(xa3, xb0, 0, 3); VDB_FENCE();
+        VDB_MM(xa3, xb1, 1, 3); VDB_FENCE();
+        // chunk 1 (set Y) while chunk 2 travels into set X; the coming step's rows are parked
+        VDB_MM(ya0, yb0, 0, 0); VDB_RB(xb0, pb, 2, 0); VDB_FENCE();
+        VDB_MM(ya0, yb1, 1, 0); VDB_RB(xb1, pb, 2, 1); VDB_FENCE();
+        VDB_MM(ya1, yb0, 0, 1); VDB_RA(xa0, pa, 2, 0); *reinterpret_cast<float4*>(wa_ + 0 * 64 * LW) = ra0; VDB_FENCE();
+        VDB_MM(ya1, yb1, 1, 1); VDB_RA(xa1, pa, 2, 1); *reinterpret_cast<float4*>(wa_ + 1 * 64 * LW) = ra1; VDB_FENCE();
+        VDB_MM(ya2, yb0, 0, 2); VDB_RA(xa2, pa, 2, 2); *reinterpret_cast<float4*>(wa_ + 2 * 64 * LW) = ra2; VDB_FENCE();
+        VDB_MM(ya2, yb1, 1, 2); VDB_RA(xa3, pa, 2, 3); *reinterpret_cast<float4*>(wa_ + 3 * 64 * LW) = ra3; VDB_FENCE();
+        VDB_MM(ya3, yb0, 0, 3); VDB_FENCE();
+        VDB_MM(ya3, yb1, 1, 3); VDB_FENCE();
+        // chunk 2 (set X) while chunk 3 travels into set Y; the coming step's queries are parked
+        VDB_MM(xa0, xb0, 0, 0); VDB_RB(yb0, pb, 3, 0); VDB_FENCE();
+        VDB_MM(xa0, xb1, 1, 0); VDB_RB(yb1, pb, 3, 1); VDB_FENCE();
+        VDB_MM(xa1, xb0, 0, 1); VDB_RA(ya0, pa, 3, 0); *reinterpret_cast<float4*>(wb_ + 0 * 64 * LW) = rb0; VDB_FENCE();
+        VDB_MM(xa1, xb1, 1, 1); VDB_RA(ya1, pa, 3, 1); *reinterpret_cast<float4*>(wb_ + 1 * 64 * LW) = rb1; VDB_FENCE();
+        VDB_MM(xa2, xb0, 0, 2); VDB_RA(ya2, pa, 3, 2); *reinterpret_cast<float4*>(wb_ + 2 * 64 * LW) = rb2; VDB_FENCE();
+        VDB_MM(xa2, xb1, 1, 2); VDB_RA(ya3, pa, 3, 3); *reinterpret_cast<float4*>(wb_ + 3 * 64 * LW) = rb3; VDB_FENCE();
+        VDB_MM(xa3, xb0, 0, 3); VDB_FENCE();
+        VDB_MM(xa3, xb1, 1, 3); VDB_FENCE();
+        // The step's only barrier: everyone has read this stage (chunk 3 is in registers) and
+        // written the other one.  Chunk 3 is multiplied behind it while the step after next is
+        // fetched and the first fragments of the coming step travel into set X.
+        __syncthreads();
+        {
+            const char* abase = rows_w + (int64_t)min(lt, tile1 - 1) * WM * p.ld_bytes + lk * TKB;
+            const char* bbase = qbase_ptr + lk * TKB;
+#pragma unroll
+            for (int ps = 0; ps < 4; ++ps) { asm("" : "+v"(offa[ps])); asm("" : "+v"(offb[ps])); }   // keep the lane offsets 32 bits wide
+            VDB_MM(ya0, yb0, 0, 0); VDB_RB(xb0, nb, 0, 0); ra0 = *reinterpret_cast<const float4*>(abase + offa[0]); VDB_FENCE();
+            VDB_MM(ya0, yb1, 1, 0); VDB_RB(xb1, nb, 0, 1); rb0 = *reinterpret_cast<const float4*>(bbase + offb[0]); VDB_FENCE();
+            VDB_MM(ya1, yb0, 0, 1); VDB_RA(xa0, na, 0, 0); ra1 = *reinterpret_cast<const float4*>(abase + offa[1]); VDB_FENCE();
+            VDB_MM(ya1, yb1, 1, 1); VDB_RA(xa1, na, 0, 1); rb1 = *reinterpret_cast<const float4*>(bbase + offb[1]); VDB_FENCE();
+            VDB_MM(ya2, yb0, 0, 2); VDB_RA(xa2, na, 0, 2); ra2 = *reinterpret_cast<const float4*>(abase + offa[2]); VDB_FENCE();
+            VDB_MM(ya2, yb1, 1, 2); VDB_RA(xa3, na, 0, 3); rb2 = *reinterpret_cast<const float4*>(bbase + offb[2]); VDB_FENCE();
+            VDB_MM(ya3, yb0, 0, 3); ra3 = *reinterpret_cast<const float4*>(abase + offa[3]); VDB_FENCE();
+            VDB_MM(ya3, yb1, 1, 3); rb3 = *reinterpret_cast<const float4*>(bbase + offb[3]); VDB_FENCE();
+            if (++lk == ksteps) { lk = 0; ++lt; }
+        }
+        if (ck == ksteps - 1) {
+            // row terms of the next tile travel while this tile's survivors are picked
+            float nxt = 1.0f;
+            const bool has_next = ct + 1 < tile1;
+            if (METRIC != VDB_DOT && has_next && tid < WM) nxt = row_term[(int64_t)(ct + 1) * WM + tid];
+            const float* rs = Rs + (ct & 1) * WM + wr * 128;
+            const int64_t rbase = (int64_t)ct * WM + wr * 128;
+            queue_epilogue<METRIC>(acc[0], rs, rbase, p.n, p.mask, half, bound[0], q_term[0], my_cnt[0], my_queue[0], p.cap);
+            queue_epilogue<METRIC>(acc[1], rs, rbase, p.n, p.mask, half, bound[1], q_term[1], my_cnt[1], my_queue[1], p.cap);
+            if (METRIC != VDB_DOT && has_next && tid < WM) {
+                if (METRIC == VDB_COSINE && nxt < 1e-8f) nxt = 1.0f;
+                Rs[((ct + 1) & 1) * WM + tid] = nxt;
+            }
+#pragma unroll
+            for (int qd = 0; qd < 2; ++qd)
+#pragma unroll
+                for (int r = 0; r < 4; ++r)
+#pragma unroll
+                    for (int e = 0; e < 16; ++e) acc[qd][r][e] = 0.0f;
+            ck = 0; ++ct;
+        } else {
+            ++ck;
+        }
+      }
+    }
+    __syncthreads();
+#undef VDB_LOAD_STEP
+#undef VDB_MM
+#undef VDB_RA
+#undef VDB_RB
+
+    if (tid < WQ && q_base + tid < p.nq) p.counts[(q_base + tid) * p.n_slabs + slab] = Cnt[tid];
+}
+
+// --------------------------------------------------------------------------
+bool queue_use_wide(const Rows& r) {
+    static const bool off = getenv("VDB_NO_QWIDE") != nullptr;
+    const int64_t tiles = (r.n + WM - 1) / WM;
+    return !off && r.bf16 && (r.ld16 * 2) % TKB == 0 && r.cap >= tiles * WM;
+}
+
+void plan_grid_wide(int n_tiles, int nq, int num_cus, int* n_qtiles, int* n_slabs, int* tiles_per_slab) {
+    *n_qtiles = (nq + WQ - 1) / WQ;
+    int want = (num_cus + *n_qtiles - 1) / *n_qtiles;       // one block per CU in total
+    if (want < 1) want = 1;
+    if (want > n_tiles) want = n_tiles;
+    *tiles_per_slab = (n_tiles + want - 1) / want;
+    *n_slabs = (n_tiles + *tiles_per_slab - 1) / *tiles_per_slab;
+}
+
+int launch_queue_wide(int metric, QueueParams& p, hipStream_t s) {
+    const int groups = (p.n_slabs + 7) / 8;
+    const dim3 grid(p.n_slabs >= 8 ? groups * 8 * p.n_qtiles : p.n_slabs * p.n_qtiles);
+    const size_t lds = (size_t)(2 * WM * LW + 2 * WQ * LW + 2 * WM + WQ) * sizeof(float);
+    KernelTimer timer(s, true);
+#define VDB_LAUNCH_WIDE(M)                                                                     \
+    case M: {                                                                                  \
+        auto kern = flat_queue_wide_kernel<M, true>;                                           \
+        VDB_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern),                       \
+                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));    \
+        hipLaunchKernelGGL(kern, grid, dim3(WNT), lds, s, p);                                  \
+        break;                                                                                 \
+    }
+    switch (metric) {
+        VDB_LAUNCH_WIDE(VDB_EUCLIDEAN)
+        VDB_LAUNCH_WIDE(VDB_EUCLIDEAN_SQ)
+        VDB_LAUNCH_WIDE(VDB_COSINE)
+        VDB_LAUNCH_WIDE(VDB_DOT)
+        default:
+            set_error("metric %d has no matrix-core path", metric);
+            return VDB_ERR_INVALID;
+    }
+#undef VDB_LAUNCH_WIDE
+    VDB_HIP(hipGetLastError());
+    return VDB_OK;
+}
+
+}  // namespace vdb

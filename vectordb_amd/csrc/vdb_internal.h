@@ -127,7 +127,7 @@ int launch_flat_gemm_topk(const Rows& r, int metric, const void* q, const float*
 // bound go to queues of `cap` entries per (query, slab) and the k best of them come out directly.
 // `*overflow` is set to 1 when a queue was too small (the caller then repeats the search with
 // launch_flat_gemm_topk(..., run_if = overflow)); it must be zero on entry.
-int flat_queue_plan(int64_t n, int nq, int k, int sample_stride, int* n_slabs, int* cap);
+int flat_queue_plan(const Rows& r, int nq, int k, int sample_stride, int* n_slabs, int* cap);
 int launch_flat_queue(const Rows& r, int metric, const void* q, const float* q_sq, const float* q_nrm, int nq, int k,
                       const uint32_t* mask, const float* thr, int n_slabs, int cap, void* queue, int* counts,
                       int* overflow, float* out_d, int64_t* out_i, int* out_i32, hipStream_t s);
