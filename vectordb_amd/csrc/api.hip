@@ -162,13 +162,13 @@ static int fill_results(float* d, int64_t* i, int64_t total, hipStream_t s) {
 // ============================================================== workspaces
 struct Workspace {
     DevBuf q_buf, q_sq, q_nrm, part_d, part_i, lb_d, lb_k, thr_d, thr_k, mask, out_d, out_i, dist, probes, probe_d, lut, stage;
-    DevBuf queue, queue_cnt, flag;
+    DevBuf queue, queue_cnt, flag, mins;
     DevBuf round32, q16, cand, seg_row_off, seg_q_off, seg_item_off, sq_qid, sq_out, cand_off, tile_off, list_cnt, cursor, slots, items;
     void release() {
         DevBuf* all[] = {&q_buf, &q_sq, &q_nrm, &part_d, &part_i, &lb_d, &lb_k, &thr_d, &thr_k, &mask, &out_d, &out_i, &dist,
                          &probes, &probe_d, &lut, &stage, &round32, &q16, &cand, &seg_row_off, &seg_q_off, &seg_item_off, &sq_qid, &sq_out,
                          &cand_off, &tile_off, &list_cnt, &cursor, &slots, &items,
-                         &queue, &queue_cnt, &flag};
+                         &queue, &queue_cnt, &flag, &mins};
         for (DevBuf* b : all) b->release();
     }
 };
@@ -412,11 +412,28 @@ static int flat_search_impl(vdb_rows* h, int metric, const float* d_q, int nq, i
         // k-th best over all rows, used as the initial filter threshold of the full pass
         VDB_TRY(ws.thr_d.reserve((size_t)nq * sizeof(float)));
         VDB_TRY(ws.thr_k.reserve((size_t)nq * sizeof(int64_t)));
-        VDB_TRY(launch_flat_gemm_topk(r, metric, q, ws.q_sq.as<float>(), ws.q_nrm.as<float>(), nq, kmax, d_mask,
-                                      nullptr, nullptr, nullptr, sample_tiles, sample_stride,
-                                      ws.part_d.as<float>(), ws.part_i.as<int>(), n_cand_sample, s));
-        SelectOut so{nullptr, nullptr, nullptr, kmax, 0, ws.thr_d.as<float>(), ws.thr_k.as<int64_t>()};
-        VDB_TRY(launch_select(ws.part_d.as<float>(), ws.part_i.as<int>(), nq, n_cand_sample, kmax, 1 << 30, nullptr, 0, so, s));
+        static const bool no_min = getenv("VDB_NO_MINPASS") != nullptr;
+        if (flat_queue_fast_ok(r) && !no_min) {
+            // per-lane minima over the sample, then the k-th smallest of them (blocks of queries keep
+            // the number of lanes per query well above k)
+            const char* qb = reinterpret_cast<const char*>(q);
+            const size_t q_pitch = r.bf16 ? (size_t)r.ld16 * 2 : (size_t)r.ld * 4;
+            for (int q0 = 0; q0 < nq; q0 += QUEUE_Q_BLOCK) {
+                const int nb = std::min(QUEUE_Q_BLOCK, nq - q0);
+                int ns = 0;
+                const int n_lists = flat_min_sample_lists(sample_tiles, nb, kmax, &ns);
+                VDB_TRY(ws.mins.reserve((size_t)nb * n_lists * sizeof(float)));
+                VDB_TRY(launch_flat_min_sample(r, metric, qb + (size_t)q0 * q_pitch, ws.q_sq.as<float>() + q0,
+                                               ws.q_nrm.as<float>() + q0, nb, kmax, d_mask, sample_tiles, sample_stride,
+                                               ws.mins.as<float>(), ws.thr_d.as<float>() + q0, s));
+            }
+        } else {
+            VDB_TRY(launch_flat_gemm_topk(r, metric, q, ws.q_sq.as<float>(), ws.q_nrm.as<float>(), nq, kmax, d_mask,
+                                          nullptr, nullptr, nullptr, sample_tiles, sample_stride,
+                                          ws.part_d.as<float>(), ws.part_i.as<int>(), n_cand_sample, s));
+            SelectOut so{nullptr, nullptr, nullptr, kmax, 0, ws.thr_d.as<float>(), ws.thr_k.as<int64_t>()};
+            VDB_TRY(launch_select(ws.part_d.as<float>(), ws.part_i.as<int>(), nq, n_cand_sample, kmax, 1 << 30, nullptr, 0, so, s));
+        }
         thr_init = ws.thr_d.as<float>();
     }
 

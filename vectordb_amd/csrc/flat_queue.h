@@ -17,7 +17,46 @@ struct QueueParams {
     int cap;                                       // queue slots per (query, slab)
     float2* queue;                                 // [nq][n_slabs][cap]  (dot product, row number bits)
     int* counts;                                   // [nq][n_slabs]       survivors seen (may exceed cap)
+    // bound pass (flat_queue_fast_kernel<..., MINPASS = true>): visited tile t is database tile
+    // t * tile_stride, and every lane's smallest distance goes to min_out[(query * n_slabs + slab) * 2 + half]
+    int tile_stride;
+    float* min_out;
 };
+
+// Smallest "key" of the 16 values of one accumulator, for the bound pass.  Keys order like the
+// distances of one query: -dot (dot), (|q|^2+|c|^2) - 2 dot (both Euclidean forms, the exact
+// pre-clamp term of finish<>()), -(dot / |c|) (cosine; `rs` then holds 1/|c|).
+template <int METRIC>
+__device__ __forceinline__ float min_key16(const f32x16& a, const float* rs, int s, int half, float q_term, uint32_t avail) {
+    float v[16];
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+        float4 t = make_float4(0, 0, 0, 0);
+        if (METRIC != VDB_DOT) t = *reinterpret_cast<const float4*>(rs + s * 32 + 8 * g + 4 * half);
+        const float rts[4] = {t.x, t.y, t.z, t.w};
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const float d = a[g * 4 + j];
+            float key = (METRIC == VDB_DOT) ? -d : (METRIC == VDB_COSINE) ? -(d * rts[j]) : __fmaf_rn(-2.0f, d, q_term + rts[j]);
+            if (!((avail >> (g * 4 + j)) & 1u)) key = INFINITY;
+            v[g * 4 + j] = key;
+        }
+    }
+    float m = v[0];
+#pragma unroll
+    for (int e = 1; e < 16; ++e) m = fminf(m, v[e]);
+    return m;
+}
+
+// per-lane availability bits (value e = 4g + j <-> row 8g + 4*half + j of the 32-row sub-tile at r0)
+__device__ __forceinline__ uint32_t avail16(const uint32_t* mask, int64_t r0, int64_t n, int half) {
+    uint32_t bits = 0xffffffffu;
+    if (mask) bits = (r0 < n) ? mask[r0 >> 5] : 0u;
+    const int64_t left = n - r0;
+    if (left < 32) bits = left <= 0 ? 0u : (bits & ((1u << left) - 1u));
+    bits >>= (4 * half);
+    return (bits & 0xFu) | ((bits >> 4) & 0xF0u) | ((bits >> 8) & 0xF00u) | ((bits >> 12) & 0xF000u);
+}
 
 // Survivors of one finished 128 x 128 tile -> queue.  `acc[s]` holds the dot products of this
 // lane's query with rows rbase + 32 s + 8 g + 4 half + j (value index 4 g + j); `rs` the row terms

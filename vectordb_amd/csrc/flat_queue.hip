@@ -241,7 +241,7 @@ __global__ __launch_bounds__(NT, 2) void flat_queue_kernel(QueueParams p) {
 #endif
 #define VDB_FENCE() __builtin_amdgcn_sched_barrier(0)
 
-template <int METRIC, bool BF16>
+template <int METRIC, bool BF16, bool MINPASS>
 __global__ __launch_bounds__(NT, 2) void flat_queue_fast_kernel(QueueParams p) {
     extern __shared__ __align__(16) float smem[];
     float* As = smem;                                   // [2][TM][LW]
@@ -280,9 +280,15 @@ __global__ __launch_bounds__(NT, 2) void flat_queue_fast_kernel(QueueParams p) {
     } else if (METRIC != VDB_DOT) {
         q_term = p.q_sq[my_q_ld];
     }
-    float bound = filter_bound<METRIC>(p.thr[my_q_ld], q_term);
-    if (!q_ok) bound = (METRIC == VDB_DOT || METRIC == VDB_COSINE) ? INFINITY : -INFINITY;
-    float2* my_queue = p.queue + ((int64_t)my_q_ld * p.n_slabs + slab) * p.cap;
+    float bound = 0.0f;
+    float2* my_queue = nullptr;
+    float best = INFINITY;                              // bound pass: this lane's smallest key
+    if (!MINPASS) {
+        bound = filter_bound<METRIC>(p.thr[my_q_ld], q_term);
+        if (!q_ok) bound = (METRIC == VDB_DOT || METRIC == VDB_COSINE) ? INFINITY : -INFINITY;
+        my_queue = p.queue + ((int64_t)my_q_ld * p.n_slabs + slab) * p.cap;
+    }
+    const int tstride = MINPASS ? p.tile_stride : 1;    // visited tile t is database tile t * tstride
     int* my_cnt = &Cnt[wave * 32 + col];
     if (tid < TQ) Cnt[tid] = 0;
 
@@ -319,7 +325,7 @@ __global__ __launch_bounds__(NT, 2) void flat_queue_fast_kernel(QueueParams p) {
     int lk = 0, lt = tile0;
 #define VDB_LOAD_STEP()                                                                     \
     do {                                                                                    \
-        const char* abase = rows_w + (int64_t)min(lt, tile1 - 1) * TM * p.ld_bytes + lk * TKB; \
+        const char* abase = rows_w + (int64_t)min(lt, tile1 - 1) * tstride * TM * p.ld_bytes + lk * TKB; \
         const char* bbase = qbase_ptr + lk * TKB;                                           \
         ra0 = *reinterpret_cast<const float4*>(abase + offa[0]); rb0 = *reinterpret_cast<const float4*>(bbase + offb[0]); \
         ra1 = *reinterpret_cast<const float4*>(abase + offa[1]); rb1 = *reinterpret_cast<const float4*>(bbase + offb[1]); \
@@ -336,8 +342,9 @@ __global__ __launch_bounds__(NT, 2) void flat_queue_fast_kernel(QueueParams p) {
         *reinterpret_cast<float4*>(wr_a + 2 * 32 * LW) = ra2; *reinterpret_cast<float4*>(wr_b + 2 * 32 * LW) = rb2;
         *reinterpret_cast<float4*>(wr_a + 3 * 32 * LW) = ra3; *reinterpret_cast<float4*>(wr_b + 3 * 32 * LW) = rb3;
         if (METRIC != VDB_DOT && tid < TM) {
-            float t = row_term[(int64_t)tile0 * TM + tid];
+            float t = row_term[(int64_t)tile0 * tstride * TM + tid];
             if (METRIC == VDB_COSINE && t < 1e-8f) t = 1.0f;
+            if (MINPASS && METRIC == VDB_COSINE) t = 1.0f / t;
             Rs[(tile0 & 1) * TM + tid] = t;
         }
         VDB_LOAD_STEP();
@@ -387,7 +394,7 @@ __global__ __launch_bounds__(NT, 2) void flat_queue_fast_kernel(QueueParams p) {
         VDB_MFMA4(2, 2); VDB_WR_A(2); VDB_WR_B(2); VDB_FENCE();
         VDB_MFMA4(2, 3); VDB_WR_A(3); VDB_WR_B(3); VDB_FENCE();
         {
-            const char* abase = rows_w + (int64_t)min(lt, tile1 - 1) * TM * p.ld_bytes + lk * TKB;
+            const char* abase = rows_w + (int64_t)min(lt, tile1 - 1) * tstride * TM * p.ld_bytes + lk * TKB;
             const char* bbase = qbase_ptr + lk * TKB;
             // keep the per-thread offsets 32 bits wide here, so that every load is "uniform base +
             // 32-bit lane offset" in one instruction and no vector ALU work is left in the step
@@ -403,11 +410,22 @@ __global__ __launch_bounds__(NT, 2) void flat_queue_fast_kernel(QueueParams p) {
             // row terms of the next tile travel while this tile's survivors are picked
             float nxt = 1.0f;
             const bool has_next = ct + 1 < tile1;
-            if (METRIC != VDB_DOT && has_next && tid < TM) nxt = row_term[(int64_t)(ct + 1) * TM + tid];
-            queue_epilogue<METRIC>(acc, Rs + (ct & 1) * TM, (int64_t)ct * TM, p.n, p.mask, half, bound, q_term,
-                                   my_cnt, my_queue, p.cap);
+            if (METRIC != VDB_DOT && has_next && tid < TM) nxt = row_term[(int64_t)(ct + 1) * tstride * TM + tid];
+            if (MINPASS) {
+                const int64_t rbase = (int64_t)ct * tstride * TM;
+                const bool masked = (rbase + TM > p.n) || p.mask != nullptr;
+#pragma unroll
+                for (int s = 0; s < 4; ++s) {
+                    const uint32_t avail = masked ? avail16(p.mask, rbase + s * 32, p.n, half) : 0xFFFFu;
+                    best = fminf(best, min_key16<METRIC>(acc[s], Rs + (ct & 1) * TM, s, half, q_term, avail));
+                }
+            } else {
+                queue_epilogue<METRIC>(acc, Rs + (ct & 1) * TM, (int64_t)ct * TM, p.n, p.mask, half, bound, q_term,
+                                       my_cnt, my_queue, p.cap);
+            }
             if (METRIC != VDB_DOT && has_next && tid < TM) {
                 if (METRIC == VDB_COSINE && nxt < 1e-8f) nxt = 1.0f;
+                if (MINPASS && METRIC == VDB_COSINE) nxt = 1.0f / nxt;
                 Rs[((ct + 1) & 1) * TM + tid] = nxt;
             }
 #pragma unroll
@@ -428,6 +446,17 @@ __global__ __launch_bounds__(NT, 2) void flat_queue_fast_kernel(QueueParams p) {
 #undef VDB_WR_A
 #undef VDB_WR_B
 
+    if (MINPASS) {
+        // key -> distance, the way finish<>() ends; cosine goes through a reciprocal, hence the margin
+        float d = best;
+        if (best < INFINITY) {
+            if (METRIC == VDB_EUCLIDEAN) d = sqrtf(fmaxf(best, 0.0f));
+            else if (METRIC == VDB_EUCLIDEAN_SQ) d = fmaxf(best, 0.0f);
+            else if (METRIC == VDB_COSINE) d = (1.0f - fminf(fmaxf(-best / q_term, -1.0f), 1.0f)) + 4e-6f;
+        }
+        if (q_ok) p.min_out[((int64_t)my_q * p.n_slabs + slab) * 2 + half] = d;
+        return;
+    }
     if (tid < TQ && q_base + tid < p.nq) p.counts[(q_base + tid) * p.n_slabs + slab] = Cnt[tid];
 }
 
@@ -502,6 +531,79 @@ __global__ __launch_bounds__(256) void queue_select_kernel(QueueSelectParams p) 
 }
 
 // --------------------------------------------------------------------------
+// Bound pass: per query, the k-th smallest of its per-lane minima over the sampled tiles.  Every
+// minimum is the distance of a real row, and minima of different lanes belong to different rows, so
+// the k-th smallest of them is at least the k-th best distance of the whole row set.
+__global__ __launch_bounds__(256) void kth_of_minima_kernel(const float* __restrict__ mins, int n_lists, int nq, int k,
+                                                            float* __restrict__ thr) {
+    const int lane = threadIdx.x & 63;
+    const int q = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (q >= nq) return;
+    WaveTopK top;
+    top.init(k);
+    for (int l0 = 0; l0 < n_lists; l0 += 64) {
+        const int l = l0 + lane;
+        const float v = l < n_lists ? mins[(int64_t)q * n_lists + l] : INFINITY;
+        top.offer(l < n_lists && v < INFINITY, v, l, lane);
+    }
+    if (lane == 0) thr[q] = top.thr;        // +inf while fewer than k lanes saw a row
+}
+
+bool flat_queue_fast_ok(const Rows& r) {
+    static const bool no_fast = getenv("VDB_NO_QFAST") != nullptr;
+    const int ld_bytes = r.bf16 ? r.ld16 * 2 : r.ld * 4;
+    return !no_fast && ld_bytes % TKB == 0 && r.cap >= ((r.n + WM - 1) / WM) * WM;
+}
+
+int flat_min_sample_lists(int sample_tiles, int nq, int k, int* n_slabs) {
+    int nqt, tps;
+    plan_grid(sample_tiles, nq, ctx().num_cus, &nqt, n_slabs, &tps);
+    (void)k;
+    return 2 * *n_slabs;
+}
+
+template <bool BF16>
+static int launch_min_pass(int metric, QueueParams& p, hipStream_t s) {
+    const int groups = (p.n_slabs + 7) / 8;
+    const dim3 grid(p.n_slabs >= 8 ? groups * 8 * p.n_qtiles : p.n_slabs * p.n_qtiles);
+    const size_t lds = (size_t)(2 * TM * LW + 2 * TQ * LW + 2 * TM + TQ) * sizeof(float);
+#define VDB_LAUNCH_MIN(M)                                                                      \
+    case M: {                                                                                  \
+        auto kern = flat_queue_fast_kernel<M, BF16, true>;                                     \
+        VDB_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern),                       \
+                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));    \
+        hipLaunchKernelGGL(kern, grid, dim3(NT), lds, s, p);                                   \
+        break;                                                                                 \
+    }
+    switch (metric) {
+        VDB_LAUNCH_MIN(VDB_EUCLIDEAN)
+        VDB_LAUNCH_MIN(VDB_EUCLIDEAN_SQ)
+        VDB_LAUNCH_MIN(VDB_COSINE)
+        VDB_LAUNCH_MIN(VDB_DOT)
+        default:
+            set_error("metric %d has no matrix-core path", metric);
+            return VDB_ERR_INVALID;
+    }
+#undef VDB_LAUNCH_MIN
+    VDB_HIP(hipGetLastError());
+    return VDB_OK;
+}
+
+int launch_flat_min_sample(const Rows& r, int metric, const void* q, const float* q_sq, const float* q_nrm, int nq, int k,
+                           const uint32_t* mask, int sample_tiles, int tile_stride, float* mins, float* thr, hipStream_t s) {
+    VDB_REQUIRE(flat_queue_fast_ok(r) && sample_tiles >= 1 && k >= 1 && k <= 64, "bad bound pass arguments");
+    QueueParams p{};
+    p.rows = r.bf16 ? (const void*)r.data16 : (const void*)r.data; p.n = r.n;
+    p.ld_bytes = r.bf16 ? r.ld16 * 2 : r.ld * 4; p.row_sq = r.sq; p.row_nrm = r.nrm;
+    p.q = q; p.nq = nq; p.q_sq = q_sq; p.q_nrm = q_nrm; p.mask = mask;
+    p.n_tiles = sample_tiles; p.tile_stride = tile_stride; p.min_out = mins;
+    plan_grid(p.n_tiles, nq, ctx().num_cus, &p.n_qtiles, &p.n_slabs, &p.tiles_per_slab);
+    VDB_TRY(r.bf16 ? launch_min_pass<true>(metric, p, s) : launch_min_pass<false>(metric, p, s));
+    hipLaunchKernelGGL(kth_of_minima_kernel, dim3((nq + 3) / 4), dim3(256), 0, s, mins, 2 * p.n_slabs, nq, k, thr);
+    VDB_HIP(hipGetLastError());
+    return VDB_OK;
+}
+
 int flat_queue_plan(const Rows& r, int nq, int k, int sample_stride, int* n_slabs, int* cap) {
     int nqt, tps;
     if (queue_use_wide(r)) plan_grid_wide((int)((r.n + WM - 1) / WM), nq, ctx().num_cus, &nqt, n_slabs, &tps);
@@ -523,7 +625,7 @@ static int launch_queue(int metric, QueueParams& p, bool fast, hipStream_t s) {
     KernelTimer timer(s, true);
 #define VDB_LAUNCH_QUEUE(M)                                                                    \
     case M: {                                                                                  \
-        auto kern = fast ? flat_queue_fast_kernel<M, BF16> : flat_queue_kernel<M, BF16>;       \
+        auto kern = fast ? flat_queue_fast_kernel<M, BF16, false> : flat_queue_kernel<M, BF16>; \
         VDB_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern),                       \
                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));    \
         hipLaunchKernelGGL(kern, grid, dim3(NT), lds, s, p);                                   \
@@ -563,8 +665,7 @@ int launch_flat_queue(const Rows& r, int metric, const void* q, const float* q_s
     VDB_REQUIRE(p.n_slabs == n_slabs, "queue plan mismatch (%d slabs planned, %d now)", n_slabs, p.n_slabs);
     p.cap = cap; p.queue = reinterpret_cast<float2*>(queue); p.counts = counts;
     // whole tiles readable and no partial K step: the branch-free kernel
-    static const bool no_fast = getenv("VDB_NO_QFAST") != nullptr;
-    const bool fast = !no_fast && p.ld_bytes % TKB == 0 && r.cap >= (int64_t)p.n_tiles * TM;
+    const bool fast = flat_queue_fast_ok(r);
     if (wide) VDB_TRY(launch_queue_wide(metric, p, s));
     else VDB_TRY(r.bf16 ? launch_queue<true>(metric, p, fast, s) : launch_queue<false>(metric, p, fast, s));
 

@@ -127,6 +127,13 @@ int launch_flat_gemm_topk(const Rows& r, int metric, const void* q, const float*
 // bound go to queues of `cap` entries per (query, slab) and the k best of them come out directly.
 // `*overflow` is set to 1 when a queue was too small (the caller then repeats the search with
 // launch_flat_gemm_topk(..., run_if = overflow)); it must be zero on entry.
+// Bound pass for stores the branch-free kernel can read (flat_queue_fast_ok): per-lane minima over
+// `sample_tiles` tiles (every tile_stride-th), then thr[q] = k-th smallest of query q's minima.
+// `mins` needs nq * flat_min_sample_lists(...) floats.
+bool flat_queue_fast_ok(const Rows& r);
+int flat_min_sample_lists(int sample_tiles, int nq, int k, int* n_slabs);
+int launch_flat_min_sample(const Rows& r, int metric, const void* q, const float* q_sq, const float* q_nrm, int nq, int k,
+                           const uint32_t* mask, int sample_tiles, int tile_stride, float* mins, float* thr, hipStream_t s);
 int flat_queue_plan(const Rows& r, int nq, int k, int sample_stride, int* n_slabs, int* cap);
 int launch_flat_queue(const Rows& r, int metric, const void* q, const float* q_sq, const float* q_nrm, int nq, int k,
                       const uint32_t* mask, const float* thr, int n_slabs, int cap, void* queue, int* counts,
