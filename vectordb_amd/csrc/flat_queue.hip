@@ -236,9 +236,6 @@ __global__ __launch_bounds__(NT, 2) void flat_queue_kernel(QueueParams p) {
 // order, between this wave's own matrix instructions.  (Vector ALU and LDS/VMEM issue of a
 // wave crawls while the other block's wave on the same SIMD runs dependent matrix
 // instructions back to back, so nothing is left for a separate phase to do.)
-#ifndef VDB_QFAST_INDEP
-#define VDB_QFAST_INDEP 0       // 1: consecutive matrix instructions go to different accumulators
-#endif
 #define VDB_FENCE() __builtin_amdgcn_sched_barrier(0)
 
 template <int METRIC, bool BF16, bool MINPASS>
