@@ -307,7 +307,11 @@ static int cand_splits(int64_t tiles, int nq) {
     if (forced > 0) return (int)std::min<int64_t>(tiles, forced);
     const int64_t by_chip = (4 * (int64_t)ctx().num_cus + nq - 1) / nq;
     const int64_t by_walk = (tiles + 63) / 64;
-    return (int)std::max<int64_t>(1, std::min<int64_t>(tiles, std::max(by_chip, by_walk)));
+    int64_t splits = std::max<int64_t>(1, std::min<int64_t>(tiles, std::max(by_chip, by_walk)));
+    // a handful of queries: the selection is latency, not bandwidth.  At most 64 splits (256 lists:
+    // one merge launch) of at least 16 tiles each, so a small candidate set goes through one block.
+    if (nq <= 8) splits = std::max<int64_t>(1, std::min<int64_t>(std::min<int64_t>(splits, 64), tiles / 16));
+    return (int)splits;
 }
 
 static int stream_flat_sums(Workspace& ws, const Rows& r, int metric, const float* q, int nq, float* out, hipStream_t s) {
