@@ -73,3 +73,28 @@ def test_repeated_searches_equal_first_and_follow_changes(kind):
     fresh.add_batch(ids_of(len(more), start=100000), more)
     for rep in range(3):
         assert [r.id for r in ix.search(q[3], k=7)] == [r.id for r in fresh.search(q[3], k=7)]
+
+
+@pytest.mark.parametrize("d", [1, 5, 8, 13, 32, 100, 128, 130, 384, 768, 1000, 3000])
+def test_norms_of_a_few_rows_bit_exact(native, d):
+    """Up to 64 rows (a batch of queries) take a one-launch kernel for |x|^2 and |x|: the same
+    pairwise order as np.sum (distance/metrics.py:455-456,469-470), bit for bit.  Checked on
+    stored rows, and on query norms through the distance to a zero row:
+    sqrt(|q|^2 + 0 - 2*0) in the identity form (distance/metrics.py:453-459)."""
+    from vectordb_amd import _native as nat
+    rng = np.random.RandomState(d)
+    for n in (1, 3, 64):
+        x = (rng.randn(n, d) * rng.uniform(0.1, 10.0)).astype(np.float32)
+        store = nat.RowStore(d)
+        store.append(x)
+        sq, nrm = store.norms()
+        np.testing.assert_array_equal(sq, np.sum(x * x, axis=1))
+        np.testing.assert_array_equal(nrm, np.linalg.norm(x, axis=1))
+        store.close()
+    zero = nat.RowStore(d)
+    zero.append(np.zeros((1, d), np.float32))
+    q = rng.randn(3, d).astype(np.float32)
+    for i in range(3):
+        dist, rows = zero.search(q[i], 1, nat.EUCLIDEAN)
+        assert dist[0, 0] == np.sqrt(np.sum(q[i] * q[i])) and rows[0, 0] == 0
+    zero.close()

@@ -163,12 +163,17 @@ static int fill_results(float* d, int64_t* i, int64_t total, hipStream_t s) {
 struct Workspace {
     DevBuf q_buf, q_sq, q_nrm, part_d, part_i, lb_d, lb_k, thr_d, thr_k, mask, out_d, out_i, dist, probes, probe_d, lut, stage;
     DevBuf queue, queue_cnt, flag, mins;
+    // item table of the last flat scan, kept between calls: it depends on (rows, queries, group) only
+    DevBuf fp_seg_row_off, fp_seg_q_off, fp_seg_item_off, fp_sq_qid, fp_sq_out, fp_items;
+    int64_t fp_n = -1; int fp_nq = -1, fp_group = -1;
     DevBuf round32, q16, cand, seg_row_off, seg_q_off, seg_item_off, sq_qid, sq_out, cand_off, tile_off, list_cnt, cursor, slots, items;
     void release() {
         DevBuf* all[] = {&q_buf, &q_sq, &q_nrm, &part_d, &part_i, &lb_d, &lb_k, &thr_d, &thr_k, &mask, &out_d, &out_i, &dist,
                          &probes, &probe_d, &lut, &stage, &round32, &q16, &cand, &seg_row_off, &seg_q_off, &seg_item_off, &sq_qid, &sq_out,
                          &cand_off, &tile_off, &list_cnt, &cursor, &slots, &items,
-                         &queue, &queue_cnt, &flag, &mins};
+                         &queue, &queue_cnt, &flag, &mins,
+                         &fp_seg_row_off, &fp_seg_q_off, &fp_seg_item_off, &fp_sq_qid, &fp_sq_out, &fp_items};
+        fp_n = -1;
         for (DevBuf* b : all) b->release();
     }
 };
@@ -317,8 +322,25 @@ static int cand_splits(int64_t tiles, int nq) {
 static int stream_flat_sums(Workspace& ws, const Rows& r, int metric, const float* q, int nq, float* out, hipStream_t s) {
     StreamPlanBufs b{};
     const int group = nq == 1 ? 1 : 8;
-    VDB_TRY(reserve_stream_plan(ws, 1, nq, ((r.n + 255) / 256) * ((nq + group - 1) / group), &b));
-    VDB_TRY(launch_flat_plan(r.n, nq, group, r.n, b, s));
+    const int64_t items_cap = ((r.n + 255) / 256) * ((nq + group - 1) / group);
+    // the plan buffers of a flat scan are its own (row norms and the IVF plans use the shared ones),
+    // so a repeated search of the same shape skips the two planning launches
+    DevBuf* bufs[] = {&ws.fp_seg_row_off, &ws.fp_seg_q_off, &ws.fp_seg_item_off, &ws.fp_sq_qid, &ws.fp_sq_out, &ws.fp_items};
+    const size_t need[] = {2 * sizeof(int64_t), 2 * sizeof(int), 2 * sizeof(int64_t), (size_t)std::max(nq, 1) * sizeof(int),
+                           (size_t)std::max(nq, 1) * sizeof(int64_t), (size_t)std::max<int64_t>(items_cap, 1) * sizeof(StreamItem)};
+    bool moved = false;
+    for (int i = 0; i < 6; ++i) {
+        void* before = bufs[i]->p;
+        VDB_TRY(bufs[i]->reserve(need[i]));
+        moved = moved || bufs[i]->p != before;
+    }
+    b.seg_row_off = ws.fp_seg_row_off.as<int64_t>(); b.seg_q_off = ws.fp_seg_q_off.as<int>();
+    b.seg_item_off = ws.fp_seg_item_off.as<int64_t>(); b.sq_qid = ws.fp_sq_qid.as<int>(); b.sq_out = ws.fp_sq_out.as<int64_t>();
+    b.items = ws.fp_items.as<StreamItem>(); b.items_cap = items_cap;
+    if (moved || ws.fp_n != r.n || ws.fp_nq != nq || ws.fp_group != group) {
+        VDB_TRY(launch_flat_plan(r.n, nq, group, r.n, b, s));
+        ws.fp_n = r.n; ws.fp_nq = nq; ws.fp_group = group;
+    }
     StreamJob j{};
     j.data = r.data; j.ld = r.ld; j.dim = r.dim; j.plan = r.plan;
     j.op = op_of_metric(metric); j.post = post_of_metric(metric);

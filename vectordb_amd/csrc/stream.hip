@@ -812,9 +812,68 @@ __global__ void sqrt_kernel(const float* __restrict__ sq, float* __restrict__ nr
         nrm[i] = sqrtf(sq[i]);
 }
 
+// A few rows (a batch of queries): one thread per row walks the same pairwise plan on its own,
+// one launch instead of four.  Same sums bit for bit: leaves of at most 128 elements with 8 strided
+// accumulators combined as ((r0+r1)+(r2+r3))+((r4+r5)+(r6+r7)) and a sequential tail, leaves
+// folded right into left (np.sum of a contiguous fp32 run; distance/metrics.py:455-456,469-470).
+struct SmallNormPlan { int n_leaves; short leaf_len[SumPlan::MAX_LEAVES]; unsigned char folds[SumPlan::MAX_LEAVES]; };
+
+__global__ void small_norms_kernel(const float* __restrict__ data, int ld, int64_t n, SmallNormPlan plan,
+                                   float* __restrict__ sq, float* __restrict__ nrm) {
+    const int64_t row = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (row >= n) return;
+    const float* x = data + row * ld;
+    float stack[8];
+    int sp = 0, off = 0;
+    for (int l = 0; l < plan.n_leaves; ++l) {
+        const int len = plan.leaf_len[l];
+        float res;
+        if (len < 8) {
+            res = 0.0f;
+            for (int i = 0; i < len; ++i) res = res + x[off + i] * x[off + i];
+        } else {
+            float r[8];
+#pragma unroll
+            for (int j = 0; j < 8; ++j) r[j] = x[off + j] * x[off + j];
+            int i = 8;
+            for (; i + 8 <= len; i += 8) {
+#pragma unroll
+                for (int j = 0; j < 8; ++j) r[j] = r[j] + x[off + i + j] * x[off + i + j];
+            }
+            res = ((r[0] + r[1]) + (r[2] + r[3])) + ((r[4] + r[5]) + (r[6] + r[7]));
+            for (; i < len; ++i) res = res + x[off + i] * x[off + i];
+        }
+        off += len;
+        stack[sp++] = res;
+        for (int f = 0; f < plan.folds[l]; ++f) {
+            const float b = stack[--sp];
+            const float a = stack[--sp];
+            stack[sp++] = a + b;
+        }
+    }
+    const float total = stack[0];
+    sq[row] = total;
+    nrm[row] = sqrtf(total);
+}
+
+static bool plan_depth_ok(const SumPlan& plan) {
+    int sp = 0, depth = 0;
+    for (int i = 0; i < plan.n_leaves; ++i) { ++sp; depth = std::max(depth, sp); sp -= plan.folds[i]; }
+    return depth <= 8;
+}
+
 int launch_row_norms(const float* data, int ld, int dim, int64_t n, const SumPlan& plan, const StreamPlanBufs& b,
                      float* sq, float* nrm, hipStream_t s) {
     if (n <= 0) return VDB_OK;
+    if (n <= 64 && plan_depth_ok(plan)) {
+        SmallNormPlan sp{};
+        sp.n_leaves = plan.n_leaves;
+        for (int i = 0; i < plan.n_leaves; ++i) { sp.leaf_len[i] = plan.leaf_len[i]; sp.folds[i] = plan.folds[i]; }
+        (void)dim;
+        hipLaunchKernelGGL(small_norms_kernel, dim3(1), dim3(64), 0, s, data, ld, n, sp, sq, nrm);
+        VDB_HIP(hipGetLastError());
+        return VDB_OK;
+    }
     VDB_REQUIRE(b.items_cap >= (n + S_NT - 1) / S_NT, "item table too small for %lld rows", (long long)n);
     VDB_TRY(launch_flat_plan(n, 1, 1, n, b, s));
     StreamJob j{};
