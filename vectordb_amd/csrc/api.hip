@@ -314,8 +314,9 @@ static int cand_splits(int64_t tiles, int nq) {
     const int64_t by_walk = (tiles + 63) / 64;
     int64_t splits = std::max<int64_t>(1, std::min<int64_t>(tiles, std::max(by_chip, by_walk)));
     // a handful of queries: the selection is latency, not bandwidth.  At most 64 splits (256 lists:
-    // one merge launch) of at least 16 tiles each, so a small candidate set goes through one block.
-    if (nq <= 8) splits = std::max<int64_t>(1, std::min<int64_t>(std::min<int64_t>(splits, 64), tiles / 16));
+    // one merge launch; 256 splits and two merge levels past a quarter of a million candidates) of
+    // at least 16 tiles each, so a small candidate set goes through one block.
+    if (nq <= 8) splits = std::max<int64_t>(1, std::min<int64_t>(std::min<int64_t>(splits, tiles > 1024 ? 256 : 64), tiles / 16));
     return (int)splits;
 }
 
