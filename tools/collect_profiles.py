@@ -34,7 +34,8 @@ with open(f"profiles/{tag}_bench_pmc.csv", "w", newline="") as f:
 import json
 vals = {}
 for r in csv.DictReader(open(f"profiles/{tag}_bench_pmc.csv")):
-    if "flat_queue_fast_kernel" in r["kernel"] and r["counter"] in ("FETCH_SIZE", "WRITE_SIZE"):
+    # the full pass is the instantiation whose last template argument (bound pass) is false
+    if "flat_queue_fast_kernel" in r["kernel"] and "true>(" not in r["kernel"] and r["counter"] in ("FETCH_SIZE", "WRITE_SIZE"):
         vals[r["counter"]] = float(r["mean_per_dispatch"])
 if len(vals) == 2:
     traffic = 2 * vals["FETCH_SIZE"] * 1024 + vals["WRITE_SIZE"] * 1024
