@@ -112,6 +112,7 @@ def main() -> None:
     elapsed = time.perf_counter() - t0
     _native.profile_enable(False)
     kernel_ms, launches = _native.profile_read()
+    used_queue, _ = backend.store.search_stats()          # which kernel the library took for this shard size
 
     if world > 1:
         t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
@@ -133,7 +134,7 @@ def main() -> None:
         traffic = None
     roofline = {"bound": "mfma", "achieved": round(achieved, 2), "peak": MFMA_F32_PEAK_TFLOPS, "unit": "TFLOP/s",
                 "frac": round(achieved / MFMA_F32_PEAK_TFLOPS, 4), "traffic": traffic,
-                "kernel": "flat_queue_fast_kernel<cosine>" if (hi - lo) >= 2048 * 128 else "flat_gemm_kernel<cosine>", "kernel_ms": round(kern_ms, 4), "launches": launches,
+                "kernel": "flat_queue_fast_kernel<cosine>" if used_queue else "flat_gemm_kernel<cosine>", "kernel_ms": round(kern_ms, 4), "launches": launches,
                 "flop_per_launch": flop_per_launch}
 
     # ---- CPU baseline + parity spot check (rank 0, single GPU only)

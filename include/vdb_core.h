@@ -230,6 +230,15 @@ int vdb_ivfpq_search_dev(vdb_ivfpq* h, const float* d_queries, int nq, int k, in
  * Layout of the inputs: [n_lists][nq][k].  Device pointers. */
 int vdb_topk_merge_dev(const float* d_dist, const int64_t* d_row, int n_lists, int nq, int k,
                        float* d_out_dist, int64_t* d_out_row, void* stream);
+/* Same for lists that do not lie back to back and carry shard-local rows: list
+ * l of the distances starts at d_dist + l*list_stride_dist, of the rows at
+ * d_row + l*list_stride_row (strides in elements, each >= nq*k), and
+ * d_row_base[l] (device, n_lists values, or NULL) is added to the rows of list
+ * l before they are compared and written.  Lets every shard send distances
+ * and local rows in ONE all-gather of a packed block. */
+int vdb_topk_merge_strided_dev(const float* d_dist, const int64_t* d_row, int64_t list_stride_dist, int64_t list_stride_row,
+                               const int64_t* d_row_base, int n_lists, int nq, int k,
+                               float* d_out_dist, int64_t* d_out_row, void* stream);
 /* Same, ordered by (distance, key) with the rows carried along: the merge of
  * IVF shards, key = the visiting order of vdb_ivf_search_ordered_dev. */
 int vdb_topk_merge_keyed_dev(const float* d_dist, const int64_t* d_key, const int64_t* d_row, int n_lists, int nq, int k,

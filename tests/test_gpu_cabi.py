@@ -496,11 +496,17 @@ def test_sharded_merge_equals_single_store(nat, shards):
     for metric, code in (("manhattan", nat.MANHATTAN), ("cosine", nat.COSINE)):
         gd = torch.empty((shards, len(q), k), device=dev, dtype=torch.float32)
         gr = torch.empty((shards, len(q), k), device=dev, dtype=torch.int64)
+        blocks = []
         for r in range(shards):
             lo, hi = shard_range(len(x), shards, r)
             be = HipFlatBackend(40, code)
             be.add_device(torch.from_numpy(x[lo:hi]).to(dev))
             d, rows = ShardedFlat(be, hi - lo, 0, 1).search(tq, k)         # local search, local row numbers
+            # the packed block rank r of a `shards`-rank group would hand to the all-gather
+            as_rank = ShardedFlat(be, len(x), r, shards)
+            local, gathered, ld, lr, pgd, pgr, base, pod, porow = as_rank._buffers(len(q), k, dev)
+            be.local_search(tq, k, ld, lr)
+            blocks.append(local.clone())
             gd[r] = d
             gr[r] = rows + (rows >= 0).to(torch.int64) * lo              # what rank r contributes to the all-gather
             ref_r, ref_d = R.flat_search(q[1], x[lo:hi], k, metric)
@@ -513,6 +519,11 @@ def test_sharded_merge_equals_single_store(nat, shards):
         nat.topk_merge_device(gd.data_ptr(), gr.data_ptr(), shards, len(q), k, od.data_ptr(), orow.data_ptr(),
                               stream=torch.cuda.current_stream().cuda_stream)
         torch.cuda.synchronize()
+        # the same merge over the packed blocks in place (rank stride > nq*k, local rows + per-rank base)
+        gathered.copy_(torch.cat(blocks))
+        HipFlatBackend.merge(be, pgd, pgr, k, pod, porow, base)
+        torch.cuda.synchronize()
+        assert torch.equal(pod, od) and torch.equal(porow, orow)
         od, orow = od.cpu().numpy(), orow.cpu().numpy()
         single = nat.RowStore(40)
         single.append(x)

@@ -77,13 +77,14 @@ def test_repeated_searches_equal_first_and_follow_changes(kind):
 
 @pytest.mark.parametrize("d", [1, 5, 8, 13, 32, 100, 128, 130, 384, 768, 1000, 3000])
 def test_norms_of_a_few_rows_bit_exact(native, d):
-    """Up to 64 rows (a batch of queries) take a one-launch kernel for |x|^2 and |x|: the same
+    """Up to 64 rows take a one-launch kernel for |x|^2 and |x| (a thread per row), up to 16384 another
+    (eight lanes per row), more the streaming kernel: all the same
     pairwise order as np.sum (distance/metrics.py:455-456,469-470), bit for bit.  Checked on
     stored rows, and on query norms through the distance to a zero row:
     sqrt(|q|^2 + 0 - 2*0) in the identity form (distance/metrics.py:453-459)."""
     from vectordb_amd import _native as nat
     rng = np.random.RandomState(d)
-    for n in (1, 3, 64):
+    for n in (1, 3, 64, 65, 1000, 16384, 16385):
         x = (rng.randn(n, d) * rng.uniform(0.1, 10.0)).astype(np.float32)
         store = nat.RowStore(d)
         store.append(x)

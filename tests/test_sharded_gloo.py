@@ -31,8 +31,10 @@ class OracleBackend:
             out_rows[i, :len(r)] = torch.from_numpy(r)
             out_dist[i, :len(r)] = torch.from_numpy(np.asarray(d, dtype=np.float32))
 
-    def merge(self, all_dist, all_rows, k, out_dist, out_rows):
+    def merge(self, all_dist, all_rows, k, out_dist, out_rows, row_base=None):
         world, nq, _ = all_dist.shape
+        if row_base is not None:            # local -> global row numbers; -1 stays -1
+            all_rows = torch.where(all_rows >= 0, all_rows + row_base.view(-1, 1, 1), all_rows)
         d = all_dist.permute(1, 0, 2).reshape(nq, -1).numpy()
         r = all_rows.permute(1, 0, 2).reshape(nq, -1).numpy()
         for i in range(nq):

@@ -104,6 +104,8 @@ SIGNATURES = {
                                        C.c_void_p, C.c_void_p]),
     "vdb_topk_merge_dev": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p,
                                      C.c_void_p]),
+    "vdb_topk_merge_strided_dev": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_int64, C.c_void_p, C.c_int, C.c_int,
+                                             C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]),
     "vdb_topk_merge_keyed_dev": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p,
                                            C.c_void_p, C.c_void_p]),
 }
@@ -561,6 +563,16 @@ def topk_merge_device(dist_ptr: int, row_ptr: int, n_lists: int, nq: int, k: int
     init()
     check(load().vdb_topk_merge_dev(C.c_void_p(dist_ptr), C.c_void_p(row_ptr), n_lists, nq, k,
                                     C.c_void_p(out_dist_ptr), C.c_void_p(out_row_ptr), C.c_void_p(stream or None)))
+
+
+def topk_merge_strided_device(dist_ptr: int, row_ptr: int, list_stride_dist: int, list_stride_row: int, row_base_ptr: int,
+                              n_lists: int, nq: int, k: int, out_dist_ptr: int, out_row_ptr: int, stream: int = 0) -> None:
+    """vdb_topk_merge_dev over lists `list_stride_*` elements apart, with row_base[l] (device int64, or 0 for none)
+    added to the rows of list l."""
+    init()
+    check(load().vdb_topk_merge_strided_dev(C.c_void_p(dist_ptr), C.c_void_p(row_ptr), list_stride_dist, list_stride_row,
+                                            C.c_void_p(row_base_ptr or None), n_lists, nq, k,
+                                            C.c_void_p(out_dist_ptr), C.c_void_p(out_row_ptr), C.c_void_p(stream or None)))
 
 
 def topk_merge_keyed_device(dist_ptr: int, key_ptr: int, row_ptr: int, n_lists: int, nq: int, k: int,

@@ -434,6 +434,10 @@ static int flat_search_impl(vdb_rows* h, int metric, const float* d_q, int nq, i
         VDB_TRY(ws.lb_k.reserve((size_t)nq * sizeof(int64_t)));
     }
     const float* thr_init = nullptr;
+    static const bool no_queue = getenv("VDB_NO_QUEUE") != nullptr;
+    const bool will_queue = sample_tiles > 0 && !multi && !no_queue;
+    bool flag_cleared = false;
+    if (will_queue) VDB_TRY(ws.flag.reserve(sizeof(int)));
     if (sample_tiles > 0) {
         // k-th best distance over a strided sample of the rows: an upper bound of the
         // k-th best over all rows, used as the initial filter threshold of the full pass
@@ -452,8 +456,10 @@ static int flat_search_impl(vdb_rows* h, int metric, const float* d_q, int nq, i
                 VDB_TRY(ws.mins.reserve((size_t)nb * n_lists * sizeof(float)));
                 VDB_TRY(launch_flat_min_sample(r, metric, qb + (size_t)q0 * q_pitch, ws.q_sq.as<float>() + q0,
                                                ws.q_nrm.as<float>() + q0, nb, kmax, d_mask, sample_tiles, sample_stride,
-                                               ws.mins.as<float>(), ws.thr_d.as<float>() + q0, s));
+                                               ws.mins.as<float>(), ws.thr_d.as<float>() + q0,
+                                               will_queue ? ws.flag.as<int>() : nullptr, s));
             }
+            flag_cleared = will_queue;
         } else {
             VDB_TRY(launch_flat_gemm_topk(r, metric, q, ws.q_sq.as<float>(), ws.q_nrm.as<float>(), nq, kmax, d_mask,
                                           nullptr, nullptr, nullptr, sample_tiles, sample_stride,
@@ -467,12 +473,10 @@ static int flat_search_impl(vdb_rows* h, int metric, const float* d_q, int nq, i
     // With a bound in hand and a single pass (k <= KMAX_FUSED) the survivors are queued and selected
     // directly; the list kernel below then runs only if a queue overflowed (a device-side flag, no
     // host round trip).
-    static const bool no_queue = getenv("VDB_NO_QUEUE") != nullptr;
     const int* run_if = nullptr;
-    if (thr_init && !multi && !no_queue) {
+    if (will_queue) {
         h->last_used_queue = true;
-        VDB_TRY(ws.flag.reserve(sizeof(int)));
-        VDB_HIP(hipMemsetAsync(ws.flag.p, 0, sizeof(int), s));
+        if (!flag_cleared) VDB_HIP(hipMemsetAsync(ws.flag.p, 0, sizeof(int), s));
         const char* qb = reinterpret_cast<const char*>(q);
         const size_t q_pitch = r.bf16 ? (size_t)r.ld16 * 2 : (size_t)r.ld * 4;
         for (int q0 = 0; q0 < nq; q0 += QUEUE_Q_BLOCK) {
@@ -1672,7 +1676,21 @@ int vdb_topk_merge_dev(const float* d_dist, const int64_t* d_row, int n_lists, i
     VDB_TRY(ensure_init());
     VDB_REQUIRE(d_dist && d_row && d_out_dist && d_out_row && n_lists >= 1 && nq >= 0 && k >= 1,
                 "bad arguments to vdb_topk_merge_dev");
-    return launch_select_i64(d_dist, d_row, nullptr, n_lists, nq, k, d_out_dist, d_out_row, pick_stream(stream));
+    return launch_select_i64(d_dist, d_row, nullptr, (int64_t)nq * k, (int64_t)nq * k, nullptr, n_lists, nq, k,
+                             d_out_dist, d_out_row, pick_stream(stream));
+}
+
+int vdb_topk_merge_strided_dev(const float* d_dist, const int64_t* d_row, int64_t list_stride_dist, int64_t list_stride_row,
+                               const int64_t* d_row_base, int n_lists, int nq, int k,
+                               float* d_out_dist, int64_t* d_out_row, void* stream) {
+    VDB_TRY(ensure_init());
+    VDB_REQUIRE(d_dist && d_row && d_out_dist && d_out_row && n_lists >= 1 && nq >= 0 && k >= 1,
+                "bad arguments to vdb_topk_merge_strided_dev");
+    VDB_REQUIRE(list_stride_dist >= (int64_t)nq * k && list_stride_row >= (int64_t)nq * k,
+                "list strides (%lld, %lld) are shorter than one list of %lld entries", (long long)list_stride_dist,
+                (long long)list_stride_row, (long long)nq * k);
+    return launch_select_i64(d_dist, d_row, nullptr, list_stride_dist, list_stride_row, d_row_base, n_lists, nq, k,
+                             d_out_dist, d_out_row, pick_stream(stream));
 }
 
 int vdb_topk_merge_keyed_dev(const float* d_dist, const int64_t* d_key, const int64_t* d_row, int n_lists, int nq, int k,
@@ -1680,7 +1698,8 @@ int vdb_topk_merge_keyed_dev(const float* d_dist, const int64_t* d_key, const in
     VDB_TRY(ensure_init());
     VDB_REQUIRE(d_dist && d_key && d_row && d_out_dist && d_out_row && n_lists >= 1 && nq >= 0 && k >= 1,
                 "bad arguments to vdb_topk_merge_keyed_dev");
-    return launch_select_i64(d_dist, d_key, d_row, n_lists, nq, k, d_out_dist, d_out_row, pick_stream(stream));
+    return launch_select_i64(d_dist, d_key, d_row, (int64_t)nq * k, (int64_t)nq * k, nullptr, n_lists, nq, k,
+                             d_out_dist, d_out_row, pick_stream(stream));
 }
 
 }  // extern "C"

@@ -532,9 +532,10 @@ __global__ __launch_bounds__(256) void queue_select_kernel(QueueSelectParams p) 
 // minimum is the distance of a real row, and minima of different lanes belong to different rows, so
 // the k-th smallest of them is at least the k-th best distance of the whole row set.
 __global__ __launch_bounds__(256) void kth_of_minima_kernel(const float* __restrict__ mins, int n_lists, int nq, int k,
-                                                            float* __restrict__ thr) {
+                                                            float* __restrict__ thr, int* __restrict__ clear) {
     const int lane = threadIdx.x & 63;
     const int q = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (clear && blockIdx.x == 0 && threadIdx.x == 0) *clear = 0;      // the overflow flag of the pass that follows
     if (q >= nq) return;
     WaveTopK top;
     top.init(k);
@@ -587,7 +588,7 @@ static int launch_min_pass(int metric, QueueParams& p, hipStream_t s) {
 }
 
 int launch_flat_min_sample(const Rows& r, int metric, const void* q, const float* q_sq, const float* q_nrm, int nq, int k,
-                           const uint32_t* mask, int sample_tiles, int tile_stride, float* mins, float* thr, hipStream_t s) {
+                           const uint32_t* mask, int sample_tiles, int tile_stride, float* mins, float* thr, int* clear_flag, hipStream_t s) {
     VDB_REQUIRE(flat_queue_fast_ok(r) && sample_tiles >= 1 && k >= 1 && k <= 64, "bad bound pass arguments");
     QueueParams p{};
     p.rows = r.bf16 ? (const void*)r.data16 : (const void*)r.data; p.n = r.n;
@@ -596,7 +597,7 @@ int launch_flat_min_sample(const Rows& r, int metric, const void* q, const float
     p.n_tiles = sample_tiles; p.tile_stride = tile_stride; p.min_out = mins;
     plan_grid(p.n_tiles, nq, ctx().num_cus, &p.n_qtiles, &p.n_slabs, &p.tiles_per_slab);
     VDB_TRY(r.bf16 ? launch_min_pass<true>(metric, p, s) : launch_min_pass<false>(metric, p, s));
-    hipLaunchKernelGGL(kth_of_minima_kernel, dim3((nq + 3) / 4), dim3(256), 0, s, mins, 2 * p.n_slabs, nq, k, thr);
+    hipLaunchKernelGGL(kth_of_minima_kernel, dim3((nq + 3) / 4), dim3(256), 0, s, mins, 2 * p.n_slabs, nq, k, thr, clear_flag);
     VDB_HIP(hipGetLastError());
     return VDB_OK;
 }

@@ -25,7 +25,8 @@ template <> struct IdxTraits<int64_t> {
 // one wave per query
 template <class IdxT>
 __global__ __launch_bounds__(64) void select_kernel(const float* __restrict__ d, const IdxT* __restrict__ idx,
-                                                    int64_t q_stride, int64_t l_stride, int n_lists, int k,
+                                                    int64_t q_stride, int64_t l_stride, int64_t l_stride_idx,
+                                                    const int64_t* __restrict__ list_base, int n_lists, int k,
                                                     int tie_group, const int* __restrict__ idx_map, int64_t idx_offset,
                                                     const int64_t* __restrict__ payload, SelectOut o) {
     extern __shared__ int heads[];
@@ -48,10 +49,12 @@ __global__ __launch_bounds__(64) void select_kernel(const float* __restrict__ d,
             const int h = heads[l];
             if (h >= k) continue;
             const float v = dq[(int64_t)l * l_stride + h];
-            const IdxT id = iq[(int64_t)l * l_stride + h];
+            const IdxT id = iq[(int64_t)l * l_stride_idx + h];
             if (IdxTraits<IdxT>::empty(id)) continue;
-            const int64_t key = (sizeof(IdxT) == 4) ? (((int64_t)(l / tie_group) << 32) | (uint32_t)id) : (int64_t)id;
-            if (v < bd || (v == bd && key < bkey)) { bd = v; bkey = key; bidx = (int64_t)id; bl = l; }
+            // ids of list l count from list_base[l] (shards of consecutive rows)
+            const int64_t gid = (int64_t)id + (list_base ? list_base[l] : 0);
+            const int64_t key = (sizeof(IdxT) == 4) ? (((int64_t)(l / tie_group) << 32) | (uint32_t)id) : gid;
+            if (v < bd || (v == bd && key < bkey)) { bd = v; bkey = key; bidx = gid; bl = l; }
         }
 #pragma unroll
         for (int off = 32; off >= 1; off >>= 1) {
@@ -66,7 +69,7 @@ __global__ __launch_bounds__(64) void select_kernel(const float* __restrict__ d,
             float dist = INFINITY;
             if (bl != 0x7fffffff) {
                 heads[bl] += 1;
-                row = pq ? pq[(int64_t)bl * l_stride + heads[bl] - 1] : (idx_map ? (int64_t)idx_map[bidx] : bidx) + idx_offset;
+                row = pq ? pq[(int64_t)bl * l_stride_idx + heads[bl] - 1] : (idx_map ? (int64_t)idx_map[bidx] : bidx) + idx_offset;
                 dist = bd;
                 last_d = bd;
                 last_key = bkey;
@@ -256,13 +259,14 @@ int launch_select(const float* part_d, const int* part_i, int nq, int n_cand, in
     return VDB_OK;
 }
 
-// lists laid out [n_lists][nq][k] (the shape an all-gather of per-shard results produces)
-int launch_select_i64(const float* d, const int64_t* i, const int64_t* payload, int n_lists, int nq, int k,
-                      float* out_d, int64_t* out_i, hipStream_t s) {
+// lists laid out [n_lists][nq][k] (the shape an all-gather of per-shard results produces); list l of
+// the distances starts at d + l * stride_d, of the ids (and payload) at i + l * stride_i
+int launch_select_i64(const float* d, const int64_t* i, const int64_t* payload, int64_t stride_d, int64_t stride_i,
+                      const int64_t* list_base, int n_lists, int nq, int k, float* out_d, int64_t* out_i, hipStream_t s) {
     if (nq <= 0) return VDB_OK;
     SelectOut o{out_d, out_i, nullptr, k, 0, nullptr, nullptr, nullptr};
     hipLaunchKernelGGL(select_kernel<int64_t>, dim3(nq), dim3(64), (size_t)n_lists * sizeof(int), s,
-                       d, i, (int64_t)k, (int64_t)nq * k, n_lists, k, 1, (const int*)nullptr, (int64_t)0, payload, o);
+                       d, i, (int64_t)k, stride_d, stride_i, list_base, n_lists, k, 1, (const int*)nullptr, (int64_t)0, payload, o);
     VDB_HIP(hipGetLastError());
     return VDB_OK;
 }

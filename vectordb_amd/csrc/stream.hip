@@ -856,6 +856,52 @@ __global__ void small_norms_kernel(const float* __restrict__ data, int ld, int64
     nrm[row] = sqrtf(total);
 }
 
+// A batch of rows (up to a few thousand queries): eight lanes per row, lane j keeps the strided
+// accumulator r[j] of every leaf, and the leaf result ((r0+r1)+(r2+r3))+((r4+r5)+(r6+r7)) comes from
+// three exchange steps (a + b and b + a are the same float, so all eight lanes hold the same bits).
+// Tails and short leaves are summed by every lane on its own.  Same plan walk as small_norms_kernel.
+__global__ __launch_bounds__(256) void group_norms_kernel(const float* __restrict__ data, int ld, int64_t n, SmallNormPlan plan,
+                                                          float* __restrict__ sq, float* __restrict__ nrm) {
+    const int j = threadIdx.x & 7;
+    const int64_t row = (int64_t)blockIdx.x * 32 + (threadIdx.x >> 3);
+    const bool live = row < n;
+    const float* x = data + (live ? row : 0) * ld;          // idle groups walk row 0 and store nothing
+    float stack[8];
+    int sp = 0, off = 0;
+    for (int l = 0; l < plan.n_leaves; ++l) {
+        const int len = plan.leaf_len[l];
+        float res;
+        if (len < 8) {
+            res = 0.0f;
+            for (int i = 0; i < len; ++i) res = res + x[off + i] * x[off + i];
+        } else {
+            float r = x[off + j] * x[off + j];
+            int i = 8;
+            for (; i + 8 <= len; i += 8) {
+                const float v = x[off + i + j];
+                r = r + v * v;
+            }
+            r = r + __shfl_xor(r, 1);
+            r = r + __shfl_xor(r, 2);
+            res = r + __shfl_xor(r, 4);
+            for (; i < len; ++i) res = res + x[off + i] * x[off + i];
+        }
+        off += len;
+        stack[sp++] = res;
+        for (int f = 0; f < plan.folds[l]; ++f) {
+            const float b = stack[--sp];
+            const float a = stack[--sp];
+            stack[sp++] = a + b;
+        }
+    }
+    if (live && j == 0) {
+        sq[row] = stack[0];
+        nrm[row] = sqrtf(stack[0]);
+    }
+}
+
+static constexpr int64_t GROUP_NORMS_MAX_ROWS = 16384;
+
 static bool plan_depth_ok(const SumPlan& plan) {
     int sp = 0, depth = 0;
     for (int i = 0; i < plan.n_leaves; ++i) { ++sp; depth = std::max(depth, sp); sp -= plan.folds[i]; }
@@ -871,6 +917,14 @@ int launch_row_norms(const float* data, int ld, int dim, int64_t n, const SumPla
         for (int i = 0; i < plan.n_leaves; ++i) { sp.leaf_len[i] = plan.leaf_len[i]; sp.folds[i] = plan.folds[i]; }
         (void)dim;
         hipLaunchKernelGGL(small_norms_kernel, dim3(1), dim3(64), 0, s, data, ld, n, sp, sq, nrm);
+        VDB_HIP(hipGetLastError());
+        return VDB_OK;
+    }
+    if (n <= GROUP_NORMS_MAX_ROWS && plan_depth_ok(plan)) {
+        SmallNormPlan sp{};
+        sp.n_leaves = plan.n_leaves;
+        for (int i = 0; i < plan.n_leaves; ++i) { sp.leaf_len[i] = plan.leaf_len[i]; sp.folds[i] = plan.folds[i]; }
+        hipLaunchKernelGGL(group_norms_kernel, dim3((unsigned)((n + 31) / 32)), dim3(256), 0, s, data, ld, n, sp, sq, nrm);
         VDB_HIP(hipGetLastError());
         return VDB_OK;
     }

@@ -129,11 +129,13 @@ int launch_flat_gemm_topk(const Rows& r, int metric, const void* q, const float*
 // launch_flat_gemm_topk(..., run_if = overflow)); it must be zero on entry.
 // Bound pass for stores the branch-free kernel can read (flat_queue_fast_ok): per-lane minima over
 // `sample_tiles` tiles (every tile_stride-th), then thr[q] = k-th smallest of query q's minima.
-// `mins` needs nq * flat_min_sample_lists(...) floats.
+// `mins` needs nq * flat_min_sample_lists(...) floats.  A non-null `clear_flag` is set to 0 on the way
+// (the overflow flag of the queue pass that follows).
 bool flat_queue_fast_ok(const Rows& r);
 int flat_min_sample_lists(int sample_tiles, int nq, int k, int* n_slabs);
 int launch_flat_min_sample(const Rows& r, int metric, const void* q, const float* q_sq, const float* q_nrm, int nq, int k,
-                           const uint32_t* mask, int sample_tiles, int tile_stride, float* mins, float* thr, hipStream_t s);
+                           const uint32_t* mask, int sample_tiles, int tile_stride, float* mins, float* thr,
+                           int* clear_flag, hipStream_t s);
 int flat_queue_plan(const Rows& r, int nq, int k, int sample_stride, int* n_slabs, int* cap);
 int launch_flat_queue(const Rows& r, int metric, const void* q, const float* q_sq, const float* q_nrm, int nq, int k,
                       const uint32_t* mask, const float* thr, int n_slabs, int cap, void* queue, int* counts,
@@ -223,9 +225,11 @@ struct SelectOut {
 int launch_select(const float* part_d, const int* part_i, int nq, int n_cand, int k, int tie_group,
                   const int* idx_map, int64_t idx_offset, const SelectOut& o, hipStream_t s);
 // lists laid out [n_lists][nq][k] with int64 ids (negative = empty), ordered by (distance, id);
-// with a payload of the same layout the payload of every selected entry is written instead of its id
-int launch_select_i64(const float* d, const int64_t* i, const int64_t* payload, int n_lists, int nq, int k,
-                      float* out_d, int64_t* out_i, hipStream_t s);
+// with a payload of the same layout the payload of every selected entry is written instead of its id.
+// List l of the distances starts at d + l * stride_d, of the ids and the payload at i + l * stride_i
+// (elements); with list_base, list_base[l] is added to the ids of list l before comparing and writing.
+int launch_select_i64(const float* d, const int64_t* i, const int64_t* payload, int64_t stride_d, int64_t stride_i,
+                      const int64_t* list_base, int n_lists, int nq, int k, float* out_d, int64_t* out_i, hipStream_t s);
 
 // sort every row of a [nq][n] matrix (n <= 16384) ascending by (value, index); writes the first k of each
 int launch_row_sort_topk(const float* dist, int nq, int n, int k, float* out_d, int* out_i, hipStream_t s);

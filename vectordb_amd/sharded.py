@@ -12,10 +12,10 @@ greedily on list length, with the centroids replicated (ShardedIVF).  K-means
 training all-reduces the per-cluster sums and counts (kmeans_update_allreduce).
 
 Partition: rank r owns the contiguous global rows [r*N//G, (r+1)*N//G).  Every
-query goes to every rank; each rank returns its local k best with GLOBAL row
+query goes to every rank; each rank returns its local k best with LOCAL row
 numbers; one all-gather (RCCL over xGMI when the tensors are on GPUs) moves
-G*nq*k (distance, row) pairs, and each rank merges them with the same
-selection kernel that merges the per-block lists of a single-GPU search.
+G*nq*k (distance, row) pairs, and each rank merges them by (distance, global
+row), adding every rank's first global row on the way.
 """
 
 from __future__ import annotations
@@ -51,11 +51,17 @@ class HipFlatBackend:
                                  stream=torch.cuda.current_stream().cuda_stream)
 
     def merge(self, all_dist: torch.Tensor, all_rows: torch.Tensor, k: int,
-              out_dist: torch.Tensor, out_rows: torch.Tensor) -> None:
+              out_dist: torch.Tensor, out_rows: torch.Tensor, row_base: Optional[torch.Tensor] = None) -> None:
+        """all_dist / all_rows: [world][nq][k] views whose rank stride may exceed nq*k (blocks of a packed
+        gather); row_base[r] is added to the rows of rank r."""
         world, nq = all_dist.shape[0], all_dist.shape[1]
-        self._n.topk_merge_device(all_dist.data_ptr(), all_rows.data_ptr(), world, nq, k,
-                                  out_dist.data_ptr(), out_rows.data_ptr(),
-                                  stream=torch.cuda.current_stream().cuda_stream)
+        assert all_dist.stride(1) == k and all_dist.stride(2) == 1 and all_rows.stride(1) == k and all_rows.stride(2) == 1
+        self._n.topk_merge_strided_device(all_dist.data_ptr(), all_rows.data_ptr(),
+                                          all_dist.stride(0) if world > 1 else nq * k,
+                                          all_rows.stride(0) if world > 1 else nq * k,
+                                          row_base.data_ptr() if row_base is not None else 0, world, nq, k,
+                                          out_dist.data_ptr(), out_rows.data_ptr(),
+                                          stream=torch.cuda.current_stream().cuda_stream)
 
 
 class HipPqBackend:
@@ -79,36 +85,46 @@ class HipPqBackend:
 
 
 class ShardedFlat:
-    """Flat search over rows sharded across the ranks of a process group."""
+    """Flat search over rows sharded across the ranks of a process group.
+
+    A rank's result travels as one packed block, [nq*k fp32 distances | pad to 8 bytes | nq*k int64
+    LOCAL rows], so one all-gather moves everything; the merge reads the gathered blocks in place
+    and adds every rank's first global row to its rows."""
 
     def __init__(self, backend, n_total: int, rank: int = 0, world: int = 1, group=None):
         self.backend = backend
         self.rank, self.world, self.group = rank, world, group
+        self.n_total = n_total
         self.lo, self.hi = shard_range(n_total, world, rank)
         self._buf = {}
 
     def _buffers(self, nq: int, k: int, device):
         key = (nq, k, str(device))
         if key not in self._buf:
-            f = dict(device=device, dtype=torch.float32)
-            i = dict(device=device, dtype=torch.int64)
-            self._buf[key] = (torch.empty((nq, k), **f), torch.empty((nq, k), **i),
-                              torch.empty((self.world, nq, k), **f), torch.empty((self.world, nq, k), **i),
-                              torch.empty((nq, k), **f), torch.empty((nq, k), **i))
+            dist_bytes = (nq * k * 4 + 7) // 8 * 8
+            block = dist_bytes + nq * k * 8
+            local = torch.empty(block, device=device, dtype=torch.uint8)
+            gathered = torch.empty(self.world * block, device=device, dtype=torch.uint8)
+            ld = local[:nq * k * 4].view(torch.float32).view(nq, k)
+            lr = local[dist_bytes:].view(torch.int64).view(nq, k)
+            g2 = gathered.view(self.world, block)
+            gd = g2[:, :nq * k * 4].view(torch.float32).view(self.world, nq, k)      # rank stride = block / 4 floats
+            gr = g2[:, dist_bytes:].view(torch.int64).view(self.world, nq, k)       # rank stride = block / 8 rows
+            base = torch.tensor([shard_range(self.n_total, self.world, r)[0] for r in range(self.world)],
+                                device=device, dtype=torch.int64)
+            self._buf[key] = (local, gathered, ld, lr, gd, gr, base,
+                              torch.empty((nq, k), device=device, dtype=torch.float32),
+                              torch.empty((nq, k), device=device, dtype=torch.int64))
         return self._buf[key]
 
     def search(self, queries: torch.Tensor, k: int) -> Tuple[torch.Tensor, torch.Tensor]:
         nq = queries.shape[0]
-        ld, lr, gd, gr, od, orow = self._buffers(nq, k, queries.device)
+        local, gathered, ld, lr, gd, gr, base, od, orow = self._buffers(nq, k, queries.device)
         self.backend.local_search(queries, k, ld, lr)
-        if self.lo:
-            lr.add_((lr >= 0).to(torch.int64) * self.lo)       # local -> global row numbers; -1 stays -1
         if self.world == 1:
             return ld, lr
-        # output = the ranks' (nq, k) blocks concatenated along dim 0, i.e. [rank][query][k]
-        dist.all_gather_into_tensor(gd.view(self.world * nq, k), ld, group=self.group)
-        dist.all_gather_into_tensor(gr.view(self.world * nq, k), lr, group=self.group)
-        self.backend.merge(gd, gr, k, od, orow)
+        dist.all_gather_into_tensor(gathered, local, group=self.group)
+        self.backend.merge(gd, gr, k, od, orow, base)
         return od, orow
 
 
