@@ -99,16 +99,7 @@ __device__ __forceinline__ void queue_epilogue(const f32x16 (&acc)[4], const flo
                 const bool pass = want_max ? (v[e] >= lim) : (v[e] <= lim);
                 hits |= pass ? (1u << e) : 0u;
             }
-            if (masked) {
-                uint32_t bits = 0xffffffffu;
-                const int64_t r0 = rbase + s * 32;
-                if (mask) bits = (r0 < n) ? mask[r0 >> 5] : 0u;
-                const int64_t left = n - r0;
-                if (left < 32) bits = left <= 0 ? 0u : (bits & ((1u << left) - 1u));
-                bits >>= (4 * half);
-                // value e = 4g + j of this lane is row 8g + 4*half + j of the 32-row sub-tile
-                hits &= (bits & 0xFu) | ((bits >> 4) & 0xF0u) | ((bits >> 8) & 0xF00u) | ((bits >> 12) & 0xF000u);
-            }
+            if (masked) hits &= avail16(mask, rbase + s * 32, n, half);
             while (hits) {
                 const int e = __ffs(hits) - 1;
                 hits &= hits - 1;

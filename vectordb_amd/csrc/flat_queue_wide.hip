@@ -9,7 +9,11 @@
 // per 8 matrix instructions instead of 5 per 4).  One block per CU (147 KB of LDS for
 // two stages), so both waves of a SIMD belong to it and meet every barrier together:
 // the step's barrier sits before its last quarter of matrix instructions, and the
-// first fragments of the coming step are fetched behind it.
+// first fragments of the coming step are fetched behind it.  The global loads of the
+// step after next are issued right behind the barrier and parked in LDS in the quarter
+// before the next one: three quarters of a step in flight.  The kernel is bound by
+// that delivery (64 KB per step and CU out of L2 and HBM), not by the matrix cores:
+// with three of four matrix instructions removed a step takes 82 % of its full time.
 //
 // Everything else — the conservative filter, the queues, queue_select_kernel, the
 // overflow flag and the list-kernel fallback — is shared with flat_queue.hip
@@ -175,24 +179,30 @@ __global__ __launch_bounds__(WNT, 1) void flat_queue_wide_kernel(QueueParams p) 
         VDB_MM(xa2, xb1, 1, 2); VDB_RA(ya3, pa, 1, 3); VDB_FENCE();
         VDB_MM(xa3, xb0, 0, 3); VDB_FENCE();
         VDB_MM(xa3, xb1, 1, 3); VDB_FENCE();
-        // chunk 1 (set Y) while chunk 2 travels into set X; the coming step's rows are parked
+#define VDB_WA(I) *reinterpret_cast<float4*>(wa_ + (I) * 64 * LW) = ra##I
+#define VDB_WB(I) *reinterpret_cast<float4*>(wb_ + (I) * 64 * LW) = rb##I
+#define VDB_GA(I) ra##I = *reinterpret_cast<const float4*>(abase + offa[I])
+#define VDB_GB(I) rb##I = *reinterpret_cast<const float4*>(bbase + offb[I])
+        // chunk 1 (set Y) while chunk 2 travels into set X
         VDB_MM(ya0, yb0, 0, 0); VDB_RB(xb0, pb, 2, 0); VDB_FENCE();
         VDB_MM(ya0, yb1, 1, 0); VDB_RB(xb1, pb, 2, 1); VDB_FENCE();
-        VDB_MM(ya1, yb0, 0, 1); VDB_RA(xa0, pa, 2, 0); *reinterpret_cast<float4*>(wa_ + 0 * 64 * LW) = ra0; VDB_FENCE();
-        VDB_MM(ya1, yb1, 1, 1); VDB_RA(xa1, pa, 2, 1); *reinterpret_cast<float4*>(wa_ + 1 * 64 * LW) = ra1; VDB_FENCE();
-        VDB_MM(ya2, yb0, 0, 2); VDB_RA(xa2, pa, 2, 2); *reinterpret_cast<float4*>(wa_ + 2 * 64 * LW) = ra2; VDB_FENCE();
-        VDB_MM(ya2, yb1, 1, 2); VDB_RA(xa3, pa, 2, 3); *reinterpret_cast<float4*>(wa_ + 3 * 64 * LW) = ra3; VDB_FENCE();
+        VDB_MM(ya1, yb0, 0, 1); VDB_RA(xa0, pa, 2, 0); VDB_FENCE();
+        VDB_MM(ya1, yb1, 1, 1); VDB_RA(xa1, pa, 2, 1); VDB_FENCE();
+        VDB_MM(ya2, yb0, 0, 2); VDB_RA(xa2, pa, 2, 2); VDB_FENCE();
+        VDB_MM(ya2, yb1, 1, 2); VDB_RA(xa3, pa, 2, 3); VDB_FENCE();
         VDB_MM(ya3, yb0, 0, 3); VDB_FENCE();
         VDB_MM(ya3, yb1, 1, 3); VDB_FENCE();
-        // chunk 2 (set X) while chunk 3 travels into set Y; the coming step's queries are parked
-        VDB_MM(xa0, xb0, 0, 0); VDB_RB(yb0, pb, 3, 0); VDB_FENCE();
-        VDB_MM(xa0, xb1, 1, 0); VDB_RB(yb1, pb, 3, 1); VDB_FENCE();
-        VDB_MM(xa1, xb0, 0, 1); VDB_RA(ya0, pa, 3, 0); *reinterpret_cast<float4*>(wb_ + 0 * 64 * LW) = rb0; VDB_FENCE();
-        VDB_MM(xa1, xb1, 1, 1); VDB_RA(ya1, pa, 3, 1); *reinterpret_cast<float4*>(wb_ + 1 * 64 * LW) = rb1; VDB_FENCE();
-        VDB_MM(xa2, xb0, 0, 2); VDB_RA(ya2, pa, 3, 2); *reinterpret_cast<float4*>(wb_ + 2 * 64 * LW) = rb2; VDB_FENCE();
-        VDB_MM(xa2, xb1, 1, 2); VDB_RA(ya3, pa, 3, 3); *reinterpret_cast<float4*>(wb_ + 3 * 64 * LW) = rb3; VDB_FENCE();
-        VDB_MM(xa3, xb0, 0, 3); VDB_FENCE();
-        VDB_MM(xa3, xb1, 1, 3); VDB_FENCE();
+        // chunk 2 (set X) while chunk 3 travels into set Y; the coming step's rows and queries are
+        // parked in the quarter before the barrier, one store per matrix instruction, so that their
+        // loads (issued behind the previous barrier) have three quarters of a step to arrive
+        VDB_MM(xa0, xb0, 0, 0); VDB_RB(yb0, pb, 3, 0); VDB_WA(0); VDB_FENCE();
+        VDB_MM(xa0, xb1, 1, 0); VDB_RB(yb1, pb, 3, 1); VDB_WB(0); VDB_FENCE();
+        VDB_MM(xa1, xb0, 0, 1); VDB_RA(ya0, pa, 3, 0); VDB_WA(1); VDB_FENCE();
+        VDB_MM(xa1, xb1, 1, 1); VDB_RA(ya1, pa, 3, 1); VDB_WB(1); VDB_FENCE();
+        VDB_MM(xa2, xb0, 0, 2); VDB_RA(ya2, pa, 3, 2); VDB_WA(2); VDB_FENCE();
+        VDB_MM(xa2, xb1, 1, 2); VDB_RA(ya3, pa, 3, 3); VDB_WB(2); VDB_FENCE();
+        VDB_MM(xa3, xb0, 0, 3); VDB_WA(3); VDB_FENCE();
+        VDB_MM(xa3, xb1, 1, 3); VDB_WB(3); VDB_FENCE();
         // The step's only barrier: everyone has read this stage (chunk 3 is in registers) and
         // written the other one.  Chunk 3 is multiplied behind it while the step after next is
         // fetched and the first fragments of the coming step travel into set X.
@@ -202,14 +212,14 @@ __global__ __launch_bounds__(WNT, 1) void flat_queue_wide_kernel(QueueParams p) 
             const char* bbase = qbase_ptr + lk * TKB;
 #pragma unroll
             for (int ps = 0; ps < 4; ++ps) { asm("" : "+v"(offa[ps])); asm("" : "+v"(offb[ps])); }   // keep the lane offsets 32 bits wide
-            VDB_MM(ya0, yb0, 0, 0); VDB_RB(xb0, nb, 0, 0); ra0 = *reinterpret_cast<const float4*>(abase + offa[0]); VDB_FENCE();
-            VDB_MM(ya0, yb1, 1, 0); VDB_RB(xb1, nb, 0, 1); rb0 = *reinterpret_cast<const float4*>(bbase + offb[0]); VDB_FENCE();
-            VDB_MM(ya1, yb0, 0, 1); VDB_RA(xa0, na, 0, 0); ra1 = *reinterpret_cast<const float4*>(abase + offa[1]); VDB_FENCE();
-            VDB_MM(ya1, yb1, 1, 1); VDB_RA(xa1, na, 0, 1); rb1 = *reinterpret_cast<const float4*>(bbase + offb[1]); VDB_FENCE();
-            VDB_MM(ya2, yb0, 0, 2); VDB_RA(xa2, na, 0, 2); ra2 = *reinterpret_cast<const float4*>(abase + offa[2]); VDB_FENCE();
-            VDB_MM(ya2, yb1, 1, 2); VDB_RA(xa3, na, 0, 3); rb2 = *reinterpret_cast<const float4*>(bbase + offb[2]); VDB_FENCE();
-            VDB_MM(ya3, yb0, 0, 3); ra3 = *reinterpret_cast<const float4*>(abase + offa[3]); VDB_FENCE();
-            VDB_MM(ya3, yb1, 1, 3); rb3 = *reinterpret_cast<const float4*>(bbase + offb[3]); VDB_FENCE();
+            VDB_MM(ya0, yb0, 0, 0); VDB_RB(xb0, nb, 0, 0); VDB_GA(0); VDB_FENCE();
+            VDB_MM(ya0, yb1, 1, 0); VDB_RB(xb1, nb, 0, 1); VDB_GB(0); VDB_FENCE();
+            VDB_MM(ya1, yb0, 0, 1); VDB_RA(xa0, na, 0, 0); VDB_GA(1); VDB_FENCE();
+            VDB_MM(ya1, yb1, 1, 1); VDB_RA(xa1, na, 0, 1); VDB_GB(1); VDB_FENCE();
+            VDB_MM(ya2, yb0, 0, 2); VDB_RA(xa2, na, 0, 2); VDB_GA(2); VDB_FENCE();
+            VDB_MM(ya2, yb1, 1, 2); VDB_RA(xa3, na, 0, 3); VDB_GB(2); VDB_FENCE();
+            VDB_MM(ya3, yb0, 0, 3); VDB_GA(3); VDB_FENCE();
+            VDB_MM(ya3, yb1, 1, 3); VDB_GB(3); VDB_FENCE();
             if (++lk == ksteps) { lk = 0; ++lt; }
         }
         if (ck == ksteps - 1) {
@@ -242,6 +252,10 @@ __global__ __launch_bounds__(WNT, 1) void flat_queue_wide_kernel(QueueParams p) 
 #undef VDB_MM
 #undef VDB_RA
 #undef VDB_RB
+#undef VDB_WA
+#undef VDB_WB
+#undef VDB_GA
+#undef VDB_GB
 
     if (tid < WQ && q_base + tid < p.nq) p.counts[(q_base + tid) * p.n_slabs + slab] = Cnt[tid];
 }
