@@ -131,7 +131,10 @@ template <int PER_STAGE> __device__ __forceinline__ void wait_loads(int stages_b
 // the chunk against the G/QS queries of set (t >> 8).  More than one set keeps two or
 // more waves on every SIMD, so one wave's scalar work and waits hide behind another's
 // arithmetic.
-template <int OP, int G, int QS>
+// WHOLE: every leaf of the plan is a whole number of stages (dimensions such as 128, 256, 384,
+// 768, 1024): the group-by-group path for leaf ends inside a stage is compiled out, and with it
+// the register copies where the two paths meet.
+template <int OP, int G, int QS, bool WHOLE>
 __global__ __launch_bounds__(S_NT * QS) void stream_sums_kernel(const StreamParams p) {
     extern __shared__ __align__(16) float smem[];
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -280,7 +283,7 @@ __global__ __launch_bounds__(S_NT * QS) void stream_sums_kernel(const StreamPara
 
         const int col0 = c_ks * S_CK;
         if (p.diag & 2) {
-        } else if (L - in_leaf >= S_CK) {
+        } else if (WHOLE || L - in_leaf >= S_CK) {
             // the whole stage lies inside one leaf: four full groups of 8, no control flow
 #pragma unroll
             for (int unit = 0; unit < (S_CK / 8) * U; ++unit) {
@@ -305,7 +308,7 @@ __global__ __launch_bounds__(S_NT * QS) void stream_sums_kernel(const StreamPara
                 for (int g = 0; g < GT; ++g) res[g] = s_tree2<OP>(acc[g]);
                 end_leaf();
             }
-        } else {
+        } else if constexpr (!WHOLE) {
             // a leaf ends inside the stage, or the dimension does: group by group (rare, kept simple)
 #pragma unroll
             for (int grp = 0; grp < S_CK / 8; ++grp) {
@@ -395,10 +398,13 @@ int launch_stream_sums(const StreamJob& j, hipStream_t s) {
     static const int diag = getenv("VDB_STREAM_DIAG") ? atoi(getenv("VDB_STREAM_DIAG")) : 0;
     p.diag = diag;
     const int grid = ctx().num_cus * blocks_per_cu;   // blocks past the item count leave at once
+    static const bool no_whole = getenv("VDB_NO_WHOLE") != nullptr;
+    bool whole = !no_whole && j.dim == j.ld;
+    for (int i = 0; i < j.plan.n_leaves; ++i) whole = whole && j.plan.leaf_len[i] % S_CK == 0;
     KernelTimer timer(s, j.timed);
 #define VDB_LAUNCH_STREAM(O, GG, QQ)                                                            \
     {                                                                                            \
-        auto kern = stream_sums_kernel<O, GG, QQ>;                                               \
+        auto kern = whole ? stream_sums_kernel<O, GG, QQ, true> : stream_sums_kernel<O, GG, QQ, false>; \
         VDB_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern),                         \
                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));      \
         hipLaunchKernelGGL(kern, dim3(grid), dim3(S_NT * QQ), lds, s, p);                        \
