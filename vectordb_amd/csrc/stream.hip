@@ -147,7 +147,11 @@ __global__ __launch_bounds__(S_NT * QS) void stream_sums_kernel(const StreamPara
     constexpr int ROW_GLDS = 32 / NW;             // row LDS-DMA instructions per wave and stage
     constexpr int PER_STAGE = ROW_GLDS + 1;
     constexpr int SLOT = S_STAGE + G * S_CK;      // floats per stage slot: 256 row pieces, then the G query pieces
-    const int g_first = __builtin_amdgcn_readfirstlane(tid >> 8) * GT;
+    const int qset = __builtin_amdgcn_readfirstlane(tid >> 8);
+    const int g_first = qset * GT;                // this thread's slots of the pending-sum stack
+    // The group's queries are dealt to the wave sets unit by unit (H at a time), so a group that
+    // is only partly filled keeps every set busy: local query g is group query gq(g).
+    auto gq = [&](int g) { return ((g / H) * QS + qset) * H + (g % H); };
     float* St = smem + nbuf * SLOT;               // [depth][G][256] pending partial sums (more than one leaf only)
 
     const int ksteps = (p.ld + S_CK - 1) / S_CK;
@@ -263,7 +267,7 @@ __global__ __launch_bounds__(S_NT * QS) void stream_sums_kernel(const StreamPara
         }
 
         const float* xb = smem + c_buf * SLOT + row * S_CK;
-        const float* qb = smem + c_buf * SLOT + S_STAGE + g_first * S_CK;
+        const float* qb = smem + c_buf * SLOT + S_STAGE;
         if (++c_buf == nbuf) c_buf = 0;
         float4 xv[8];
 #pragma unroll
@@ -272,7 +276,7 @@ __global__ __launch_bounds__(S_NT * QS) void stream_sums_kernel(const StreamPara
         // the stage's query values, fetched one unit (8 floats of H queries) ahead of their use
         float4 qv[2][H][2];
         auto load_q = [&](int buf, int unit) {
-            const float* src = qb + (unit % U) * H * S_CK + (unit / U) * 8;
+            const float* src = qb + gq((unit % U) * H) * S_CK + (unit / U) * 8;
 #pragma unroll
             for (int h = 0; h < H; ++h) {
                 qv[buf][h][0] = *reinterpret_cast<const float4*>(src + h * S_CK);
@@ -289,7 +293,7 @@ __global__ __launch_bounds__(S_NT * QS) void stream_sums_kernel(const StreamPara
             for (int unit = 0; unit < (S_CK / 8) * U; ++unit) {
                 const int grp = unit / U, g0 = (unit % U) * H;
                 if (unit + 1 < (S_CK / 8) * U) load_q((unit + 1) & 1, unit + 1);
-                if (g_first + g0 < c_it.qcnt) {         // units whose queries are all padding do no arithmetic
+                if (gq(g0) < c_it.qcnt) {               // units whose queries are all padding do no arithmetic
                     const f2 x2[4] = {f2{xv[2 * grp].x, xv[2 * grp].y}, f2{xv[2 * grp].z, xv[2 * grp].w},
                                       f2{xv[2 * grp + 1].x, xv[2 * grp + 1].y}, f2{xv[2 * grp + 1].z, xv[2 * grp + 1].w}};
 #pragma unroll
@@ -319,8 +323,8 @@ __global__ __launch_bounds__(S_NT * QS) void stream_sums_kernel(const StreamPara
                     const int cnt = min(8, L - in_leaf);
 #pragma unroll
                     for (int g = 0; g < GT; ++g) {
-                        const float4 qa = *reinterpret_cast<const float4*>(qb + g * S_CK + grp * 8);
-                        const float4 qc = *reinterpret_cast<const float4*>(qb + g * S_CK + grp * 8 + 4);
+                        const float4 qa = *reinterpret_cast<const float4*>(qb + gq(g) * S_CK + grp * 8);
+                        const float4 qc = *reinterpret_cast<const float4*>(qb + gq(g) * S_CK + grp * 8 + 4);
                         if (cnt == 8) {
                             const f2 q2[4] = {f2{qa.x, qa.y}, f2{qa.z, qa.w}, f2{qc.x, qc.y}, f2{qc.z, qc.w}};
 #pragma unroll
@@ -350,11 +354,11 @@ __global__ __launch_bounds__(S_NT * QS) void stream_sums_kernel(const StreamPara
             const bool live = row < c_it.rows;
 #pragma unroll
             for (int g = 0; g < GT; ++g) {
-                if (g_first + g < c_it.qcnt) {
+                if (gq(g) < c_it.qcnt) {
                     float v = one_leaf ? res[g] : St[(g_first + g) * S_NT + row];
                     if (p.post == POST_SQRT) v = sqrtf(v);
                     else if (p.post == POST_NEG) v = -v;
-                    const int64_t ob = uload(p.sq_out + c_it.qbeg + g_first + g);
+                    const int64_t ob = uload(p.sq_out + c_it.qbeg + gq(g));
                     if (live) p.out[ob + chunk_off] = v;
                 }
             }
