@@ -670,6 +670,11 @@ static constexpr int CAND_WAVES = LIST_NT / 64;   // candidate lists one block w
 static constexpr int CAND_UNROLL = 4;       // tiles whose loads are in flight together
 static constexpr int RUN_CHUNK = 256;      // probed lists whose ranges are staged in LDS at a time
 
+// FIN: how a candidate value becomes a distance, fixed per launch so that the row terms of the
+// CAND_UNROLL tiles are fetched together instead of one dependent load per tile:
+// 0 = the value is the distance (direct forms, Manhattan, Chebyshev, negated dot), 1 = the Euclidean
+// identity form, 2 = cosine of the matrix form, 3 = cosine of the pair form.
+template <int FIN>
 __global__ __launch_bounds__(LIST_NT) void topk_cand_kernel(CandParams p) {
     extern __shared__ __align__(16) float smem[];
     int64_t* R_pos0 = reinterpret_cast<int64_t*>(smem);         // first stored row of the run
@@ -737,11 +742,32 @@ __global__ __launch_bounds__(LIST_NT) void topk_cand_kernel(CandParams p) {
 #pragma unroll
             for (int u = 0; u < CAND_UNROLL; ++u) {
                 raw[u] = ok[u] ? cq[slot[u]] : 0.0f;
-                rown[u] = (ok[u] && p.row_ids) ? p.row_ids[pos[u]] : (int)pos[u];
+                rown[u] = (ok[u] && p.row_ids && p.mask) ? p.row_ids[pos[u]] : (int)pos[u];   // row numbers serve the filter only
+            }
+            float rt[CAND_UNROLL];
+#pragma unroll
+            for (int u = 0; u < CAND_UNROLL; ++u) {
+                rt[u] = 1.0f;
+                if (FIN == 1 && ok[u]) rt[u] = p.fin.row_sq[pos[u]];
+                if (FIN >= 2 && ok[u]) rt[u] = p.fin.row_nrm[pos[u]];
             }
             float d[CAND_UNROLL];
 #pragma unroll
-            for (int u = 0; u < CAND_UNROLL; ++u) d[u] = ok[u] ? finish_value(p.fin, raw[u], q_sq, q_nrm, pos[u]) : INFINITY;
+            for (int u = 0; u < CAND_UNROLL; ++u) {
+                float v = raw[u];
+                if (FIN == 1) {
+                    const float sq = fmaxf(__fmaf_rn(-2.0f, v, q_sq + rt[u]), 0.0f);            // metrics.py:456-462
+                    v = p.fin.metric == VDB_EUCLIDEAN ? sqrtf(sq) : sq;
+                } else if (FIN == 2) {
+                    const float cn = rt[u] < 1e-8f ? 1.0f : rt[u];                              // metrics.py:476
+                    const float sim = fminf(fmaxf(v / (q_nrm * cn), -1.0f), 1.0f);
+                    v = q_nrm < 1e-8f ? 1.0f : 1.0f - sim;                                      // metrics.py:472-473
+                } else if (FIN == 3) {
+                    const float den = q_nrm * rt[u];                                            // metrics.py:96-100
+                    v = 1.0f - (den < 1e-8f ? 0.0f : v / den);
+                }
+                d[u] = ok[u] ? v : INFINITY;
+            }
             if (p.mask) {
 #pragma unroll
                 for (int u = 0; u < CAND_UNROLL; ++u)
@@ -774,9 +800,11 @@ int launch_topk_cand(const CandJob& j, hipStream_t s) {
     VDB_REQUIRE(j.probes == nullptr || (j.cand_off && j.tile_off), "list candidates need their slot and tile offsets");
     p.cand_off = j.cand_off; p.tile_off = j.tile_off;
     const size_t lds = (size_t)RUN_CHUNK * 24 + 8;
-    VDB_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(topk_cand_kernel),
-                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    hipLaunchKernelGGL(topk_cand_kernel, dim3(j.nq, j.splits), dim3(LIST_NT), lds, s, p);
+    const int fin = (j.metric == VDB_EUCLIDEAN || j.metric == VDB_EUCLIDEAN_SQ) ? 1
+                    : j.metric == VDB_COSINE ? 2 : j.metric == VDB_COSINE_PAIR ? 3 : 0;
+    auto kern = fin == 1 ? topk_cand_kernel<1> : fin == 2 ? topk_cand_kernel<2> : fin == 3 ? topk_cand_kernel<3> : topk_cand_kernel<0>;
+    VDB_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    hipLaunchKernelGGL(kern, dim3(j.nq, j.splits), dim3(LIST_NT), lds, s, p);
     VDB_HIP(hipGetLastError());
     return VDB_OK;
 }
