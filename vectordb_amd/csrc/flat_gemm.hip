@@ -43,8 +43,6 @@ struct GemmParams {
     float* part_d; int* part_i; int n_cand;
     float* dist_out;
     const int* run_if;              // optional device flag: the launch does nothing while it is zero
-    int diag;                       // timing experiments only (env VDB_DIAG, results are wrong when set): 1 no epilogue,
-                                    // 2 no exact/insert stage, 4 no row terms, 8 no staging loads, 16 no LDS staging, 32 one block per CU
 };
 
 // SAMPLE only gives the strided warm-up pass a kernel name of its own, so that
@@ -163,27 +161,23 @@ __global__ __launch_bounds__(NT, 2) void flat_gemm_kernel(GemmParams p) {
             for (int e = 0; e < 16; ++e) acc[s][e] = 0.0f;
 
         for (int ks = 0; ks < ksteps; ++ks) {
-            if (!(p.diag & 16)) __syncthreads();            // everyone is done reading the previous step (and Rs)
-            if (!(p.diag & 16)) {
+            __syncthreads();            // everyone is done reading the previous step (and Rs)
 #pragma unroll
             for (int ps = 0; ps < 4; ++ps) {
                 const int r = ps * 32 + srow;
                 *reinterpret_cast<float4*>(As + r * LW + skc) = ra[ps];
                 *reinterpret_cast<float4*>(Bs + r * LW + skc) = rb[ps];
             }
-            }
-            if (ks == 0 && METRIC != VDB_DOT && tid < TM && !(p.diag & 4)) {
+            if (ks == 0 && METRIC != VDB_DOT && tid < TM) {
                 const int64_t gr = min(rbase + tid, p.n - 1);
                 float t = (METRIC == VDB_COSINE) ? p.row_nrm[gr] : p.row_sq[gr];
                 if (METRIC == VDB_COSINE && t < 1e-8f) t = 1.0f;    // metrics.py:476
                 Rs[tid] = t;
             }
-            if (!(p.diag & 16)) __syncthreads();
+            __syncthreads();
             // prefetch the next step (possibly of the next tile) while computing
-            if (!(p.diag & 8)) {
-                if (ks + 1 < ksteps) issue_loads(tile, ks + 1);
-                else if (tile + 1 < tile1) issue_loads(tile + 1, 0);
-            }
+            if (ks + 1 < ksteps) issue_loads(tile, ks + 1);
+            else if (tile + 1 < tile1) issue_loads(tile + 1, 0);
 
             // all fragment reads of this K step go out first; the MFMAs then start as
             // soon as their own operands have landed while the rest are still in flight
@@ -216,10 +210,7 @@ __global__ __launch_bounds__(NT, 2) void flat_gemm_kernel(GemmParams p) {
         }
 
         // ---- epilogue: lane owns query `my_q`, rows rbase + 32s + 8g + 4*half + j
-        if (TOPK && (p.diag & 1)) {
-#pragma unroll
-            for (int s = 0; s < 4; ++s) asm volatile("" ::"v"(acc[s]));
-        } else if (TOPK) {
+        if (TOPK) {
             const bool tail = rbase + TM > p.n;
             const bool masked = tail || p.mask != nullptr;
 #pragma unroll
@@ -251,7 +242,7 @@ __global__ __launch_bounds__(NT, 2) void flat_gemm_kernel(GemmParams p) {
                     }
                 }
                 // exact distance and insertion, only for the values that passed
-                if (hits && !(p.diag & 2)) {
+                if (hits) {
                     float* ld = Ld + tid;
                     int* li = Li + tid;
                     do {
@@ -343,10 +334,7 @@ static int launch_gemm(int metric, GemmParams& p, hipStream_t s) {
     plan_grid(p.n_tiles, p.nq, ctx().num_cus, &p.n_qtiles, &p.n_slabs, &p.tiles_per_slab);
     const int groups = (p.n_slabs + 7) / 8;
     const dim3 grid(p.n_slabs >= 8 ? groups * 8 * p.n_qtiles : p.n_slabs * p.n_qtiles);
-    static const int diag = getenv("VDB_DIAG") ? atoi(getenv("VDB_DIAG")) : 0;
-    p.diag = diag;
-    size_t lds = (size_t)(2 * TM * LW + TM) * sizeof(float) + (TOPK ? (size_t)p.k * NT * 8 : 0);
-    if (diag & 32) lds = 100 * 1024;       // one block per CU
+    const size_t lds = (size_t)(2 * TM * LW + TM) * sizeof(float) + (TOPK ? (size_t)p.k * NT * 8 : 0);
     KernelTimer timer(s, p.tile_stride == 1 && p.run_if == nullptr);
 #define VDB_LAUNCH_GEMM(M)                                                                     \
     case M: {                                                                                  \

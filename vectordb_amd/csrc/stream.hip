@@ -45,7 +45,6 @@ struct StreamParams {
     int n_leaves; int leaf_len[SumPlan::MAX_LEAVES]; int folds[SumPlan::MAX_LEAVES];   // SumPlan, dword fields (scalar loads)
     int post;                         // StreamPost applied to the sum before it is stored
     int nbuf;                         // stage buffers in LDS
-    int diag;                         // timing experiments: 1 = no loads, 2 = no arithmetic
     const float* q; int ldq;
     const float* zeros;               // >= 16 zero bytes, source of the columns past ld
     int n_seg;
@@ -258,7 +257,7 @@ __global__ __launch_bounds__(S_NT * QS) void stream_sums_kernel(const StreamPara
     for (int n = 0; n < n_stages; ++n) {
         wait_loads<PER_STAGE>(pn - n - 1);
         __builtin_amdgcn_s_barrier();
-        if (pn < n_stages) { if (p.diag & 1) ++pn; else issue(); }
+        if (pn < n_stages) issue();
 
         if (c_ks == 0) {
             c_it = load_item(p, c_item);
@@ -286,8 +285,7 @@ __global__ __launch_bounds__(S_NT * QS) void stream_sums_kernel(const StreamPara
         load_q(0, 0);
 
         const int col0 = c_ks * S_CK;
-        if (p.diag & 2) {
-        } else if (WHOLE || L - in_leaf >= S_CK) {
+        if (WHOLE || L - in_leaf >= S_CK) {
             // the whole stage lies inside one leaf: four full groups of 8, no control flow
 #pragma unroll
             for (int unit = 0; unit < (S_CK / 8) * U; ++unit) {
@@ -399,8 +397,6 @@ int launch_stream_sums(const StreamJob& j, hipStream_t s) {
     p.nbuf = (int)std::max<size_t>(2, std::min<size_t>(want_nbuf, (budget - stack) / slot));
     const size_t lds = (size_t)p.nbuf * slot + stack;
     const int blocks_per_cu = (int)std::max<size_t>(1, std::min<size_t>(2, budget / lds));
-    static const int diag = getenv("VDB_STREAM_DIAG") ? atoi(getenv("VDB_STREAM_DIAG")) : 0;
-    p.diag = diag;
     const int grid = ctx().num_cus * blocks_per_cu;   // blocks past the item count leave at once
     static const bool no_whole = getenv("VDB_NO_WHOLE") != nullptr;
     bool whole = !no_whole && j.dim == j.ld;
