@@ -135,3 +135,50 @@ def test_queue_search_bf16_storage(nat):
             atol = ids_atol(metric, qr[i], xr, float(ref_dist[-1]))
             assert same_ids_or_near_ties(rows[i], ref_rows, lambda r: full[r], float(ref_dist[-1]), rtol=RTOL, atol=atol)
             assert_close(metric, dist[i], ref_dist, qr[i], xr)
+
+
+def test_queue_search_more_queries_than_one_block(nat):
+    """1030 queries: the library walks them in blocks of 1024 (bound pass per block, then queue pass
+    per block, one overflow flag for all).  The ragged second block returns what a small batch of
+    the same queries returns, bit for bit, and the first block matches the oracle."""
+    rng = np.random.default_rng(21)
+    n, d = N_MIN + 300, 32
+    x = rng.standard_normal((n, d), dtype=np.float32)
+    q = rng.standard_normal((1030, d), dtype=np.float32)
+    for metric in ("cosine", "euclidean"):
+        d_all, r_all, stats = search_and_stats(nat, x, q, 10, metric)
+        assert stats == (True, False)
+        d_tail, r_tail, _ = search_and_stats(nat, x, q[1020:1030], 10, metric)
+        np.testing.assert_array_equal(r_all[1020:1030], r_tail)
+        np.testing.assert_array_equal(d_all[1020:1030], d_tail)
+        d_mid, r_mid, _ = search_and_stats(nat, x, q[500:520], 10, metric)
+        np.testing.assert_array_equal(r_all[500:520], r_mid)
+        np.testing.assert_array_equal(d_all[500:520], d_mid)
+        for i in (0, 777, 1023, 1024, 1029):
+            ref_rows, ref_dist = R.flat_search(q[i], x, 10, metric)
+            full = R.query_distances(q[i], x, metric)
+            atol = ids_atol(metric, q[i], x, float(ref_dist[-1]))
+            assert same_ids_or_near_ties(r_all[i], ref_rows, lambda r: full[r], float(ref_dist[-1]), rtol=RTOL, atol=atol)
+            assert_close(metric, d_all[i], ref_dist, q[i], x)
+
+
+def test_queue_search_bf16_two_query_tiles(nat):
+    """bf16 rows, 300 queries: the 256 x 256 kernel with a ragged second query tile and a ragged
+    last row tile; queries 256.. return what a batch of their own returns."""
+    rng = np.random.default_rng(22)
+    n, d = N_MIN + 131, 64
+    x = rng.standard_normal((n, d), dtype=np.float32)
+    q = rng.standard_normal((300, d), dtype=np.float32)
+    xr, qr = _bf16_round(x), _bf16_round(q)
+    for metric in ("dot", "cosine"):
+        d_all, r_all, stats = search_and_stats(nat, x, q, 10, metric, storage="bf16")
+        assert stats == (True, False)
+        d_tail, r_tail, _ = search_and_stats(nat, x, q[256:300], 10, metric, storage="bf16")
+        np.testing.assert_array_equal(r_all[256:300], r_tail)
+        np.testing.assert_array_equal(d_all[256:300], d_tail)
+        for i in (0, 255, 256, 299):
+            ref_rows, ref_dist = R.flat_search(qr[i], xr, 10, metric)
+            full = R.query_distances(qr[i], xr, metric)
+            atol = ids_atol(metric, qr[i], xr, float(ref_dist[-1]))
+            assert same_ids_or_near_ties(r_all[i], ref_rows, lambda r: full[r], float(ref_dist[-1]), rtol=RTOL, atol=atol)
+            assert_close(metric, d_all[i], ref_dist, qr[i], xr)
