@@ -752,3 +752,40 @@ def test_ivfpq_vs_oracle_batch(nat):
             np.testing.assert_array_equal(rows[i], ref_rows)
             np.testing.assert_array_equal(dist[i], ref_dist)
     h.close()
+
+
+def test_sharded_merge_with_short_shards(nat):
+    """Shards holding fewer rows than k: their lists end in empty entries (row -1), which the
+    packed merge skips before it adds the shard's first global row."""
+    import torch
+    from vectordb_amd.sharded import HipFlatBackend, ShardedFlat, shard_range
+    rng = np.random.RandomState(3)
+    shards, k, d = 8, 10, 16
+    x = rng.randn(25, d).astype(np.float32)
+    x[24] = x[2]                                    # a tie between the first and the last shard
+    q = rng.randn(5, d).astype(np.float32)
+    q[0] = x[2]
+    dev = torch.device("cuda", 0)
+    tq = torch.from_numpy(q).to(dev)
+    blocks = []
+    for r in range(shards):
+        lo, hi = shard_range(len(x), shards, r)
+        be = HipFlatBackend(d, nat.MANHATTAN)
+        be.add_device(torch.from_numpy(x[lo:hi]).to(dev))
+        as_rank = ShardedFlat(be, len(x), r, shards)
+        local, gathered, ld, lr, gd, gr, base, od, orow = as_rank._buffers(len(q), k, dev)
+        be.local_search(tq, k, ld, lr)
+        torch.cuda.synchronize()
+        assert int((lr >= 0).sum()) == len(q) * (hi - lo)
+        blocks.append(local.clone())
+        be.store.close()
+    gathered.copy_(torch.cat(blocks))
+    HipFlatBackend.merge(be, gd, gr, k, od, orow, base)
+    torch.cuda.synchronize()
+    single = nat.RowStore(d)
+    single.append(x)
+    sd, sr = single.search(q, k, nat.MANHATTAN)
+    single.close()
+    np.testing.assert_array_equal(orow.cpu().numpy(), sr)
+    np.testing.assert_array_equal(od.cpu().numpy(), sd)
+    assert list(orow[0, :2].cpu().numpy()) == [2, 24]
