@@ -182,3 +182,29 @@ def test_queue_search_bf16_two_query_tiles(nat):
             atol = ids_atol(metric, qr[i], xr, float(ref_dist[-1]))
             assert same_ids_or_near_ties(r_all[i], ref_rows, lambda r: full[r], float(ref_dist[-1]), rtol=RTOL, atol=atol)
             assert_close(metric, d_all[i], ref_dist, qr[i], xr)
+
+
+@pytest.mark.parametrize("metric", ["cosine", "euclidean", "dot"])
+def test_queue_search_zero_and_tiny_vectors(nat, metric):
+    """Zero and near-zero rows and queries in a row set large enough for the queue path: the
+    norm guards of distance/metrics.py:472-476 (norms under 1e-8 count as 1) decide the cosine
+    distances there, and the conservative filter must not lose such rows."""
+    rng = np.random.default_rng(31)
+    n, d = N_MIN + 17, 32
+    x = rng.standard_normal((n, d), dtype=np.float32)
+    x[[3, 40000, n - 1]] = 0.0
+    x[[7, 50001]] = (1e-10 * rng.standard_normal((2, d))).astype(np.float32)
+    x[[9, 60000]] *= 1e3
+    q = rng.standard_normal((8, d), dtype=np.float32)
+    q[1] = 0.0
+    q[2] = (1e-10 * rng.standard_normal(d)).astype(np.float32)
+    q[3] *= 1e3
+    q[4] = x[9]
+    dist, rows, stats = search_and_stats(nat, x, q, 10, metric)
+    assert stats[0]
+    for i in range(len(q)):
+        ref_rows, ref_dist = R.flat_search(q[i], x, 10, metric)
+        full = R.query_distances(q[i], x, metric)
+        atol = ids_atol(metric, q[i], x, float(ref_dist[-1]))
+        assert same_ids_or_near_ties(rows[i], ref_rows, lambda r: full[r], float(ref_dist[-1]), rtol=RTOL, atol=atol), (metric, i)
+        assert_close(metric, dist[i], ref_dist, q[i], x)
