@@ -911,6 +911,7 @@ __global__ __launch_bounds__(256) void group_norms_kernel(const float* __restric
         } else {
             float r = x[off + j] * x[off + j];
             int i = 8;
+#pragma unroll 4
             for (; i + 8 <= len; i += 8) {
                 const float v = x[off + i + j];
                 r = r + v * v;
