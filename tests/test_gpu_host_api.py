@@ -674,3 +674,43 @@ def test_index_files_round_trip(tmp_path):
     assert not empty.is_trained() and len(empty) == 0
     with pytest.raises(TypeError):
         save_index(object(), str(tmp_path / "x"))
+
+
+def test_flat_find_duplicates_and_sample():
+    """index/flat.py:903-956, the cases of the reference's unit tests: an exact copy is the only pair
+    under 1e-5; pairs come out with i < j in insertion order; sample(n, seed) draws through NumPy's
+    global generator, so the same seed gives the reference's choice of rows."""
+    from vectordb_amd.index import FlatIndex
+    rng = np.random.RandomState(4)
+    for metric in ("euclidean", "cosine", "manhattan"):
+        ix = FlatIndex(dimension=10, metric=metric)
+        v1 = rng.randn(10).astype(np.float32)
+        ix.add("vec1", v1)
+        ix.add("vec2", v1.copy())
+        ix.add("vec3", rng.randn(10).astype(np.float32))
+        dup = ix.find_duplicates(threshold=1e-5)
+        assert [(a, b) for a, b, _ in dup] == [("vec1", "vec2")], metric
+        assert dup[0][2] <= 1e-5
+    # near-duplicates under a larger threshold, against the oracle's pair distances
+    ix = FlatIndex(dimension=24, metric="euclidean")
+    x = rng.randn(300, 24).astype(np.float32)
+    x[100] = x[7] + 1e-3
+    x[200] = x[7]
+    x[250] = x[100]
+    ix.add_batch([f"id{i}" for i in range(300)], x)
+    dup = ix.find_duplicates(threshold=0.05)
+    assert [(a, b) for a, b, _ in dup] == [("id7", "id100"), ("id7", "id200"), ("id7", "id250"), ("id100", "id200"),
+                                           ("id100", "id250"), ("id200", "id250")]
+    for a, b, d in dup:
+        i, j = int(a[2:]), int(b[2:])
+        assert abs(d - float(np.sqrt(np.sum((x[i] - x[j]) ** 2)))) <= 1e-6
+    assert FlatIndex(dimension=4).find_duplicates() == []
+
+    s1 = ix.sample(5, seed=42)
+    np.random.seed(42)
+    want = np.random.choice(300, 5, replace=False)
+    assert [id for id, _, _ in s1] == [f"id{i}" for i in want]
+    for (id, vec, meta), i in zip(s1, want):
+        np.testing.assert_array_equal(vec, x[i])
+        assert meta == {}
+    assert len(ix.sample(1000)) == 300

@@ -318,6 +318,40 @@ class FlatIndex(BaseIndex):
             return np.zeros((0, 0), dtype=np.float32)
         return self._device().distances(self._vectors[:self._size], self._metric_code())
 
+    def find_duplicates(self, threshold: float = 1e-6) -> List[Tuple[str, str, float]]:
+        """index/flat.py:903-930: pairs (id_i, id_j, distance), i < j in insertion order, whose distance is
+        at most `threshold`.  The reference asks query_distances for every pair; here blocks of rows go
+        through the device's distance kernels against all rows.  Euclidean pairs are taken in the direct
+        form sum((a-b)^2), which is exactly 0 for identical rows (the identity form the reference uses
+        there cancels to rounding noise around sqrt(eps)*|a|; away from the threshold both agree to 1e-4)."""
+        out: List[Tuple[str, str, float]] = []
+        n = self._size
+        if n < 2:
+            return out
+        code = self._metric_code()
+        if code == N.EUCLIDEAN:
+            code = N.EUCLIDEAN_DIRECT
+        elif code == N.EUCLIDEAN_SQ:
+            code = N.EUCLIDEAN_SQ_DIRECT
+        store = self._device()
+        block = max(1, min(n, (64 << 20) // (4 * n)))                 # at most 64 MB of distances at a time
+        for i0 in range(0, n, block):
+            d = store.distances(self._vectors[i0:min(i0 + block, n)], code)
+            ii, jj = np.nonzero(d <= threshold)
+            keep = jj > ii + i0
+            for a, b in zip(ii[keep], jj[keep]):                       # row-major: i ascending, then j ascending
+                out.append((self._ids[i0 + int(a)], self._ids[int(b)], float(d[a, b])))
+        return out
+
+    def sample(self, n: int, seed: Optional[int] = None) -> List[Tuple[str, np.ndarray, Dict[str, Any]]]:
+        """index/flat.py:932-956: n rows drawn without replacement through NumPy's global generator
+        (seeded when `seed` is given), as (id, vector, metadata)."""
+        if seed is not None:
+            np.random.seed(seed)
+        n = min(n, self._size)
+        indices = np.random.choice(self._size, n, replace=False)
+        return [(self._ids[i], self._vectors[i].copy(), self._metadata.get(self._ids[i], {})) for i in indices]
+
     def __del__(self):
         store = getattr(self, "_store", None)
         if store is not None:
