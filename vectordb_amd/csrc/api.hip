@@ -5,6 +5,7 @@
 
 #include <algorithm>
 #include <cstdarg>
+#include <cstring>
 #include <functional>
 #include <limits>
 #include <numeric>
@@ -160,7 +161,27 @@ static int fill_results(float* d, int64_t* i, int64_t total, hipStream_t s) {
 }
 
 // ============================================================== workspaces
+// page-locked host memory: copies to and from it are asynchronous and need no staging by the runtime
+struct PinBuf {
+    void* p = nullptr;
+    size_t cap = 0;
+    int reserve(size_t bytes) {
+        if (bytes <= cap) return VDB_OK;
+        release();
+        const size_t want = std::max<size_t>(bytes, 64 * 1024);
+        VDB_HIP(hipHostMalloc(&p, want, hipHostMallocDefault));
+        cap = want;
+        return VDB_OK;
+    }
+    void release() {
+        if (p) (void)hipHostFree(p);
+        p = nullptr; cap = 0;
+    }
+    template <class T> T* as() const { return reinterpret_cast<T*>(p); }
+};
+
 struct Workspace {
+    PinBuf pin_in, pin_out;             // host ends of the small transfers of the host-pointer entry points
     DevBuf q_buf, q_sq, q_nrm, part_d, part_i, lb_d, lb_k, thr_d, thr_k, mask, out_d, out_i, dist, probes, probe_d, lut, stage;
     DevBuf queue, queue_cnt, flag, mins;
     // item table of the last flat scan, kept between calls: it depends on (rows, queries, group) only
@@ -175,6 +196,7 @@ struct Workspace {
                          &fp_seg_row_off, &fp_seg_q_off, &fp_seg_item_off, &fp_sq_qid, &fp_sq_out, &fp_items};
         fp_n = -1;
         for (DevBuf* b : all) b->release();
+        pin_in.release(); pin_out.release();
     }
 };
 
@@ -538,18 +560,41 @@ static int upload_mask(Workspace& ws, const uint32_t* mask, int64_t n, const uin
     return VDB_OK;
 }
 
-// host-pointer wrapper: queries up, results down
+// host-pointer wrapper: queries up, results down.  Small transfers (a query or a batch of them, k results
+// each) go through page-locked buffers: one asynchronous copy up, one down (distances and rows lie in one
+// device block), one wait.  Copies straight to pageable memory cost a staging round trip each.
+static const size_t PINNED_IO_MAX = 4u << 20;
+
 template <class F>
 static int with_host_io(Workspace& ws, const float* queries, int nq, int dim, int k, float* out_dist, int64_t* out_row,
                         hipStream_t s, F&& run) {
     if (nq <= 0) return VDB_OK;
-    VDB_TRY(ws.stage.reserve((size_t)nq * dim * sizeof(float)));
-    VDB_TRY(ws.out_d.reserve((size_t)nq * k * sizeof(float)));
-    VDB_TRY(ws.out_i.reserve((size_t)nq * k * sizeof(int64_t)));
-    VDB_HIP(hipMemcpyAsync(ws.stage.p, queries, (size_t)nq * dim * sizeof(float), hipMemcpyHostToDevice, s));
-    VDB_TRY(run(ws.stage.as<float>(), ws.out_d.as<float>(), ws.out_i.as<int64_t>()));
-    if (out_dist) VDB_HIP(hipMemcpyAsync(out_dist, ws.out_d.p, (size_t)nq * k * sizeof(float), hipMemcpyDeviceToHost, s));
-    if (out_row) VDB_HIP(hipMemcpyAsync(out_row, ws.out_i.p, (size_t)nq * k * sizeof(int64_t), hipMemcpyDeviceToHost, s));
+    const size_t q_bytes = (size_t)nq * dim * sizeof(float);
+    const size_t d_bytes = (size_t)nq * k * sizeof(float), d_pad = (d_bytes + 7) / 8 * 8;
+    const size_t i_bytes = (size_t)nq * k * sizeof(int64_t);
+    VDB_TRY(ws.stage.reserve(q_bytes));
+    VDB_TRY(ws.out_d.reserve(d_pad + i_bytes));          // distances, then rows
+    float* dd = ws.out_d.as<float>();
+    int64_t* di = reinterpret_cast<int64_t*>(ws.out_d.as<char>() + d_pad);
+    const bool pinned = q_bytes <= PINNED_IO_MAX && d_pad + i_bytes <= PINNED_IO_MAX;
+    if (pinned) {
+        VDB_TRY(ws.pin_in.reserve(q_bytes));
+        VDB_TRY(ws.pin_out.reserve(d_pad + i_bytes));
+        std::memcpy(ws.pin_in.p, queries, q_bytes);
+        VDB_HIP(hipMemcpyAsync(ws.stage.p, ws.pin_in.p, q_bytes, hipMemcpyHostToDevice, s));
+    } else {
+        VDB_HIP(hipMemcpyAsync(ws.stage.p, queries, q_bytes, hipMemcpyHostToDevice, s));
+    }
+    VDB_TRY(run(ws.stage.as<float>(), dd, di));
+    if (pinned) {
+        if (out_dist || out_row) VDB_HIP(hipMemcpyAsync(ws.pin_out.p, ws.out_d.p, d_pad + i_bytes, hipMemcpyDeviceToHost, s));
+        VDB_HIP(hipStreamSynchronize(s));
+        if (out_dist) std::memcpy(out_dist, ws.pin_out.p, d_bytes);
+        if (out_row) std::memcpy(out_row, ws.pin_out.as<char>() + d_pad, i_bytes);
+        return VDB_OK;
+    }
+    if (out_dist) VDB_HIP(hipMemcpyAsync(out_dist, dd, d_bytes, hipMemcpyDeviceToHost, s));
+    if (out_row) VDB_HIP(hipMemcpyAsync(out_row, di, i_bytes, hipMemcpyDeviceToHost, s));
     VDB_HIP(hipStreamSynchronize(s));
     return VDB_OK;
 }
