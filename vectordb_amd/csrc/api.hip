@@ -1109,7 +1109,10 @@ static int ivf_probe_impl(vdb_ivf* h, const float* q_pad_unused, const float* d_
     (void)q_pad_unused;
     Workspace& ws = h->ws;
     const int cm = scan_metric_of(h->metric);
-    if (n_probe <= KMAX_FUSED) {
+    // a few queries over at most 1024 centroids: one full sort of the distance row in LDS is quicker than
+    // selection plus list merge (0.197 -> 0.179 ms per query at 1024 lists; slower from 4096 lists on)
+    const bool few_small = nq <= 8 && h->n_lists <= 1024;
+    if (n_probe <= KMAX_FUSED && !few_small) {
         VDB_TRY(flat_search_impl(h->centroids, cm, d_q, nq, n_probe, nullptr, d_probe_dist, nullptr, d_probes, s));
     } else {
         VDB_REQUIRE(h->n_lists <= 16384, "n_probe > %d needs n_lists <= 16384", KMAX_FUSED);
