@@ -1639,7 +1639,8 @@ static int ivfpq_search_impl(vdb_ivfpq* h, const float* d_q, int nq, int k, int 
     // coarse ranking: identity-form squared distances to the centroids (hybrid.py:296-300)
     VDB_TRY(ws.probes.reserve((size_t)nq * n_probe * sizeof(int)));
     VDB_TRY(ws.probe_d.reserve((size_t)nq * n_probe * sizeof(float)));
-    if (n_probe <= KMAX_FUSED) {
+    const bool few_small = nq <= 8 && h->n_lists <= 1024;      // as in ivf_probe_impl
+    if (n_probe <= KMAX_FUSED && !few_small) {
         VDB_TRY(flat_search_impl(h->centroids, VDB_EUCLIDEAN_SQ, d_q, nq, n_probe, nullptr, ws.probe_d.as<float>(), nullptr,
                                  ws.probes.as<int>(), s));
     } else {
