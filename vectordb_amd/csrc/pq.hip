@@ -217,7 +217,7 @@ __global__ __launch_bounds__(256) void pq_scan_kernel(PqScanParams p) {
                 if (p.dist_out && ok[u] && q < qcnt) p.dist_out[(int64_t)(q0 + q) * p.n + row] = d;
                 if (k > 0) {
                     const bool above = (d > lbd[q]) || (d == lbd[q] && row > lbk[q]);
-                    best[q].offer(pass && above, d, (int)row, lane);
+                    best[q].template offer<false>(pass && above, d, (int)row, lane);
                 }
             }
         }

@@ -9,6 +9,10 @@ namespace vdb {
 
 static constexpr int LIST_NT = 256;         // threads per block of every kernel that keeps lists
 static constexpr int EMPTY_IDX = 0x7fffffff;
+#ifndef VDB_WAVE_BULK_MIN
+#define VDB_WAVE_BULK_MIN 12
+#endif
+static constexpr int WAVE_BULK_MIN = VDB_WAVE_BULK_MIN;   // candidates in one offer from which the sort-and-merge path is taken
 
 // One LDS-DMA instruction: every lane fetches 16 bytes from its own global address; the
 // wave's 1 KiB lands at lds_dst (a wave-uniform LDS byte address) in lane order.  Written
@@ -47,6 +51,39 @@ __device__ __forceinline__ static void list_init(float* Ld, int* Li, int k, int 
 // lane j holding the j-th smallest (k <= 64; lanes >= k carry spill-over).  The
 // k-th pair is the acceptance bound, so after a warm-up almost every tile of
 // candidates is rejected with one compare and one ballot per wave.
+__device__ __forceinline__ static bool pair_less(float a, int ai, float b, int bi) { return (a < b) || (a == b && ai < bi); }
+
+// The 64 smallest of (the wave's sorted pairs (e, eid), one candidate pair per lane), sorted again: the candidates
+// are sorted across the lanes by a bitonic network, reversed, merged lane by lane (the smaller pair stays) and the
+// resulting bitonic sequence is sorted with six more exchanges.  Pairs are ordered by (distance, id); lanes without
+// a candidate pass (INFINITY, EMPTY_IDX).  Returns this lane's new pair, id in the high word.  Not inlined: it
+// is the rare path of WaveTopK::offer, taken when many lanes bring a candidate at once.
+__device__ __noinline__ static unsigned long long wave_merge_candidates(float e, int eid, float cd, int cid) {
+    const int lane = threadIdx.x & 63;
+#pragma unroll
+    for (int k2 = 2; k2 <= 64; k2 <<= 1) {
+#pragma unroll
+        for (int j = k2 >> 1; j > 0; j >>= 1) {
+            const float pd = __shfl_xor(cd, j);
+            const int pid = __shfl_xor(cid, j);
+            const bool keep_min = ((lane & k2) == 0) == ((lane & j) == 0);
+            const bool take = keep_min ? pair_less(pd, pid, cd, cid) : pair_less(cd, cid, pd, pid);
+            if (take) { cd = pd; cid = pid; }
+        }
+    }
+    const float rd = __shfl(cd, 63 - lane);
+    const int rid = __shfl(cid, 63 - lane);
+    if (pair_less(rd, rid, e, eid)) { e = rd; eid = rid; }
+#pragma unroll
+    for (int j = 32; j > 0; j >>= 1) {
+        const float pd = __shfl_xor(e, j);
+        const int pid = __shfl_xor(eid, j);
+        const bool take = ((lane & j) == 0) ? pair_less(pd, pid, e, eid) : pair_less(e, eid, pd, pid);
+        if (take) { e = pd; eid = pid; }
+    }
+    return ((unsigned long long)(unsigned)eid << 32) | (unsigned)__float_as_int(e);
+}
+
 struct WaveTopK {
     float e; int eid;            // this lane's element
     float thr; int thr_id;       // the k-th element (wave-uniform)
@@ -66,8 +103,21 @@ struct WaveTopK {
     }
 
     // offer every lane's candidate (want = this lane has one); lanes are taken in lane order
+    // BULK = false leaves the sort-and-merge path (a function call) out of kernels whose inner loop cannot
+    // afford the registers saved around it
+    template <bool BULK = true>
     __device__ __forceinline__ void offer(bool want, float d, int id, int lane) {
         unsigned long long m = __ballot(want && ((d < thr) || (d == thr && id < thr_id)));
+        if (BULK && __popcll(m) >= WAVE_BULK_MIN) {
+            // many at once (an empty or a loosely bounded list): one sort-and-merge instead of that many insertions
+            const bool mine = (m >> lane) & 1ull;
+            const unsigned long long r = wave_merge_candidates(e, eid, mine ? d : INFINITY, mine ? id : EMPTY_IDX);
+            e = __int_as_float((int)(unsigned)r);
+            eid = (int)(r >> 32);
+            thr = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(e), k - 1));
+            thr_id = __builtin_amdgcn_readlane(eid, k - 1);
+            return;
+        }
         while (m) {
             const int l = __builtin_ctzll(m);
             m &= m - 1;
