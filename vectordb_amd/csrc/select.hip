@@ -220,6 +220,39 @@ __global__ __launch_bounds__(256) void merge_few_kernel(const float* __restrict_
     }
 }
 
+// A few queries with a modest number of candidates each: one wave per query offers the lists' entries, 64 at a
+// time, to a register-resident selection (loads coalesced, no dependent load per output as in merge_few_kernel).
+__global__ __launch_bounds__(256) void merge_wave_kernel(const float* __restrict__ d, const int* __restrict__ idx, int nq,
+                                                         int n_lists, int k, const int* __restrict__ idx_map,
+                                                         int64_t idx_offset, SelectOut o) {
+    const int lane = threadIdx.x & 63;
+    const int q = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (q >= nq || (o.run_if && *o.run_if == 0)) return;
+    const int total = n_lists * k;
+    const float* dq = d + (int64_t)q * total;
+    const int* iq = idx + (int64_t)q * total;
+    WaveTopK top;
+    top.init(k);
+    for (int i0 = 0; i0 < total; i0 += 64) {
+        const int i = i0 + lane;
+        const float v = i < total ? dq[i] : INFINITY;
+        const int id = i < total ? iq[i] : EMPTY_IDX;
+        top.offer(id != EMPTY_IDX, v, id, lane);
+    }
+    if (lane < k) {
+        const bool empty = top.eid == EMPTY_IDX;
+        const int64_t row = empty ? -1 : (idx_map ? (int64_t)idx_map[top.eid] : (int64_t)top.eid) + idx_offset;
+        const int64_t at = (int64_t)q * o.out_stride + o.out_off + lane;
+        if (o.out_d) o.out_d[at] = empty ? INFINITY : top.e;
+        if (o.out_i) o.out_i[at] = row;
+        if (o.out_i32) o.out_i32[at] = (int)row;
+        if (lane == k - 1 && o.last_d) {
+            o.last_d[q] = empty ? INFINITY : top.e;
+            o.last_key[q] = empty ? INT64_MAX : (int64_t)top.eid;
+        }
+    }
+}
+
 static DevBuf g_mid_d[2], g_mid_i[2];
 
 int launch_select(const float* part_d, const int* part_i, int nq, int n_cand, int k, int tie_group,
@@ -227,6 +260,12 @@ int launch_select(const float* part_d, const int* part_i, int nq, int n_cand, in
     if (nq <= 0) return VDB_OK;
     (void)tie_group;        // every caller orders equal distances by id alone
     VDB_REQUIRE(k >= 1 && k <= 64, "selection merges lists of at most 64, got %d", k);
+    if (nq <= 1024 && (int64_t)n_cand * k <= 2048) {
+        hipLaunchKernelGGL(merge_wave_kernel, dim3((nq + 3) / 4), dim3(256), 0, s, part_d, part_i, nq, n_cand, k,
+                           idx_map, idx_offset, o);
+        VDB_HIP(hipGetLastError());
+        return VDB_OK;
+    }
     if (n_cand <= FEW_LISTS) {
         hipLaunchKernelGGL(merge_few_kernel, dim3((nq + 255) / 256), dim3(256), 0, s, part_d, part_i, nq, n_cand, k,
                            idx_map, idx_offset, o);
