@@ -1,0 +1,109 @@
+#!/usr/bin/env python3
+"""Randomised parity soak of the IVF list scan and the PQ ADC scan against the CPU oracle (not collected by
+pytest):   python tests/fuzz_ivf_pq.py --seconds 300 [--seed 0]
+IVF: random rows, centroids drawn from them, the oracle's assignment on both sides, random n_probe / k /
+batch size / filter; rows and fp32 distances must equal the oracle's, in its visiting order (cosine: 1e-4).  A case whose
+probe ranking has two centroid distances closer than 1e-5 relative at the n_probe boundary is skipped (the
+ranking is a matrix form with a 1e-4 bar).  PQ: random codebooks and codes; rows and distances bit for bit."""
+import argparse, os, sys, time
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, HERE)
+sys.path.insert(0, os.path.dirname(HERE))
+from vectordb_amd import _native as nat
+from oracle import ref_numpy as R
+from conftest import same_ids_or_near_ties
+
+ap = argparse.ArgumentParser()
+ap.add_argument("--seconds", type=float, default=120)
+ap.add_argument("--seed", type=int, default=0)
+args = ap.parse_args()
+nat.init(0)
+rng = np.random.default_rng(args.seed)
+t0 = time.time()
+case = skipped = 0
+
+
+def ivf_case():
+    global skipped
+    n = int(rng.choice([50, 300, 3000, 20000, 60000]))
+    d = int(rng.choice([4, 16, 32, 100, 128]))
+    nlist = int(min(n, rng.choice([1, 3, 17, 64, 300, 1024, 1500])))
+    metric = str(rng.choice(["euclidean", "cosine", "manhattan"]))
+    x = rng.standard_normal((n, d), dtype=np.float32)
+    cent = x[rng.choice(n, nlist, replace=False)].copy()
+    assign = R.ivf_assign_batch(x, cent, metric)
+    lists_ref = R.ivf_build_lists(assign, nlist)
+    nq = int(rng.choice([1, 2, 8, 9, 33]))
+    q = rng.standard_normal((nq, d), dtype=np.float32)
+    k = int(rng.choice([1, 5, 10, 40, 100]))
+    n_probe = int(min(nlist, rng.choice([1, 2, 8, 32, 33, 70])))
+    mask = (rng.random(n) < 0.3) if rng.random() < 0.3 else None
+    label = f"ivf n={n} d={d} nlist={nlist} {metric} nq={nq} k={k} n_probe={n_probe} mask={'none' if mask is None else int(mask.sum())}"
+    lists = nat.IvfLists(d, nat.METRIC_CODES[metric])
+    lists.set_centroids(cent)
+    lists.build(x, assign)
+    dist, rows = lists.search(q, k, n_probe, nat.pack_mask(mask))
+    lists.close()
+    for i in range(min(nq, 4)):
+        cd = np.sort(R.query_distances(q[i], cent, metric).astype(np.float64))
+        if n_probe < nlist and abs(cd[n_probe] - cd[n_probe - 1]) <= 1e-5 * max(abs(cd[n_probe]), 1e-3):
+            skipped += 1
+            continue
+        if n_probe > 1 and np.min(np.diff(cd[:n_probe + 1 if n_probe < nlist else n_probe])) <= 1e-6 * max(abs(cd[n_probe - 1]), 1e-3):
+            skipped += 1
+            continue
+        ref_rows, ref_dist = R.ivf_search(q[i], x, cent, lists_ref, k, n_probe, metric, mask=mask)
+        m = len(ref_rows)
+        assert (rows[i, m:] == -1).all(), label
+        if metric == "cosine":
+            # the pair form goes through np.dot, whose summation order is BLAS's: the 1e-4 bar, ids up to near ties
+            np.testing.assert_allclose(dist[i, :m], ref_dist, rtol=1e-4, atol=2e-6, err_msg=label)
+            if m:
+                full = R.rows_scalar_metric(q[i], x, metric)
+                assert same_ids_or_near_ties(rows[i, :m], ref_rows, lambda r: full[r], float(ref_dist[-1]), rtol=1e-4, atol=2e-6), label
+        else:
+            assert (rows[i, :m] == ref_rows).all(), label
+            assert (dist[i, :m] == ref_dist.astype(np.float32)).all(), label
+    return label
+
+
+def pq_case():
+    m = int(rng.choice([1, 2, 4, 8, 16, 32]))
+    dsub = int(rng.choice([1, 2, 4, 8]))
+    d = m * dsub
+    n = int(rng.choice([10, 300, 5000, 70000, 300000]))
+    book = rng.standard_normal((m, 256, dsub), dtype=np.float32)
+    codes = rng.integers(0, 256, size=(n, m)).astype(np.uint8)
+    if n > 20:
+        codes[rng.integers(0, n, 5)] = codes[rng.integers(0, n, 5)]       # equal distances
+    nq = int(rng.choice([1, 3, 4, 5, 8, 9]))
+    q = rng.standard_normal((nq, d), dtype=np.float32)
+    k = int(rng.choice([1, 10, 33, 64, 100]))
+    mask = (rng.random(n) < 0.4) if rng.random() < 0.4 else None
+    label = f"pq n={n} m={m} dsub={dsub} nq={nq} k={k} mask={'none' if mask is None else int(mask.sum())}"
+    pq = nat.PqCodes(d, m, 256)
+    pq.set_codebook(book)
+    pq.append_codes(codes)
+    dist, rows = pq.search(q, k, nat.pack_mask(mask))
+    pq.close()
+    for i in range(min(nq, 3)):
+        ref_rows, ref_dist = R.pq_search(q[i], book, codes, k, mask=mask)
+        mm = len(ref_rows)
+        assert (rows[i, :mm] == ref_rows).all(), label
+        assert (dist[i, :mm] == ref_dist).all(), label
+        assert (rows[i, mm:] == -1).all(), label
+    return label
+
+
+while time.time() - t0 < args.seconds:
+    case += 1
+    fn = ivf_case if rng.random() < 0.6 else pq_case
+    try:
+        label = fn()
+    except Exception:       # noqa: BLE001
+        print("FAILED case", case, "seed", args.seed, flush=True)
+        raise
+    print("ok", case, label, flush=True)
+print(f"{case} cases ({skipped} IVF queries skipped for near-tied probe rankings), no failure")
