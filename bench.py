@@ -10,7 +10,7 @@ One process per GPU.  With N > 1 the 1M rows are sharded by contiguous row
 blocks (strong scaling: total work per step is fixed), every rank searches all
 1024 queries against its shard, and the per-rank top-10 lists are merged after
 one all-gather (RCCL).  Rows and queries are resident in HBM before the timed
-region starts; a step is: query norms -> a strided 1/61 sample pass that bounds
+region starts; a step is: query norms -> a strided 1/64 sample pass that bounds
 each query's 10th best distance -> the MFMA distance kernel over all rows, which
 queues the few survivors of that bound -> per-query selection of the queue
 [-> all-gather -> merge].  (A shard too small for a sample runs the list form of
