@@ -2,30 +2,47 @@
 """Headline benchmark: Flat index, cosine, 1M x 384 fp32 rows, one batch of
 1024 queries per step, k = 10 (BASELINE.json configs[1]), through the C ABI.
 
-    python bench.py --gpus 1 --steps 20 --warmup 3
-    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
-        --master-port P bench.py --gpus N --steps K --warmup W
+    python bench.py --gpus N --steps K --warmup W
 
-One process per GPU.  With N > 1 the 1M rows are sharded by contiguous row
-blocks (strong scaling: total work per step is fixed), every rank searches all
-1024 queries against its shard, and the per-rank top-10 lists are merged after
-one all-gather (RCCL).  Rows and queries are resident in HBM before the timed
-region starts; a step is: query norms -> a strided 1/64 sample pass that bounds
-each query's 10th best distance -> the MFMA distance kernel over all rows, which
-queues the few survivors of that bound -> per-query selection of the queue
-[-> all-gather -> merge].  (A shard too small for a sample runs the list form of
-the kernel instead.)
+One process per GPU.  With N > 1 and no WORLD_SIZE in the environment the
+script starts `python -m torch.distributed.run --nproc-per-node N` on itself
+as a child process (before anything touches a GPU), relays its output and
+exits with its code; under torch.distributed.run it reads RANK / LOCAL_RANK /
+WORLD_SIZE as usual.
+
+The rows are generated in fixed blocks of global rows, each block from its own
+seed, so every world size searches the SAME 1M rows.  With N > 1 they are
+sharded by contiguous row blocks (strong scaling: total work per step is
+fixed), every rank searches all 1024 queries against its shard, and the
+per-rank top-10 lists are merged after one all-gather (RCCL).  Rows and queries
+are resident in HBM before the timed region starts; a step is: query norms ->
+a strided 1/64 sample pass that bounds each query's 10th best distance -> the
+MFMA distance kernel over all rows, which queues the few survivors of that
+bound -> per-query selection of the queue [-> all-gather -> merge].
 
 Rank 0 prints one JSON line.  `roofline` rates the dominant kernel
-(flat_queue_fast_kernel, fp32 MFMA) by 2*Q*N_local*D flop per launch over its HIP-event
-time; `cpu_baseline` times the NumPy oracle (the reference's arithmetic) on a
-sample of the same queries and rows on the host cores, and the same sample is
-used to check the GPU results.
+(flat_queue_fast_kernel, fp32 MFMA) by 2*Q*N_local*D flop per launch over its
+HIP-event time; `cpu_baseline` (N = 1) times the NumPy oracle (the reference's
+arithmetic) on a sample of the same queries and rows on the host cores; a
+sample of the queries is checked against that oracle at every N.
+
+`extra` holds side measurements that do not enter `value`:
+  c3        BASELINE.json configs[2]: Flat dot 10M x 768, rows / N per GPU,
+            fp32 and bf16 storage, batch 1024 (queries/s, kernel ms, fraction
+            of the MFMA peak of the storage type), with a spot check of the
+            returned distances against the oracle;
+  c1        configs[0]: 10k x 128 euclidean, 100 single queries, through the
+            Collection.search-shaped path and as bare distances + top-k, on the
+            GPU and on the host oracle (N = 1 only);
+  ceilings  a device-to-device copy and a register-only MFMA loop measured on
+            this GPU, beside the spec peaks the fractions are quoted against.
 """
 
 import argparse
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
 
@@ -36,7 +53,11 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 N_ROWS, DIM, N_QUERIES, TOP_K = 1_000_000, 384, 1024, 10
+C3_ROWS, C3_DIM = 10_000_000, 768
 MFMA_F32_PEAK_TFLOPS = 157.3          # MI355X dense fp32 matrix peak
+MFMA_BF16_PEAK_TFLOPS = 2500.0        # MI355X dense bf16 matrix peak
+HBM_PEAK_GBS = 8000.0
+GEN_BLOCK = 15625                      # rows per generation block: 1M = 64 blocks, 10M = 640 blocks
 
 
 def host_threads() -> int:
@@ -50,6 +71,68 @@ def host_threads() -> int:
     return int(os.environ.get("OMP_NUM_THREADS", os.cpu_count() or 1))
 
 
+def launch_ranks(n: int) -> int:
+    """Start n ranks of this script under torch.distributed.run as a child process.
+    Called before any GPU call of this process (device_count does not initialise the GPU)."""
+    visible = torch.cuda.device_count()
+    if visible < n:
+        print(f"bench.py: --gpus {n} asked, {visible} GPU(s) visible on this node", file=sys.stderr)
+        return 2
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}",
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    return subprocess.run(cmd).returncode
+
+
+def block_rows(lo: int, hi: int, d: int, seed: int, dev, gen) -> "torch.Tensor":
+    """Global rows [lo, hi) of the synthetic set: standard normal, block b of GEN_BLOCK rows from seed + b."""
+    parts = []
+    for b in range(lo // GEN_BLOCK, (hi + GEN_BLOCK - 1) // GEN_BLOCK):
+        gen.manual_seed(seed + b)
+        blk = torch.randn((GEN_BLOCK, d), device=dev, dtype=torch.float32, generator=gen)
+        b0 = b * GEN_BLOCK
+        parts.append(blk[max(lo - b0, 0):min(hi - b0, GEN_BLOCK)])
+    return parts[0] if len(parts) == 1 else torch.cat(parts)
+
+
+def fill_store(backend, lo: int, hi: int, d: int, seed: int, dev, gen, chunk_rows: int = 8 * GEN_BLOCK) -> None:
+    """Append global rows [lo, hi) to the backend's row store, a few blocks at a time."""
+    for c0 in range(lo, hi, chunk_rows):
+        part = block_rows(c0, min(hi, c0 + chunk_rows), d, seed, dev, gen).contiguous()
+        backend.add_device(part)
+        torch.cuda.synchronize()
+        del part
+
+
+def same_ids_or_near_ties(got, want, ref_dist_of_row, kth, rtol, atol) -> bool:
+    # ids may differ only where the oracle's own distance ties its k-th distance to rounding
+    return all(abs(float(ref_dist_of_row(r)) - kth) <= rtol * abs(kth) + atol
+               for r in set(map(int, got)) ^ set(map(int, want)))
+
+
+def timed_steps(index, queries, k, steps, warmup, barrier, native):
+    """warmup untimed steps, then `steps` timed ones between barriers; returns (seconds, kernel ms, launches, out)."""
+    out = None
+    for _ in range(warmup):
+        out = index.search(queries, k)
+    torch.cuda.synchronize()
+    barrier()
+    native.profile_read()
+    native.profile_enable(True)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        out = index.search(queries, k)
+    torch.cuda.synchronize()
+    barrier()
+    elapsed = time.perf_counter() - t0
+    native.profile_enable(False)
+    kernel_ms, launches = native.profile_read()
+    return elapsed, kernel_ms, launches, out
+
+
 def main() -> None:
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -58,8 +141,12 @@ def main() -> None:
     ap.add_argument("--rows", type=int, default=N_ROWS)
     ap.add_argument("--dim", type=int, default=DIM)
     ap.add_argument("--queries", type=int, default=N_QUERIES)
-    ap.add_argument("--cpu-sample", type=int, default=48, help="queries timed on the host oracle (0 = skip)")
+    ap.add_argument("--cpu-sample", type=int, default=48, help="queries timed on the host oracle at N = 1 (0 = skip)")
+    ap.add_argument("--no-extra", action="store_true", help="skip the side measurements (c3, c1, ceilings)")
     args = ap.parse_args()
+
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        sys.exit(launch_ranks(args.gpus))
 
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
@@ -77,48 +164,30 @@ def main() -> None:
     from vectordb_amd.sharded import HipFlatBackend, ShardedFlat, shard_range
     _native.init(local_rank)
 
-    n_total, d, nq, k = args.rows, args.dim, args.queries, TOP_K
-    lo, hi = shard_range(n_total, world, rank)
-    gen = torch.Generator(device=dev)
-    gen.manual_seed(42 + rank)
-    rows = torch.randn((hi - lo, d), device=dev, dtype=torch.float32, generator=gen)
-    gen.manual_seed(123)
-    queries = torch.randn((nq, d), device=dev, dtype=torch.float32, generator=gen)
-
-    backend = HipFlatBackend(d, _native.COSINE)
-    backend.add_device(rows)
-    torch.cuda.synchronize()
-    rows_host = rows.cpu().numpy() if (world == 1 and args.cpu_sample > 0) else None
-    del rows
-    torch.cuda.empty_cache()
-    index = ShardedFlat(backend, n_total, rank, world)
-
     def barrier():
         if world > 1:
             dist.barrier()
 
-    for _ in range(args.warmup):
-        index.search(queries, k)
-    torch.cuda.synchronize()
-    barrier()
-    _native.profile_read()
-    _native.profile_enable(True)
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        out_d, out_r = index.search(queries, k)
-    torch.cuda.synchronize()
-    barrier()
-    elapsed = time.perf_counter() - t0
-    _native.profile_enable(False)
-    kernel_ms, launches = _native.profile_read()
-    used_queue, _ = backend.store.search_stats()          # which kernel the library took for this shard size
-
-    if world > 1:
-        t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
+    def max_over_ranks(x: float) -> float:
+        if world == 1:
+            return x
+        t = torch.tensor([x], device=dev, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
+        return float(t.item())
 
+    n_total, d, nq, k = args.rows, args.dim, args.queries, TOP_K
+    lo, hi = shard_range(n_total, world, rank)
+    gen = torch.Generator(device=dev)
+    gen.manual_seed(123)
+    queries = torch.randn((nq, d), device=dev, dtype=torch.float32, generator=gen)
+
+    backend = HipFlatBackend(d, _native.COSINE)
+    fill_store(backend, lo, hi, d, 42, dev, gen)
+    index = ShardedFlat(backend, n_total, rank, world)
+
+    elapsed, kernel_ms, launches, (out_d, out_r) = timed_steps(index, queries, k, args.steps, args.warmup, barrier, _native)
+    used_queue, _ = backend.store.search_stats()          # which kernel the library took for this shard size
+    elapsed = max_over_ranks(elapsed)
     ms_per_step = elapsed / args.steps * 1e3
     qps = nq * args.steps / elapsed
 
@@ -137,20 +206,19 @@ def main() -> None:
                 "kernel": "flat_queue_fast_kernel<cosine>" if used_queue else "flat_gemm_kernel<cosine>", "kernel_ms": round(kern_ms, 4), "launches": launches,
                 "flop_per_launch": flop_per_launch}
 
-    # ---- CPU baseline + parity spot check (rank 0, single GPU only)
+    # ---- parity sample (rank 0, every N) and CPU baseline (N = 1): the oracle over ALL rows for a few queries
     cpu_baseline = None
     parity = None
-    if rank == 0 and rows_host is not None:
+    out_d_h, out_r_h = out_d.cpu().numpy(), out_r.cpu().numpy()
+    s = min(args.cpu_sample if world == 1 else min(args.cpu_sample, 8), nq)
+    if rank == 0 and s > 0:
         from oracle import ref_numpy as R
-
-        def same_ids_or_near_ties(got, want, ref_dist_of_row, kth, rtol, atol):
-            # ids may differ only where the oracle's own distance ties its k-th distance to rounding
-            return all(abs(float(ref_dist_of_row(r)) - kth) <= rtol * abs(kth) + atol
-                       for r in set(map(int, got)) ^ set(map(int, want)))
-
-        s = min(args.cpu_sample, nq)
+        rows_host = np.empty((n_total, d), np.float32)
+        step = 8 * GEN_BLOCK
+        for c0 in range(0, n_total, step):
+            c1 = min(n_total, c0 + step)
+            rows_host[c0:c1] = block_rows(c0, c1, d, 42, dev, gen).cpu().numpy()
         q_host = queries[:s].cpu().numpy()
-        got_d, got_r = out_d[:s].cpu().numpy(), out_r[:s].cpu().numpy()
         R.flat_search(q_host[0], rows_host[:1000], k, "cosine")           # warm the BLAS threads
         t0 = time.perf_counter()
         ref = [R.flat_search(q_host[i], rows_host, k, "cosine") for i in range(s)]
@@ -158,12 +226,32 @@ def main() -> None:
         ok = True
         for i in range(min(s, 16)):          # the near-tie check recomputes full distance rows: 16 queries are enough
             full = R.query_distances(q_host[i], rows_host, "cosine")
-            ok &= same_ids_or_near_ties(got_r[i], ref[i][0], lambda r: full[r], float(ref[i][1][-1]), rtol=1e-4, atol=2e-6)
-            ok &= bool(np.allclose(got_d[i], ref[i][1], rtol=1e-4, atol=2e-6))
+            ok &= same_ids_or_near_ties(out_r_h[i], ref[i][0], lambda r: full[r], float(ref[i][1][-1]), rtol=1e-4, atol=2e-6)
+            ok &= bool(np.allclose(out_d_h[i], ref[i][1], rtol=1e-4, atol=2e-6))
         parity = bool(ok)
-        cpu_baseline = {"value": round(s / cpu_s, 3), "unit": "queries/s", "cores": host_threads(), "kind": "port",
-                        "sample": f"{s} of the {nq} queries, one at a time, against all {n_total} rows "
-                                  f"(NumPy restatement of query_distances + stable top-{k})"}
+        if world == 1:
+            cpu_baseline = {"value": round(s / cpu_s, 3), "unit": "queries/s", "cores": host_threads(), "kind": "port",
+                            "sample": f"{s} of the {nq} queries, one at a time, against all {n_total} rows "
+                                      f"(NumPy restatement of query_distances + stable top-{k})"}
+        del rows_host
+
+    backend.store.close()
+    del index, backend
+    torch.cuda.empty_cache()
+
+    extra = None
+    if not args.no_extra:
+        extra = {}
+        try:
+            extra["c3"] = bench_c3(world, rank, dev, gen, barrier, max_over_ranks, _native)
+        except Exception as e:          # a side measurement must not take the headline line with it
+            extra["c3"] = {"error": f"{type(e).__name__}: {e}"}
+        if world == 1:
+            for name, fn in (("c1", bench_c1), ("ceilings", bench_ceilings)):
+                try:
+                    extra[name] = fn(dev, _native)
+                except Exception as e:
+                    extra[name] = {"error": f"{type(e).__name__}: {e}"}
 
     if rank == 0:
         print(json.dumps({
@@ -174,10 +262,113 @@ def main() -> None:
             "config": {"workload": "Flat cosine 1M x 384 fp32, batch 1024 queries, k=10 (BASELINE configs[1])",
                        "rows": n_total, "dim": d, "queries_per_step": nq, "k": k,
                        "sharding": f"rows/{world}" + (" + all-gather top-k merge" if world > 1 else "")},
-            "roofline": roofline, "cpu_baseline": cpu_baseline, "parity_sample_ok": parity,
+            "roofline": roofline, "cpu_baseline": cpu_baseline, "parity_sample_ok": parity, "extra": extra,
         }))
     if world > 1:
         dist.destroy_process_group()
+
+
+def bench_c3(world, rank, dev, gen, barrier, max_over_ranks, native, steps=5, warmup=2):
+    """BASELINE.json configs[2]: Flat dot-product over 10M x 768 rows, rows / world per GPU, batch 1024, k = 10,
+    fp32 and bf16 storage.  Same step as the headline: local search [-> all-gather -> merge]."""
+    from oracle import ref_numpy as R
+    from vectordb_amd.sharded import HipFlatBackend, ShardedFlat, shard_range
+    n_total, d, nq, k = C3_ROWS, C3_DIM, N_QUERIES, TOP_K
+    lo, hi = shard_range(n_total, world, rank)
+    gen.manual_seed(321)
+    queries = torch.randn((nq, d), device=dev, dtype=torch.float32, generator=gen)
+    out = {"workload": f"Flat dot 10M x 768, batch {nq}, k={k}, rows/{world} per GPU (BASELINE configs[2])",
+           "rows_per_gpu": hi - lo, "steps": steps, "warmup": warmup}
+    for storage, peak in (("f32", MFMA_F32_PEAK_TFLOPS), ("bf16", MFMA_BF16_PEAK_TFLOPS)):
+        backend = HipFlatBackend(d, native.DOT, storage=storage)
+        fill_store(backend, lo, hi, d, 4242, dev, gen)
+        index = ShardedFlat(backend, n_total, rank, world)
+        elapsed, kernel_ms, launches, (od, orow) = timed_steps(index, queries, k, steps, warmup, barrier, native)
+        elapsed = max_over_ranks(elapsed)
+        kern = kernel_ms / max(launches, 1)
+        tflops = 2.0 * nq * (hi - lo) * d / (kern * 1e-3) / 1e12 if launches else 0.0
+        # spot check: the returned rows of a few queries, regenerated from their blocks, against the oracle's
+        # distances (on bf16-rounded values for bf16 storage); 1e-4 relative + the dot form's rounding floor
+        ok = None
+        if rank == 0:
+            ok = True
+            od_h, or_h = od.cpu().numpy(), orow.cpu().numpy()
+            qh = queries.cpu().numpy()
+            for qi in (0, nq // 2, nq - 1):
+                rows = np.stack([block_rows(int(r), int(r) + 1, d, 4242, dev, gen)[0].cpu().numpy() for r in or_h[qi]])
+                qv = qh[qi]
+                if storage == "bf16":
+                    rows = torch.from_numpy(rows).to(torch.bfloat16).to(torch.float32).numpy()
+                    qv = torch.from_numpy(qv).to(torch.bfloat16).to(torch.float32).numpy()
+                ref = R.query_distances(qv, rows, "dot")
+                atol = 1e-5 * float(np.max(np.abs(rows).sum(axis=1)) * np.max(np.abs(qv)))
+                ok &= bool(np.allclose(od_h[qi], ref, rtol=1e-4, atol=atol)) and bool(np.all(np.diff(od_h[qi]) >= 0))
+        out[storage] = {"queries_per_s": round(nq * steps / elapsed, 1), "ms_per_step": round(elapsed / steps * 1e3, 4),
+                        "kernel_ms": round(kern, 4), "tflops": round(tflops, 1), "peak_tflops": peak,
+                        "frac": round(tflops / peak, 4), "returned_distances_ok": ok}
+        backend.store.close()
+        del index, backend
+        torch.cuda.empty_cache()
+    return out
+
+
+def bench_c1(dev, native, n=10_000, d=128, nq=100, k=10):
+    """BASELINE.json configs[0]: 10k x 128 euclidean, 100 queries one at a time, k = 10.  Two shapes on each side:
+    the whole Collection.search call (validation, search, ids, scores, result objects) and the bare kernel
+    (distances + top-k on raw arrays).  CPU = the NumPy oracle of the same two shapes on the host cores."""
+    from oracle import ref_numpy as R
+    from vectordb_amd.core.collection import Collection
+    rng = np.random.RandomState(42)
+    x = rng.randn(n, d).astype(np.float32)
+    rng = np.random.RandomState(123)
+    q = rng.randn(nq, d).astype(np.float32)
+    ids = [f"vec_{i}" for i in range(n)]
+
+    col = Collection("bench", dimension=d, metric="euclidean")
+    col.add_batch(ids, x)
+    col.search(q[0], k)
+    t0 = time.perf_counter()
+    got = [col.search(q[i], k) for i in range(nq)]
+    gpu_collection = nq / (time.perf_counter() - t0)
+
+    store = native.RowStore(d)
+    store.append(x)
+    store.search(q[:1], k, native.EUCLIDEAN)
+    t0 = time.perf_counter()
+    bare = [store.search(q[i:i + 1], k, native.EUCLIDEAN) for i in range(nq)]
+    gpu_bare = nq / (time.perf_counter() - t0)
+    store.close()
+
+    t0 = time.perf_counter()
+    ref = [R.collection_search(q[i], x, ids, k, "euclidean") for i in range(nq)]
+    cpu_collection = nq / (time.perf_counter() - t0)
+    t0 = time.perf_counter()
+    ref_bare = [R.flat_search(q[i], x, k, "euclidean") for i in range(nq)]
+    cpu_bare = nq / (time.perf_counter() - t0)
+
+    ok = True
+    for i in range(nq):
+        want_rows, want_d = ref_bare[i]
+        full = None
+        got_rows = bare[i][1][0]
+        if set(map(int, got_rows)) != set(map(int, want_rows)):
+            full = R.query_distances(q[i], x, "euclidean")
+            ok &= same_ids_or_near_ties(got_rows, want_rows, lambda r: full[r], float(want_d[-1]), 1e-4, 1e-5)
+        ok &= bool(np.allclose(bare[i][0][0], want_d, rtol=1e-4, atol=1e-4))
+        ok &= [r.id for r in got[i]] == [ids[int(r)] for r in got_rows] or full is not None
+    return {"workload": f"Flat euclidean {n} x {d}, {nq} single queries, k={k} (BASELINE configs[0])",
+            "gpu_collection_search_qps": round(gpu_collection, 1), "gpu_bare_search_qps": round(gpu_bare, 1),
+            "cpu_collection_search_qps": round(cpu_collection, 1), "cpu_bare_search_qps": round(cpu_bare, 1),
+            "cpu_cores": host_threads(), "cpu_kind": "port", "results_match_oracle": bool(ok)}
+
+
+def bench_ceilings(dev, native):
+    """What this GPU reaches on the two limits the fractions are quoted against: a large device-to-device copy
+    (read + write bytes per second) and register-only MFMA loops (no memory traffic at all)."""
+    copy_gbs, f32_tflops, bf16_tflops = native.measure_ceilings()
+    return {"copy_gbs_read_plus_write": round(copy_gbs, 1), "hbm_spec_gbs": HBM_PEAK_GBS,
+            "mfma_f32_loop_tflops": round(f32_tflops, 1), "mfma_f32_spec_tflops": MFMA_F32_PEAK_TFLOPS,
+            "mfma_bf16_loop_tflops": round(bf16_tflops, 1), "mfma_bf16_spec_tflops": MFMA_BF16_PEAK_TFLOPS}
 
 
 if __name__ == "__main__":

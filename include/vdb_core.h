@@ -67,13 +67,22 @@ typedef enum vdb_metric {
 /* ---- library ---------------------------------------------------------- */
 
 /* Select the GPU this process uses (one process per GPU).  Replaces the
- * device selection of distance/gpu.py:63-67.  Idempotent. */
+ * device selection of distance/gpu.py:63-67.  The first call fixes the device:
+ * a repeated call with the same device is a no-op, one with another device
+ * returns VDB_ERR_STATE (handles, streams and buffers live on the first).  Every
+ * entry point makes that device current on the calling thread, so handles may
+ * be used from any thread; calls on ONE handle are serialised by the library,
+ * calls on different handles run concurrently (each handle has its own stream). */
 int vdb_init(int device);
 const char* vdb_last_error(void);
 /* distance/gpu.py:205-225 get_gpu_info(): name (<=255 chars), total and free bytes */
 int vdb_device_info(char* name, int name_len, int64_t* mem_total, int64_t* mem_free);
-/* block until everything the library has enqueued on its own stream is done */
+/* block until everything enqueued on the device is done (every handle has a stream of its own) */
 int vdb_synchronize(void);
+/* What this GPU reaches on the two limits the roofline fractions are quoted against (no counterpart in the
+ * reference): a 1 GiB device-to-device copy in GB/s (bytes read + bytes written) and register-only
+ * loops of v_mfma_f32_32x32x2_f32 / v_mfma_f32_32x32x16_bf16 in TFLOP/s.  Allocates 2 GiB while it runs. */
+int vdb_measure_ceilings(float* copy_gbs, float* mfma_f32_tflops, float* mfma_bf16_tflops);
 /* Kernel timing for roofline accounting (no counterpart in the reference; its
  * only timers are wall clocks around Collection.search, query/executor.py:255-272).
  * While enabled, every launch of a path's dominant kernel (the MFMA flat

@@ -215,6 +215,25 @@ def collection_scores(dist: np.ndarray) -> np.ndarray:
     return out
 
 
+def collection_search(query: np.ndarray, rows: np.ndarray, ids: Sequence[str], k: int,
+                      metric: str = "euclidean") -> List[Tuple[str, float, float]]:
+    """Collection.search without a filter, written the way the reference spends
+    its time (core/collection.py:750-780): a1 over the whole matrix, a Python
+    list of (id, distance) pairs, a stable ``list.sort`` on the distance, the
+    first k, and the score of each against the k-th distance.  Returns
+    (id, distance, score) triples."""
+    distances = query_distances(query, rows, metric)
+    id_distances = list(zip([ids[i] for i in range(len(distances))], distances))   # collection.py:751-754
+    id_distances.sort(key=lambda x: x[1])                                           # collection.py:757
+    top_k = id_distances[:k]
+    max_distance = top_k[-1][1] if top_k else 1.0                                   # collection.py:762
+    out = []
+    for id_, distance in top_k:
+        score = 1.0 - (distance / (max_distance + 1e-8)) if max_distance > 0 else 1.0   # collection.py:768-771
+        out.append((id_, float(distance), float(score)))
+    return out
+
+
 def batch_top_k(query: np.ndarray, rows: np.ndarray, k: int, metric: str = "euclidean",
                 chunk_size: int = 10000) -> Tuple[np.ndarray, np.ndarray]:
     """BatchDistanceCalculator.top_k (distance/batch.py:136-220).  Both of the

@@ -212,3 +212,146 @@ def test_pq_100m_codes_with_filter(nat):
     d1, r1 = search_dev(fn, q[5:6].contiguous(), k)
     assert np.array_equal(r1[0], rows[5]) and np.array_equal(d1[0], dist[5])
     pq.close()
+
+
+# ---------------------------------------------------------------- Flat dot 10M x 768 over 8 shards (configs[2])
+def _bf16_round_t(t):
+    return t.to(torch.bfloat16).to(torch.float32)
+
+
+def _dot_atol(rows_h, q_h):
+    """Rounding floor of a dot product: a few ulps of sum |c_i q_i| (bounded by max |c|_1 * max |q_i|)."""
+    return 1e-5 * float(np.max(np.abs(rows_h).sum(axis=1)) * np.max(np.abs(q_h)))
+
+
+@pytest.mark.parametrize("storage", ["f32", "bf16"])
+def test_flat_dot_c3_one_shard(nat, storage):
+    """One GPU's shard of configs[2]: 1.25M x 768 rows, dot product, batch 1024, k = 10, fp32 and bf16 storage.
+    bf16 storage is checked against the oracle on bf16-rounded rows and queries (products of bf16 values are
+    exact in fp32, the sums are fp32): the fp32 bar, 1e-4 relative plus the rounding floor of a 768-term dot
+    product.  Recall@10 of the bf16 results against the unrounded fp32 oracle is reported."""
+    n, d, nq, k = 1_250_000, 768, 1024, 10
+    x = randn(n, d, 4242)
+    q = randn(nq, d, 321)
+    store = nat.RowStore(d, storage=storage)
+    store.append_device(x.data_ptr(), n, d, 0)
+    fn = lambda qp, m, kk, dp, rp: store.search_device(qp, m, kk, nat.DOT, dp, rp)
+    dist, rows = search_dev(fn, q, k)
+    assert store.search_stats() == (True, False), "the batch must take the candidate-queue kernel without overflow"
+    dist2, rows2 = search_dev(fn, q, k)
+    assert np.array_equal(rows, rows2) and np.array_equal(dist, dist2), "same call, same bits"
+    check_shape_properties(dist, rows, n)
+
+    x_true = x.cpu().numpy()
+    q_true = q.cpu().numpy()
+    if storage == "bf16":
+        xh, qh = _bf16_round_t(x).cpu().numpy(), _bf16_round_t(q).cpu().numpy()
+    else:
+        xh, qh = x_true, q_true
+    del x
+    torch.cuda.empty_cache()
+    # every returned distance against the oracle's value for that row
+    for qi in range(0, nq, 37):
+        ref = R.query_distances(qh[qi], xh[rows[qi]], "dot")
+        np.testing.assert_allclose(dist[qi], ref, rtol=1e-4, atol=_dot_atol(xh[rows[qi]], qh[qi]))
+    # completeness: the oracle over all rows for a few queries
+    recall = []
+    for qi in (0, 1, 255, 511, 777, 1023):
+        ref_all = R.query_distances(qh[qi], xh, "dot")
+        ref_rows = R.topk_stable(ref_all, k)
+        atol = _dot_atol(xh[ref_rows], qh[qi])
+        assert same_ids_or_near_ties(rows[qi], ref_rows, lambda r: ref_all[r], float(ref_all[ref_rows[-1]]),
+                                     rtol=1e-4, atol=atol)
+        if storage == "bf16":
+            true_rows = R.topk_stable(R.query_distances(q_true[qi], x_true, "dot"), k)
+            recall.append(len(set(rows[qi].tolist()) & set(true_rows.tolist())) / k)
+            # stated tolerance against the unrounded fp32 reference: 2e-2 of the distance scale |q| |c|
+            full_true = R.query_distances(q_true[qi], x_true[rows[qi]], "dot")
+            scale = np.linalg.norm(q_true[qi]) * np.linalg.norm(x_true[rows[qi]], axis=1)
+            assert np.all(np.abs(dist[qi] - full_true) <= 2e-2 * scale)
+    if recall:
+        print(f"bf16 dot 1.25M x 768: recall@10 vs the fp32 oracle = {np.mean(recall):.3f}")
+        assert np.mean(recall) >= 0.8
+    # one query at a time agrees with the batch (fp32: the streaming kernel; bf16: the matrix-core kernel with one query)
+    for qi in (3, 700):
+        d1, r1 = search_dev(fn, q[qi:qi + 1].contiguous(), k)
+        ref_all = R.query_distances(qh[qi], xh, "dot")
+        kth = float(np.sort(ref_all)[k - 1])
+        assert same_ids_or_near_ties(r1[0], rows[qi], lambda r: ref_all[r], kth, rtol=1e-4,
+                                     atol=_dot_atol(xh[rows[qi]], qh[qi]))
+        np.testing.assert_allclose(d1[0], dist[qi], rtol=1e-4, atol=_dot_atol(xh[rows[qi]], qh[qi]))
+    store.close()
+
+
+@pytest.mark.parametrize("storage", ["f32", "bf16"])
+def test_flat_dot_c3_10m_eight_logical_shards(nat, storage):
+    """All of configs[2] on one GPU: 10M x 768 rows held once as a single store and once as 8 row shards.  Every
+    shard is searched as rank r of an 8-rank group would search it, its packed block goes where the all-gather
+    would put it, and the merge that follows the all-gather must return exactly what the single store returns
+    (same rows, same order, same bits).  The returned rows are gathered on the device and checked against the
+    oracle; for fp32 the oracle also scans all 10M rows, shard by shard, for three queries."""
+    from vectordb_amd.sharded import HipFlatBackend, ShardedFlat, shard_range
+    n, d, nq, k, shards = 10_000_000, 768, 1024, 10, 8
+    dev = torch.device("cuda", 0)
+    q = randn(nq, d, 321)
+    qh = (_bf16_round_t(q) if storage == "bf16" else q).cpu().numpy()
+    single = HipFlatBackend(d, nat.DOT, storage=storage)
+    parts, backends, blocks = [], [], []
+    full_scan_q = (0, 500, 1023)
+    ref_scan = {qi: [] for qi in full_scan_q}
+    for r in range(shards):
+        lo, hi = shard_range(n, shards, r)
+        part = randn(hi - lo, d, 9000 + r)
+        single.add_device(part)
+        be = HipFlatBackend(d, nat.DOT, storage=storage)
+        be.add_device(part)
+        torch.cuda.synchronize()
+        backends.append(be)
+        if storage == "f32":
+            parts.append(part)                                   # kept on the device for the row gather below
+            part_h = part.cpu().numpy()
+            for qi in full_scan_q:
+                ref_scan[qi].append(R.query_distances(qh[qi], part_h, "dot"))
+            del part_h
+        else:
+            parts.append(part.to(torch.bfloat16))                 # the rounded values, half the bytes
+        del part
+    one = ShardedFlat(single, n, 0, 1)
+    sd, sr = one.search(q, k)
+    torch.cuda.synchronize()
+    assert single.store.search_stats() == (True, False)
+    sd_h, sr_h = sd.cpu().numpy(), sr.cpu().numpy()
+    check_shape_properties(sd_h, sr_h, n)
+
+    gathered = None
+    for r in range(shards):
+        as_rank = ShardedFlat(backends[r], n, r, shards)
+        local, g, ld, lr, gd, gr, base, od, orow = as_rank._buffers(nq, k, dev)
+        backends[r].local_search(q, k, ld, lr)
+        blocks.append(local.clone())
+        if r == shards - 1:
+            gathered, m_gd, m_gr, m_base, m_od, m_orow = g, gd, gr, base, od, orow
+    gathered.copy_(torch.cat(blocks))                            # what all_gather_into_tensor leaves on every rank
+    backends[-1].merge(m_gd, m_gr, k, m_od, m_orow, m_base)
+    torch.cuda.synchronize()
+    assert torch.equal(m_orow, sr), "merged shards must return the rows of the single store, in its order"
+    assert torch.equal(m_od, sd), "and the same distance bits"
+
+    # returned rows, gathered on the device, against the oracle
+    per = n // shards
+    for qi in range(0, nq, 61):
+        rows_t = torch.stack([parts[int(g) // per][int(g) % per] for g in sr_h[qi]]).to(torch.float32)
+        rows_h = rows_t.cpu().numpy()
+        ref = R.query_distances(qh[qi], rows_h, "dot")
+        np.testing.assert_allclose(sd_h[qi], ref, rtol=1e-4, atol=_dot_atol(rows_h, qh[qi]))
+    # completeness against the oracle's scan of all 10M rows (fp32)
+    if storage == "f32":
+        for qi in full_scan_q:
+            ref_all = np.concatenate(ref_scan[qi])
+            ref_rows = topk_big(ref_all, k)
+            ref_rows_h = torch.stack([parts[int(g) // per][int(g) % per] for g in ref_rows]).cpu().numpy()
+            assert same_ids_or_near_ties(sr_h[qi], ref_rows, lambda r: ref_all[r], float(ref_all[ref_rows[-1]]),
+                                         rtol=1e-4, atol=_dot_atol(ref_rows_h, qh[qi]))
+    single.store.close()
+    for be in backends:
+        be.store.close()

@@ -47,6 +47,7 @@ SIGNATURES = {
     "vdb_last_error": (C.c_char_p, []),
     "vdb_device_info": (C.c_int, [C.c_char_p, C.c_int, c_i64_p, c_i64_p]),
     "vdb_synchronize": (C.c_int, []),
+    "vdb_measure_ceilings": (C.c_int, [c_float_p, c_float_p, c_float_p]),
     "vdb_profile_enable": (C.c_int, [C.c_int]),
     "vdb_profile_read": (C.c_int, [c_float_p, C.POINTER(C.c_int)]),
     "vdb_rows_create": (C.c_int, [C.POINTER(C.c_void_p), C.c_int]),
@@ -164,17 +165,25 @@ def check(status: int) -> None:
 
 
 _initialised = False
+_device: Optional[int] = None
 
 
 def init(device: Optional[int] = None) -> None:
-    """One process per GPU: LOCAL_RANK picks the device unless one is given."""
-    global _initialised
+    """One process per GPU: LOCAL_RANK picks the device unless one is given.  The first call
+    fixes the device; asking for another one later raises RuntimeError (vdb_init refuses)."""
+    global _initialised, _device
     if device is None:
         if _initialised:
             return
         device = int(os.environ.get("LOCAL_RANK", "0"))
     check(load().vdb_init(int(device)))
     _initialised = True
+    _device = int(device)
+
+
+def current_device() -> Optional[int]:
+    """The device the library was initialised on, or None before the first init()."""
+    return _device
 
 
 def device_info() -> dict:
@@ -187,6 +196,14 @@ def device_info() -> dict:
 
 def synchronize() -> None:
     check(load().vdb_synchronize())
+
+
+def measure_ceilings():
+    """(device-to-device copy GB/s counting read + write, fp32 MFMA loop TFLOP/s, bf16 MFMA loop TFLOP/s)."""
+    init()
+    a, b, c = C.c_float(0.0), C.c_float(0.0), C.c_float(0.0)
+    check(load().vdb_measure_ceilings(C.byref(a), C.byref(b), C.byref(c)))
+    return a.value, b.value, c.value
 
 
 def profile_enable(on: bool) -> None:

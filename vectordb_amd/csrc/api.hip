@@ -34,6 +34,11 @@ int ensure_init() {
     return vdb_init(0);
 }
 
+// a stream of its own for an entry point that has no handle (one-shot conversions of host arrays)
+struct ScopedHandle : Handle {
+    ~ScopedHandle() { close(); }
+};
+
 // ---- kernel timing ---------------------------------------------------------
 static bool g_profile = false;
 static std::mutex g_prof_mu;
@@ -56,6 +61,19 @@ KernelTimer::~KernelTimer() {
 
 int DevBuf::reserve(size_t bytes) {
     if (bytes <= cap) return VDB_OK;
+    if (arena) {
+        // carve the block out of the arena (a block grown within one call leaves its old place unused)
+        const size_t at = (arena->used + 255) / 256 * 256;
+        if (at + bytes > arena->size) {
+            set_error("the static scratch of %zu bytes is too small for this call (%zu bytes in use, %zu more asked): "
+                      "fewer queries or rows per call, or the allocating entry point", arena->size, arena->used, bytes);
+            return VDB_ERR_INVALID;
+        }
+        p = arena->base + at;
+        cap = bytes;
+        arena->used = at + bytes;
+        return VDB_OK;
+    }
     if (p) { VDB_HIP(hipFree(p)); p = nullptr; cap = 0; }
     const size_t want = std::max(bytes, (size_t)256);
     VDB_HIP(hipMalloc(&p, want));
@@ -65,6 +83,7 @@ int DevBuf::reserve(size_t bytes) {
 
 int DevBuf::reserve_keep(size_t bytes, size_t keep_bytes, hipStream_t s) {
     if (bytes <= cap) return VDB_OK;
+    if (arena) { set_error("a buffer bound to the static scratch cannot grow in place"); return VDB_ERR_STATE; }
     size_t want = std::max(bytes, cap + cap / 2);
     want = std::max(want, (size_t)4096);
     void* np = nullptr;
@@ -77,9 +96,24 @@ int DevBuf::reserve_keep(size_t bytes, size_t keep_bytes, hipStream_t s) {
 }
 
 void DevBuf::release() {
-    if (p) (void)hipFree(p);
+    if (p && !arena) (void)hipFree(p);
     p = nullptr;
     cap = 0;
+}
+
+int Handle::open() {
+    VDB_TRY(ensure_init());
+    (void)hipSetDevice(ctx().device);
+    // a blocking stream: ordered with work the caller put on the null stream
+    if (!stream) VDB_HIP(hipStreamCreateWithFlags(&stream, hipStreamDefault));
+    return VDB_OK;
+}
+
+void Handle::close() {
+    if (!stream) return;
+    (void)hipStreamSynchronize(stream);
+    (void)hipStreamDestroy(stream);
+    stream = nullptr;
 }
 
 static void plan_rec(int n, std::vector<int>& leaves, std::vector<int>& folds) {
@@ -188,16 +222,21 @@ struct Workspace {
     DevBuf fp_seg_row_off, fp_seg_q_off, fp_seg_item_off, fp_sq_qid, fp_sq_out, fp_items;
     int64_t fp_n = -1; int fp_nq = -1, fp_group = -1;
     DevBuf round32, q16, cand, seg_row_off, seg_q_off, seg_item_off, sq_qid, sq_out, cand_off, tile_off, list_cnt, cursor, slots, items;
-    void release() {
+    template <class F> void each(F&& f) {
         DevBuf* all[] = {&q_buf, &q_sq, &q_nrm, &part_d, &part_i, &lb_d, &lb_k, &thr_d, &thr_k, &mask, &out_d, &out_i, &dist,
                          &probes, &probe_d, &lut, &stage, &round32, &q16, &cand, &seg_row_off, &seg_q_off, &seg_item_off, &sq_qid, &sq_out,
                          &cand_off, &tile_off, &list_cnt, &cursor, &slots, &items,
                          &queue, &queue_cnt, &flag, &mins,
                          &fp_seg_row_off, &fp_seg_q_off, &fp_seg_item_off, &fp_sq_qid, &fp_sq_out, &fp_items};
+        for (DevBuf* b : all) f(b);
+    }
+    void release() {
         fp_n = -1;
-        for (DevBuf* b : all) b->release();
+        each([](DevBuf* b) { b->release(); });
         pin_in.release(); pin_out.release();
     }
+    // every device buffer of this workspace comes out of `a` from now on (a fresh, empty workspace only)
+    void bind(Arena* a) { each([a](DevBuf* b) { b->arena = a; }); }
 };
 
 static bool is_dot_metric(int m) {
@@ -251,12 +290,13 @@ static int prepare_queries(Workspace& ws, const float* d_q, int nq, int dim, int
 using namespace vdb;
 
 // ============================================================== row store
-struct vdb_rows {
+struct vdb_rows : Handle {
     Rows r;
     DevBuf data, data16, sq, nrm;
     Workspace ws;
     bool last_used_queue = false;       // diagnostics of the last flat search
     hipStream_t last_stream = nullptr;
+    const int* last_flag = nullptr;     // overflow flag of that search (device)
 };
 
 static int rows_reserve(vdb_rows* h, int64_t n_total, hipStream_t s) {
@@ -281,6 +321,7 @@ static int rows_reserve(vdb_rows* h, int64_t n_total, hipStream_t s) {
 static int rows_append_dev_impl(vdb_rows* h, const float* d_rows, int64_t n, int64_t src_ld, hipStream_t s) {
     Rows& r = h->r;
     if (n <= 0) return VDB_OK;
+    h->last_stream = s;
     VDB_TRY(rows_reserve(h, r.n + n, s));
     if (r.bf16) {
         // in chunks: round, store bf16, norms of the rounded values
@@ -374,10 +415,9 @@ static int stream_flat_sums(Workspace& ws, const Rows& r, int metric, const floa
 }
 
 // streamed search of a flat row set (any metric): per block of queries, sums -> candidate buffer -> k best
-static int stream_flat_search(vdb_rows* h, int metric, const float* q, int nq, int k, int64_t k_eff, const uint32_t* d_mask,
-                              float* d_out_d, int64_t* d_out_i, int* d_out_i32, hipStream_t s) {
+static int stream_flat_search(vdb_rows* h, Workspace& ws, int metric, const float* q, int nq, int k, int64_t k_eff,
+                              const uint32_t* d_mask, float* d_out_d, int64_t* d_out_i, int* d_out_i32, hipStream_t s) {
     Rows& r = h->r;
-    Workspace& ws = h->ws;
     const int q_block = (int)std::max<int64_t>(1, std::min<int64_t>(nq, CAND_BUDGET / (r.n * (int64_t)sizeof(float))));
     const int64_t ntiles = (r.n + 255) / 256;
     const int kmax = (int)std::min<int64_t>(KMAX_FUSED, k_eff);
@@ -414,12 +454,14 @@ static int stream_flat_search(vdb_rows* h, int metric, const float* q, int nq, i
 }
 
 // ---- flat search on device pointers ------------------------------------
+// `ws_in` replaces the handle's own workspace (the no-allocation entry point passes one bound to the static scratch)
 static int flat_search_impl(vdb_rows* h, int metric, const float* d_q, int nq, int k, const uint32_t* d_mask,
-                            float* d_out_d, int64_t* d_out_i, int* d_out_i32, hipStream_t s) {
+                            float* d_out_d, int64_t* d_out_i, int* d_out_i32, hipStream_t s, Workspace* ws_in = nullptr) {
     Rows& r = h->r;
-    Workspace& ws = h->ws;
+    Workspace& ws = ws_in ? *ws_in : h->ws;
     h->last_used_queue = false;
     h->last_stream = s;
+    h->last_flag = nullptr;
     VDB_REQUIRE(valid_metric(metric), "unknown metric code %d", metric);
     VDB_REQUIRE(nq >= 0 && k >= 1, "need nq >= 0 and k >= 1 (got nq=%d, k=%d)", nq, k);
     if (nq == 0) return VDB_OK;
@@ -438,7 +480,7 @@ static int flat_search_impl(vdb_rows* h, int metric, const float* d_q, int nq, i
         const float* qf = nullptr;
         VDB_TRY(prepare_queries(ws, d_q, nq, r.dim, r.ld, r.plan, &qf, s));
         const bool gemm = is_dot_metric(metric) && nq >= GEMM_MIN_NQ;
-        if (!gemm) return stream_flat_search(h, metric, qf, nq, k, k_eff, d_mask, d_out_d, d_out_i, d_out_i32, s);
+        if (!gemm) return stream_flat_search(h, ws, metric, qf, nq, k, k_eff, d_mask, d_out_d, d_out_i, d_out_i32, s);
         q = qf;
     }
 
@@ -498,6 +540,7 @@ static int flat_search_impl(vdb_rows* h, int metric, const float* d_q, int nq, i
     const int* run_if = nullptr;
     if (will_queue) {
         h->last_used_queue = true;
+        h->last_flag = ws.flag.as<int>();
         if (!flag_cleared) VDB_HIP(hipMemsetAsync(ws.flag.p, 0, sizeof(int), s));
         const char* qb = reinterpret_cast<const char*>(q);
         const size_t q_pitch = r.bf16 ? (size_t)r.ld16 * 2 : (size_t)r.ld * 4;
@@ -600,7 +643,7 @@ static int with_host_io(Workspace& ws, const float* queries, int nq, int dim, in
 }
 
 // ============================================================== IVF handle
-struct vdb_ivf {
+struct vdb_ivf : Handle {
     int dim = 0, metric = 0;
     vdb_rows* centroids = nullptr;      // n_lists rows
     vdb_rows* members = nullptr;        // all rows, stored in list order
@@ -622,17 +665,19 @@ struct vdb_ivf {
     }
     int64_t last_scan_rows = -1;
     int last_nq = 0, last_nprobe = 0;
+    hipStream_t last_stream = nullptr;  // stream of the last search (its probe lists are read back for the statistics)
     Workspace ws;
 };
 
 // ============================================================== PQ handle
-struct vdb_pq {
+struct vdb_pq : Handle {
     int dim = 0, m = 0, ksub = 0, dsub = 0;
     bool trained = false;
     SumPlan plan;                       // over one sub-vector
     DevBuf book;                        // float [m][ksub][dsub]
     DevBuf codes;                       // uint8 [cap][m]
     int64_t n = 0, cap = 0;
+    hipStream_t last_stream = nullptr;  // stream of the last *_dev call
     Workspace ws;
     Workspace io;                       // staging of the host-pointer entry points
 };
@@ -652,21 +697,28 @@ extern "C" {
 // ============================================================== library
 int vdb_init(int device) {
     Context& c = ctx();
-    if (c.device == device && c.stream) return VDB_OK;
+    std::lock_guard<std::mutex> g(c.mu);
+    if (c.device >= 0) {
+        // one process, one GPU: every handle, stream and buffer lives on the device of the first call
+        if (c.device != device) {
+            set_error("the library is already initialised on device %d; device %d asked (one process per GPU)", c.device, device);
+            return VDB_ERR_STATE;
+        }
+        VDB_HIP(hipSetDevice(device));
+        return VDB_OK;
+    }
     int count = 0;
     VDB_HIP(hipGetDeviceCount(&count));
     VDB_REQUIRE(device >= 0 && device < count, "device %d out of range (%d visible)", device, count);
     VDB_HIP(hipSetDevice(device));
     hipDeviceProp_t prop;
     VDB_HIP(hipGetDeviceProperties(&prop, device));
-    // a blocking stream: ordered with work the caller put on the null stream
-    if (!c.stream) VDB_HIP(hipStreamCreateWithFlags(&c.stream, hipStreamDefault));
     if (!c.zeros) {
         VDB_HIP(hipMalloc(reinterpret_cast<void**>(&c.zeros), 256));
         VDB_HIP(hipMemset(c.zeros, 0, 256));
     }
-    c.device = device;
     c.num_cus = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
+    c.device = device;
     return VDB_OK;
 }
 
@@ -682,6 +734,13 @@ int vdb_device_info(char* name, int name_len, int64_t* mem_total, int64_t* mem_f
     if (mem_total) *mem_total = (int64_t)tot;
     if (mem_free) *mem_free = (int64_t)fr;
     return VDB_OK;
+}
+
+int vdb_measure_ceilings(float* copy_gbs, float* mfma_f32_tflops, float* mfma_bf16_tflops) {
+    VDB_REQUIRE(copy_gbs && mfma_f32_tflops && mfma_bf16_tflops, "null argument");
+    ScopedHandle tmp;
+    VDB_TRY(tmp.open());
+    return measure_ceilings(tmp.stream, copy_gbs, mfma_f32_tflops, mfma_bf16_tflops);
 }
 
 int vdb_profile_enable(int on) {
@@ -711,7 +770,8 @@ int vdb_profile_read(float* kernel_ms, int* launches) {
 
 int vdb_synchronize(void) {
     VDB_TRY(ensure_init());
-    VDB_HIP(hipStreamSynchronize(ctx().stream));
+    VDB_HIP(hipSetDevice(ctx().device));
+    VDB_HIP(hipDeviceSynchronize());        // every handle has its own stream
     return VDB_OK;
 }
 
@@ -728,16 +788,23 @@ int vdb_rows_create_typed(vdb_rows** out, int dim, int storage) {
     h->r.ld = round_up(dim, 4);
     h->r.bf16 = storage == VDB_STORE_BF16;
     h->r.ld16 = round_up(dim, 8);
-    VDB_TRY(make_sum_plan(dim, &h->r.plan));
+    int st = make_sum_plan(dim, &h->r.plan);
+    if (st == VDB_OK) st = h->open();
+    if (st != VDB_OK) { delete h; return st; }
     *out = h;
     return VDB_OK;
 }
 
 int vdb_rows_destroy(vdb_rows* h) {
     if (!h) return VDB_OK;
-    std::lock_guard<std::mutex> g(ctx().mu);
-    (void)hipStreamSynchronize(ctx().stream);
-    h->data.release(); h->data16.release(); h->sq.release(); h->nrm.release(); h->ws.release();
+    {
+        Entry g(h);
+        // work on this handle may still be queued on its own stream or, from a *_dev call, on the caller's
+        (void)hipStreamSynchronize(h->stream);
+        if (h->last_stream && h->last_stream != h->stream) (void)hipStreamSynchronize(h->last_stream);
+        h->data.release(); h->data16.release(); h->sq.release(); h->nrm.release(); h->ws.release();
+    }
+    h->close();
     delete h;
     return VDB_OK;
 }
@@ -745,8 +812,8 @@ int vdb_rows_destroy(vdb_rows* h) {
 int vdb_rows_append(vdb_rows* h, const float* rows, int64_t n) {
     VDB_REQUIRE(h && (rows || n == 0) && n >= 0, "bad arguments to vdb_rows_append");
     if (n == 0) return VDB_OK;
-    std::lock_guard<std::mutex> g(ctx().mu);
-    hipStream_t s = ctx().stream;
+    Entry g(h);
+    hipStream_t s = h->stream;
     Rows& r = h->r;
     VDB_TRY(rows_reserve(h, r.n + n, s));
     if (r.ld == r.dim && !r.bf16) {
@@ -771,14 +838,14 @@ int vdb_rows_append(vdb_rows* h, const float* rows, int64_t n) {
 
 int vdb_rows_append_dev(vdb_rows* h, const float* d_rows, int64_t n, int64_t ld, void* stream) {
     VDB_REQUIRE(h && (d_rows || n == 0) && n >= 0 && ld >= h->r.dim, "bad arguments to vdb_rows_append_dev");
-    std::lock_guard<std::mutex> g(ctx().mu);
+    Entry g(h);
     return rows_append_dev_impl(h, d_rows, n, ld, pick_stream(stream));
 }
 
 int vdb_rows_set(vdb_rows* h, int64_t row, const float* vec) {
     VDB_REQUIRE(h && vec && row >= 0 && row < h->r.n, "row %lld out of range", (long long)row);
-    std::lock_guard<std::mutex> g(ctx().mu);
-    hipStream_t s = ctx().stream;
+    Entry g(h);
+    hipStream_t s = h->stream;
     Rows& r = h->r;
     if (r.bf16) {
         VDB_TRY(h->ws.stage.reserve((size_t)r.dim * sizeof(float)));
@@ -800,7 +867,7 @@ int vdb_rows_set(vdb_rows* h, int64_t row, const float* vec) {
 
 int vdb_rows_truncate(vdb_rows* h, int64_t n) {
     VDB_REQUIRE(h && n >= 0 && n <= h->r.n, "cannot truncate %lld rows to %lld", h ? (long long)h->r.n : 0LL, (long long)n);
-    std::lock_guard<std::mutex> g(ctx().mu);
+    Entry g(h);
     h->r.n = n;
     return VDB_OK;
 }
@@ -813,8 +880,8 @@ int vdb_rows_size(const vdb_rows* h, int64_t* n) {
 
 int vdb_rows_norms(vdb_rows* h, float* sqnorm_out, float* norm_out) {
     VDB_REQUIRE(h, "null handle");
-    std::lock_guard<std::mutex> g(ctx().mu);
-    hipStream_t s = ctx().stream;
+    Entry g(h);
+    hipStream_t s = h->stream;
     if (h->r.n == 0) return VDB_OK;
     if (sqnorm_out) VDB_HIP(hipMemcpyAsync(sqnorm_out, h->r.sq, (size_t)h->r.n * sizeof(float), hipMemcpyDeviceToHost, s));
     if (norm_out) VDB_HIP(hipMemcpyAsync(norm_out, h->r.nrm, (size_t)h->r.n * sizeof(float), hipMemcpyDeviceToHost, s));
@@ -826,7 +893,7 @@ int vdb_rows_norms(vdb_rows* h, float* sqnorm_out, float* norm_out) {
 int vdb_flat_search_dev(vdb_rows* h, int metric, const float* d_queries, int nq, int k, const uint32_t* d_mask,
                         float* d_out_dist, int64_t* d_out_row, void* stream) {
     VDB_REQUIRE(h && (d_queries || nq == 0), "null argument");
-    std::lock_guard<std::mutex> g(ctx().mu);
+    Entry g(h);
     return flat_search_impl(h, metric, d_queries, nq, k, d_mask, d_out_dist, d_out_row, nullptr, pick_stream(stream));
 }
 
@@ -834,8 +901,8 @@ int vdb_flat_search(vdb_rows* h, int metric, const float* queries, int nq, int k
                     float* out_dist, int64_t* out_row) {
     VDB_REQUIRE(h && (queries || nq == 0), "null argument");
     VDB_REQUIRE(k >= 1, "k must be >= 1, got %d", k);
-    std::lock_guard<std::mutex> g(ctx().mu);
-    hipStream_t s = ctx().stream;
+    Entry g(h);
+    hipStream_t s = h->stream;
     const uint32_t* d_mask = nullptr;
     VDB_TRY(upload_mask(h->ws, mask, h->r.n, &d_mask, s));
     return with_host_io(h->ws, queries, nq, h->r.dim, k, out_dist, out_row, s,
@@ -846,12 +913,12 @@ int vdb_flat_search(vdb_rows* h, int metric, const float* queries, int nq, int k
 
 int vdb_flat_search_stats(vdb_rows* h, int* used_queue, int* overflowed) {
     VDB_REQUIRE(h && used_queue && overflowed, "null argument");
-    std::lock_guard<std::mutex> g(ctx().mu);
+    Entry g(h);
     *used_queue = h->last_used_queue ? 1 : 0;
     *overflowed = 0;
-    if (h->last_used_queue && h->ws.flag.p) {
-        hipStream_t s = h->last_stream ? h->last_stream : ctx().stream;
-        VDB_HIP(hipMemcpyAsync(overflowed, h->ws.flag.p, sizeof(int), hipMemcpyDeviceToHost, s));
+    if (h->last_used_queue && h->last_flag) {
+        hipStream_t s = h->last_stream ? h->last_stream : h->stream;
+        VDB_HIP(hipMemcpyAsync(overflowed, h->last_flag, sizeof(int), hipMemcpyDeviceToHost, s));
         VDB_HIP(hipStreamSynchronize(s));
     }
     return VDB_OK;
@@ -859,15 +926,15 @@ int vdb_flat_search_stats(vdb_rows* h, int* used_queue, int* overflowed) {
 
 int vdb_flat_distances_dev(vdb_rows* h, int metric, const float* d_queries, int nq, float* d_out, void* stream) {
     VDB_REQUIRE(h && (d_queries || nq == 0), "null argument");
-    std::lock_guard<std::mutex> g(ctx().mu);
+    Entry g(h);
     return flat_distances_impl(h, metric, d_queries, nq, d_out, pick_stream(stream));
 }
 
 int vdb_flat_distances(vdb_rows* h, int metric, const float* queries, int nq, float* out) {
     VDB_REQUIRE(h && (queries || nq == 0) && (out || nq == 0), "null argument");
     if (nq <= 0 || h->r.n == 0) return VDB_OK;
-    std::lock_guard<std::mutex> g(ctx().mu);
-    hipStream_t s = ctx().stream;
+    Entry g(h);
+    hipStream_t s = h->stream;
     Workspace& ws = h->ws;
     VDB_TRY(ws.stage.reserve((size_t)nq * h->r.dim * sizeof(float)));
     VDB_TRY(ws.dist.reserve((size_t)nq * h->r.n * sizeof(float)));
@@ -882,8 +949,8 @@ int vdb_flat_range_search(vdb_rows* h, int metric, const float* query, float rad
                           int64_t cap, float* out_dist, int64_t* out_row, int64_t* count) {
     VDB_REQUIRE(h && query && count, "null argument");
     VDB_REQUIRE(valid_metric(metric), "unknown metric code %d", metric);
-    std::lock_guard<std::mutex> g(ctx().mu);
-    hipStream_t s = ctx().stream;
+    Entry g(h);
+    hipStream_t s = h->stream;
     Rows& r = h->r;
     Workspace& ws = h->ws;
     *count = 0;
@@ -947,8 +1014,8 @@ int vdb_assign(const float* x, int64_t n, const float* centroids, int n_centroid
     VDB_TRY(vdb_rows_create(&c, dim));
     int st = vdb_rows_append(c, centroids, n_centroids);
     if (st == VDB_OK) {
-        std::lock_guard<std::mutex> g(ctx().mu);
-        hipStream_t s = ctx().stream;
+        Entry g(c);
+        hipStream_t s = c->stream;
         Workspace& ws = c->ws;
         const int64_t chunk = std::max<int64_t>(1024, std::min<int64_t>(n, (int64_t)(256 << 20) / (dim * (int64_t)sizeof(float))));
         DevBuf i32;
@@ -981,8 +1048,9 @@ int vdb_kmeans_accumulate(const float* x, int64_t n, int dim, const int32_t* ass
     VDB_TRY(ensure_init());
     VDB_REQUIRE(x && assign && out_sums && out_counts && n >= 0 && dim >= 1 && n_clusters >= 1,
                 "bad arguments to vdb_kmeans_accumulate");
-    std::lock_guard<std::mutex> g(ctx().mu);
-    hipStream_t s = ctx().stream;
+    ScopedHandle tmp;
+    VDB_TRY(tmp.open());
+    hipStream_t s = tmp.stream;
     DevBuf sums, counts, xs, as;
     auto body = [&]() -> int {
         VDB_TRY(sums.reserve((size_t)n_clusters * dim * sizeof(double)));
@@ -1020,23 +1088,30 @@ int vdb_ivf_create(vdb_ivf** out, int dim, int metric) {
     h->metric = metric;
     int st = vdb_rows_create(&h->centroids, dim);
     if (st == VDB_OK) st = vdb_rows_create(&h->members, dim);
-    if (st != VDB_OK) { vdb_rows_destroy(h->centroids); delete h; return st; }
+    if (st == VDB_OK) st = h->open();
+    if (st != VDB_OK) { vdb_rows_destroy(h->centroids); vdb_rows_destroy(h->members); delete h; return st; }
     *out = h;
     return VDB_OK;
 }
 
 int vdb_ivf_destroy(vdb_ivf* h) {
     if (!h) return VDB_OK;
+    {
+        Entry g(h);
+        (void)hipStreamSynchronize(h->stream);
+        if (h->last_stream && h->last_stream != h->stream) (void)hipStreamSynchronize(h->last_stream);
+        h->list_off.release(); h->row_ids.release(); h->ws.release();
+    }
     vdb_rows_destroy(h->centroids);
     vdb_rows_destroy(h->members);
-    std::lock_guard<std::mutex> g(ctx().mu);
-    h->list_off.release(); h->row_ids.release(); h->ws.release();
+    h->close();
     delete h;
     return VDB_OK;
 }
 
 int vdb_ivf_set_centroids(vdb_ivf* h, const float* centroids, int n_lists) {
     VDB_REQUIRE(h && centroids && n_lists >= 1, "bad arguments to vdb_ivf_set_centroids");
+    Entry g(h);
     VDB_TRY(vdb_rows_truncate(h->centroids, 0));
     VDB_TRY(vdb_rows_append(h->centroids, centroids, n_lists));
     h->n_lists = n_lists;
@@ -1058,8 +1133,8 @@ int vdb_ivf_build_lists(vdb_ivf* h, const float* rows, int64_t n, const int64_t*
         VDB_REQUIRE(list_rows[i] >= 0 && list_rows[i] < n, "row number %lld out of range", (long long)list_rows[i]);
         perm[(size_t)i] = (int)list_rows[i];
     }
-    std::lock_guard<std::mutex> g(ctx().mu);
-    hipStream_t s = ctx().stream;
+    Entry g(h);
+    hipStream_t s = h->stream;
     vdb_rows* m = h->members;
     m->r.n = 0;
     h->h_list_off.assign(list_offsets, list_offsets + h->n_lists + 1);
@@ -1151,7 +1226,7 @@ static int ivf_search_impl(vdb_ivf* h, const float* d_q, int nq, int k, int n_pr
     VDB_TRY(ws.probes.reserve((size_t)nq * n_probe * sizeof(int)));
     VDB_TRY(ws.probe_d.reserve((size_t)nq * n_probe * sizeof(float)));
     VDB_TRY(ivf_probe_impl(h, nullptr, d_q, nq, n_probe, ws.probes.as<int>(), ws.probe_d.as<float>(), s));
-    h->last_nq = nq; h->last_nprobe = n_probe; h->last_scan_rows = -1;
+    h->last_nq = nq; h->last_nprobe = n_probe; h->last_scan_rows = -1; h->last_stream = s;
 
     const float* q = nullptr;
     VDB_TRY(prepare_queries(ws, d_q, nq, m->r.dim, m->r.ld, m->r.plan, &q, s));
@@ -1214,14 +1289,14 @@ static int ivf_search_impl(vdb_ivf* h, const float* d_q, int nq, int k, int n_pr
 int vdb_ivf_search_dev(vdb_ivf* h, const float* d_queries, int nq, int k, int n_probe, const uint32_t* d_mask,
                        float* d_out_dist, int64_t* d_out_row, void* stream) {
     VDB_REQUIRE(h && (d_queries || nq == 0), "null argument");
-    std::lock_guard<std::mutex> g(ctx().mu);
+    Entry g(h);
     return ivf_search_impl(h, d_queries, nq, k, n_probe, d_mask, d_out_dist, d_out_row, nullptr, pick_stream(stream));
 }
 
 int vdb_ivf_search_ordered_dev(vdb_ivf* h, const float* d_queries, int nq, int k, int n_probe, const uint32_t* d_mask,
                                float* d_out_dist, int64_t* d_out_row, int64_t* d_out_order, void* stream) {
     VDB_REQUIRE(h && (d_queries || nq == 0) && d_out_order, "null argument");
-    std::lock_guard<std::mutex> g(ctx().mu);
+    Entry g(h);
     return ivf_search_impl(h, d_queries, nq, k, n_probe, d_mask, d_out_dist, d_out_row, d_out_order, pick_stream(stream));
 }
 
@@ -1229,8 +1304,8 @@ int vdb_ivf_search(vdb_ivf* h, const float* queries, int nq, int k, int n_probe,
                    float* out_dist, int64_t* out_row) {
     VDB_REQUIRE(h && (queries || nq == 0), "null argument");
     VDB_REQUIRE(k >= 1, "k must be >= 1, got %d", k);
-    std::lock_guard<std::mutex> g(ctx().mu);
-    hipStream_t s = ctx().stream;
+    Entry g(h);
+    hipStream_t s = h->stream;
     const uint32_t* d_mask = nullptr;
     VDB_TRY(upload_mask(h->ws, mask, h->members->r.n, &d_mask, s));
     return with_host_io(h->members->ws, queries, nq, h->dim, k, out_dist, out_row, s,
@@ -1242,8 +1317,8 @@ int vdb_ivf_search(vdb_ivf* h, const float* queries, int nq, int k, int n_probe,
 int vdb_ivf_probe(vdb_ivf* h, const float* queries, int nq, int n_probe, int32_t* out_lists, float* out_dist) {
     VDB_REQUIRE(h && (queries || nq == 0) && h->n_lists >= 1 && n_probe >= 1, "bad arguments to vdb_ivf_probe");
     if (nq <= 0) return VDB_OK;
-    std::lock_guard<std::mutex> g(ctx().mu);
-    hipStream_t s = ctx().stream;
+    Entry g(h);
+    hipStream_t s = h->stream;
     Workspace& ws = h->ws;
     n_probe = std::min(n_probe, h->n_lists);
     VDB_TRY(ws.stage.reserve((size_t)nq * h->dim * sizeof(float)));
@@ -1259,13 +1334,14 @@ int vdb_ivf_probe(vdb_ivf* h, const float* queries, int nq, int n_probe, int32_t
 
 int vdb_ivf_last_scan_rows(vdb_ivf* h, int64_t* rows_scanned) {
     VDB_REQUIRE(h && rows_scanned, "null argument");
-    std::lock_guard<std::mutex> g(ctx().mu);
-    hipStream_t s = ctx().stream;
+    Entry g(h);
+    hipStream_t s = h->stream;
     *rows_scanned = 0;
     const size_t cnt = (size_t)h->last_nq * h->last_nprobe;
     if (cnt == 0 || h->ws.probes.cap < cnt * sizeof(int)) return VDB_OK;
     std::vector<int> probes(cnt);
-    VDB_HIP(hipDeviceSynchronize());
+    // the probe lists were written on the stream of that search
+    if (h->last_stream && h->last_stream != s) VDB_HIP(hipStreamSynchronize(h->last_stream));
     VDB_HIP(hipMemcpyAsync(probes.data(), h->ws.probes.p, cnt * sizeof(int), hipMemcpyDeviceToHost, s));
     VDB_HIP(hipStreamSynchronize(s));
     int64_t total = 0;
@@ -1281,8 +1357,9 @@ int vdb_pq_encode(const float* x, int64_t n, const float* codebook, int m, int k
     VDB_REQUIRE(x && codebook && out_codes && n >= 0 && m >= 1 && ksub >= 1 && ksub <= 256 && dsub >= 1,
                 "bad arguments to vdb_pq_encode");
     if (n == 0) return VDB_OK;
-    std::lock_guard<std::mutex> g(ctx().mu);
-    hipStream_t s = ctx().stream;
+    ScopedHandle tmp;
+    VDB_TRY(tmp.open());
+    hipStream_t s = tmp.stream;
     SumPlan plan;
     VDB_TRY(make_sum_plan(dsub, &plan));
     const int dim = m * dsub;
@@ -1314,24 +1391,30 @@ int vdb_pq_create(vdb_pq** out, int dim, int m, int ksub) {
     VDB_REQUIRE(ksub >= 1 && ksub <= 256, "codewords per sub-space must be in 1..256, got %d", ksub);
     vdb_pq* h = new vdb_pq();
     h->dim = dim; h->m = m; h->ksub = ksub; h->dsub = dim / m;
-    VDB_TRY(make_sum_plan(h->dsub, &h->plan));
+    int st = make_sum_plan(h->dsub, &h->plan);
+    if (st == VDB_OK) st = h->open();
+    if (st != VDB_OK) { delete h; return st; }
     *out = h;
     return VDB_OK;
 }
 
 int vdb_pq_destroy(vdb_pq* h) {
     if (!h) return VDB_OK;
-    std::lock_guard<std::mutex> g(ctx().mu);
-    (void)hipStreamSynchronize(ctx().stream);
-    h->book.release(); h->codes.release(); h->ws.release(); h->io.release();
+    {
+        Entry g(h);
+        (void)hipStreamSynchronize(h->stream);
+        if (h->last_stream && h->last_stream != h->stream) (void)hipStreamSynchronize(h->last_stream);
+        h->book.release(); h->codes.release(); h->ws.release(); h->io.release();
+    }
+    h->close();
     delete h;
     return VDB_OK;
 }
 
 int vdb_pq_set_codebook(vdb_pq* h, const float* codebook) {
     VDB_REQUIRE(h && codebook, "null argument");
-    std::lock_guard<std::mutex> g(ctx().mu);
-    hipStream_t s = ctx().stream;
+    Entry g(h);
+    hipStream_t s = h->stream;
     const size_t bytes = (size_t)h->m * h->ksub * h->dsub * sizeof(float);
     VDB_TRY(h->book.reserve(bytes));
     VDB_HIP(hipMemcpyAsync(h->book.p, codebook, bytes, hipMemcpyHostToDevice, s));
@@ -1352,8 +1435,8 @@ static int pq_reserve(vdb_pq* h, int64_t n_total, hipStream_t s) {
 int vdb_pq_append_codes(vdb_pq* h, const uint8_t* codes, int64_t n) {
     VDB_REQUIRE(h && (codes || n == 0) && n >= 0, "bad arguments to vdb_pq_append_codes");
     if (n == 0) return VDB_OK;
-    std::lock_guard<std::mutex> g(ctx().mu);
-    hipStream_t s = ctx().stream;
+    Entry g(h);
+    hipStream_t s = h->stream;
     VDB_TRY(pq_reserve(h, h->n + n, s));
     VDB_HIP(hipMemcpyAsync(h->codes.as<uint8_t>() + h->n * h->m, codes, (size_t)n * h->m, hipMemcpyHostToDevice, s));
     VDB_HIP(hipStreamSynchronize(s));
@@ -1364,8 +1447,9 @@ int vdb_pq_append_codes(vdb_pq* h, const uint8_t* codes, int64_t n) {
 int vdb_pq_append_codes_dev(vdb_pq* h, const uint8_t* d_codes, int64_t n, void* stream) {
     VDB_REQUIRE(h && (d_codes || n == 0) && n >= 0, "bad arguments to vdb_pq_append_codes_dev");
     if (n == 0) return VDB_OK;
-    std::lock_guard<std::mutex> g(ctx().mu);
+    Entry g(h);
     hipStream_t s = pick_stream(stream);
+    h->last_stream = s;
     VDB_TRY(pq_reserve(h, h->n + n, s));
     VDB_HIP(hipMemcpyAsync(h->codes.as<uint8_t>() + h->n * h->m, d_codes, (size_t)n * h->m, hipMemcpyDeviceToDevice, s));
     h->n += n;
@@ -1376,8 +1460,8 @@ int vdb_pq_append_rows(vdb_pq* h, const float* rows, int64_t n, uint8_t* out_cod
     VDB_REQUIRE(h && (rows || n == 0) && n >= 0, "bad arguments to vdb_pq_append_rows");
     VDB_REQUIRE(h->trained, "codebook not set");
     if (n == 0) return VDB_OK;
-    std::lock_guard<std::mutex> g(ctx().mu);
-    hipStream_t s = ctx().stream;
+    Entry g(h);
+    hipStream_t s = h->stream;
     VDB_TRY(pq_reserve(h, h->n + n, s));
     const int64_t chunk = std::max<int64_t>(1024, (int64_t)(256 << 20) / (h->dim * (int64_t)sizeof(float)));
     for (int64_t o = 0; o < n; o += chunk) {
@@ -1396,15 +1480,15 @@ int vdb_pq_append_rows(vdb_pq* h, const float* rows, int64_t n, uint8_t* out_cod
 
 int vdb_pq_truncate(vdb_pq* h, int64_t n) {
     VDB_REQUIRE(h && n >= 0 && n <= h->n, "cannot truncate to %lld rows", (long long)n);
-    std::lock_guard<std::mutex> g(ctx().mu);
+    Entry g(h);
     h->n = n;
     return VDB_OK;
 }
 
 int vdb_pq_set_code(vdb_pq* h, int64_t row, const uint8_t* code) {
     VDB_REQUIRE(h && code && row >= 0 && row < h->n, "row %lld out of range", (long long)row);
-    std::lock_guard<std::mutex> g(ctx().mu);
-    hipStream_t s = ctx().stream;
+    Entry g(h);
+    hipStream_t s = h->stream;
     VDB_HIP(hipMemcpyAsync(h->codes.as<uint8_t>() + row * h->m, code, (size_t)h->m, hipMemcpyHostToDevice, s));
     VDB_HIP(hipStreamSynchronize(s));
     return VDB_OK;
@@ -1419,8 +1503,8 @@ int vdb_pq_size(const vdb_pq* h, int64_t* n) {
 int vdb_pq_lut(vdb_pq* h, const float* query, float* out_lut) {
     VDB_REQUIRE(h && query && out_lut, "null argument");
     VDB_REQUIRE(h->trained, "codebook not set");
-    std::lock_guard<std::mutex> g(ctx().mu);
-    hipStream_t s = ctx().stream;
+    Entry g(h);
+    hipStream_t s = h->stream;
     Workspace& ws = h->ws;
     const size_t lut_bytes = (size_t)h->m * h->ksub * sizeof(float);
     VDB_TRY(ws.stage.reserve((size_t)h->dim * sizeof(float)));
@@ -1437,6 +1521,7 @@ static int pq_search_impl(vdb_pq* h, const float* d_q, int nq, int k, const uint
     VDB_REQUIRE(h->trained, "index is not trained");
     VDB_REQUIRE(nq >= 0 && k >= 1, "need nq >= 0 and k >= 1");
     if (nq == 0) return VDB_OK;
+    h->last_stream = s;
     Workspace& ws = h->ws;
     const int64_t k_eff = std::min<int64_t>(k, h->n);
     if (k_eff < k) VDB_TRY(fill_results(d_out_d, d_out_i, (int64_t)nq * k, s));
@@ -1469,15 +1554,15 @@ static int pq_search_impl(vdb_pq* h, const float* d_q, int nq, int k, const uint
 int vdb_pq_search_dev(vdb_pq* h, const float* d_queries, int nq, int k, const uint32_t* d_mask,
                       float* d_out_dist, int64_t* d_out_row, void* stream) {
     VDB_REQUIRE(h && (d_queries || nq == 0), "null argument");
-    std::lock_guard<std::mutex> g(ctx().mu);
+    Entry g(h);
     return pq_search_impl(h, d_queries, nq, k, d_mask, d_out_dist, d_out_row, pick_stream(stream));
 }
 
 int vdb_pq_search(vdb_pq* h, const float* queries, int nq, int k, const uint32_t* mask, float* out_dist, int64_t* out_row) {
     VDB_REQUIRE(h && (queries || nq == 0), "null argument");
     VDB_REQUIRE(k >= 1, "k must be >= 1, got %d", k);
-    std::lock_guard<std::mutex> g(ctx().mu);
-    hipStream_t s = ctx().stream;
+    Entry g(h);
+    hipStream_t s = h->stream;
     const uint32_t* d_mask = nullptr;
     VDB_TRY(upload_mask(h->ws, mask, h->n, &d_mask, s));
     return with_host_io(h->io, queries, nq, h->dim, k, out_dist, out_row, s,
@@ -1487,7 +1572,7 @@ int vdb_pq_search(vdb_pq* h, const float* queries, int nq, int k, const uint32_t
 }
 
 // ============================================================== IVF-PQ (index/hybrid.py)
-struct vdb_ivfpq {
+struct vdb_ivfpq : Handle {
     int dim = 0, m = 0, ksub = 0, dsub = 0;
     SumPlan plan;                       // over one sub-vector
     vdb_rows* centroids = nullptr;      // coarse centroids
@@ -1499,6 +1584,7 @@ struct vdb_ivfpq {
     int n_lists = 0;
     int64_t n = 0;
     bool ready = false;
+    hipStream_t last_stream = nullptr;  // stream of the last *_dev call
     Workspace ws, io;
     int64_t probe_bound(int n_probe) {
         if (len_desc.size() != (size_t)n_lists) {
@@ -1521,27 +1607,32 @@ int vdb_ivfpq_create(vdb_ivfpq** out, int dim, int m, int ksub) {
     h->dim = dim; h->m = m; h->ksub = ksub; h->dsub = dim / m;
     int st = make_sum_plan(h->dsub, &h->plan);
     if (st == VDB_OK) st = vdb_rows_create(&h->centroids, dim);
-    if (st != VDB_OK) { delete h; return st; }
+    if (st == VDB_OK) st = h->open();
+    if (st != VDB_OK) { vdb_rows_destroy(h->centroids); delete h; return st; }
     *out = h;
     return VDB_OK;
 }
 
 int vdb_ivfpq_destroy(vdb_ivfpq* h) {
     if (!h) return VDB_OK;
+    {
+        Entry g(h);
+        (void)hipStreamSynchronize(h->stream);
+        if (h->last_stream && h->last_stream != h->stream) (void)hipStreamSynchronize(h->last_stream);
+        h->book.release(); h->codes.release(); h->list_off.release(); h->row_ids.release(); h->ws.release(); h->io.release();
+    }
     vdb_rows_destroy(h->centroids);
-    std::lock_guard<std::mutex> g(ctx().mu);
-    (void)hipStreamSynchronize(ctx().stream);
-    h->book.release(); h->codes.release(); h->list_off.release(); h->row_ids.release(); h->ws.release(); h->io.release();
+    h->close();
     delete h;
     return VDB_OK;
 }
 
 int vdb_ivfpq_set_quantizers(vdb_ivfpq* h, const float* centroids, int n_lists, const float* codebook) {
     VDB_REQUIRE(h && centroids && codebook && n_lists >= 1, "bad arguments to vdb_ivfpq_set_quantizers");
+    Entry g(h);
     VDB_TRY(vdb_rows_truncate(h->centroids, 0));
     VDB_TRY(vdb_rows_append(h->centroids, centroids, n_lists));
-    std::lock_guard<std::mutex> g(ctx().mu);
-    hipStream_t s = ctx().stream;
+    hipStream_t s = h->stream;
     const size_t bytes = (size_t)h->m * h->ksub * h->dsub * sizeof(float);
     VDB_TRY(h->book.reserve(bytes));
     VDB_HIP(hipMemcpyAsync(h->book.p, codebook, bytes, hipMemcpyHostToDevice, s));
@@ -1557,8 +1648,8 @@ int vdb_ivfpq_set_quantizers(vdb_ivfpq* h, const float* centroids, int n_lists, 
 int vdb_ivfpq_encode(vdb_ivfpq* h, const float* rows, int64_t n, int32_t* out_list, uint8_t* out_codes) {
     VDB_REQUIRE(h && h->ready && (rows || n == 0) && n >= 0 && out_list && out_codes, "bad arguments to vdb_ivfpq_encode");
     if (n == 0) return VDB_OK;
-    std::lock_guard<std::mutex> g(ctx().mu);
-    hipStream_t s = ctx().stream;
+    Entry g(h);
+    hipStream_t s = h->stream;
     Workspace& ws = h->ws;
     vdb_rows* c = h->centroids;
     DevBuf i32, res, codes;
@@ -1603,8 +1694,8 @@ int vdb_ivfpq_build(vdb_ivfpq* h, const uint8_t* codes, int64_t n, const int64_t
         perm[(size_t)i] = (int)list_rows[i];
         memcpy(&ordered[(size_t)i * h->m], codes + list_rows[i] * h->m, h->m);
     }
-    std::lock_guard<std::mutex> g(ctx().mu);
-    hipStream_t s = ctx().stream;
+    Entry g(h);
+    hipStream_t s = h->stream;
     h->h_list_off.assign(list_offsets, list_offsets + h->n_lists + 1);
     h->len_desc.clear();
     VDB_TRY(h->list_off.reserve((size_t)(h->n_lists + 1) * sizeof(int64_t)));
@@ -1625,6 +1716,7 @@ static int ivfpq_search_impl(vdb_ivfpq* h, const float* d_q, int nq, int k, int 
     VDB_REQUIRE(h->ready, "index is not trained");
     VDB_REQUIRE(nq >= 0 && k >= 1 && n_probe >= 1, "need nq >= 0, k >= 1, n_probe >= 1");
     if (nq == 0) return VDB_OK;
+    h->last_stream = s;
     n_probe = std::min(n_probe, h->n_lists);
     Workspace& ws = h->ws;
     VDB_TRY(fill_results(d_out_d, d_out_i, (int64_t)nq * k, s));
@@ -1701,7 +1793,7 @@ static int ivfpq_search_impl(vdb_ivfpq* h, const float* d_q, int nq, int k, int 
 int vdb_ivfpq_search_dev(vdb_ivfpq* h, const float* d_queries, int nq, int k, int n_probe, const uint32_t* d_mask,
                          float* d_out_dist, int64_t* d_out_row, void* stream) {
     VDB_REQUIRE(h && (d_queries || nq == 0), "null argument");
-    std::lock_guard<std::mutex> g(ctx().mu);
+    Entry g(h);
     return ivfpq_search_impl(h, d_queries, nq, k, n_probe, d_mask, d_out_dist, d_out_row, pick_stream(stream));
 }
 
@@ -1709,8 +1801,8 @@ int vdb_ivfpq_search(vdb_ivfpq* h, const float* queries, int nq, int k, int n_pr
                      float* out_dist, int64_t* out_row) {
     VDB_REQUIRE(h && (queries || nq == 0), "null argument");
     VDB_REQUIRE(k >= 1, "k must be >= 1, got %d", k);
-    std::lock_guard<std::mutex> g(ctx().mu);
-    hipStream_t s = ctx().stream;
+    Entry g(h);
+    hipStream_t s = h->stream;
     const uint32_t* d_mask = nullptr;
     VDB_TRY(upload_mask(h->ws, mask, h->n, &d_mask, s));
     return with_host_io(h->io, queries, nq, h->dim, k, out_dist, out_row, s,
@@ -1723,6 +1815,7 @@ int vdb_ivfpq_search(vdb_ivfpq* h, const float* queries, int nq, int k, int n_pr
 int vdb_topk_merge_dev(const float* d_dist, const int64_t* d_row, int n_lists, int nq, int k,
                        float* d_out_dist, int64_t* d_out_row, void* stream) {
     VDB_TRY(ensure_init());
+    (void)hipSetDevice(ctx().device);
     VDB_REQUIRE(d_dist && d_row && d_out_dist && d_out_row && n_lists >= 1 && nq >= 0 && k >= 1,
                 "bad arguments to vdb_topk_merge_dev");
     return launch_select_i64(d_dist, d_row, nullptr, (int64_t)nq * k, (int64_t)nq * k, nullptr, n_lists, nq, k,
@@ -1733,6 +1826,7 @@ int vdb_topk_merge_strided_dev(const float* d_dist, const int64_t* d_row, int64_
                                const int64_t* d_row_base, int n_lists, int nq, int k,
                                float* d_out_dist, int64_t* d_out_row, void* stream) {
     VDB_TRY(ensure_init());
+    (void)hipSetDevice(ctx().device);
     VDB_REQUIRE(d_dist && d_row && d_out_dist && d_out_row && n_lists >= 1 && nq >= 0 && k >= 1,
                 "bad arguments to vdb_topk_merge_strided_dev");
     VDB_REQUIRE(list_stride_dist >= (int64_t)nq * k && list_stride_row >= (int64_t)nq * k,
@@ -1745,6 +1839,7 @@ int vdb_topk_merge_strided_dev(const float* d_dist, const int64_t* d_row, int64_
 int vdb_topk_merge_keyed_dev(const float* d_dist, const int64_t* d_key, const int64_t* d_row, int n_lists, int nq, int k,
                              float* d_out_dist, int64_t* d_out_row, void* stream) {
     VDB_TRY(ensure_init());
+    (void)hipSetDevice(ctx().device);
     VDB_REQUIRE(d_dist && d_key && d_row && d_out_dist && d_out_row && n_lists >= 1 && nq >= 0 && k >= 1,
                 "bad arguments to vdb_topk_merge_keyed_dev");
     return launch_select_i64(d_dist, d_key, d_row, (int64_t)nq * k, (int64_t)nq * k, nullptr, n_lists, nq, k,

@@ -1,0 +1,95 @@
+// Measured ceilings of the GPU the library runs on: what a large device-to-device copy and
+// register-only matrix-core loops reach, for reporting beside the spec peaks that the roofline
+// fractions are quoted against.  Nothing on the search path calls this file.
+#include "flat_math.h"
+
+namespace vdb {
+
+// Every wave runs `iters` rounds of four independent 32x32 accumulators (no memory traffic, no
+// dependency between consecutive instructions of different accumulators); the result is stored so
+// that the loop cannot be dropped.
+template <bool BF16>
+__global__ __launch_bounds__(256) void mfma_loop_kernel(float* out, int iters) {
+    f32x16 acc[4];
+#pragma unroll
+    for (int a = 0; a < 4; ++a)
+#pragma unroll
+        for (int i = 0; i < 16; ++i) acc[a][i] = 0.0f;
+    const float x = 1.0f + (float)(threadIdx.x & 7) * 0.125f, y = 0.5f;
+    bf16x8 xa, xb;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) { xa[i] = (short)(0x3f80 + (threadIdx.x & 3)); xb[i] = (short)0x3f00; }
+    for (int it = 0; it < iters; ++it) {
+#pragma unroll
+        for (int rep = 0; rep < 4; ++rep) {
+#pragma unroll
+            for (int a = 0; a < 4; ++a) {
+                if (BF16) acc[a] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(xa, xb, acc[a], 0, 0, 0);
+                else acc[a] = __builtin_amdgcn_mfma_f32_32x32x2f32(x, y, acc[a], 0, 0, 0);
+            }
+        }
+    }
+    float s = 0.0f;
+#pragma unroll
+    for (int a = 0; a < 4; ++a)
+#pragma unroll
+        for (int i = 0; i < 16; ++i) s += acc[a][i];
+    out[(size_t)blockIdx.x * blockDim.x + threadIdx.x] = s;
+}
+
+template <bool BF16>
+static int time_mfma_loop(float* out, int blocks, int iters, hipStream_t s, float* tflops) {
+    hipEvent_t e0, e1;
+    VDB_HIP(hipEventCreate(&e0));
+    VDB_HIP(hipEventCreate(&e1));
+    hipLaunchKernelGGL(mfma_loop_kernel<BF16>, dim3(blocks), dim3(256), 0, s, out, 16);          // warm-up
+    VDB_HIP(hipEventRecord(e0, s));
+    hipLaunchKernelGGL(mfma_loop_kernel<BF16>, dim3(blocks), dim3(256), 0, s, out, iters);
+    VDB_HIP(hipEventRecord(e1, s));
+    VDB_HIP(hipEventSynchronize(e1));
+    float ms = 0.0f;
+    VDB_HIP(hipEventElapsedTime(&ms, e0, e1));
+    (void)hipEventDestroy(e0);
+    (void)hipEventDestroy(e1);
+    // one instruction: 32 x 32 outputs x K products x 2 flop
+    const double flop_per_inst = 2.0 * 32 * 32 * (BF16 ? 16 : 2);
+    const double insts = (double)blocks * 4 /* waves */ * iters * 16.0;
+    *tflops = (float)(insts * flop_per_inst / (ms * 1e-3) / 1e12);
+    return VDB_OK;
+}
+
+int measure_ceilings(hipStream_t s, float* copy_gbs, float* mfma_f32_tflops, float* mfma_bf16_tflops) {
+    const size_t bytes = (size_t)1 << 30;
+    void *a = nullptr, *b = nullptr;
+    VDB_HIP(hipMalloc(&a, bytes));
+    if (hipMalloc(&b, bytes) != hipSuccess) { (void)hipFree(a); set_error("out of memory in measure_ceilings"); return VDB_ERR_NOMEM; }
+    int st = VDB_OK;
+    auto body = [&]() -> int {
+        VDB_HIP(hipMemsetAsync(a, 1, bytes, s));
+        VDB_HIP(hipMemcpyAsync(b, a, bytes, hipMemcpyDeviceToDevice, s));                       // warm-up
+        hipEvent_t e0, e1;
+        VDB_HIP(hipEventCreate(&e0));
+        VDB_HIP(hipEventCreate(&e1));
+        const int reps = 10;
+        VDB_HIP(hipEventRecord(e0, s));
+        for (int i = 0; i < reps; ++i) VDB_HIP(hipMemcpyAsync(b, a, bytes, hipMemcpyDeviceToDevice, s));
+        VDB_HIP(hipEventRecord(e1, s));
+        VDB_HIP(hipEventSynchronize(e1));
+        float ms = 0.0f;
+        VDB_HIP(hipEventElapsedTime(&ms, e0, e1));
+        (void)hipEventDestroy(e0);
+        (void)hipEventDestroy(e1);
+        *copy_gbs = (float)(2.0 * bytes * reps / (ms * 1e-3) / 1e9);                            // bytes read + bytes written
+        const int blocks = ctx().num_cus * 2;                                                   // 8 waves per CU, 2 per SIMD
+        VDB_TRY(time_mfma_loop<false>(reinterpret_cast<float*>(a), blocks, 4096, s, mfma_f32_tflops));
+        VDB_TRY(time_mfma_loop<true>(reinterpret_cast<float*>(a), blocks, 16384, s, mfma_bf16_tflops));
+        return VDB_OK;
+    };
+    st = body();
+    (void)hipStreamSynchronize(s);
+    (void)hipFree(a);
+    (void)hipFree(b);
+    return st;
+}
+
+}  // namespace vdb

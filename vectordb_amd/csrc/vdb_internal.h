@@ -44,14 +44,30 @@ void set_error(const char* fmt, ...);
 
 // ---------------------------------------------------------------- device state
 struct Context {
-    int device = -1;
-    hipStream_t stream = nullptr;   // the library's own stream
+    int device = -1;                // the one GPU this process uses; fixed by the first vdb_init
     int num_cus = 256;
     float* zeros = nullptr;         // 256 zero bytes in device memory
-    std::mutex mu;                  // serialises calls that share workspaces
+    void* scratch = nullptr;        // device address of the static scratch array (no-allocation entry point)
+    std::mutex mu;                  // guards initialisation only
 };
 Context& ctx();
 int ensure_init();
+
+// Base of every handle.  Calls on one handle are serialised by its mutex (they share its
+// workspaces); different handles run concurrently.  The host-pointer entry points of a handle
+// enqueue on its own stream, a blocking stream, i.e. ordered with the null stream.
+struct Handle {
+    std::mutex mu;
+    hipStream_t stream = nullptr;
+    int open();                     // creates the stream
+    void close();                   // waits for the stream and destroys it
+};
+// Scope of one entry point on a handle: takes the handle's mutex and makes the library's device
+// current on the calling thread (the HIP device is a per-thread setting).
+struct Entry {
+    std::lock_guard<std::mutex> g;
+    explicit Entry(Handle* h) : g(h->mu) { (void)hipSetDevice(ctx().device); }
+};
 
 // HIP-event bracket around a dominant kernel launch (no-op unless profiling is on)
 struct KernelTimer {
@@ -61,10 +77,19 @@ struct KernelTimer {
     ~KernelTimer();
 };
 
-// A grow-only device buffer (workspace).
+// A fixed block of device memory handed out front to back, never returned: the workspaces of a
+// call that must not allocate are carved out of it.
+struct Arena {
+    char* base = nullptr;
+    size_t size = 0, used = 0;
+};
+
+// A grow-only device buffer (workspace).  Bound to an arena it takes its memory from there
+// instead of hipMalloc and fails with VDB_ERR_INVALID when the arena is exhausted.
 struct DevBuf {
     void* p = nullptr;
     size_t cap = 0;
+    Arena* arena = nullptr;
     int reserve(size_t bytes);      // may reallocate (contents lost)
     int reserve_keep(size_t bytes, size_t keep_bytes, hipStream_t s);  // grows geometrically, keeps a prefix
     void release();
@@ -250,6 +275,8 @@ int launch_residual(const float* x, int64_t ldx, const float* cent, int ldc, con
 int launch_ivfpq_scan(const float* q, int ldq, int dim, int nq, const float* cent, int ldc, const float* book, int m, int ksub,
                       int dsub, const SumPlan& plan, const uint8_t* codes, const int64_t* list_off, int n_lists,
                       const int* probes, int n_probe, const int64_t* cand_off, int64_t cand_stride, float* cand, hipStream_t s);
+// measured ceilings of this GPU (ceilings.hip): device-to-device copy GB/s (read + write), register-only MFMA loops
+int measure_ceilings(hipStream_t s, float* copy_gbs, float* mfma_f32_tflops, float* mfma_bf16_tflops);
 // k-means
 int launch_kmeans_accumulate(const float* x, int64_t n, int dim, int ldx, const int* assign, int n_clusters,
                              double* sums, unsigned long long* counts, hipStream_t s);

@@ -37,8 +37,12 @@ class GPUDistanceCalculator:
         self.device_id = device_id
         self._gpu_available = HAS_GPU
         if self._gpu_available:
+            # One process drives one GPU (LOCAL_RANK picks it): the calculator works on the device the
+            # library already uses.  `device_id` is the reference's argument (gpu.py:63-67 switches the
+            # CuPy device); here it is recorded, and a value that names another device than the
+            # selected one does not move the library.
             try:
-                N.init(device_id)
+                N.init()
             except Exception:
                 self._gpu_available = False
 
@@ -82,7 +86,7 @@ def get_gpu_info() -> dict:
         return {"available": False}
     try:
         info = N.device_info()
-        return {"available": True, "device_id": int(__import__("os").environ.get("LOCAL_RANK", "0")),
+        return {"available": True, "device_id": N.current_device(),
                 "name": info["name"], "memory_total": info["memory_total"], "memory_free": info["memory_free"]}
     except Exception as e:
         return {"available": False, "error": str(e)}

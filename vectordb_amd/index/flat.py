@@ -67,6 +67,8 @@ class FlatIndex(BaseIndex):
 
     # ------------------------------------------------------------ device mirror
     def _device(self) -> N.RowStore:
+        """Device mirror with the pending host tail uploaded.  Call with ``self._lock`` held: two
+        threads that both saw the same pending tail would append it twice."""
         if self._store is None:
             self._store = N.RowStore(self._dimension, storage=self._storage)
             self._synced = 0
@@ -156,8 +158,14 @@ class FlatIndex(BaseIndex):
         if k <= 0:
             return []
         code = self._metric_code()
-        dist, rows = self._device().search(query, k, code, self._mask_words(filter_fn))
-        return self._results(dist[0], rows[0], include_vectors, include_metadata)
+        # mirror sync, device call and row -> id mapping under the index lock: a concurrent add or
+        # remove must not move rows between the search and the mapping
+        with self._lock:
+            k = min(k, self._size)
+            if k <= 0:
+                return []
+            dist, rows = self._device().search(query, k, code, self._mask_words(filter_fn))
+            return self._results(dist[0], rows[0], include_vectors, include_metadata)
 
     def search_batch(self, queries, k: int = 10, filter_fn: Optional[FilterFunction] = None) -> List[List[SearchResult]]:
         """One device call for the whole batch (the reference loops over
@@ -167,11 +175,12 @@ class FlatIndex(BaseIndex):
             return [[] for _ in range(len(queries))]
         if self.config.normalize:
             queries = unit_rows(queries)
-        k = min(k, self._size)
-        if k <= 0 or len(queries) == 0:
-            return [[] for _ in range(len(queries))]
-        dist, rows = self._device().search(queries, k, self._metric_code(), self._mask_words(filter_fn))
-        return [self._results(dist[i], rows[i], False, True) for i in range(len(queries))]
+        with self._lock:
+            k = min(k, self._size)
+            if k <= 0 or len(queries) == 0:
+                return [[] for _ in range(len(queries))]
+            dist, rows = self._device().search(queries, k, self._metric_code(), self._mask_words(filter_fn))
+            return [self._results(dist[i], rows[i], False, True) for i in range(len(queries))]
 
     def search_by_id(self, id: str, k: int = 10, exclude_self: bool = True,
                      filter_fn: Optional[FilterFunction] = None) -> List[SearchResult]:
@@ -193,9 +202,12 @@ class FlatIndex(BaseIndex):
         query = self._validate_vector(query)
         if self.config.normalize:
             query = unit_vector(query)
-        dist, rows = self._device().range_search(query, radius, self._metric_code(), self._mask_words(filter_fn),
-                                                 cap=max_results or self._size)
-        return self._results(dist, rows, False, True)
+        with self._lock:
+            if self._size == 0:
+                return []
+            dist, rows = self._device().range_search(query, radius, self._metric_code(), self._mask_words(filter_fn),
+                                                     cap=max_results or self._size)
+            return self._results(dist, rows, False, True)
 
     # ------------------------------------------------------------ remove / update
     def remove(self, id: str) -> bool:
@@ -283,7 +295,7 @@ class FlatIndex(BaseIndex):
     def to_dict(self) -> Dict[str, Any]:
         return {"index_type": self.index_type.value, "dimension": self._dimension, "metric": self._metric,
                 "config": {"normalize": self.config.normalize, "use_matrix": self.config.use_matrix,
-                           "initial_capacity": self.config.initial_capacity},
+                           "initial_capacity": self.config.initial_capacity, "storage": self._storage},
                 "ids": self._ids.copy(), "vectors": self._vectors[:self._size].tolist(),
                 "metadata": {id: meta.copy() for id, meta in self._metadata.items()}}
 
@@ -293,7 +305,8 @@ class FlatIndex(BaseIndex):
         ids = data.get("ids", [])
         index = cls(dimension=data["dimension"], metric=data["metric"], normalize=cfg.get("normalize", False),
                     use_matrix=cfg.get("use_matrix", True),
-                    initial_capacity=max(cfg.get("initial_capacity", 1000), len(ids)))
+                    initial_capacity=max(cfg.get("initial_capacity", 1000), len(ids)),
+                    storage=cfg.get("storage", "f32"))
         if len(ids) > 0:
             meta = data.get("metadata", {})
             index.add_batch(ids, np.array(data.get("vectors", []), dtype=np.float32), [meta.get(i, {}) for i in ids])
@@ -314,9 +327,10 @@ class FlatIndex(BaseIndex):
 
     def compute_distance_matrix(self) -> np.ndarray:
         """index/flat.py:880-901"""
-        if self._size == 0:
-            return np.zeros((0, 0), dtype=np.float32)
-        return self._device().distances(self._vectors[:self._size], self._metric_code())
+        with self._lock:
+            if self._size == 0:
+                return np.zeros((0, 0), dtype=np.float32)
+            return self._device().distances(self._vectors[:self._size], self._metric_code())
 
     def find_duplicates(self, threshold: float = 1e-6) -> List[Tuple[str, str, float]]:
         """index/flat.py:903-930: pairs (id_i, id_j, distance), i < j in insertion order, whose distance is
@@ -333,14 +347,16 @@ class FlatIndex(BaseIndex):
             code = N.EUCLIDEAN_DIRECT
         elif code == N.EUCLIDEAN_SQ:
             code = N.EUCLIDEAN_SQ_DIRECT
-        store = self._device()
-        block = max(1, min(n, (64 << 20) // (4 * n)))                 # at most 64 MB of distances at a time
-        for i0 in range(0, n, block):
-            d = store.distances(self._vectors[i0:min(i0 + block, n)], code)
-            ii, jj = np.nonzero(d <= threshold)
-            keep = jj > ii + i0
-            for a, b in zip(ii[keep], jj[keep]):                       # row-major: i ascending, then j ascending
-                out.append((self._ids[i0 + int(a)], self._ids[int(b)], float(d[a, b])))
+        with self._lock:
+            n = self._size
+            store = self._device()
+            block = max(1, min(n, (64 << 20) // (4 * max(n, 1))))     # at most 64 MB of distances at a time
+            for i0 in range(0, n, block):
+                d = store.distances(self._vectors[i0:min(i0 + block, n)], code)
+                ii, jj = np.nonzero(d <= threshold)
+                keep = jj > ii + i0
+                for a, b in zip(ii[keep], jj[keep]):                   # row-major: i ascending, then j ascending
+                    out.append((self._ids[i0 + int(a)], self._ids[int(b)], float(d[a, b])))
         return out
 
     def sample(self, n: int, seed: Optional[int] = None) -> List[Tuple[str, np.ndarray, Dict[str, Any]]]:

@@ -336,13 +336,16 @@ class IVFIndex(BaseIndex):
         if self.config.normalize:
             query = unit_vector(query)
         n_probe = min(n_probe or self.config.n_probe, self.config.n_clusters)      # ivf.py:607-608
-        k = min(k, self.size)
-        if k <= 0:
-            return []
-        dev = self._device()
-        dist, rows = dev.search(query, k, n_probe, self._mask_words(filter_fn))
-        self._n_distance_computations += dev.last_scan_rows()
-        return self._results(dist[0], rows[0], include_vectors, include_metadata)
+        # list upload, device call and row -> id mapping under the index lock (a concurrent write
+        # swaps the device row numbering)
+        with self._lock:
+            k = min(k, self.size)
+            if k <= 0:
+                return []
+            dev = self._device()
+            dist, rows = dev.search(query, k, n_probe, self._mask_words(filter_fn))
+            self._n_distance_computations += dev.last_scan_rows()
+            return self._results(dist[0], rows[0], include_vectors, include_metadata)
 
     def search_batch(self, queries, k: int = 10, filter_fn: Optional[FilterFunction] = None,
                      n_probe: Optional[int] = None) -> List[List[SearchResult]]:
@@ -355,11 +358,14 @@ class IVFIndex(BaseIndex):
         if self.config.normalize:
             queries = unit_rows(queries)
         n_probe = min(n_probe or self.config.n_probe, self.config.n_clusters)
-        k = min(k, self.size)
-        dev = self._device()
-        dist, rows = dev.search(queries, k, n_probe, self._mask_words(filter_fn))
-        self._n_distance_computations += dev.last_scan_rows()
-        return [self._results(dist[i], rows[i], False, True) for i in range(len(queries))]
+        with self._lock:
+            k = min(k, self.size)
+            if k <= 0:
+                return [[] for _ in range(len(queries))]
+            dev = self._device()
+            dist, rows = dev.search(queries, k, n_probe, self._mask_words(filter_fn))
+            self._n_distance_computations += dev.last_scan_rows()
+            return [self._results(dist[i], rows[i], False, True) for i in range(len(queries))]
 
     def search_with_scores(self, query, k: int = 10, n_probe: Optional[int] = None) -> Tuple[List[str], List[float]]:
         res = self.search(query, k=k, n_probe=n_probe, include_vectors=False, include_metadata=False)

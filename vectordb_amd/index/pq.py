@@ -182,12 +182,15 @@ class PQIndex(BaseIndex):
         if self.size == 0:
             return []
         query = self._validate_vector(query)
-        k = min(k, self.size)
-        if k <= 0:
-            return []
-        self._sync()
-        dist, rows = self._dev.search(query, k, self._mask_words(filter_fn))
-        return self._results(dist[0], rows[0], include_vectors, include_metadata)
+        # mirror sync, device call and row -> id mapping under the index lock (a concurrent add or
+        # remove renumbers rows)
+        with self._lock:
+            k = min(k, self.size)
+            if k <= 0:
+                return []
+            self._sync()
+            dist, rows = self._dev.search(query, k, self._mask_words(filter_fn))
+            return self._results(dist[0], rows[0], include_vectors, include_metadata)
 
     def search_batch(self, queries, k: int = 10, filter_fn: Optional[FilterFunction] = None) -> List[List[SearchResult]]:
         if not self._is_trained:
@@ -195,26 +198,30 @@ class PQIndex(BaseIndex):
         queries = self._validate_vectors(queries)
         if self.size == 0 or len(queries) == 0:
             return [[] for _ in range(len(queries))]
-        k = min(k, self.size)
-        self._sync()
-        dist, rows = self._dev.search(queries, k, self._mask_words(filter_fn))
-        return [self._results(dist[i], rows[i], False, True) for i in range(len(queries))]
+        with self._lock:
+            k = min(k, self.size)
+            if k <= 0:
+                return [[] for _ in range(len(queries))]
+            self._sync()
+            dist, rows = self._dev.search(queries, k, self._mask_words(filter_fn))
+            return [self._results(dist[i], rows[i], False, True) for i in range(len(queries))]
 
     # ------------------------------------------------------------ remove / get
     def remove(self, id: str) -> bool:
         """Order-preserving removal (``list.remove``, pq.py:329-337): later
         rows move up by one, so the device codes are re-uploaded lazily."""
-        if id not in self._row_of:
-            return False
-        r = self._row_of.pop(id)
-        n = self.size
-        self._codes_arr[r:n - 1] = self._codes_arr[r + 1:n]
-        del self._ids[r]
-        del self._metadata[id]
-        for j in range(r, n - 1):
-            self._row_of[self._ids[j]] = j
-        self._synced = -1
-        return True
+        with self._lock:
+            if id not in self._row_of:
+                return False
+            r = self._row_of.pop(id)
+            n = self.size
+            self._codes_arr[r:n - 1] = self._codes_arr[r + 1:n]
+            del self._ids[r]
+            del self._metadata[id]
+            for j in range(r, n - 1):
+                self._row_of[self._ids[j]] = j
+            self._synced = -1
+            return True
 
     def remove_batch(self, ids: List[str]) -> int:
         return sum(1 for id in ids if self.remove(id))
@@ -228,10 +235,11 @@ class PQIndex(BaseIndex):
         return id in self._row_of
 
     def clear(self) -> int:
-        count = self.size
-        self._ids.clear(); self._row_of.clear(); self._metadata.clear()
-        self._synced = -1
-        return count
+        with self._lock:
+            count = self.size
+            self._ids.clear(); self._row_of.clear(); self._metadata.clear()
+            self._synced = -1
+            return count
 
     def stats(self) -> IndexStats:
         code_mem = self.size * self.config.n_subvectors

@@ -34,10 +34,10 @@ def shard_range(n_total: int, world: int, rank: int) -> Tuple[int, int]:
 class HipFlatBackend:
     """Local search and merge on the GPU through the C ABI."""
 
-    def __init__(self, dim: int, metric: int):
+    def __init__(self, dim: int, metric: int, storage: str = "f32"):
         from . import _native
         self._n = _native
-        self.store = _native.RowStore(dim)
+        self.store = _native.RowStore(dim, storage=storage)
         self.metric = metric
 
     def add_device(self, rows: torch.Tensor) -> None:
