@@ -325,7 +325,7 @@ def bench_c1(dev, native, n=10_000, d=128, nq=100, k=10):
     ids = [f"vec_{i}" for i in range(n)]
 
     col = Collection("bench", dimension=d, metric="euclidean")
-    col.add_batch(ids, x)
+    col.add_batch([{"id": ids[i], "vector": x[i]} for i in range(n)])
     col.search(q[0], k)
     t0 = time.perf_counter()
     got = [col.search(q[i], k) for i in range(nq)]

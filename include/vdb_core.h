@@ -125,6 +125,20 @@ int vdb_flat_search(vdb_rows* h, int metric, const float* queries, int nq, int k
 int vdb_flat_search_dev(vdb_rows* h, int metric, const float* d_queries, int nq, int k,
                         const uint32_t* d_mask, float* d_out_dist, int64_t* d_out_row, void* stream);
 
+/* vdb_flat_search_dev for callers that cannot allocate: code under HIP graph capture, tight serving
+ * loops, harnesses that forbid hipMalloc.  No counterpart in the reference.  Same arguments, same
+ * kernels, same results, but every workspace of the call (padded queries and their norms, the bound
+ * pass's minima, the candidate queues and counters, candidate lists, plan tables) lives in ONE static
+ * device array of VDB_STATIC_SCRATCH_BYTES that the library holds on its GPU from load to exit, and the
+ * call makes no hipMalloc / hipFree / hipHostMalloc (kernel timing, vdb_profile_enable, must be off: it
+ * creates events).  A call whose workspaces do not fit returns VDB_ERR_INVALID and names the size; 64 MiB
+ * holds 1024 queries x 1M rows at k = 10.  Every call on a GPU shares the array and finds the last call's
+ * bytes in it (what must start at zero is cleared by the call itself): two calls that overlap on the
+ * device - different streams, or different handles from different threads - race; order them. */
+#define VDB_STATIC_SCRATCH_BYTES (64u << 20)
+int vdb_flat_search_static_dev(vdb_rows* h, int metric, const float* d_queries, int nq, int k,
+                               const uint32_t* d_mask, float* d_out_dist, int64_t* d_out_row, void* stream);
+
 /* Diagnostics of the last vdb_flat_search* call on this handle (no counterpart in the reference;
  * the analogue of IVFIndex's distance_computations counter, index/ivf.py:626,838):
  * *used_queue = 1 when the batch ran the candidate-queue kernel behind a sampled bound,

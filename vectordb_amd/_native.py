@@ -63,6 +63,8 @@ SIGNATURES = {
     "vdb_flat_search": (C.c_int, [C.c_void_p, C.c_int, c_float_p, C.c_int, C.c_int, c_u32_p, c_float_p, c_i64_p]),
     "vdb_flat_search_dev": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p,
                                       C.c_void_p, C.c_void_p]),
+    "vdb_flat_search_static_dev": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p,
+                                             C.c_void_p, C.c_void_p]),
     "vdb_flat_distances": (C.c_int, [C.c_void_p, C.c_int, c_float_p, C.c_int, c_float_p]),
     "vdb_flat_distances_dev": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p]),
     "vdb_flat_range_search": (C.c_int, [C.c_void_p, C.c_int, c_float_p, C.c_float, c_u32_p, C.c_int64, c_float_p,
@@ -318,6 +320,13 @@ class RowStore:
                       mask_ptr: int = 0, stream: int = 0) -> None:
         check(self.lib.vdb_flat_search_dev(self.h, metric, C.c_void_p(q_ptr), nq, k, C.c_void_p(mask_ptr or None),
                                            C.c_void_p(out_dist_ptr), C.c_void_p(out_row_ptr), C.c_void_p(stream or None)))
+
+    def search_device_static(self, q_ptr: int, nq: int, k: int, metric: int, out_dist_ptr: int, out_row_ptr: int,
+                             mask_ptr: int = 0, stream: int = 0) -> None:
+        """search_device without any allocation: workspaces come from the library's static scratch array."""
+        check(self.lib.vdb_flat_search_static_dev(self.h, metric, C.c_void_p(q_ptr), nq, k, C.c_void_p(mask_ptr or None),
+                                                  C.c_void_p(out_dist_ptr), C.c_void_p(out_row_ptr),
+                                                  C.c_void_p(stream or None)))
 
     def distances(self, queries: np.ndarray, metric: int) -> np.ndarray:
         q = f32(queries)

@@ -15,6 +15,22 @@ namespace vdb {
 // ============================================================== plumbing
 static thread_local std::string g_err;
 
+int raise_dynamic_lds(const void* kernel, size_t bytes) {
+    static std::mutex mu;
+    static std::vector<std::pair<const void*, size_t>> seen;
+    std::lock_guard<std::mutex> g(mu);
+    for (auto& e : seen) {
+        if (e.first != kernel) continue;
+        if (bytes <= e.second) return VDB_OK;
+        VDB_HIP(hipFuncSetAttribute(kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes));
+        e.second = bytes;
+        return VDB_OK;
+    }
+    VDB_HIP(hipFuncSetAttribute(kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes));
+    seen.emplace_back(kernel, bytes);
+    return VDB_OK;
+}
+
 void set_error(const char* fmt, ...) {
     char buf[1024];
     va_list ap;
@@ -218,6 +234,7 @@ struct Workspace {
     PinBuf pin_in, pin_out;             // host ends of the small transfers of the host-pointer entry points
     DevBuf q_buf, q_sq, q_nrm, part_d, part_i, lb_d, lb_k, thr_d, thr_k, mask, out_d, out_i, dist, probes, probe_d, lut, stage;
     DevBuf queue, queue_cnt, flag, mins;
+    DevBuf mid[4];                      // intermediate levels of a hierarchical list merge (launch_select)
     // item table of the last flat scan, kept between calls: it depends on (rows, queries, group) only
     DevBuf fp_seg_row_off, fp_seg_q_off, fp_seg_item_off, fp_sq_qid, fp_sq_out, fp_items;
     int64_t fp_n = -1; int fp_nq = -1, fp_group = -1;
@@ -226,7 +243,7 @@ struct Workspace {
         DevBuf* all[] = {&q_buf, &q_sq, &q_nrm, &part_d, &part_i, &lb_d, &lb_k, &thr_d, &thr_k, &mask, &out_d, &out_i, &dist,
                          &probes, &probe_d, &lut, &stage, &round32, &q16, &cand, &seg_row_off, &seg_q_off, &seg_item_off, &sq_qid, &sq_out,
                          &cand_off, &tile_off, &list_cnt, &cursor, &slots, &items,
-                         &queue, &queue_cnt, &flag, &mins,
+                         &queue, &queue_cnt, &flag, &mins, &mid[0], &mid[1], &mid[2], &mid[3],
                          &fp_seg_row_off, &fp_seg_q_off, &fp_seg_item_off, &fp_sq_qid, &fp_sq_out, &fp_items};
         for (DevBuf* b : all) f(b);
     }
@@ -447,7 +464,7 @@ static int stream_flat_search(vdb_rows* h, Workspace& ws, int metric, const floa
             SelectOut o{d_out_d ? d_out_d + (int64_t)q0 * k : nullptr, d_out_i ? d_out_i + (int64_t)q0 * k : nullptr,
                         d_out_i32 ? d_out_i32 + (int64_t)q0 * k : nullptr, k, (int)done,
                         multi ? ws.lb_d.as<float>() : nullptr, multi ? ws.lb_k.as<int64_t>() : nullptr};
-            VDB_TRY(launch_select(ws.part_d.as<float>(), ws.part_i.as<int>(), nb, n_cand, kk, 1 << 30, nullptr, 0, o, s));
+            VDB_TRY(launch_select(ws.part_d.as<float>(), ws.part_i.as<int>(), nb, n_cand, kk, 1 << 30, nullptr, 0, o, s, ws.mid));
         }
     }
     return VDB_OK;
@@ -529,7 +546,7 @@ static int flat_search_impl(vdb_rows* h, int metric, const float* d_q, int nq, i
                                           nullptr, nullptr, nullptr, sample_tiles, sample_stride,
                                           ws.part_d.as<float>(), ws.part_i.as<int>(), n_cand_sample, s));
             SelectOut so{nullptr, nullptr, nullptr, kmax, 0, ws.thr_d.as<float>(), ws.thr_k.as<int64_t>()};
-            VDB_TRY(launch_select(ws.part_d.as<float>(), ws.part_i.as<int>(), nq, n_cand_sample, kmax, 1 << 30, nullptr, 0, so, s));
+            VDB_TRY(launch_select(ws.part_d.as<float>(), ws.part_i.as<int>(), nq, n_cand_sample, kmax, 1 << 30, nullptr, 0, so, s, ws.mid));
         }
         thr_init = ws.thr_d.as<float>();
     }
@@ -568,7 +585,7 @@ static int flat_search_impl(vdb_rows* h, int metric, const float* d_q, int nq, i
                                       ws.part_d.as<float>(), ws.part_i.as<int>(), n_cand, s, run_if));
         SelectOut o{d_out_d, d_out_i, d_out_i32, k, (int)done,
                     multi ? ws.lb_d.as<float>() : nullptr, multi ? ws.lb_k.as<int64_t>() : nullptr, run_if};
-        VDB_TRY(launch_select(ws.part_d.as<float>(), ws.part_i.as<int>(), nq, n_cand, kk, 1 << 30, nullptr, 0, o, s));
+        VDB_TRY(launch_select(ws.part_d.as<float>(), ws.part_i.as<int>(), nq, n_cand, kk, 1 << 30, nullptr, 0, o, s, ws.mid));
     }
     return VDB_OK;
 }
@@ -682,6 +699,21 @@ struct vdb_pq : Handle {
     Workspace io;                       // staging of the host-pointer entry points
 };
 
+// ---- static scratch of the no-allocation entry point ---------------------------------------
+// Device memory the library holds from load to exit on the GPU it runs on.  In host code the name
+// `scratch` is only a stand-in for the symbol: the device address is taken once, in vdb_init, with
+// hipGetSymbolAddress, and only that pointer is ever handed to kernels and copies.
+static __device__ __align__(256) unsigned char scratch[VDB_STATIC_SCRATCH_BYTES];
+static std::mutex g_scratch_mu;        // one call at a time enqueues work that uses the array
+
+static int resolve_scratch(void** out) {
+    void* p = nullptr;
+    VDB_HIP(hipGetSymbolAddress(&p, HIP_SYMBOL(scratch)));
+    VDB_REQUIRE(p != nullptr, "hipGetSymbolAddress returned a null address for the static scratch");
+    *out = p;
+    return VDB_OK;
+}
+
 static int scan_metric_of(int metric) {
     // the per-pair scalar functions behind get_metric_fn (distance/registry.py:95-177)
     switch (metric) {
@@ -718,6 +750,9 @@ int vdb_init(int device) {
         VDB_HIP(hipMemset(c.zeros, 0, 256));
     }
     c.num_cus = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
+    // device address of the static scratch on THIS device (the device is current here); the library
+    // never runs on a second device in one process, so one pointer is all there is to keep
+    VDB_TRY(resolve_scratch(&c.scratch));
     c.device = device;
     return VDB_OK;
 }
@@ -911,6 +946,22 @@ int vdb_flat_search(vdb_rows* h, int metric, const float* queries, int nq, int k
                         });
 }
 
+int vdb_flat_search_static_dev(vdb_rows* h, int metric, const float* d_queries, int nq, int k, const uint32_t* d_mask,
+                               float* d_out_dist, int64_t* d_out_row, void* stream) {
+    VDB_REQUIRE(h && (d_queries || nq == 0), "null argument");
+    Entry g(h);
+    // every workspace of this call is carved out of the static array: no hipMalloc, no hipFree.  The
+    // array is shared by all calls on this GPU; the lock orders the host side, the caller orders streams.
+    std::lock_guard<std::mutex> sg(g_scratch_mu);
+    VDB_REQUIRE(ctx().scratch != nullptr, "the static scratch was not resolved at initialisation");
+    Arena arena;
+    arena.base = reinterpret_cast<char*>(ctx().scratch);
+    arena.size = VDB_STATIC_SCRATCH_BYTES;
+    Workspace ws;
+    ws.bind(&arena);
+    return flat_search_impl(h, metric, d_queries, nq, k, d_mask, d_out_dist, d_out_row, nullptr, pick_stream(stream), &ws);
+}
+
 int vdb_flat_search_stats(vdb_rows* h, int* used_queue, int* overflowed) {
     VDB_REQUIRE(h && used_queue && overflowed, "null argument");
     Entry g(h);
@@ -987,7 +1038,7 @@ int vdb_flat_range_search(vdb_rows* h, int metric, const float* query, float rad
         c.k = kk; c.splits = splits; c.part_d = ws.part_d.as<float>(); c.part_i = ws.part_i.as<int>();
         VDB_TRY(launch_topk_cand(c, s));
         SelectOut o{ws.out_d.as<float>(), ws.out_i.as<int64_t>(), nullptr, kk, 0, ws.lb_d.as<float>(), ws.lb_k.as<int64_t>()};
-        VDB_TRY(launch_select(ws.part_d.as<float>(), ws.part_i.as<int>(), 1, n_cand, kk, 1 << 30, nullptr, 0, o, s));
+        VDB_TRY(launch_select(ws.part_d.as<float>(), ws.part_i.as<int>(), 1, n_cand, kk, 1 << 30, nullptr, 0, o, s, ws.mid));
         VDB_HIP(hipMemcpyAsync(hd, ws.out_d.p, kk * sizeof(float), hipMemcpyDeviceToHost, s));
         VDB_HIP(hipMemcpyAsync(hi, ws.out_i.p, kk * sizeof(int64_t), hipMemcpyDeviceToHost, s));
         VDB_HIP(hipStreamSynchronize(s));
@@ -1277,7 +1328,7 @@ static int ivf_search_impl(vdb_ivf* h, const float* d_q, int nq, int k, int n_pr
             VDB_TRY(launch_topk_cand(c, s));
             SelectOut o{d_out_d + (int64_t)q0 * k, nullptr, ws.slots.as<int>() + (int64_t)q0 * k, k, (int)done,
                         multi ? ws.lb_d.as<float>() : nullptr, multi ? ws.lb_k.as<int64_t>() : nullptr};
-            VDB_TRY(launch_select(ws.part_d.as<float>(), ws.part_i.as<int>(), nb, n_cand, kk, 1 << 30, nullptr, 0, o, s));
+            VDB_TRY(launch_select(ws.part_d.as<float>(), ws.part_i.as<int>(), nb, n_cand, kk, 1 << 30, nullptr, 0, o, s, ws.mid));
             VDB_TRY(launch_ivf_rows(ws.slots.as<int>() + (int64_t)q0 * k, nb, kk, k, (int)done, probes, n_probe, h->n_lists,
                                     ws.cand_off.as<int64_t>(), h->list_off.as<int64_t>(), h->row_ids.as<int>(),
                                     d_out_i + (int64_t)q0 * k, d_out_order ? d_out_order + (int64_t)q0 * k : nullptr, s));
@@ -1546,7 +1597,7 @@ static int pq_search_impl(vdb_pq* h, const float* d_q, int nq, int k, const uint
                                ws.part_d.as<float>(), ws.part_i.as<int>(), nullptr, s));
         SelectOut o{d_out_d, d_out_i, nullptr, k, (int)done,
                     multi ? ws.lb_d.as<float>() : nullptr, multi ? ws.lb_k.as<int64_t>() : nullptr};
-        VDB_TRY(launch_select(ws.part_d.as<float>(), ws.part_i.as<int>(), nq, n_cand, kk, 1 << 30, nullptr, 0, o, s));
+        VDB_TRY(launch_select(ws.part_d.as<float>(), ws.part_i.as<int>(), nq, n_cand, kk, 1 << 30, nullptr, 0, o, s, ws.mid));
     }
     return VDB_OK;
 }
@@ -1781,7 +1832,7 @@ static int ivfpq_search_impl(vdb_ivfpq* h, const float* d_q, int nq, int k, int 
             VDB_TRY(launch_topk_cand(c, s));
             SelectOut o{d_out_d + (int64_t)q0 * k, nullptr, ws.slots.as<int>() + (int64_t)q0 * k, k, (int)done,
                         multi ? ws.lb_d.as<float>() : nullptr, multi ? ws.lb_k.as<int64_t>() : nullptr};
-            VDB_TRY(launch_select(ws.part_d.as<float>(), ws.part_i.as<int>(), nb, n_cand, kk, 1 << 30, nullptr, 0, o, s));
+            VDB_TRY(launch_select(ws.part_d.as<float>(), ws.part_i.as<int>(), nb, n_cand, kk, 1 << 30, nullptr, 0, o, s, ws.mid));
             VDB_TRY(launch_ivf_rows(ws.slots.as<int>() + (int64_t)q0 * k, nb, kk, k, (int)done, probes, n_probe, h->n_lists,
                                     ws.cand_off.as<int64_t>(), h->list_off.as<int64_t>(), h->row_ids.as<int>(),
                                     d_out_i + (int64_t)q0 * k, nullptr, s));

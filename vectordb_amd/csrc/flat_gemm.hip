@@ -339,8 +339,8 @@ static int launch_gemm(int metric, GemmParams& p, hipStream_t s) {
 #define VDB_LAUNCH_GEMM(M)                                                                     \
     case M: {                                                                                  \
         auto kern = (TOPK && p.tile_stride != 1) ? flat_gemm_kernel<M, TOPK, TOPK, BF16> : flat_gemm_kernel<M, TOPK, false, BF16>; \
-        VDB_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern),                       \
-                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));    \
+        VDB_TRY(raise_dynamic_lds(reinterpret_cast<const void*>(kern),                       \
+                                    lds));    \
         hipLaunchKernelGGL(kern, grid, dim3(NT), lds, s, p);                                   \
         break;                                                                                 \
     }

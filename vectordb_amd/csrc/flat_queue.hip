@@ -568,8 +568,8 @@ static int launch_min_pass(int metric, QueueParams& p, hipStream_t s) {
 #define VDB_LAUNCH_MIN(M)                                                                      \
     case M: {                                                                                  \
         auto kern = flat_queue_fast_kernel<M, BF16, true>;                                     \
-        VDB_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern),                       \
-                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));    \
+        VDB_TRY(raise_dynamic_lds(reinterpret_cast<const void*>(kern),                       \
+                                    lds));    \
         hipLaunchKernelGGL(kern, grid, dim3(NT), lds, s, p);                                   \
         break;                                                                                 \
     }
@@ -624,8 +624,8 @@ static int launch_queue(int metric, QueueParams& p, bool fast, hipStream_t s) {
 #define VDB_LAUNCH_QUEUE(M)                                                                    \
     case M: {                                                                                  \
         auto kern = fast ? flat_queue_fast_kernel<M, BF16, false> : flat_queue_kernel<M, BF16>; \
-        VDB_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern),                       \
-                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));    \
+        VDB_TRY(raise_dynamic_lds(reinterpret_cast<const void*>(kern),                       \
+                                    lds));    \
         hipLaunchKernelGGL(kern, grid, dim3(NT), lds, s, p);                                   \
         break;                                                                                 \
     }

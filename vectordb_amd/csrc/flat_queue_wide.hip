@@ -284,8 +284,8 @@ int launch_queue_wide(int metric, QueueParams& p, hipStream_t s) {
 #define VDB_LAUNCH_WIDE(M)                                                                     \
     case M: {                                                                                  \
         auto kern = flat_queue_wide_kernel<M, true>;                                           \
-        VDB_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern),                       \
-                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));    \
+        VDB_TRY(raise_dynamic_lds(reinterpret_cast<const void*>(kern),                       \
+                                    lds));    \
         hipLaunchKernelGGL(kern, grid, dim3(WNT), lds, s, p);                                  \
         break;                                                                                 \
     }

@@ -306,8 +306,8 @@ int launch_ivfpq_scan(const float* q, int ldq, int dim, int nq, const float* cen
                       cand_off, cand_stride, cand};
     const size_t lds = ((size_t)m * ksub + dim) * sizeof(float);
     VDB_REQUIRE(lds <= 160 * 1024, "%d sub-spaces x %d codewords need %zu bytes of LDS", m, ksub, lds);
-    VDB_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(ivfpq_scan_kernel),
-                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    VDB_TRY(raise_dynamic_lds(reinterpret_cast<const void*>(ivfpq_scan_kernel),
+                                lds));
     KernelTimer timer(s);
     hipLaunchKernelGGL(ivfpq_scan_kernel, dim3((unsigned)((int64_t)nq * n_probe)), dim3(256), lds, s, p);
     VDB_HIP(hipGetLastError());
@@ -337,8 +337,8 @@ int launch_pq_encode(const float* x, int64_t n, int ldx, const float* book, int 
 #define VDB_LAUNCH_ENC(C, X)                                                                   \
     {                                                                                          \
         auto kern = pq_encode_kernel<C, X>;                                                    \
-        VDB_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern),                       \
-                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));    \
+        VDB_TRY(raise_dynamic_lds(reinterpret_cast<const void*>(kern),                       \
+                                    lds));    \
         hipLaunchKernelGGL(kern, grid, dim3(256), lds, s, x, n, ldx, book, m, ksub, dsub, plan, codes); \
     }
     if (cb_lds && x_lds) VDB_LAUNCH_ENC(true, true)
@@ -370,8 +370,8 @@ int launch_pq_scan(const uint8_t* codes, int64_t n, int m, int ksub, const float
 #define VDB_LAUNCH_PQ(MM, QQ)                                                                  \
     {                                                                                          \
         auto kern = pq_scan_kernel<MM, QQ>;                                                    \
-        VDB_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern),                       \
-                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));    \
+        VDB_TRY(raise_dynamic_lds(reinterpret_cast<const void*>(kern),                       \
+                                    lds));    \
         hipLaunchKernelGGL(kern, grid, dim3(256), lds, s, p);                                  \
     }
 #define VDB_LAUNCH_PQ_M(MM)                                                                    \

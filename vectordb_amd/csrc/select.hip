@@ -253,10 +253,8 @@ __global__ __launch_bounds__(256) void merge_wave_kernel(const float* __restrict
     }
 }
 
-static DevBuf g_mid_d[2], g_mid_i[2];
-
 int launch_select(const float* part_d, const int* part_i, int nq, int n_cand, int k, int tie_group,
-                  const int* idx_map, int64_t idx_offset, const SelectOut& o, hipStream_t s) {
+                  const int* idx_map, int64_t idx_offset, const SelectOut& o, hipStream_t s, DevBuf* mid) {
     if (nq <= 0) return VDB_OK;
     (void)tie_group;        // every caller orders equal distances by id alone
     VDB_REQUIRE(k >= 1 && k <= 64, "selection merges lists of at most 64, got %d", k);
@@ -273,17 +271,17 @@ int launch_select(const float* part_d, const int* part_i, int nq, int n_cand, in
         return VDB_OK;
     }
     const size_t lds = (size_t)(MERGE_LISTS + 4) * k * 8;
-    VDB_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(merge_lists_kernel<false>),
-                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    VDB_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(merge_lists_kernel<true>),
-                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    VDB_TRY(raise_dynamic_lds(reinterpret_cast<const void*>(merge_lists_kernel<false>),
+                                lds));
+    VDB_TRY(raise_dynamic_lds(reinterpret_cast<const void*>(merge_lists_kernel<true>),
+                                lds));
     const float* cur_d = part_d;
     const int* cur_i = part_i;
     int n = n_cand, level = 0;
     while (n > MERGE_LISTS) {
         const int groups = (n + MERGE_LISTS - 1) / MERGE_LISTS;
-        DevBuf& md = g_mid_d[level & 1];
-        DevBuf& mi = g_mid_i[level & 1];
+        DevBuf& md = mid[level & 1];
+        DevBuf& mi = mid[2 + (level & 1)];
         VDB_TRY(md.reserve((size_t)nq * groups * k * sizeof(float)));
         VDB_TRY(mi.reserve((size_t)nq * groups * k * sizeof(int)));
         hipLaunchKernelGGL(merge_lists_kernel<false>, dim3(nq, groups), dim3(256), lds, s, cur_d, cur_i, n, k,
@@ -349,8 +347,8 @@ int launch_row_sort_topk(const float* dist, int nq, int n, int k, float* out_d, 
     int n_pad = 2;
     while (n_pad < n) n_pad <<= 1;
     const size_t lds = (size_t)n_pad * 8;
-    VDB_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(row_sort_kernel),
-                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    VDB_TRY(raise_dynamic_lds(reinterpret_cast<const void*>(row_sort_kernel),
+                                lds));
     hipLaunchKernelGGL(row_sort_kernel, dim3(nq), dim3(256), lds, s, dist, n, n_pad, k, out_d, out_i);
     VDB_HIP(hipGetLastError());
     return VDB_OK;

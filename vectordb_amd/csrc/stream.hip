@@ -405,8 +405,8 @@ int launch_stream_sums(const StreamJob& j, hipStream_t s) {
 #define VDB_LAUNCH_STREAM(O, GG, QQ)                                                            \
     {                                                                                            \
         auto kern = whole ? stream_sums_kernel<O, GG, QQ, true> : stream_sums_kernel<O, GG, QQ, false>; \
-        VDB_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern),                         \
-                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));      \
+        VDB_TRY(raise_dynamic_lds(reinterpret_cast<const void*>(kern),                         \
+                                    lds));      \
         hipLaunchKernelGGL(kern, dim3(grid), dim3(S_NT * QQ), lds, s, p);                        \
     }
 #define VDB_LAUNCH_STREAM_OP(O)                                                                  \
@@ -799,7 +799,7 @@ int launch_topk_cand(const CandJob& j, hipStream_t s) {
     const int fin = (j.metric == VDB_EUCLIDEAN || j.metric == VDB_EUCLIDEAN_SQ) ? 1
                     : j.metric == VDB_COSINE ? 2 : j.metric == VDB_COSINE_PAIR ? 3 : 0;
     auto kern = fin == 1 ? topk_cand_kernel<1> : fin == 2 ? topk_cand_kernel<2> : fin == 3 ? topk_cand_kernel<3> : topk_cand_kernel<0>;
-    VDB_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    VDB_TRY(raise_dynamic_lds(reinterpret_cast<const void*>(kern), lds));
     hipLaunchKernelGGL(kern, dim3(j.nq, j.splits), dim3(LIST_NT), lds, s, p);
     VDB_HIP(hipGetLastError());
     return VDB_OK;

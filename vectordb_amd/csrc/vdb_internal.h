@@ -96,6 +96,10 @@ struct DevBuf {
     template <class T> T* as() const { return reinterpret_cast<T*>(p); }
 };
 
+// Dynamic LDS a kernel may be launched with (hipFuncAttributeMaxDynamicSharedMemorySize).  Only ever raised,
+// under a lock, so concurrent launches of one kernel with different sizes cannot undercut each other.
+int raise_dynamic_lds(const void* kernel, size_t bytes);
+
 static inline int round_up(int x, int m) { return (x + m - 1) / m * m; }
 static inline int64_t round_up64(int64_t x, int64_t m) { return (x + m - 1) / m * m; }
 static inline int ceil_div(int64_t a, int64_t b) { return (int)((a + b - 1) / b); }
@@ -247,8 +251,10 @@ struct SelectOut {
     float* last_d; int64_t* last_key;             // (distance, tie key) of the last result, for a follow-up pass
     const int* run_if;                            // optional device flag: the launch does nothing while it is zero
 };
+// `mid` = four workspace buffers of the caller (distances and ids of two intermediate levels), used when more
+// than one block's worth of lists has to be merged hierarchically.
 int launch_select(const float* part_d, const int* part_i, int nq, int n_cand, int k, int tie_group,
-                  const int* idx_map, int64_t idx_offset, const SelectOut& o, hipStream_t s);
+                  const int* idx_map, int64_t idx_offset, const SelectOut& o, hipStream_t s, DevBuf* mid);
 // lists laid out [n_lists][nq][k] with int64 ids (negative = empty), ordered by (distance, id);
 // with a payload of the same layout the payload of every selected entry is written instead of its id.
 // List l of the distances starts at d + l * stride_d, of the ids and the payload at i + l * stride_i
