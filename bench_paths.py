@@ -3,7 +3,7 @@
 headline bench): bandwidth-bound scans and build steps at BASELINE.json sizes,
 each rated against the HBM roofline with its algorithmic bytes.
 
-    python bench_paths.py [--only flat1,l1,c3,bf16,ivf,ivfpq,pq,assign,encode] [--scale 1.0]
+    python bench_paths.py [--only flat1,l1,c3,bf16,ivf,ivfpq,pq,assign,encode,train,l1batch] [--scale 1.0]
 
 Prints one JSON line per path.  Inputs are synthetic standard-normal (or
 uniform random codes) and resident in HBM before timing.
@@ -48,7 +48,7 @@ def emit(name, **kw):
 
 def main():
     ap = argparse.ArgumentParser()
-    ap.add_argument("--only", default="flat1,l1,c3,bf16,ivf,ivfpq,pq,assign,encode")
+    ap.add_argument("--only", default="flat1,l1,c3,bf16,ivf,ivfpq,pq,assign,encode,train,l1batch")
     ap.add_argument("--scale", type=float, default=1.0, help="scale the row counts (1.0 = BASELINE sizes)")
     args = ap.parse_args()
     only = set(args.only.split(","))
@@ -152,6 +152,44 @@ def main():
                        "frac": round(flop / kern / 1e12 / MFMA_F32_PEAK, 4), "flop_per_launch": flop})
         cent.close()
         del x, od, orow
+        torch.cuda.empty_cache()
+
+    # ---- IVF training as BASELINE configs[3] states it: k-means++ and 20 Lloyd steps over 256 x 4096 = 1 048 576
+    #      sampled rows, 4096 clusters, seed 42, through IVFIndex.train (rows uploaded once, everything else on the device)
+    if "train" in only:
+        from vectordb_amd.index import IVFIndex
+        n, d, nlist = int(1_048_576 * args.scale), 128, max(8, int(4096 * args.scale))
+        rng = np.random.default_rng(42)
+        x = rng.standard_normal((n, d), dtype=np.float32)
+        index = IVFIndex(dimension=d, n_clusters=nlist, n_probe=32, n_iter=20, seed=42)
+        t0 = time.perf_counter()
+        index.train(x)
+        wall = time.perf_counter() - t0
+        ph = index._last_kmeans.phase_seconds
+        steps = max(1, ph["lloyd_steps"])
+        emit("train", workload=f"IVFIndex.train: k-means++ + Lloyd, {n} x {d} rows, {nlist} clusters, n_iter=20, seed=42",
+             seconds=round(wall, 3), upload_s=round(ph["upload"], 3), init_pp_s=round(ph["init_pp"], 3),
+             lloyd_s=round(ph["lloyd"], 3), lloyd_steps=ph["lloyd_steps"], ms_per_lloyd_step=round(ph["lloyd"] / steps * 1e3, 2),
+             assign_tflops_if_all_of_a_step=round(2.0 * n * nlist * d / (ph["lloyd"] / steps) / 1e12, 1))
+        del x, index
+        torch.cuda.empty_cache()
+
+    # ---- Manhattan with a real batch: 1M x 128, 1024 queries (no matrix form; the streaming kernel, 8 queries per row chunk)
+    if "l1batch" in only:
+        n, d, nq = int(1_000_000 * args.scale), 128, 1024
+        rows = randn(n, d, 42)
+        store = N.RowStore(d)
+        store.append_device(rows.data_ptr(), n, d, stream)
+        torch.cuda.synchronize()
+        del rows
+        q = randn(nq, d, 123)
+        od, orow = outputs(nq, 10)
+        wall, kern, launches = timed(lambda: store.search_device(q.data_ptr(), nq, 10, N.MANHATTAN, od.data_ptr(), orow.data_ptr()), 5)
+        pair_ops = 3.0 * nq * n * d                  # subtract, abs, add per (row, query, dimension)
+        emit("l1batch", workload=f"Flat manhattan {n}x{d} fp32, batch {nq}, k=10", qps=round(nq / wall, 1),
+             ms_per_batch=round(wall * 1e3, 3), kernel_ms_avg=round(kern * 1e3, 3), kernels_per_batch=launches,
+             valu_tops=round(pair_ops / wall / 1e12, 2))
+        store.close()
         torch.cuda.empty_cache()
 
     # ---- IVF nlist=4096 nprobe=32 over 10M x 128

@@ -61,7 +61,11 @@ typedef enum vdb_metric {
      * (distance/gpu.py:118-120): */
     VDB_EUCLIDEAN_DIRECT = 6,   /* sqrt(sum (q - c)^2), metrics.py:43    */
     VDB_COSINE_PAIR = 7,        /* 1 - c.q/(|q||c|), 0 if |q||c| < 1e-8, metrics.py:92-100,123 */
-    VDB_EUCLIDEAN_SQ_DIRECT = 8 /* sum (q - c)^2, metrics.py:68-69       */
+    VDB_EUCLIDEAN_SQ_DIRECT = 8,/* sum (q - c)^2, metrics.py:68-69       */
+    /* the two remaining per-pair functions of the registry (distance/registry.py:179-205); reachable
+     * through get_metric_fn, e.g. IVFIndex(metric="angular") (index/ivf.py:611-613,625): */
+    VDB_HAMMING = 9,            /* number of positions where q != c, metrics.py:237 */
+    VDB_ANGULAR = 10            /* arccos(clip(c.q/(|q||c|), -1, 1)), similarity 0 if |q||c| < 1e-8, metrics.py:535-538 */
 } vdb_metric;
 
 /* ---- library ---------------------------------------------------------- */
@@ -115,6 +119,10 @@ int vdb_rows_set(vdb_rows* h, int64_t row, const float* vec);             /* fla
 int vdb_rows_truncate(vdb_rows* h, int64_t n);                            /* flat.py:608-609 */
 int vdb_rows_size(const vdb_rows* h, int64_t* n);
 int vdb_rows_norms(vdb_rows* h, float* sqnorm_out, float* norm_out);      /* test hook: copies of the stored terms */
+/* pairwise_cosine(X, Y, eps) (distance/metrics.py:336-373): norms below eps count as 1.  Applies to the
+ * cosine distance MATRIX of this handle (vdb_flat_distances*); searches keep the fixed 1e-8 of
+ * query_distances (metrics.py:469-477), which has no such argument.  Default 1e-8. */
+int vdb_rows_set_cosine_eps(vdb_rows* h, float eps);
 
 /* FlatIndex.search / search_batch (index/flat.py:288-460), the search part of
  * Collection.search (core/collection.py:733-758) and
@@ -152,9 +160,11 @@ int vdb_flat_search_stats(vdb_rows* h, int* used_queue, int* overflowed);
 int vdb_flat_distances(vdb_rows* h, int metric, const float* queries, int nq, float* out);
 int vdb_flat_distances_dev(vdb_rows* h, int metric, const float* d_queries, int nq, float* d_out, void* stream);
 
-/* FlatIndex.range_search (index/flat.py:501-572): rows with distance <= radius
- * for one query, ascending (distance, row).  *count receives the number found;
- * at most cap are written. */
+/* FlatIndex.range_search (index/flat.py:501-572): rows with distance <= radius for one
+ * query.  Like the reference, the FIRST `cap` such rows in row (= insertion) order are kept
+ * (:545-567, max_results) and those are returned ascending by distance, equal distances in row
+ * order (the stable sort of :570).  *count receives the number written (<= cap).  One pass over
+ * the rows; compaction and the sort run on the device. */
 int vdb_flat_range_search(vdb_rows* h, int metric, const float* query, float radius,
                           const uint32_t* mask, int64_t cap, float* out_dist, int64_t* out_row, int64_t* count);
 
@@ -171,6 +181,49 @@ int vdb_assign(const float* x, int64_t n, const float* centroids, int n_centroid
  * fp64 sums of the rows assigned to it and the member counts. */
 int vdb_kmeans_accumulate(const float* x, int64_t n, int dim, const int32_t* assign, int n_clusters,
                           double* out_sums, int64_t* out_counts);
+
+/* ---- k-means on resident rows ---------------------------------------------
+ * KMeans (index/ivf.py:102-237) and the sub-quantizer training of PQIndex (index/pq.py:144-180) and
+ * HybridIndex (index/hybrid.py:174-203) without a host round trip per step: the training rows are a
+ * vdb_rows handle (uploaded once), the centroids, assignments and sums stay on the device, and only what
+ * the host's RandomState and stopping rule need comes back (k counts and one number per step).
+ * A trainer works on columns [col0, col0 + dsub) of the rows (a PQ sub-space) and borrows `train`, which
+ * must outlive it and must not be written meanwhile.
+ *
+ * Arithmetic of a step, per form:
+ *   VDB_KMEANS_IVF  assignment = argmin of pairwise_euclidean (identity form, clamp, sqrt; ivf.py:228-231);
+ *                   sums fp32, one row at a time in sample order (:180-182); new = float(sum / float64(count))
+ *                   (:187); a cluster without members is left for vdb_kmeans_reseed (:188-190).
+ *   VDB_KMEANS_PQ   first step: argmin of |x|^2 + |c|^2 - 2 x.c in fp32 (pq.py:182-186), fp32 sums, new =
+ *                   float64(sum) / max(count, 1) kept as FLOAT64 (:168-169); later steps: the same distances
+ *                   and sums in float64, as NumPy promotes them there.  Empty clusters become zero vectors.
+ * The sums are taken in the reference's order (a stable sort of the rows by cluster, then one sequential
+ * pass per cluster and column), so equal assignments give bit-identical centroids. */
+typedef struct vdb_kmeans vdb_kmeans;
+enum vdb_kmeans_form { VDB_KMEANS_IVF = 0, VDB_KMEANS_PQ = 1 };
+int vdb_kmeans_create(vdb_kmeans** out, vdb_rows* train, int col0, int dsub, int n_clusters);
+int vdb_kmeans_destroy(vdb_kmeans* h);
+/* centroids = these training rows (pq.py:150-151: rows drawn by rng.choice(n, k, replace=False)) */
+int vdb_kmeans_init_rows(vdb_kmeans* h, const int64_t* rows, int n_rows);
+/* k-means++ (ivf.py:204-226).  first_row = rng.randint(n); uniforms[j] = the (j+1)-th rng.random_sample(),
+ * the one draw rng.choice(n, p=probs) makes for centroid j+1 (n_clusters - 1 values).  The running minimum of
+ * the squared distances and every draw (first row whose cumulative share of the total exceeds the uniform
+ * number) stay on the device; out_rows (n_clusters values, may be NULL) receives the chosen rows. */
+int vdb_kmeans_init_pp(vdb_kmeans* h, int64_t first_row, const double* uniforms, int64_t* out_rows);
+int vdb_kmeans_set_centroids(vdb_kmeans* h, const float* centroids);       /* start from given fp32 centroids */
+/* One Lloyd step into a pending set of centroids: out_counts (n_clusters values) and
+ * out_shift = sum((new - old)^2) (ivf.py:193) come back; nothing else leaves the device. */
+int vdb_kmeans_step(vdb_kmeans* h, int form, int64_t* out_counts, double* out_shift);
+/* ivf.py:188-190: pending centroid clusters[i] = training row rows[i] (rows drawn by rng.randint(n), in
+ * ascending cluster order); out_shift is recomputed. */
+int vdb_kmeans_reseed(vdb_kmeans* h, const int32_t* clusters, const int64_t* rows, int count, double* out_shift);
+int vdb_kmeans_commit(vdb_kmeans* h);                                      /* pending centroids become current */
+/* current centroids: fp32 (always; the float64 ones rounded, as `codebook[m] = centroids` rounds them,
+ * pq.py:140) and, after a PQ-form step, the float64 values themselves (out64 may be NULL) */
+int vdb_kmeans_centroids(vdb_kmeans* h, float* out32, double* out64);
+/* assignments of the last step (or, with no step pending, KMeans.predict of the training rows, ivf.py:233-237)
+ * and, for the fp32 forms, the distance to the assigned centroid */
+int vdb_kmeans_assignments(vdb_kmeans* h, int32_t* out_assign, float* out_dist);
 
 /* ---- IVF ------------------------------------------------------------------
  * Inverted lists stored contiguously in list order (CSR offsets), the

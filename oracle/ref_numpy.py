@@ -155,13 +155,15 @@ def rows_scalar_metric(a: np.ndarray, rows: np.ndarray, metric: str) -> np.ndarr
         for i, r in enumerate(rows):
             out[i] = -float(np.dot(a, r))
         return out
-    if metric == "cosine":               # metrics.py:92-100,123
+    if metric in ("cosine", "angular"):  # metrics.py:92-100,123 / :535-538
         na = np.linalg.norm(a)
         for i, r in enumerate(rows):
             den = na * np.linalg.norm(r)
             sim = 0.0 if den < 1e-8 else float(np.dot(a, r) / den)
-            out[i] = 1.0 - sim
+            out[i] = 1.0 - sim if metric == "cosine" else float(np.arccos(np.clip(sim, -1.0, 1.0)))
         return out
+    if metric == "hamming":              # metrics.py:237
+        return np.sum(a != rows, axis=1).astype(np.float64)
     raise KeyError(f"Unknown metric: '{metric}'")   # registry.py:241-245
 
 
@@ -195,6 +197,41 @@ def flat_search(query: np.ndarray, rows: np.ndarray, k: int, metric: str,
     else:
         sel = topk_stable(d, k)
     return sel.astype(np.int64), d[sel]
+
+
+def flat_range_search(query: np.ndarray, rows: np.ndarray, radius: float, metric: str,
+                      mask: Optional[np.ndarray] = None, max_results: Optional[int] = None) -> Tuple[np.ndarray, np.ndarray]:
+    """FlatIndex.range_search (index/flat.py:501-572): rows inside the radius (and the filter) are
+    collected in insertion order until ``max_results`` of them are found (:545-567; a max_results of
+    0 or None means no limit), then sorted by distance with a stable sort (:570).  Returns
+    (row indices int64, distances)."""
+    d = query_distances(query, rows, metric)
+    inside = ~(d > radius)                                   # :546 skips rows with distance > radius
+    if mask is not None:
+        inside &= np.asarray(mask, dtype=bool)
+    sel = np.flatnonzero(inside)
+    if max_results:
+        sel = sel[:max_results]
+    order = np.argsort(d[sel].astype(np.float64), kind="stable")
+    sel = sel[order]
+    return sel.astype(np.int64), d[sel]
+
+
+def simd_batch(metric: str, query: np.ndarray, vectors: np.ndarray) -> np.ndarray:
+    """The functions get_optimized_distance_fn returns when Numba is absent (distance/simd.py:122-146,
+    170-176): direct-form L2, the +1e-10 cosine, the POSITIVE dot product, Manhattan."""
+    if metric == "euclidean":
+        diff = vectors - query
+        return np.sqrt(np.sum(diff * diff, axis=1))
+    if metric == "cosine":
+        qn = np.linalg.norm(query)
+        vn = np.linalg.norm(vectors, axis=1)
+        return 1.0 - np.dot(vectors, query) / (qn * vn + 1e-10)
+    if metric == "dot":
+        return np.dot(vectors, query)
+    if metric == "manhattan":
+        return np.sum(np.abs(vectors - query), axis=1)
+    raise ValueError(f"Unknown metric: {metric}")            # simd.py:178-179
 
 
 def flat_scores(dist: np.ndarray) -> np.ndarray:

@@ -3,7 +3,7 @@
 
 Run in the build container only (it needs the reference checkout):
 
-    python tests/golden/make_golden.py [/root/reference]
+    python tests/golden/make_golden.py [/root/reference] [--only-round2]
 
 The reference's ``vectordb/index/__init__.py`` uses ``Dict``/``Any`` without
 importing them, so the two names are put into ``builtins`` before the import;
@@ -19,7 +19,8 @@ import typing
 
 import numpy as np
 
-REF = sys.argv[1] if len(sys.argv) > 1 else "/root/reference"
+_paths = [a for a in sys.argv[1:] if not a.startswith("--")]
+REF = _paths[0] if _paths else "/root/reference"
 OUT = os.path.dirname(os.path.abspath(__file__))
 
 builtins.Dict = typing.Dict
@@ -338,7 +339,102 @@ def gen_hybrid():
     save("hybrid.npz", **out)
 
 
+def gen_round2():
+    """Cases added later: range_search with max_results, pairwise_cosine with a caller's eps, the
+    hamming / angular functions and an angular IVF index, the batch functions of distance/simd.py,
+    the dtype of a zero cosine query, and k-means one step at a time (KMeans, the PQ and the
+    IVF-PQ sub-quantizers)."""
+    from vectordb.distance.simd import get_optimized_distance_fn
+    out = {}
+    rng = np.random.RandomState(5)
+    x = rng.randn(1500, 24).astype(np.float32)
+    x[40] = x[7]
+    x[1200] = x[7]
+    q = rng.randn(4, 24).astype(np.float32)
+    q[0] = x[7] + np.float32(0.01)
+    out["x"], out["q"] = x, q
+    ids = ids_of(len(x))
+    meta = [{"cat": int(i % 4)} for i in range(len(x))]
+    out["mask"] = np.array([m["cat"] != 2 for m in meta])
+    radii = {"euclidean": 6.2, "manhattan": 24.5, "cosine": 0.8, "dot": 1.0}
+    for metric, radius in radii.items():
+        idx = FlatIndex(dimension=24, metric=metric)
+        idx.add_batch(ids, x, meta)
+        out[f"range_{metric}_radius"] = np.array(radius)
+        for tag, kw in (("all", {}), ("max5", {"max_results": 5}), ("max40", {"max_results": 40}),
+                        ("filter_max10", {"max_results": 10, "filter_fn": lambda _id, m: m["cat"] != 2})):
+            res = idx.range_search(q[0] if metric != "dot" else q[1], radius=radius, **kw)
+            out[f"range_{metric}_{tag}_rows"] = rows_of(res)
+            out[f"range_{metric}_{tag}_dist"] = np.array([r.distance for r in res], dtype=np.float64)
+    # pairwise_cosine with eps: rows whose norm lies between the default 1e-8 and the caller's eps
+    y = x[:200].copy()
+    y[3] *= np.float32(1e-4)
+    y[11] *= np.float32(1e-6)
+    y[50] = 0.0
+    xs = x[300:340].copy()
+    xs[5] *= np.float32(1e-5)
+    out["eps_x"], out["eps_y"] = xs, y
+    for tag, eps in (("default", 1e-8), ("1e-3", 1e-3), ("1e-2", 1e-2)):
+        out[f"pairwise_cosine_eps_{tag}"] = M.pairwise_cosine(xs, y, eps=eps)
+    # hamming / angular through the registry, the way IVFIndex reaches them
+    xi = rng.randint(0, 3, size=(300, 24)).astype(np.float32)
+    qi = rng.randint(0, 3, size=24).astype(np.float32)
+    out["ham_x"], out["ham_q"] = xi, qi
+    out["hamming"] = np.array([get_metric_fn("hamming")(qi, v) for v in xi], dtype=np.float64)
+    out["angular"] = np.array([get_metric_fn("angular")(q[2], v) for v in x[:400]], dtype=np.float64)
+    idx = IVFIndex(dimension=24, metric="angular", n_clusters=16, n_probe=4, seed=3)
+    idx.train(x)
+    idx.add_batch(ids, x, meta)
+    out["angular_ivf_centroids"] = idx.centroids
+    out["angular_ivf_assign"] = np.array([idx._id_to_cluster[i] for i in ids], dtype=np.int64)
+    rows = np.full((len(q), 10), -1, dtype=np.int64)
+    dist = np.full((len(q), 10), np.nan, dtype=np.float64)
+    for i in range(len(q)):
+        res = idx.search(q[i], k=10, n_probe=4)
+        rows[i, :len(res)], dist[i, :len(res)] = rows_of(res), [r.distance for r in res]
+    out["angular_ivf_rows"], out["angular_ivf_dist"] = rows, dist
+    # distance/simd.py
+    for metric in ("euclidean", "cosine", "dot", "manhattan"):
+        out[f"simd_{metric}"] = np.asarray(get_optimized_distance_fn(metric)(q[3], x[:500]))
+    # a zero cosine query: dtype of the result (metrics.py:472-473)
+    z = M.query_distances(np.zeros(24, dtype=np.float32), x[:10], "cosine")
+    out["zero_query_cosine"] = z
+    out["zero_query_cosine_dtype"] = np.array(str(z.dtype))
+    # ---- k-means, one step at a time
+    xs16 = rng.randn(900, 16).astype(np.float32)
+    out["km_x"] = xs16
+    for steps in (1, 2):
+        km = KMeans(n_clusters=12, n_iter=steps, seed=42)
+        out[f"km_centroids_after_{steps}"] = km._fit_once(xs16)
+    out["km_pp_init"] = KMeans(n_clusters=12, n_iter=0, seed=42)._init_centroids_pp(xs16)
+    out["km_assign_of_pp_init"] = KMeans(n_clusters=12, seed=42)._assign(xs16, out["km_pp_init"])
+    # PQ sub-quantizer (pq.py:144-180): centroids after 1, 2, 3 and 20 steps from the same seeded start, and the
+    # assignments those centroids give (fp32 at the first step, float64 afterwards)
+    sub = rng.randn(1100, 8).astype(np.float32)
+    out["pq_sub"] = sub
+    out["pq_init_rows"] = PQIndex(dimension=8, n_subvectors=1, n_bits=6, seed=9)._rng.choice(len(sub), 64, replace=False)
+    for steps in (1, 2, 3, 20):
+        p = PQIndex(dimension=8, n_subvectors=1, n_bits=6, seed=9)
+        p.config.n_iter = steps
+        cent = p._train_subquantizer(sub)
+        out[f"pq_centroids_after_{steps}"] = np.asarray(cent)
+        out[f"pq_assign_from_{steps}"] = np.argmin(p._pairwise_l2(sub, cent), axis=1)
+    out["pq_assign_from_0"] = np.argmin(PQIndex(dimension=8, n_subvectors=1, n_bits=6)._pairwise_l2(
+        sub, sub[out["pq_init_rows"]].copy()), axis=1)
+    # IVF-PQ sub-quantizer (hybrid.py:174-203)
+    out["hy_init_rows"] = HybridIndex(dimension=8, n_clusters=4, n_subvectors=1, n_bits=6, seed=9)._rng.choice(
+        len(sub), 64, replace=False)
+    for steps in (1, 2, 5):
+        h = HybridIndex(dimension=8, n_clusters=4, n_subvectors=1, n_bits=6, seed=9)
+        h.config.n_iter = steps
+        out[f"hy_centroids_after_{steps}"] = np.asarray(h._train_subquantizer(sub))
+    save("round2.npz", **out)
+
+
 if __name__ == "__main__":
+    if "--only-round2" in sys.argv:
+        gen_round2()
+        sys.exit(0)
     gen_metrics()
     gen_flat_config1()
     gen_flat_small()

@@ -393,9 +393,22 @@ def test_ivf_index_golden(metric):
     idx.add_batch(ids_of(len(x)), x, [{"cat": int(i % 3)} for i in range(len(x))])
     got = np.array([idx._id_to_cluster[i] for i in ids_of(len(x))])
     ref = g[f"{metric}_assign_batch"]
-    assert (got != ref).sum() <= (0 if metric == "manhattan" else 2)
-    if (got != ref).any():
-        pytest.skip("a rounding-level centroid tie moved a row; list contents differ from the fixture")
+    moved = np.flatnonzero(got != ref)
+    assert len(moved) <= (0 if metric == "manhattan" else 2)
+    if len(moved):
+        # a row may sit in another list than in the reference only when the reference's own distances to the two
+        # centroids tie to rounding (argmin over BLAS-form values); verify that, then go on with the reference's
+        # lists so that every search below is still compared with the fixture
+        cent = g[f"{metric}_centroids"]
+        for i in moved:
+            d = (R.pairwise_euclidean(x[i:i + 1], cent)[0] if metric == "euclidean" else
+                 R.pairwise_cosine(x[i:i + 1], cent)[0] if metric == "cosine" else
+                 R.rows_scalar_metric(x[i], cent, metric))
+            assert abs(float(d[got[i]]) - float(d[ref[i]])) <= 1e-5 * max(1.0, abs(float(d[ref[i]]))), (i, d[got[i]], d[ref[i]])
+        idx = IVFIndex(dimension=32, metric=metric, n_clusters=32, n_probe=8, seed=42)
+        idx._set_centroids(cent)
+        for i in range(len(x)):
+            idx._append(f"v{i}", x[i], {"cat": int(i % 3)}, int(ref[i]))
     exact = metric in ("euclidean", "manhattan")
     for npb in (1, 8, 32):
         for i in range(len(q)):

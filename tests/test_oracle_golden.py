@@ -314,3 +314,81 @@ def test_hybrid_search_matches_reference():
     members = _hybrid_members(g["lists"], len(g["centroids"]), removed=g["removed"])
     rows, dist = R.hybrid_search(g["q"][0], g["centroids"], g["codebook"], g["codes"], members, 10, 16)
     assert np.array_equal(rows, g["rows_after_remove"]) and np.array_equal(dist, g["dist_after_remove"])
+
+
+# ---------------------------------------------------------------- cases added with round2.npz
+def test_range_search_max_results_golden():
+    """FlatIndex.range_search keeps the FIRST max_results rows in insertion order inside the radius, then sorts
+    them (index/flat.py:545-570)."""
+    g = load_golden("round2.npz")
+    x, q, mask = g["x"], g["q"], g["mask"]
+    for metric in ("euclidean", "manhattan", "cosine", "dot"):
+        radius = float(g[f"range_{metric}_radius"])
+        qq = q[0] if metric != "dot" else q[1]
+        for tag, kw in (("all", {}), ("max5", {"max_results": 5}), ("max40", {"max_results": 40}),
+                        ("filter_max10", {"max_results": 10, "mask": mask})):
+            rows, dist = R.flat_range_search(qq, x, radius, metric, **kw)
+            want_rows, want_dist = g[f"range_{metric}_{tag}_rows"], g[f"range_{metric}_{tag}_dist"]
+            if metric == "manhattan" or tag != "all":
+                # the kept SET is fixed by insertion order; the order inside it by (distance, row)
+                np.testing.assert_array_equal(rows, want_rows)
+            else:
+                assert set(rows.tolist()) == set(want_rows.tolist())
+            np.testing.assert_allclose(np.sort(dist.astype(np.float64)), np.sort(want_dist), rtol=2e-5, atol=2e-6)
+
+
+def test_pairwise_cosine_eps_golden():
+    g = load_golden("round2.npz")
+    for tag, eps in (("default", 1e-8), ("1e-3", 1e-3), ("1e-2", 1e-2)):
+        np.testing.assert_allclose(R.pairwise_cosine(g["eps_x"], g["eps_y"], eps=eps), g[f"pairwise_cosine_eps_{tag}"],
+                                   rtol=2e-5, atol=2e-6)
+    # the eps matters: the three matrices differ
+    assert not np.allclose(g["pairwise_cosine_eps_default"], g["pairwise_cosine_eps_1e-2"], atol=1e-3)
+
+
+def test_hamming_angular_simd_zero_query_golden():
+    g = load_golden("round2.npz")
+    np.testing.assert_array_equal(R.rows_scalar_metric(g["ham_q"], g["ham_x"], "hamming"), g["hamming"])
+    np.testing.assert_allclose(R.rows_scalar_metric(g["q"][2], g["x"][:400], "angular"), g["angular"], rtol=1e-5, atol=1e-6)
+    for metric in ("euclidean", "cosine", "dot", "manhattan"):
+        got = R.simd_batch(metric, g["q"][3], g["x"][:500])
+        if metric in ("euclidean", "manhattan"):
+            np.testing.assert_array_equal(got, g[f"simd_{metric}"])
+        else:
+            np.testing.assert_allclose(got, g[f"simd_{metric}"], rtol=2e-5, atol=2e-6)
+    z = R.query_distances(np.zeros(24, dtype=np.float32), g["x"][:10], "cosine")
+    assert str(z.dtype) == str(g["zero_query_cosine_dtype"]) == "float64"
+    np.testing.assert_array_equal(z, g["zero_query_cosine"])
+
+
+def test_angular_ivf_golden():
+    g = load_golden("round2.npz")
+    x, q, cent, assign = g["x"], g["q"], g["angular_ivf_centroids"], g["angular_ivf_assign"]
+    got_assign = R.ivf_assign_batch(x, cent, "angular")
+    assert np.mean(got_assign == assign) >= 0.999
+    lists = R.ivf_build_lists(assign, len(cent))
+    for i in range(len(q)):
+        rows, dist = R.ivf_search(q[i], x, cent, lists, 10, 4, "angular")
+        np.testing.assert_array_equal(rows, g["angular_ivf_rows"][i][:len(rows)])
+        np.testing.assert_allclose(dist, g["angular_ivf_dist"][i][:len(rows)], rtol=1e-5, atol=1e-6)
+
+
+def test_training_steps_golden():
+    """k-means one step at a time: KMeans (ivf.py:165-202), the PQ sub-quantizer (pq.py:144-180, float64 from the
+    second step on) and the IVF-PQ sub-quantizer (hybrid.py:174-203)."""
+    g = load_golden("round2.npz")
+    x = g["km_x"]
+    np.testing.assert_array_equal(R.kmeans_pp_init(x, 12, np.random.RandomState(42)), g["km_pp_init"])
+    np.testing.assert_array_equal(R.kmeans_assign(x, g["km_pp_init"]), g["km_assign_of_pp_init"])
+    for steps in (1, 2):
+        np.testing.assert_allclose(R.kmeans_fit(x, 12, n_iter=steps, seed=42), g[f"km_centroids_after_{steps}"],
+                                   rtol=1e-6, atol=1e-6)
+    sub = g["pq_sub"]
+    np.testing.assert_array_equal(np.random.RandomState(9).choice(len(sub), 64, replace=False), g["pq_init_rows"])
+    for steps in (1, 2, 3, 20):
+        got = R.pq_train_subquantizer(sub, 64, steps, np.random.RandomState(9))
+        assert got.dtype == g[f"pq_centroids_after_{steps}"].dtype == np.float64
+        np.testing.assert_allclose(got, g[f"pq_centroids_after_{steps}"], rtol=1e-9, atol=1e-9)
+    for steps in (1, 2, 5):
+        got = R.hybrid_train_subquantizer(sub, 64, steps, np.random.RandomState(9))
+        np.testing.assert_allclose(got, g[f"hy_centroids_after_{steps}"], rtol=1e-9, atol=1e-9)

@@ -24,6 +24,7 @@ VDB_OK, VDB_ERR_INVALID, VDB_ERR_HIP, VDB_ERR_STATE, VDB_ERR_NOMEM = 0, -1, -2, 
 # vdb_metric
 EUCLIDEAN, EUCLIDEAN_SQ, COSINE, DOT, MANHATTAN, CHEBYSHEV = 0, 1, 2, 3, 4, 5
 EUCLIDEAN_DIRECT, COSINE_PAIR, EUCLIDEAN_SQ_DIRECT = 6, 7, 8
+HAMMING, ANGULAR = 9, 10
 
 METRIC_CODES = {
     "euclidean": EUCLIDEAN,
@@ -59,6 +60,7 @@ SIGNATURES = {
     "vdb_rows_truncate": (C.c_int, [C.c_void_p, C.c_int64]),
     "vdb_rows_size": (C.c_int, [C.c_void_p, c_i64_p]),
     "vdb_rows_norms": (C.c_int, [C.c_void_p, c_float_p, c_float_p]),
+    "vdb_rows_set_cosine_eps": (C.c_int, [C.c_void_p, C.c_float]),
     "vdb_flat_search_stats": (C.c_int, [C.c_void_p, C.POINTER(C.c_int), C.POINTER(C.c_int)]),
     "vdb_flat_search": (C.c_int, [C.c_void_p, C.c_int, c_float_p, C.c_int, C.c_int, c_u32_p, c_float_p, c_i64_p]),
     "vdb_flat_search_dev": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p,
@@ -71,6 +73,16 @@ SIGNATURES = {
                                         c_i64_p, c_i64_p]),
     "vdb_assign": (C.c_int, [c_float_p, C.c_int64, c_float_p, C.c_int, C.c_int, C.c_int, c_i32_p, c_float_p]),
     "vdb_kmeans_accumulate": (C.c_int, [c_float_p, C.c_int64, C.c_int, c_i32_p, C.c_int, c_double_p, c_i64_p]),
+    "vdb_kmeans_create": (C.c_int, [C.POINTER(C.c_void_p), C.c_void_p, C.c_int, C.c_int, C.c_int]),
+    "vdb_kmeans_destroy": (C.c_int, [C.c_void_p]),
+    "vdb_kmeans_init_rows": (C.c_int, [C.c_void_p, c_i64_p, C.c_int]),
+    "vdb_kmeans_init_pp": (C.c_int, [C.c_void_p, C.c_int64, c_double_p, c_i64_p]),
+    "vdb_kmeans_set_centroids": (C.c_int, [C.c_void_p, c_float_p]),
+    "vdb_kmeans_step": (C.c_int, [C.c_void_p, C.c_int, c_i64_p, c_double_p]),
+    "vdb_kmeans_reseed": (C.c_int, [C.c_void_p, c_i32_p, c_i64_p, C.c_int, c_double_p]),
+    "vdb_kmeans_commit": (C.c_int, [C.c_void_p]),
+    "vdb_kmeans_centroids": (C.c_int, [C.c_void_p, c_float_p, c_double_p]),
+    "vdb_kmeans_assignments": (C.c_int, [C.c_void_p, c_i32_p, c_float_p]),
     "vdb_ivf_create": (C.c_int, [C.POINTER(C.c_void_p), C.c_int, C.c_int]),
     "vdb_ivf_destroy": (C.c_int, [C.c_void_p]),
     "vdb_ivf_set_centroids": (C.c_int, [C.c_void_p, c_float_p, C.c_int]),
@@ -293,6 +305,10 @@ class RowStore:
     def truncate(self, n: int) -> None:
         check(self.lib.vdb_rows_truncate(self.h, int(n)))
 
+    def set_cosine_eps(self, eps: float) -> None:
+        """Norm threshold of the cosine distance MATRIX of this store (pairwise_cosine's eps); searches keep 1e-8."""
+        check(self.lib.vdb_rows_set_cosine_eps(self.h, float(eps)))
+
     def norms(self):
         n = len(self)
         sq, nr = np.empty(n, np.float32), np.empty(n, np.float32)
@@ -366,6 +382,86 @@ def kmeans_accumulate(x: np.ndarray, assign_idx: np.ndarray, n_clusters: int):
     check(load().vdb_kmeans_accumulate(fptr(x), len(x), x.shape[1], a.ctypes.data_as(c_i32_p), n_clusters,
                                        sums.ctypes.data_as(c_double_p), counts.ctypes.data_as(c_i64_p)))
     return sums, counts
+
+
+KMEANS_IVF, KMEANS_PQ = 0, 1
+
+
+class KMeansTrainer:
+    """Owner of a vdb_kmeans handle: k-means over columns [col0, col0 + dsub) of the rows of a RowStore
+    that stay in HBM.  The store must outlive the trainer and must not be written meanwhile."""
+
+    def __init__(self, store: "RowStore", col0: int, dsub: int, n_clusters: int):
+        self.lib = load()
+        self.store = store                       # keeps the training rows alive
+        self.k, self.dsub = int(n_clusters), int(dsub)
+        self.n = len(store)
+        self.h = C.c_void_p()
+        check(self.lib.vdb_kmeans_create(C.byref(self.h), store.h, int(col0), self.dsub, self.k))
+
+    def close(self):
+        if getattr(self, "h", None) is not None and self.h:
+            self.lib.vdb_kmeans_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def init_rows(self, rows) -> None:
+        r = np.ascontiguousarray(rows, dtype=np.int64)
+        check(self.lib.vdb_kmeans_init_rows(self.h, r.ctypes.data_as(c_i64_p), len(r)))
+
+    def init_pp(self, first_row: int, uniforms) -> np.ndarray:
+        u = np.ascontiguousarray(uniforms, dtype=np.float64)
+        if len(u) != self.k - 1:
+            raise ValueError(f"k-means++ over {self.k} clusters takes {self.k - 1} uniform draws, got {len(u)}")
+        out = np.empty(self.k, np.int64)
+        check(self.lib.vdb_kmeans_init_pp(self.h, int(first_row), u.ctypes.data_as(c_double_p), out.ctypes.data_as(c_i64_p)))
+        return out
+
+    def set_centroids(self, centroids) -> None:
+        c = f32(centroids)
+        if c.shape != (self.k, self.dsub):
+            raise ValueError(f"centroids shape {c.shape} != {(self.k, self.dsub)}")
+        check(self.lib.vdb_kmeans_set_centroids(self.h, fptr(c)))
+
+    def step(self, form: int):
+        """One Lloyd step into the pending centroids -> (member counts int64 [k], sum((new - old)^2))."""
+        counts = np.empty(self.k, np.int64)
+        shift = C.c_double(0.0)
+        check(self.lib.vdb_kmeans_step(self.h, int(form), counts.ctypes.data_as(c_i64_p), C.byref(shift)))
+        return counts, shift.value
+
+    def reseed(self, clusters, rows) -> float:
+        c = np.ascontiguousarray(clusters, dtype=np.int32)
+        r = np.ascontiguousarray(rows, dtype=np.int64)
+        shift = C.c_double(0.0)
+        check(self.lib.vdb_kmeans_reseed(self.h, c.ctypes.data_as(c_i32_p), r.ctypes.data_as(c_i64_p), len(c), C.byref(shift)))
+        return shift.value
+
+    def commit(self) -> None:
+        check(self.lib.vdb_kmeans_commit(self.h))
+
+    def centroids(self, float64: bool = False) -> np.ndarray:
+        c32 = np.empty((self.k, self.dsub), np.float32)
+        if not float64:
+            check(self.lib.vdb_kmeans_centroids(self.h, fptr(c32), None))
+            return c32
+        c64 = np.empty((self.k, self.dsub), np.float64)
+        check(self.lib.vdb_kmeans_centroids(self.h, fptr(c32), c64.ctypes.data_as(c_double_p)))
+        return c64
+
+    def assignments(self, with_distances: bool = False):
+        a = np.empty(self.n, np.int32)
+        if not with_distances:
+            check(self.lib.vdb_kmeans_assignments(self.h, a.ctypes.data_as(c_i32_p), None))
+            return a
+        d = np.empty(self.n, np.float32)
+        check(self.lib.vdb_kmeans_assignments(self.h, a.ctypes.data_as(c_i32_p), fptr(d)))
+        return a, d
 
 
 def pq_encode(x: np.ndarray, codebook: np.ndarray) -> np.ndarray:

@@ -259,7 +259,7 @@ struct Workspace {
 static bool is_dot_metric(int m) {
     return m == VDB_EUCLIDEAN || m == VDB_EUCLIDEAN_SQ || m == VDB_COSINE || m == VDB_DOT;
 }
-static bool valid_metric(int m) { return m >= VDB_EUCLIDEAN && m <= VDB_EUCLIDEAN_SQ_DIRECT; }
+static bool valid_metric(int m) { return m >= VDB_EUCLIDEAN && m <= VDB_ANGULAR; }
 static const int QUEUE_Q_BLOCK = 1024;  // queries per launch of the candidate-queue kernel (bounds its workspace)
 static const int GEMM_MIN_NQ = 4;     // below this the streaming scan reads the rows once per query and wins
 
@@ -606,7 +606,7 @@ static int flat_distances_impl(vdb_rows* h, int metric, const float* d_q, int nq
     if (is_dot_metric(metric) && nq >= GEMM_MIN_NQ)
         return launch_flat_gemm_dist(r, metric, q, ws.q_sq.as<float>(), ws.q_nrm.as<float>(), nq, d_out, s);
     VDB_TRY(stream_flat_sums(ws, r, metric, q, nq, d_out, s));
-    return launch_finish_dist(metric, ws.q_sq.as<float>(), ws.q_nrm.as<float>(), r.sq, r.nrm, d_out, nq, r.n, s);
+    return launch_finish_dist(metric, ws.q_sq.as<float>(), ws.q_nrm.as<float>(), r.sq, r.nrm, r.cos_eps, d_out, nq, r.n, s);
 }
 
 // copy a host bitmask of n bits to the workspace
@@ -913,6 +913,13 @@ int vdb_rows_size(const vdb_rows* h, int64_t* n) {
     return VDB_OK;
 }
 
+int vdb_rows_set_cosine_eps(vdb_rows* h, float eps) {
+    VDB_REQUIRE(h && eps >= 0.0f && eps == eps, "cosine eps must be a non-negative number");
+    Entry g(h);
+    h->r.cos_eps = eps;
+    return VDB_OK;
+}
+
 int vdb_rows_norms(vdb_rows* h, float* sqnorm_out, float* norm_out) {
     VDB_REQUIRE(h, "null handle");
     Entry g(h);
@@ -1013,44 +1020,29 @@ int vdb_flat_range_search(vdb_rows* h, int metric, const float* query, float rad
     VDB_HIP(hipMemcpyAsync(ws.stage.p, query, (size_t)r.dim * sizeof(float), hipMemcpyHostToDevice, s));
     const float* q = nullptr;
     VDB_TRY(prepare_queries(ws, ws.stage.as<float>(), 1, r.dim, r.ld, r.plan, &q, s));
-    const int kk = KMAX_FUSED;
-    const int64_t ntiles = (r.n + 255) / 256;
-    const int splits = cand_splits(ntiles, 1);
-    const int n_cand = splits * topk_cand_lists_per_split();
-    VDB_TRY(ws.part_d.reserve((size_t)n_cand * kk * sizeof(float)));
-    VDB_TRY(ws.part_i.reserve((size_t)n_cand * kk * sizeof(int)));
-    VDB_TRY(ws.lb_d.reserve(sizeof(float)));
-    VDB_TRY(ws.lb_k.reserve(sizeof(int64_t)));
-    VDB_TRY(ws.out_d.reserve(kk * sizeof(float)));
-    VDB_TRY(ws.out_i.reserve(kk * sizeof(int64_t)));
-    // the rows are streamed once; every round of 32 results re-reads only the candidate buffer
+    // the rows are streamed once into a buffer of sums; everything after reads that buffer
     VDB_TRY(ws.cand.reserve((size_t)r.n * sizeof(float)));
     VDB_TRY(stream_flat_sums(ws, r, metric, q, 1, ws.cand.as<float>(), s));
-    float hd[KMAX_FUSED];
-    int64_t hi[KMAX_FUSED];
-    bool first = true;
-    while (*count < cap) {
-        CandJob c{};
-        c.cand = ws.cand.as<float>(); c.cand_stride = r.n; c.nq = 1; c.n = r.n; c.mask = d_mask;
-        c.metric = metric; c.q_sq = ws.q_sq.as<float>(); c.q_nrm = ws.q_nrm.as<float>(); c.row_sq = r.sq; c.row_nrm = r.nrm;
-        c.lb_d = first ? nullptr : ws.lb_d.as<float>(); c.lb_k = first ? nullptr : ws.lb_k.as<int64_t>();
-        c.radius = radius; c.use_radius = 1;
-        c.k = kk; c.splits = splits; c.part_d = ws.part_d.as<float>(); c.part_i = ws.part_i.as<int>();
-        VDB_TRY(launch_topk_cand(c, s));
-        SelectOut o{ws.out_d.as<float>(), ws.out_i.as<int64_t>(), nullptr, kk, 0, ws.lb_d.as<float>(), ws.lb_k.as<int64_t>()};
-        VDB_TRY(launch_select(ws.part_d.as<float>(), ws.part_i.as<int>(), 1, n_cand, kk, 1 << 30, nullptr, 0, o, s, ws.mid));
-        VDB_HIP(hipMemcpyAsync(hd, ws.out_d.p, kk * sizeof(float), hipMemcpyDeviceToHost, s));
-        VDB_HIP(hipMemcpyAsync(hi, ws.out_i.p, kk * sizeof(int64_t), hipMemcpyDeviceToHost, s));
-        VDB_HIP(hipStreamSynchronize(s));
-        first = false;
-        int got = 0;
-        for (int i = 0; i < kk && hi[i] >= 0 && *count < cap; ++i, ++got) {
-            if (out_dist) out_dist[*count] = hd[i];
-            if (out_row) out_row[*count] = hi[i];
-            ++*count;
-        }
-        if (got < kk) break;
-    }
+    RangeJob j{ws.cand.as<float>(), r.n, d_mask, metric, ws.q_sq.as<float>(), ws.q_nrm.as<float>(), r.sq, r.nrm, radius};
+    const int64_t nb = range_blocks(r.n);
+    VDB_TRY(ws.list_cnt.reserve((size_t)nb * sizeof(int)));
+    VDB_TRY(ws.cand_off.reserve((size_t)(nb + 1) * sizeof(int64_t)));
+    int64_t* d_total = ws.cand_off.as<int64_t>() + nb;
+    VDB_TRY(launch_range_count(j, ws.list_cnt.as<int>(), ws.cand_off.as<int64_t>(), d_total, s));
+    int64_t total = 0;
+    VDB_HIP(hipMemcpyAsync(&total, d_total, sizeof(int64_t), hipMemcpyDeviceToHost, s));
+    VDB_HIP(hipStreamSynchronize(s));
+    const int64_t m = std::min(total, cap);
+    if (m <= 0) return VDB_OK;
+    VDB_TRY(ws.queue.reserve((size_t)range_sort_capacity(m) * sizeof(uint64_t)));
+    VDB_TRY(ws.out_d.reserve((size_t)m * sizeof(float)));
+    VDB_TRY(ws.out_i.reserve((size_t)m * sizeof(int64_t)));
+    VDB_TRY(launch_range_collect(j, ws.cand_off.as<int64_t>(), cap, m, ws.queue.as<uint64_t>(), ws.out_d.as<float>(),
+                                 ws.out_i.as<int64_t>(), s));
+    if (out_dist) VDB_HIP(hipMemcpyAsync(out_dist, ws.out_d.p, (size_t)m * sizeof(float), hipMemcpyDeviceToHost, s));
+    if (out_row) VDB_HIP(hipMemcpyAsync(out_row, ws.out_i.p, (size_t)m * sizeof(int64_t), hipMemcpyDeviceToHost, s));
+    VDB_HIP(hipStreamSynchronize(s));
+    *count = m;
     return VDB_OK;
 }
 
@@ -1127,6 +1119,257 @@ int vdb_kmeans_accumulate(const float* x, int64_t n, int dim, const int32_t* ass
     const int st = body();
     sums.release(); counts.release(); xs.release(); as.release();
     return st;
+}
+
+// ============================================================== k-means on resident rows
+}  // extern "C"
+
+struct vdb_kmeans : Handle {
+    vdb_rows* train = nullptr;          // borrowed: the training rows (fp32 storage)
+    vdb_rows* sub = nullptr;            // own dense copy of the trained columns when they are a slice
+    vdb_rows* cent = nullptr;           // current centroids as a row store (the matrix-core assignment searches it)
+    int col0 = 0, dsub = 0, k = 0;
+    bool f64 = false;                   // the centroids are float64 (PQ form after its first step)
+    bool have_next = false;
+    int last_form = 0;
+    DevBuf cur32, next32, cur64, next64, assign, dist, nearest, hist, totals, cluster_off, members, counts, bsums,
+           chosen, qrow, csq64, scal, rows_in, dst_in, dense;
+    const Rows& x() const { return (sub ? sub : train)->r; }
+    Workspace& xws() { return (sub ? sub : train)->ws; }
+};
+
+static int kmeans_refresh_centroid_store(vdb_kmeans* h, hipStream_t s) {
+    h->cent->r.n = 0;
+    return rows_append_dev_impl(h->cent, h->cur32.as<float>(), h->k, h->dsub, s);
+}
+
+// nearest centroid of every training row under the fp32 forms: metric = VDB_EUCLIDEAN (KMeans._assign,
+// ivf.py:228-231) or VDB_EUCLIDEAN_SQ (the first PQ step, pq.py:156-157)
+static int kmeans_assign_f32(vdb_kmeans* h, int metric, hipStream_t s) {
+    const Rows& x = h->x();
+    VDB_TRY(kmeans_refresh_centroid_store(h, s));
+    VDB_TRY(h->assign.reserve((size_t)x.n * sizeof(int)));
+    VDB_TRY(h->dist.reserve((size_t)x.n * sizeof(float)));
+    const int64_t chunk = 262144;
+    const bool dense = x.ld == h->dsub;
+    if (!dense) VDB_TRY(h->dense.reserve((size_t)std::min<int64_t>(chunk, x.n) * h->dsub * sizeof(float)));
+    for (int64_t o = 0; o < x.n; o += chunk) {
+        const int nq = (int)std::min<int64_t>(chunk, x.n - o);
+        const float* q = x.data + o * x.ld;
+        if (!dense) {
+            VDB_TRY(launch_pad_rows(q, x.ld, h->dsub, nq, h->dense.as<float>(), h->dsub, s));
+            q = h->dense.as<float>();
+        }
+        VDB_TRY(flat_search_impl(h->cent, metric, q, nq, 1, nullptr, h->dist.as<float>() + o, nullptr, h->assign.as<int>() + o, s));
+    }
+    return VDB_OK;
+}
+
+extern "C" {
+
+int vdb_kmeans_create(vdb_kmeans** out, vdb_rows* train, int col0, int dsub, int n_clusters) {
+    VDB_TRY(ensure_init());
+    VDB_REQUIRE(out && train, "null argument");
+    VDB_REQUIRE(!train->r.bf16, "training rows must be stored in fp32");
+    VDB_REQUIRE(col0 >= 0 && dsub >= 1 && col0 + dsub <= train->r.dim, "columns [%d, %d) are outside the %d-dimensional rows",
+                col0, col0 + dsub, train->r.dim);
+    VDB_REQUIRE(n_clusters >= 1 && n_clusters <= 32768, "n_clusters must be in 1..32768, got %d", n_clusters);
+    VDB_REQUIRE(train->r.n >= n_clusters, "%lld training rows for %d clusters", (long long)train->r.n, n_clusters);
+    vdb_kmeans* h = new vdb_kmeans();
+    h->train = train; h->col0 = col0; h->dsub = dsub; h->k = n_clusters;
+    int st = h->open();
+    if (st == VDB_OK) st = vdb_rows_create(&h->cent, dsub);
+    if (st == VDB_OK && (col0 != 0 || dsub != train->r.dim)) {
+        st = vdb_rows_create(&h->sub, dsub);
+        if (st == VDB_OK) {
+            Entry g(train);
+            st = rows_append_dev_impl(h->sub, train->r.data + col0, train->r.n, train->r.ld, h->stream);
+            if (st == VDB_OK && hipStreamSynchronize(h->stream) != hipSuccess) { set_error("stream synchronisation failed"); st = VDB_ERR_HIP; }
+        }
+    }
+    if (st == VDB_OK) st = h->cur32.reserve((size_t)n_clusters * dsub * sizeof(float));
+    if (st == VDB_OK) st = h->next32.reserve((size_t)n_clusters * dsub * sizeof(float));
+    if (st == VDB_OK) st = h->cur64.reserve((size_t)n_clusters * dsub * sizeof(double));
+    if (st == VDB_OK) st = h->next64.reserve((size_t)n_clusters * dsub * sizeof(double));
+    if (st != VDB_OK) { std::string keep = g_err; vdb_kmeans_destroy(h); g_err = keep; return st; }
+    *out = h;
+    return VDB_OK;
+}
+
+int vdb_kmeans_destroy(vdb_kmeans* h) {
+    if (!h) return VDB_OK;
+    {
+        Entry g(h);
+        if (h->stream) (void)hipStreamSynchronize(h->stream);
+        DevBuf* all[] = {&h->cur32, &h->next32, &h->cur64, &h->next64, &h->assign, &h->dist, &h->nearest, &h->hist, &h->totals,
+                         &h->cluster_off, &h->members, &h->counts, &h->bsums, &h->chosen, &h->qrow, &h->csq64, &h->scal,
+                         &h->rows_in, &h->dst_in, &h->dense};
+        for (DevBuf* b : all) b->release();
+    }
+    vdb_rows_destroy(h->sub);
+    vdb_rows_destroy(h->cent);
+    h->close();
+    delete h;
+    return VDB_OK;
+}
+
+int vdb_kmeans_init_rows(vdb_kmeans* h, const int64_t* rows, int n_rows) {
+    VDB_REQUIRE(h && rows && n_rows == h->k, "vdb_kmeans_init_rows needs one training row per cluster (%d given)", n_rows);
+    for (int i = 0; i < n_rows; ++i) VDB_REQUIRE(rows[i] >= 0 && rows[i] < h->x().n, "row %lld out of range", (long long)rows[i]);
+    Entry g(h);
+    hipStream_t s = h->stream;
+    VDB_TRY(h->rows_in.reserve((size_t)n_rows * sizeof(int64_t)));
+    VDB_HIP(hipMemcpyAsync(h->rows_in.p, rows, (size_t)n_rows * sizeof(int64_t), hipMemcpyHostToDevice, s));
+    VDB_TRY(launch_km_gather(h->x().data, h->x().ld, h->dsub, h->rows_in.as<long long>(), nullptr, n_rows, h->cur32.as<float>(),
+                             h->cur64.as<double>(), s));
+    VDB_HIP(hipStreamSynchronize(s));
+    h->f64 = false; h->have_next = false;
+    return VDB_OK;
+}
+
+int vdb_kmeans_init_pp(vdb_kmeans* h, int64_t first_row, const double* uniforms, int64_t* out_rows) {
+    VDB_REQUIRE(h && (uniforms || h->k == 1), "null argument");
+    VDB_REQUIRE(first_row >= 0 && first_row < h->x().n, "row %lld out of range", (long long)first_row);
+    Entry g(h);
+    Entry gx(h->sub ? h->sub : h->train);        // the scan below uses the row store's own workspace
+    hipStream_t s = h->stream;
+    const Rows& x = h->x();
+    vdb_rows* xs = h->sub ? h->sub : h->train;
+    const int k = h->k;
+    VDB_TRY(h->chosen.reserve((size_t)k * sizeof(int64_t)));
+    VDB_TRY(h->dist.reserve((size_t)x.n * sizeof(float)));
+    VDB_TRY(h->nearest.reserve((size_t)x.n * sizeof(float)));
+    VDB_TRY(h->bsums.reserve((size_t)km_pp_blocks(x.n) * sizeof(double)));
+    VDB_TRY(h->qrow.reserve((size_t)h->dsub * sizeof(float) + 64));
+    long long* chosen = h->chosen.as<long long>();
+    VDB_HIP(hipMemcpyAsync(chosen, &first_row, sizeof(int64_t), hipMemcpyHostToDevice, s));
+    for (int j = 1; j < k; ++j) {
+        // distances of every row to the centroid chosen last: pairwise_euclidean against ONE new centroid; the
+        // minimum over all chosen ones is kept as a running minimum (min is exact, so the result is the same)
+        VDB_TRY(launch_km_gather(x.data, x.ld, h->dsub, chosen + (j - 1), nullptr, 1, h->qrow.as<float>(), nullptr, s));
+        VDB_TRY(flat_distances_impl(xs, VDB_EUCLIDEAN, h->qrow.as<float>(), 1, h->dist.as<float>(), s));
+        VDB_TRY(launch_km_pp_step(h->dist.as<float>(), x.n, j == 1, h->nearest.as<float>(), h->bsums.as<double>(),
+                                  uniforms[j - 1], chosen + j, s));
+    }
+    VDB_TRY(launch_km_gather(x.data, x.ld, h->dsub, chosen, nullptr, k, h->cur32.as<float>(), h->cur64.as<double>(), s));
+    if (out_rows) VDB_HIP(hipMemcpyAsync(out_rows, chosen, (size_t)k * sizeof(int64_t), hipMemcpyDeviceToHost, s));
+    VDB_HIP(hipStreamSynchronize(s));
+    h->f64 = false; h->have_next = false;
+    return VDB_OK;
+}
+
+int vdb_kmeans_step(vdb_kmeans* h, int form, int64_t* out_counts, double* out_shift) {
+    VDB_REQUIRE(h, "null handle");
+    VDB_REQUIRE(form == VDB_KMEANS_IVF || form == VDB_KMEANS_PQ, "unknown k-means form %d", form);
+    VDB_REQUIRE(form == VDB_KMEANS_PQ || !h->f64, "the float64 centroids of the PQ form cannot go back to the KMeans form");
+    Entry g(h);
+    hipStream_t s = h->stream;
+    const Rows& x = h->x();
+    const int k = h->k;
+    // ---- assignment
+    if (!h->f64) {
+        VDB_TRY(kmeans_assign_f32(h, form == VDB_KMEANS_IVF ? VDB_EUCLIDEAN : VDB_EUCLIDEAN_SQ, s));
+    } else {
+        VDB_TRY(h->assign.reserve((size_t)x.n * sizeof(int)));
+        VDB_TRY(h->csq64.reserve((size_t)k * sizeof(double)));
+        VDB_TRY(launch_km_assign_f64(x.data, x.ld, h->dsub, x.n, x.sq, h->cur64.as<double>(), h->csq64.as<double>(), k,
+                                     h->assign.as<int>(), s));
+    }
+    // ---- rows sorted by cluster, sample order kept inside a cluster; sequential sums
+    int64_t chunk; int nb;
+    km_sort_chunk(x.n, &chunk, &nb);
+    VDB_TRY(h->hist.reserve((size_t)nb * k * sizeof(int)));
+    VDB_TRY(h->totals.reserve((size_t)k * sizeof(int)));
+    VDB_TRY(h->cluster_off.reserve((size_t)(k + 1) * sizeof(int)));
+    VDB_TRY(h->members.reserve((size_t)x.n * sizeof(int)));
+    VDB_TRY(h->counts.reserve((size_t)k * sizeof(int64_t)));
+    VDB_TRY(h->scal.reserve(64));
+    VDB_TRY(launch_km_sort(h->assign.as<int>(), x.n, k, h->hist.as<int>(), h->totals.as<int>(), h->cluster_off.as<int>(),
+                           h->members.as<int>(), s));
+    const int sum_form = form == VDB_KMEANS_IVF ? 0 : (h->f64 ? 2 : 1);
+    VDB_TRY(launch_km_sums(sum_form, x.data, x.ld, h->dsub, h->members.as<int>(), h->cluster_off.as<int>(), k,
+                           h->next32.as<float>(), h->next64.as<double>(), h->counts.as<long long>(), s));
+    VDB_TRY(launch_km_shift(h->next32.as<float>(), h->cur32.as<float>(), (int64_t)k * h->dsub, h->scal.as<double>(), s));
+    if (out_counts) VDB_HIP(hipMemcpyAsync(out_counts, h->counts.p, (size_t)k * sizeof(int64_t), hipMemcpyDeviceToHost, s));
+    if (out_shift) VDB_HIP(hipMemcpyAsync(out_shift, h->scal.p, sizeof(double), hipMemcpyDeviceToHost, s));
+    VDB_HIP(hipStreamSynchronize(s));
+    h->have_next = true;
+    h->last_form = form;
+    return VDB_OK;
+}
+
+int vdb_kmeans_reseed(vdb_kmeans* h, const int32_t* clusters, const int64_t* rows, int count, double* out_shift) {
+    VDB_REQUIRE(h && (count == 0 || (clusters && rows)) && count >= 0, "bad arguments to vdb_kmeans_reseed");
+    VDB_REQUIRE(h->have_next, "vdb_kmeans_reseed follows vdb_kmeans_step");
+    for (int i = 0; i < count; ++i)
+        VDB_REQUIRE(clusters[i] >= 0 && clusters[i] < h->k && rows[i] >= 0 && rows[i] < h->x().n, "cluster or row out of range");
+    Entry g(h);
+    hipStream_t s = h->stream;
+    if (count > 0) {
+        VDB_TRY(h->rows_in.reserve((size_t)count * sizeof(int64_t)));
+        VDB_TRY(h->dst_in.reserve((size_t)count * sizeof(int)));
+        VDB_HIP(hipMemcpyAsync(h->rows_in.p, rows, (size_t)count * sizeof(int64_t), hipMemcpyHostToDevice, s));
+        VDB_HIP(hipMemcpyAsync(h->dst_in.p, clusters, (size_t)count * sizeof(int), hipMemcpyHostToDevice, s));
+        VDB_TRY(launch_km_gather(h->x().data, h->x().ld, h->dsub, h->rows_in.as<long long>(), h->dst_in.as<int>(), count,
+                                 h->next32.as<float>(), h->next64.as<double>(), s));
+    }
+    VDB_TRY(launch_km_shift(h->next32.as<float>(), h->cur32.as<float>(), (int64_t)h->k * h->dsub, h->scal.as<double>(), s));
+    if (out_shift) VDB_HIP(hipMemcpyAsync(out_shift, h->scal.p, sizeof(double), hipMemcpyDeviceToHost, s));
+    VDB_HIP(hipStreamSynchronize(s));
+    return VDB_OK;
+}
+
+int vdb_kmeans_commit(vdb_kmeans* h) {
+    VDB_REQUIRE(h && h->have_next, "vdb_kmeans_commit follows vdb_kmeans_step");
+    Entry g(h);
+    std::swap(h->cur32, h->next32);
+    std::swap(h->cur64, h->next64);
+    h->f64 = h->last_form == VDB_KMEANS_PQ;
+    h->have_next = false;
+    return VDB_OK;
+}
+
+int vdb_kmeans_centroids(vdb_kmeans* h, float* out32, double* out64) {
+    VDB_REQUIRE(h && (out32 || out64), "null argument");
+    Entry g(h);
+    hipStream_t s = h->stream;
+    const size_t cnt = (size_t)h->k * h->dsub;
+    if (out32) VDB_HIP(hipMemcpyAsync(out32, h->cur32.p, cnt * sizeof(float), hipMemcpyDeviceToHost, s));
+    if (out64) {
+        VDB_REQUIRE(h->f64, "the centroids are fp32 (float64 centroids exist after a PQ-form step)");
+        VDB_HIP(hipMemcpyAsync(out64, h->cur64.p, cnt * sizeof(double), hipMemcpyDeviceToHost, s));
+    }
+    VDB_HIP(hipStreamSynchronize(s));
+    return VDB_OK;
+}
+
+int vdb_kmeans_set_centroids(vdb_kmeans* h, const float* centroids) {
+    VDB_REQUIRE(h && centroids, "null argument");
+    Entry g(h);
+    hipStream_t s = h->stream;
+    VDB_HIP(hipMemcpyAsync(h->cur32.p, centroids, (size_t)h->k * h->dsub * sizeof(float), hipMemcpyHostToDevice, s));
+    VDB_HIP(hipStreamSynchronize(s));
+    h->f64 = false; h->have_next = false;
+    return VDB_OK;
+}
+
+int vdb_kmeans_assignments(vdb_kmeans* h, int32_t* out_assign, float* out_dist) {
+    VDB_REQUIRE(h && (out_assign || out_dist), "null argument");
+    Entry g(h);
+    hipStream_t s = h->stream;
+    const int64_t n = h->x().n;
+    if (!h->have_next) {
+        // no step pending: assign against the current centroids in the KMeans form (KMeans.predict, ivf.py:233-237)
+        VDB_REQUIRE(!h->f64, "assignments of float64 centroids are those of the last step");
+        VDB_TRY(kmeans_assign_f32(h, VDB_EUCLIDEAN, s));
+    }
+    if (out_assign) VDB_HIP(hipMemcpyAsync(out_assign, h->assign.p, (size_t)n * sizeof(int), hipMemcpyDeviceToHost, s));
+    if (out_dist) {
+        VDB_REQUIRE(h->dist.cap >= (size_t)n * sizeof(float) && !(h->have_next && h->f64), "no fp32 distances for this step");
+        VDB_HIP(hipMemcpyAsync(out_dist, h->dist.p, (size_t)n * sizeof(float), hipMemcpyDeviceToHost, s));
+    }
+    VDB_HIP(hipStreamSynchronize(s));
+    return VDB_OK;
 }
 
 // ============================================================== IVF

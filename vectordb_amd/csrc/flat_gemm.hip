@@ -43,6 +43,7 @@ struct GemmParams {
     float* part_d; int* part_i; int n_cand;
     float* dist_out;
     const int* run_if;              // optional device flag: the launch does nothing while it is zero
+    float cos_eps;                  // cosine: norms below it count as 1 (1e-8 for searches)
 };
 
 // SAMPLE only gives the strided warm-up pass a kernel name of its own, so that
@@ -90,7 +91,8 @@ __global__ __launch_bounds__(NT, 2) void flat_gemm_kernel(GemmParams p) {
     float q_term = 0.0f;
     if (METRIC == VDB_COSINE) {
         q_term = p.q_nrm[my_q_ld];
-        if (q_term < 1e-8f) q_term = INFINITY;      // metrics.py:472-473: all ones
+        // metrics.py:472-473: all ones; with a caller's eps (distance matrix only) the norm counts as 1, :360-361
+        if (q_term < p.cos_eps) q_term = (TOPK || p.cos_eps <= 1e-8f) ? INFINITY : 1.0f;
     } else if (METRIC != VDB_DOT) {
         q_term = p.q_sq[my_q_ld];
     }
@@ -171,7 +173,7 @@ __global__ __launch_bounds__(NT, 2) void flat_gemm_kernel(GemmParams p) {
             if (ks == 0 && METRIC != VDB_DOT && tid < TM) {
                 const int64_t gr = min(rbase + tid, p.n - 1);
                 float t = (METRIC == VDB_COSINE) ? p.row_nrm[gr] : p.row_sq[gr];
-                if (METRIC == VDB_COSINE && t < 1e-8f) t = 1.0f;    // metrics.py:476
+                if (METRIC == VDB_COSINE && t < p.cos_eps) t = 1.0f;    // metrics.py:476
                 Rs[tid] = t;
             }
             __syncthreads();
@@ -372,6 +374,7 @@ int launch_flat_gemm_topk(const Rows& r, int metric, const void* q, const float*
     p.n_tiles = sample_tiles > 0 ? sample_tiles : (int)((r.n + TM - 1) / TM);
     p.tile_stride = sample_tiles > 0 ? tile_stride : 1;
     p.part_d = part_d; p.part_i = part_i; p.n_cand = n_cand; p.dist_out = nullptr; p.run_if = run_if;
+    p.cos_eps = 1e-8f;
     return r.bf16 ? launch_gemm<true, true>(metric, p, s) : launch_gemm<true, false>(metric, p, s);
 }
 
@@ -382,7 +385,7 @@ int launch_flat_gemm_dist(const Rows& r, int metric, const void* q, const float*
     p.rows = r.bf16 ? (const void*)r.data16 : (const void*)r.data; p.n = r.n;
     p.ld_bytes = r.bf16 ? r.ld16 * 2 : r.ld * 4; p.row_sq = r.sq; p.row_nrm = r.nrm;
     p.q = q; p.nq = nq; p.q_sq = q_sq; p.q_nrm = q_nrm;
-    p.k = 0; p.dist_out = out;
+    p.k = 0; p.dist_out = out; p.cos_eps = r.cos_eps;
     p.n_tiles = (int)((r.n + TM - 1) / TM);
     p.tile_stride = 1;
     return r.bf16 ? launch_gemm<false, true>(metric, p, s) : launch_gemm<false, false>(metric, p, s);

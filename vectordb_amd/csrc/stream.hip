@@ -62,6 +62,7 @@ template <int OP> __device__ __forceinline__ float s_term(float x, float q) {
     if (OP == OP_SQDIFF) { const float d = q - x; return d * d; }
     if (OP == OP_ABSDIFF || OP == OP_MAXABS) return fabsf(x - q);
     if (OP == OP_SQ) return x * x;
+    if (OP == OP_NEQ) return x != q ? 1.0f : 0.0f;      // counts stay exact in fp32 up to 2^24 positions
     return x * q;
 }
 template <int OP> __device__ __forceinline__ float s_comb(float a, float b) {
@@ -81,6 +82,7 @@ template <int OP> __device__ __forceinline__ f2 s_accum2(f2 r, f2 x, f2 q) {
     if (OP == OP_DOT) return __builtin_elementwise_fma(x, q, r);
     if (OP == OP_SQDIFF) { const f2 d = q - x; return r + d * d; }
     if (OP == OP_SQ) return r + x * x;
+    if (OP == OP_NEQ) return r + f2{x.x != q.x ? 1.0f : 0.0f, x.y != q.y ? 1.0f : 0.0f};
     const f2 d = __builtin_elementwise_abs(x - q);
     if (OP == OP_MAXABS) return f2{fmaxf(r.x, d.x), fmaxf(r.y, d.y)};
     return r + d;
@@ -282,7 +284,10 @@ __global__ __launch_bounds__(S_NT * QS) void stream_sums_kernel(const StreamPara
                 qv[buf][h][1] = *reinterpret_cast<const float4*>(src + h * S_CK + 4);
             }
         };
-        load_q(0, 0);
+        // a unit whose H queries are all padding (a group that is not full) is neither fetched nor summed: the
+        // broadcast reads of the query values are what the LDS return path is busy with in a batch scan
+        auto unit_live = [&](int unit) { return gq((unit % U) * H) < c_it.qcnt; };
+        if (unit_live(0)) load_q(0, 0);
 
         const int col0 = c_ks * S_CK;
         if (WHOLE || L - in_leaf >= S_CK) {
@@ -290,7 +295,7 @@ __global__ __launch_bounds__(S_NT * QS) void stream_sums_kernel(const StreamPara
 #pragma unroll
             for (int unit = 0; unit < (S_CK / 8) * U; ++unit) {
                 const int grp = unit / U, g0 = (unit % U) * H;
-                if (unit + 1 < (S_CK / 8) * U) load_q((unit + 1) & 1, unit + 1);
+                if (unit + 1 < (S_CK / 8) * U && unit_live(unit + 1)) load_q((unit + 1) & 1, unit + 1);
                 if (gq(g0) < c_it.qcnt) {               // units whose queries are all padding do no arithmetic
                     const f2 x2[4] = {f2{xv[2 * grp].x, xv[2 * grp].y}, f2{xv[2 * grp].z, xv[2 * grp].w},
                                       f2{xv[2 * grp + 1].x, xv[2 * grp + 1].y}, f2{xv[2 * grp + 1].z, xv[2 * grp + 1].w}};
@@ -420,6 +425,7 @@ int launch_stream_sums(const StreamJob& j, hipStream_t s) {
         VDB_LAUNCH_STREAM_OP(OP_SQDIFF)
         VDB_LAUNCH_STREAM_OP(OP_ABSDIFF)
         VDB_LAUNCH_STREAM_OP(OP_MAXABS)
+        VDB_LAUNCH_STREAM_OP(OP_NEQ)
         case OP_SQ:
             VDB_REQUIRE(j.group == 1, "squared norms run one row set at a time");
             VDB_LAUNCH_STREAM(OP_SQ, 1, 1)
@@ -600,7 +606,15 @@ struct Finish {
     int metric;
     const float* q_sq; const float* q_nrm;       // per query
     const float* row_sq; const float* row_nrm;   // per stored row
+    float cos_eps;                               // cosine matrix form: norms below it count as 1
 };
+
+// arccos of a similarity the way the reference takes it (metrics.py:535-538): the fp32 quotient goes to
+// double, is clipped, and np.arccos runs in double; the result is rounded to fp32 for the caller
+__device__ __forceinline__ float angular_of(float sim) {
+    const double s = fmin(fmax((double)sim, -1.0), 1.0);
+    return (float)acos(s);
+}
 
 __device__ __forceinline__ float finish_value(const Finish& f, float sum, float q_sq, float q_nrm, int64_t pos) {
     switch (f.metric) {
@@ -609,9 +623,10 @@ __device__ __forceinline__ float finish_value(const Finish& f, float sum, float 
             return f.metric == VDB_EUCLIDEAN ? sqrtf(sq) : sq;
         }
         case VDB_COSINE: {
-            if (q_nrm < 1e-8f) return 1.0f;                          // metrics.py:472-473
+            if (q_nrm < 1e-8f && f.cos_eps <= 1e-8f) return 1.0f;    // metrics.py:472-473
+            if (q_nrm < f.cos_eps) q_nrm = 1.0f;                     // metrics.py:360-361 with a caller's eps
             float cn = f.row_nrm[pos];
-            if (cn < 1e-8f) cn = 1.0f;                               // metrics.py:476
+            if (cn < f.cos_eps) cn = 1.0f;                           // metrics.py:476, :362-363
             const float sim = fminf(fmaxf(sum / (q_nrm * cn), -1.0f), 1.0f);
             return 1.0f - sim;
         }
@@ -619,6 +634,10 @@ __device__ __forceinline__ float finish_value(const Finish& f, float sum, float 
             const float den = q_nrm * f.row_nrm[pos];                // metrics.py:96-100
             const float sim = den < 1e-8f ? 0.0f : sum / den;
             return 1.0f - sim;
+        }
+        case VDB_ANGULAR: {
+            const float den = q_nrm * f.row_nrm[pos];                // metrics.py:96-100 via :535
+            return angular_of(den < 1e-8f ? 0.0f : sum / den);
         }
         default: return sum;      // already final (direct forms, Manhattan, Chebyshev, negated dot)
     }
@@ -634,10 +653,11 @@ __global__ void finish_dist_kernel(Finish f, float* __restrict__ v, int nq, int6
 }
 
 int launch_finish_dist(int metric, const float* q_sq, const float* q_nrm, const float* row_sq, const float* row_nrm,
-                       float* v, int nq, int64_t n, hipStream_t s) {
-    if (metric != VDB_EUCLIDEAN && metric != VDB_EUCLIDEAN_SQ && metric != VDB_COSINE && metric != VDB_COSINE_PAIR)
+                       float cos_eps, float* v, int nq, int64_t n, hipStream_t s) {
+    if (metric != VDB_EUCLIDEAN && metric != VDB_EUCLIDEAN_SQ && metric != VDB_COSINE && metric != VDB_COSINE_PAIR &&
+        metric != VDB_ANGULAR)
         return VDB_OK;
-    Finish f{metric, q_sq, q_nrm, row_sq, row_nrm};
+    Finish f{metric, q_sq, q_nrm, row_sq, row_nrm, cos_eps};
     const int64_t total = (int64_t)nq * n;
     hipLaunchKernelGGL(finish_dist_kernel, dim3((unsigned)std::min<int64_t>((total + 255) / 256, 16384)), dim3(256), 0, s,
                        f, v, nq, n);
@@ -668,8 +688,8 @@ static constexpr int RUN_CHUNK = 256;      // probed lists whose ranges are stag
 
 // FIN: how a candidate value becomes a distance, fixed per launch so that the row terms of the
 // CAND_UNROLL tiles are fetched together instead of one dependent load per tile:
-// 0 = the value is the distance (direct forms, Manhattan, Chebyshev, negated dot), 1 = the Euclidean
-// identity form, 2 = cosine of the matrix form, 3 = cosine of the pair form.
+// 0 = the value is the distance (direct forms, Manhattan, Chebyshev, Hamming, negated dot), 1 = the Euclidean
+// identity form, 2 = cosine of the matrix form, 3 = cosine of the pair form, 4 = the angle of the pair form.
 template <int FIN>
 __global__ __launch_bounds__(LIST_NT) void topk_cand_kernel(CandParams p) {
     extern __shared__ __align__(16) float smem[];
@@ -761,6 +781,9 @@ __global__ __launch_bounds__(LIST_NT) void topk_cand_kernel(CandParams p) {
                 } else if (FIN == 3) {
                     const float den = q_nrm * rt[u];                                            // metrics.py:96-100
                     v = 1.0f - (den < 1e-8f ? 0.0f : v / den);
+                } else if (FIN == 4) {
+                    const float den = q_nrm * rt[u];                                            // metrics.py:535-538
+                    v = angular_of(den < 1e-8f ? 0.0f : v / den);
                 }
                 d[u] = ok[u] ? v : INFINITY;
             }
@@ -790,17 +813,218 @@ int launch_topk_cand(const CandJob& j, hipStream_t s) {
     CandParams p{};
     p.cand = j.cand; p.cand_stride = j.cand_stride; p.n = j.n; p.probes = j.probes; p.n_probe = j.n_probe; p.n_lists = j.n_lists;
     p.list_off = j.list_off; p.row_ids = j.row_ids; p.mask = j.mask;
-    p.fin = Finish{j.metric, j.q_sq, j.q_nrm, j.row_sq, j.row_nrm};
+    p.fin = Finish{j.metric, j.q_sq, j.q_nrm, j.row_sq, j.row_nrm, 1e-8f};
     p.lb_d = j.lb_d; p.lb_k = j.lb_k; p.radius = j.radius; p.use_radius = j.use_radius;
     p.k = j.k; p.splits = j.splits; p.part_d = j.part_d; p.part_i = j.part_i;
     VDB_REQUIRE(j.probes == nullptr || (j.cand_off && j.tile_off), "list candidates need their slot and tile offsets");
     p.cand_off = j.cand_off; p.tile_off = j.tile_off;
     const size_t lds = (size_t)RUN_CHUNK * 24 + 8;
     const int fin = (j.metric == VDB_EUCLIDEAN || j.metric == VDB_EUCLIDEAN_SQ) ? 1
-                    : j.metric == VDB_COSINE ? 2 : j.metric == VDB_COSINE_PAIR ? 3 : 0;
-    auto kern = fin == 1 ? topk_cand_kernel<1> : fin == 2 ? topk_cand_kernel<2> : fin == 3 ? topk_cand_kernel<3> : topk_cand_kernel<0>;
+                    : j.metric == VDB_COSINE ? 2 : j.metric == VDB_COSINE_PAIR ? 3 : j.metric == VDB_ANGULAR ? 4 : 0;
+    auto kern = fin == 1 ? topk_cand_kernel<1> : fin == 2 ? topk_cand_kernel<2> : fin == 3 ? topk_cand_kernel<3>
+                : fin == 4 ? topk_cand_kernel<4> : topk_cand_kernel<0>;
     VDB_TRY(raise_dynamic_lds(reinterpret_cast<const void*>(kern), lds));
     hipLaunchKernelGGL(kern, dim3(j.nq, j.splits), dim3(LIST_NT), lds, s, p);
+    VDB_HIP(hipGetLastError());
+    return VDB_OK;
+}
+
+// --------------------------------------------------------------------------
+// Range search (index/flat.py:501-572): the rows of one query whose distance is <= radius and that
+// pass the filter, the FIRST `cap` of them in row order (the reference walks the rows in insertion
+// order and stops at max_results, :545-567), then sorted by distance with ties in row order (the
+// stable sort of :570).  Three passes over the candidate buffer: count per block of 1024 rows, scan
+// of the block counts, ordered fill of (distance, row) keys; the keys are sorted by a bitonic network
+// and the distances are recomputed from the candidate values on the way out, so a caller sees the same
+// bits a search would return.
+static constexpr int RANGE_BLOCK = 1024;          // rows per block: four passes of 256
+
+__device__ __forceinline__ uint64_t range_key(float d, int64_t row) {
+    if (d == 0.0f) d = 0.0f;                       // -0 and +0 are one distance
+    uint32_t u = __float_as_uint(d);
+    u ^= (u >> 31) ? 0xffffffffu : 0x80000000u;    // unsigned order = float order
+    return ((uint64_t)u << 32) | (uint32_t)row;
+}
+
+struct RangeParams {
+    const float* cand; int64_t n; const uint32_t* mask; Finish fin; float radius;
+    int* block_counts; const int64_t* block_off; int64_t cap; uint64_t* keys;
+};
+
+template <bool FILL>
+__global__ __launch_bounds__(256) void range_pass_kernel(RangeParams p) {
+    __shared__ int wave_cnt[4][4];                 // [pass][wave]
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const float q_sq = p.fin.q_sq ? p.fin.q_sq[0] : 0.0f, q_nrm = p.fin.q_nrm ? p.fin.q_nrm[0] : 0.0f;
+    const int64_t base = (int64_t)blockIdx.x * RANGE_BLOCK;
+    float d[4];
+    bool hit[4];
+    int rank[4];
+#pragma unroll
+    for (int ps = 0; ps < 4; ++ps) {
+        const int64_t row = base + ps * 256 + tid;
+        hit[ps] = false;
+        d[ps] = 0.0f;
+        if (row < p.n) {
+            d[ps] = finish_value(p.fin, p.cand[row], q_sq, q_nrm, row);
+            hit[ps] = d[ps] <= p.radius;           // index/flat.py:546 (a NaN distance never passes)
+            if (hit[ps] && p.mask) hit[ps] = (p.mask[row >> 5] >> (row & 31)) & 1u;
+        }
+        const unsigned long long b = __ballot(hit[ps]);
+        rank[ps] = __popcll(b & ((1ull << lane) - 1ull));
+        if (lane == 0) wave_cnt[ps][wave] = __popcll(b);
+    }
+    __syncthreads();
+    if (!FILL) {
+        if (tid == 0) {
+            int t = 0;
+            for (int i = 0; i < 16; ++i) t += (&wave_cnt[0][0])[i];
+            p.block_counts[blockIdx.x] = t;
+        }
+        return;
+    }
+    int64_t before = p.block_off[blockIdx.x];
+#pragma unroll
+    for (int ps = 0; ps < 4; ++ps) {
+#pragma unroll
+        for (int w = 0; w < 4; ++w) {
+            if (w == wave && hit[ps]) {
+                const int64_t at = before + rank[ps];
+                if (at < p.cap) p.keys[at] = range_key(d[ps], base + ps * 256 + tid);
+            }
+            before += wave_cnt[ps][w];
+        }
+    }
+}
+
+// exclusive scan of the block counts by one block; total[0] = number of rows inside the radius
+__global__ __launch_bounds__(1024) void range_scan_kernel(const int* __restrict__ counts, int64_t nb,
+                                                          int64_t* __restrict__ off, int64_t* __restrict__ total) {
+    __shared__ int64_t sh[1024];
+    __shared__ int64_t carry;
+    const int tid = threadIdx.x;
+    if (tid == 0) carry = 0;
+    __syncthreads();
+    for (int64_t b0 = 0; b0 < nb; b0 += 1024) {
+        const int64_t b = b0 + tid;
+        const int64_t c = b < nb ? counts[b] : 0;
+        sh[tid] = c;
+        __syncthreads();
+        for (int o = 1; o < 1024; o <<= 1) {
+            const int64_t a = tid >= o ? sh[tid - o] : 0;
+            __syncthreads();
+            sh[tid] += a;
+            __syncthreads();
+        }
+        if (b < nb) off[b] = carry + sh[tid] - c;
+        __syncthreads();
+        if (tid == 1023) carry += sh[1023];
+        __syncthreads();
+    }
+    if (tid == 0) total[0] = carry;
+}
+
+// bitonic network over P = 2^x >= 1024 keys.  Element i is compared with i ^ j at stage (k, j), ascending
+// where (i & k) == 0.  Strides below 1024 run inside LDS on chunks of 1024 keys.
+__device__ __forceinline__ void bitonic_lds_steps(uint64_t* sh, int tid, int64_t chunk0, int64_t k, int j_first) {
+    for (int j = j_first; j > 0; j >>= 1) {
+        const int lo = 2 * tid - (tid & (j - 1));
+        const int hi = lo + j;
+        const bool up = ((chunk0 + lo) & k) == 0;
+        const uint64_t a = sh[lo], b = sh[hi];
+        if ((a > b) == up) { sh[lo] = b; sh[hi] = a; }
+        __syncthreads();
+    }
+}
+
+__global__ __launch_bounds__(512) void bitonic_chunk_sort_kernel(uint64_t* __restrict__ keys) {
+    __shared__ uint64_t sh[1024];
+    const int tid = threadIdx.x;
+    const int64_t chunk0 = (int64_t)blockIdx.x * 1024;
+    sh[tid] = keys[chunk0 + tid];
+    sh[tid + 512] = keys[chunk0 + tid + 512];
+    __syncthreads();
+    for (int64_t k = 2; k <= 1024; k <<= 1) bitonic_lds_steps(sh, tid, chunk0, k, (int)(k >> 1));
+    keys[chunk0 + tid] = sh[tid];
+    keys[chunk0 + tid + 512] = sh[tid + 512];
+}
+
+__global__ __launch_bounds__(256) void bitonic_global_step_kernel(uint64_t* __restrict__ keys, int64_t half, int64_t j, int64_t k) {
+    for (int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; t < half; t += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t lo = 2 * t - (t & (j - 1));
+        const int64_t hi = lo + j;
+        const bool up = (lo & k) == 0;
+        const uint64_t a = keys[lo], b = keys[hi];
+        if ((a > b) == up) { keys[lo] = b; keys[hi] = a; }
+    }
+}
+
+__global__ __launch_bounds__(512) void bitonic_chunk_merge_kernel(uint64_t* __restrict__ keys, int64_t k) {
+    __shared__ uint64_t sh[1024];
+    const int tid = threadIdx.x;
+    const int64_t chunk0 = (int64_t)blockIdx.x * 1024;
+    sh[tid] = keys[chunk0 + tid];
+    sh[tid + 512] = keys[chunk0 + tid + 512];
+    __syncthreads();
+    bitonic_lds_steps(sh, tid, chunk0, k, 512);
+    keys[chunk0 + tid] = sh[tid];
+    keys[chunk0 + tid + 512] = sh[tid + 512];
+}
+
+__global__ void range_out_kernel(const uint64_t* __restrict__ keys, int64_t m, RangeParams p,
+                                 float* __restrict__ out_d, int64_t* __restrict__ out_row) {
+    const float q_sq = p.fin.q_sq ? p.fin.q_sq[0] : 0.0f, q_nrm = p.fin.q_nrm ? p.fin.q_nrm[0] : 0.0f;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < m; i += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t row = (int64_t)(uint32_t)keys[i];
+        out_row[i] = row;
+        out_d[i] = finish_value(p.fin, p.cand[row], q_sq, q_nrm, row);
+    }
+}
+
+static RangeParams range_params(const RangeJob& j) {
+    RangeParams p{};
+    p.cand = j.cand; p.n = j.n; p.mask = j.mask; p.radius = j.radius;
+    p.fin = Finish{j.metric, j.q_sq, j.q_nrm, j.row_sq, j.row_nrm, 1e-8f};
+    return p;
+}
+
+int64_t range_blocks(int64_t n) { return (n + RANGE_BLOCK - 1) / RANGE_BLOCK; }
+
+int launch_range_count(const RangeJob& j, int* block_counts, int64_t* block_off, int64_t* total, hipStream_t s) {
+    VDB_REQUIRE(j.n >= 1 && j.n < (int64_t)0xffffffff, "range search handles up to 2^32-1 rows");
+    RangeParams p = range_params(j);
+    p.block_counts = block_counts;
+    const int64_t nb = range_blocks(j.n);
+    hipLaunchKernelGGL(range_pass_kernel<false>, dim3((unsigned)nb), dim3(256), 0, s, p);
+    hipLaunchKernelGGL(range_scan_kernel, dim3(1), dim3(1024), 0, s, block_counts, nb, block_off, total);
+    VDB_HIP(hipGetLastError());
+    return VDB_OK;
+}
+
+int64_t range_sort_capacity(int64_t m) {
+    int64_t p = 1024;
+    while (p < m) p <<= 1;
+    return p;
+}
+
+int launch_range_collect(const RangeJob& j, const int64_t* block_off, int64_t cap, int64_t m, uint64_t* keys,
+                         float* out_d, int64_t* out_row, hipStream_t s) {
+    if (m <= 0) return VDB_OK;
+    const int64_t P = range_sort_capacity(m);
+    VDB_HIP(hipMemsetAsync(keys, 0xff, (size_t)P * sizeof(uint64_t), s));       // padding sorts behind every key
+    RangeParams p = range_params(j);
+    p.block_off = block_off; p.cap = cap; p.keys = keys;
+    hipLaunchKernelGGL(range_pass_kernel<true>, dim3((unsigned)range_blocks(j.n)), dim3(256), 0, s, p);
+    const unsigned chunks = (unsigned)(P / 1024);
+    hipLaunchKernelGGL(bitonic_chunk_sort_kernel, dim3(chunks), dim3(512), 0, s, keys);
+    const unsigned gsteps = (unsigned)std::min<int64_t>((P / 2 + 255) / 256, 65535);
+    for (int64_t k = 2048; k <= P; k <<= 1) {
+        for (int64_t jj = k >> 1; jj >= 1024; jj >>= 1)
+            hipLaunchKernelGGL(bitonic_global_step_kernel, dim3(gsteps), dim3(256), 0, s, keys, P / 2, jj, k);
+        hipLaunchKernelGGL(bitonic_chunk_merge_kernel, dim3(chunks), dim3(512), 0, s, keys, k);
+    }
+    hipLaunchKernelGGL(range_out_kernel, dim3((unsigned)std::min<int64_t>((m + 255) / 256, 65535)), dim3(256), 0, s,
+                       keys, m, p, out_d, out_row);
     VDB_HIP(hipGetLastError());
     return VDB_OK;
 }

@@ -132,6 +132,7 @@ struct Rows {
     uint16_t* data16 = nullptr;   // [cap][ld16]
     float* sq = nullptr;    // [cap]  np.sum(row**2)
     float* nrm = nullptr;   // [cap]  sqrt(sq)
+    float cos_eps = 1e-8f;  // norms below this count as 1 in the cosine distance matrix (pairwise_cosine's eps)
     SumPlan plan;
 };
 
@@ -174,14 +175,15 @@ int launch_flat_gemm_dist(const Rows& r, int metric, const void* q, const float*
                           int nq, float* out, hipStream_t s);
 
 // streaming pipeline: pairwise-ordered sums for (row chunk, query group) items -> candidate buffer
-enum ScanOp { OP_DOT = 0, OP_SQDIFF = 1, OP_ABSDIFF = 2, OP_MAXABS = 3, OP_SQ = 4 };
+enum ScanOp { OP_DOT = 0, OP_SQDIFF = 1, OP_ABSDIFF = 2, OP_MAXABS = 3, OP_SQ = 4, OP_NEQ = 5 };
 enum StreamPost { POST_NONE = 0, POST_SQRT = 1, POST_NEG = 2 };
 static inline int op_of_metric(int metric) {
     switch (metric) {
-        case VDB_EUCLIDEAN: case VDB_EUCLIDEAN_SQ: case VDB_COSINE: case VDB_DOT: case VDB_COSINE_PAIR: return OP_DOT;
+        case VDB_EUCLIDEAN: case VDB_EUCLIDEAN_SQ: case VDB_COSINE: case VDB_DOT: case VDB_COSINE_PAIR: case VDB_ANGULAR: return OP_DOT;
         case VDB_EUCLIDEAN_DIRECT: case VDB_EUCLIDEAN_SQ_DIRECT: return OP_SQDIFF;
         case VDB_MANHATTAN: return OP_ABSDIFF;
         case VDB_CHEBYSHEV: return OP_MAXABS;
+        case VDB_HAMMING: return OP_NEQ;
         default: return OP_SQ;
     }
 }
@@ -222,7 +224,7 @@ int launch_ivf_plan(const int* probes, int nq, int n_probe, const int64_t* list_
                     const StreamPlanBufs& b, hipStream_t s);
 // in-place distance finish of a [nq][n] matrix of streamed sums (identity-form L2 and cosine only)
 int launch_finish_dist(int metric, const float* q_sq, const float* q_nrm, const float* row_sq, const float* row_nrm,
-                       float* v, int nq, int64_t n, hipStream_t s);
+                       float cos_eps, float* v, int nq, int64_t n, hipStream_t s);
 // per query: finish + filter + k best of its slice of the candidate buffer -> part lists
 // [nq][splits * topk_cand_lists_per_split()][k]
 int topk_cand_lists_per_split();
@@ -237,6 +239,18 @@ struct CandJob {
     int k; int splits; float* part_d; int* part_i;
 };
 int launch_topk_cand(const CandJob& j, hipStream_t s);
+// range search over the streamed sums of ONE query (candidate slot = stored row): count + scan of the rows inside
+// the radius, then the first `cap` of them in row order as sorted (distance, row) results
+struct RangeJob {
+    const float* cand; int64_t n; const uint32_t* mask;
+    int metric; const float* q_sq; const float* q_nrm; const float* row_sq; const float* row_nrm;
+    float radius;
+};
+int64_t range_blocks(int64_t n);                  // entries block_counts / block_off need
+int64_t range_sort_capacity(int64_t m);           // keys the sort of m results needs
+int launch_range_count(const RangeJob& j, int* block_counts, int64_t* block_off, int64_t* total, hipStream_t s);
+int launch_range_collect(const RangeJob& j, const int64_t* block_off, int64_t cap, int64_t m, uint64_t* keys,
+                         float* out_d, int64_t* out_row, hipStream_t s);
 int launch_ivf_rows(const int* slots, int nq, int k, int out_stride, int out_off, const int* probes, int n_probe, int n_lists,
                     const int64_t* cand_off, const int64_t* list_off, const int* row_ids, int64_t* out_rows,
                     int64_t* out_order, hipStream_t s);
@@ -286,5 +300,20 @@ int measure_ceilings(hipStream_t s, float* copy_gbs, float* mfma_f32_tflops, flo
 // k-means
 int launch_kmeans_accumulate(const float* x, int64_t n, int dim, int ldx, const int* assign, int n_clusters,
                              double* sums, unsigned long long* counts, hipStream_t s);
+
+// k-means on resident rows (kmeans.hip): stable sort of the rows by cluster, sequential per-cluster sums, the
+// float64 assignment of the later PQ steps, and the k-means++ draw
+int km_sort_chunk(int64_t n, int64_t* chunk, int* n_blocks);
+int launch_km_sort(const int* assign, int64_t n, int k, int* hist, int* totals, int* cluster_off, int* members, hipStream_t s);
+int launch_km_sums(int form, const float* x, int ldx, int dsub, const int* members, const int* cluster_off, int k,
+                   float* next32, double* next64, long long* counts, hipStream_t s);
+int launch_km_shift(const float* a, const float* b, int64_t total, double* out, hipStream_t s);
+int launch_km_gather(const float* x, int ldx, int dsub, const long long* rows, const int* dst_rows, int count,
+                     float* dst32, double* dst64, hipStream_t s);
+int launch_km_assign_f64(const float* x, int ldx, int dsub, int64_t n, const float* xsq, const double* cent, double* csq,
+                         int k, int* assign, hipStream_t s);
+int64_t km_pp_blocks(int64_t n);
+int launch_km_pp_step(const float* dist, int64_t n, bool first, float* nearest, double* block_sums, double u,
+                      long long* chosen, hipStream_t s);
 
 }  // namespace vdb

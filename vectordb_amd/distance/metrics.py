@@ -35,12 +35,14 @@ def _matrix(a, name: str) -> np.ndarray:
     return N.f32(a)
 
 
-def _distances(queries: np.ndarray, rows: np.ndarray, code: int) -> np.ndarray:
+def _distances(queries: np.ndarray, rows: np.ndarray, code: int, cosine_eps: Optional[float] = None) -> np.ndarray:
     if rows.shape[0] == 0 or queries.shape[0] == 0:
         return np.zeros((queries.shape[0], rows.shape[0]), dtype=np.float32)
     store = N.RowStore(rows.shape[1])
     try:
         store.append(rows)
+        if cosine_eps is not None:
+            store.set_cosine_eps(cosine_eps)
         return store.distances(queries, code)
     finally:
         store.close()
@@ -58,17 +60,21 @@ def query_distances(query, collection, metric: str = "euclidean") -> np.ndarray:
     if c.shape[1] != q.shape[1]:
         raise ValueError(f"query dimension {q.shape[1]} != collection dimension {c.shape[1]}")
     out = _distances(q, c, _QUERY_METRICS[metric])[0]
+    if metric == "cosine" and len(out) and float(np.linalg.norm(q[0])) < 1e-8:
+        # distance/metrics.py:469-473 returns np.ones(n), i.e. float64, for a zero query; the device wrote
+        # the same ones in fp32 (the test on |q| is the reference's own, it only picks the dtype)
+        return out.astype(np.float64)
     return out
 
 
 # ---------------------------------------------------------------- pairwise matrices
 
-def _pairwise(X, Y, code: int) -> np.ndarray:
+def _pairwise(X, Y, code: int, cosine_eps: Optional[float] = None) -> np.ndarray:
     x = _matrix(X, "X")
     y = x if Y is None else _matrix(Y, "Y")
     if x.shape[1] != y.shape[1]:
         raise ValueError(f"dimension mismatch: {x.shape[1]} != {y.shape[1]}")
-    return _distances(x, y, code)
+    return _distances(x, y, code, cosine_eps)
 
 
 def pairwise_euclidean(X, Y=None) -> np.ndarray:
@@ -82,11 +88,9 @@ def pairwise_euclidean_squared(X, Y=None) -> np.ndarray:
 
 
 def pairwise_cosine(X, Y=None, eps: float = 1e-8) -> np.ndarray:
-    """distance/metrics.py:336-373.  Rows with norm below ``eps`` count as
-    unit-norm (only the reference's default eps is supported)."""
-    if eps != 1e-8:
-        raise ValueError("pairwise_cosine supports eps=1e-8 only")
-    return _pairwise(X, Y, N.COSINE)
+    """distance/metrics.py:336-373.  Rows of X and Y whose norm is below
+    ``eps`` count as unit-norm."""
+    return _pairwise(X, Y, N.COSINE, cosine_eps=float(eps))
 
 
 def pairwise_dot(X, Y=None) -> np.ndarray:
@@ -149,6 +153,16 @@ def manhattan(a, b) -> float:
 
 def chebyshev(a, b) -> float:
     return _pair(a, b, N.CHEBYSHEV)
+
+
+def hamming(a, b) -> float:
+    """distance/metrics.py:217-237: number of positions where the (fp32) vectors differ."""
+    return _pair(a, b, N.HAMMING)
+
+
+def angular_distance(a, b, eps: float = 1e-8) -> float:
+    """distance/metrics.py:521-538: arccos of the clipped cosine similarity, in radians."""
+    return _pair(a, b, N.ANGULAR)
 
 
 def normalize_vectors(vectors, eps: float = 1e-8) -> np.ndarray:

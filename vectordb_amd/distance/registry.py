@@ -25,6 +25,8 @@ class DistanceMetric(str, Enum):
     DOT = "dot"
     MANHATTAN = "manhattan"
     CHEBYSHEV = "chebyshev"
+    HAMMING = "hamming"
+    ANGULAR = "angular"
 
     def __str__(self) -> str:
         return self.value
@@ -66,6 +68,9 @@ class MetricRegistry:
           aliases=["l1", "cityblock", "taxicab"])
         b(MetricInfo("chebyshev", M.chebyshev, None, False, 0.0, None, "Chebyshev (L-inf) distance"),
           aliases=["linf", "chessboard"])
+        b(MetricInfo("hamming", M.hamming, None, False, 0.0, None, "Hamming distance (for binary vectors)"))   # registry.py:179-191
+        b(MetricInfo("angular", M.angular_distance, None, False, 0.0, float(np.pi),
+                     "Angular distance (angle in radians)"))                                            # registry.py:193-205
 
     def register(self, info: MetricInfo, aliases: Optional[List[str]] = None) -> None:
         self._metrics[info.name] = info

@@ -194,9 +194,9 @@ class FlatIndex(BaseIndex):
 
     def range_search(self, query, radius: float, filter_fn: Optional[FilterFunction] = None,
                      max_results: Optional[int] = None) -> List[SearchResult]:
-        """index/flat.py:501-572.  With ``max_results`` the reference keeps the
-        FIRST rows in insertion order that fall inside the radius and then sorts
-        them; here the closest ``max_results`` are returned."""
+        """index/flat.py:501-572: rows inside the radius that pass the filter;
+        with ``max_results`` the FIRST that many in insertion order (:545-567),
+        sorted by distance with equal distances in insertion order (:570)."""
         if self._size == 0:
             return []
         query = self._validate_vector(query)

@@ -18,6 +18,7 @@ import numpy as np
 from .. import _native as N
 from .base import BaseIndex, FilterFunction, IndexConfig, IndexStats, IndexType, SearchResult
 from .ivf import KMeans
+from .pq import train_subquantizers
 
 
 @dataclass
@@ -87,17 +88,8 @@ class HybridIndex(BaseIndex):
         self.config.n_clusters = len(cent)
         assign, _ = N.assign(vectors, cent, N.EUCLIDEAN_SQ)
         residuals = vectors - cent[assign]
-        m, ds, ksub = self.config.n_subvectors, self._subvector_dim, self._n_centroids_pq
-        book = np.zeros((m, ksub, ds), dtype=np.float32)
-        for j in range(m):
-            sub = np.ascontiguousarray(residuals[:, j * ds:(j + 1) * ds])
-            k = min(ksub, n)
-            c = sub[self._rng.choice(n, k, replace=False)].copy()
-            for _ in range(self.config.n_iter):
-                a, _ = N.assign(sub, c, N.EUCLIDEAN_SQ)
-                sums, counts = N.kmeans_accumulate(sub, a, k)
-                c = (sums / np.maximum(counts, 1)[:, None]).astype(np.float32)
-            book[j, :k] = c
+        book = train_subquantizers(np.ascontiguousarray(residuals, dtype=np.float32), self.config.n_subvectors,
+                                   self._n_centroids_pq, self.config.n_iter, self._rng)
         self._set_quantizers(N.f32(cent), book)
 
     def _set_quantizers(self, centroids: np.ndarray, codebook: np.ndarray) -> None:

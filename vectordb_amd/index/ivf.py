@@ -26,10 +26,11 @@ from .base import (BaseIndex, FilterFunction, IndexConfig, IndexStats, IndexType
                    unit_vector)
 
 _CODES = {"euclidean": N.EUCLIDEAN, "euclidean_squared": N.EUCLIDEAN_SQ, "cosine": N.COSINE, "dot": N.DOT,
-          "manhattan": N.MANHATTAN, "chebyshev": N.CHEBYSHEV}
+          "manhattan": N.MANHATTAN, "chebyshev": N.CHEBYSHEV, "hamming": N.HAMMING, "angular": N.ANGULAR}
 # per-pair scalar forms behind get_metric_fn (distance/registry.py:95-177)
 _PAIR_CODES = {"euclidean": N.EUCLIDEAN_DIRECT, "euclidean_squared": N.EUCLIDEAN_SQ_DIRECT, "cosine": N.COSINE_PAIR,
-               "dot": N.DOT, "manhattan": N.MANHATTAN, "chebyshev": N.CHEBYSHEV}
+               "dot": N.DOT, "manhattan": N.MANHATTAN, "chebyshev": N.CHEBYSHEV, "hamming": N.HAMMING,
+               "angular": N.ANGULAR}
 
 
 @dataclass
@@ -73,59 +74,69 @@ class KMeans:
         if n < self.n_clusters:                               # ivf.py:138-141
             self.centroids = vectors.copy()
             return self.centroids
-        best, best_inertia = None, float("inf")
-        for redo in range(self.n_redo):
-            cent = self._fit_once(vectors)
-            _, d = N.assign(vectors, cent, N.EUCLIDEAN)
-            inertia = float(np.sum(d.astype(np.float64) ** 2))
-            if inertia < best_inertia:
-                best, best_inertia = cent, inertia
-            if self.verbose:
-                print(f"  K-Means redo {redo + 1}/{self.n_redo}: inertia={inertia:.2f}")
+        # the training rows go to the device once; every step of every run works on them there
+        self.phase_seconds = {"upload": 0.0, "init_pp": 0.0, "lloyd": 0.0, "lloyd_steps": 0}   # of the last fit
+        store = N.RowStore(vectors.shape[1])
+        try:
+            t0 = time.perf_counter()
+            store.append(vectors)
+            self.phase_seconds["upload"] = time.perf_counter() - t0
+            best, best_inertia = None, float("inf")
+            for redo in range(self.n_redo):
+                trainer = N.KMeansTrainer(store, 0, vectors.shape[1], self.n_clusters)
+                try:
+                    cent = self._fit_once(trainer, n)
+                    if self.n_redo > 1 or self.verbose:
+                        _, d = trainer.assignments(with_distances=True)       # ivf.py:150-153
+                        inertia = float(np.sum(d.astype(np.float64) ** 2))
+                    else:
+                        inertia = 0.0                  # a single run is the best run; the reference's loop only ranks runs
+                finally:
+                    trainer.close()
+                if inertia < best_inertia:
+                    best, best_inertia = cent, inertia
+                if self.verbose:
+                    print(f"  K-Means redo {redo + 1}/{self.n_redo}: inertia={inertia:.2f}")
+        finally:
+            store.close()
         self.centroids = best
         return self.centroids
 
-    def _fit_once(self, vectors: np.ndarray) -> np.ndarray:
-        n = len(vectors)
-        cent = self._init_centroids_pp(vectors)
+    def _fit_once(self, trainer: "N.KMeansTrainer", n: int) -> np.ndarray:
+        """ivf.py:165-202 on resident rows.  Host side: the RandomState draws, in the reference's order
+        (randint for the first centroid, one uniform per rng.choice of k-means++, randint per empty
+        cluster in ascending cluster order), and the stopping test on one number per step."""
+        t0 = time.perf_counter()
+        self._init_centroids_pp(trainer, n)
+        t1 = time.perf_counter()
+        self.phase_seconds["init_pp"] += t1 - t0
+        try:
+            return self._lloyd(trainer, n)
+        finally:
+            self.phase_seconds["lloyd"] += time.perf_counter() - t1
+
+    def _lloyd(self, trainer: "N.KMeansTrainer", n: int) -> np.ndarray:
         for it in range(self.n_iter):
-            assign = self._assign(vectors, cent)
-            sums, counts = N.kmeans_accumulate(vectors, assign, self.n_clusters)
-            new = np.zeros_like(cent)
-            for c in range(self.n_clusters):                  # ivf.py:185-190 (ascending cluster order: RNG sequence)
-                if counts[c] > 0:
-                    new[c] = (sums[c] / counts[c]).astype(np.float32)
-                else:
-                    new[c] = vectors[self._rng.randint(n)]
-            diff = float(np.sum((new - cent) ** 2))
-            cent = new
+            self.phase_seconds["lloyd_steps"] += 1
+            counts, diff = trainer.step(N.KMEANS_IVF)
+            empty = np.flatnonzero(counts == 0)
+            if len(empty):                                                     # ivf.py:185-190
+                diff = trainer.reseed(empty, [self._rng.randint(n) for _ in empty])
+            trainer.commit()
             if self.verbose and (it + 1) % 5 == 0:
                 print(f"    Iteration {it + 1}/{self.n_iter}: diff={diff:.6f}")
             if diff < 1e-6:
                 break
-        return cent
+        return trainer.centroids()
 
-    def _init_centroids_pp(self, vectors: np.ndarray) -> np.ndarray:
-        """k-means++ (ivf.py:204-226) with the reference's draw order.  The
-        distance of every point to its nearest chosen centroid is kept as a
-        running minimum, so a step costs one pass of distances to ONE new
-        centroid instead of recomputing all of them."""
-        vectors = N.f32(vectors)
-        n, d = vectors.shape
-        cent = np.zeros((self.n_clusters, d), dtype=vectors.dtype)
-        cent[0] = vectors[self._rng.randint(n)]
-        store = N.RowStore(d)
-        try:
-            store.append(vectors)
-            nearest = None
-            for k in range(1, self.n_clusters):
-                d_new = store.distances(cent[k - 1], N.EUCLIDEAN)[0] ** 2
-                nearest = d_new if nearest is None else np.minimum(nearest, d_new)
-                probs = nearest / nearest.sum()
-                cent[k] = vectors[self._rng.choice(n, p=probs)]
-        finally:
-            store.close()
-        return cent
+    def _init_centroids_pp(self, trainer: "N.KMeansTrainer", n: int) -> np.ndarray:
+        """k-means++ (ivf.py:204-226) with the reference's draw order.  rng.choice(n, p=probs) draws one
+        uniform number and takes the first row whose cumulative probability exceeds it, so the k - 1
+        uniforms are drawn up front (same generator state afterwards) and the device keeps the running
+        minimum of the squared distances and does every draw itself: no row of numbers comes back."""
+        first = self._rng.randint(n)
+        uniforms = self._rng.random_sample(self.n_clusters - 1)
+        return trainer.init_pp(first, uniforms)
 
     def _assign(self, vectors, centroids) -> np.ndarray:
         idx, _ = N.assign(vectors, centroids, N.EUCLIDEAN)    # ivf.py:228-231
@@ -206,6 +217,7 @@ class IVFIndex(BaseIndex):
         km = KMeans(n_clusters=actual, n_iter=self.config.n_iter, n_redo=self.config.n_redo, seed=self.config.seed,
                     verbose=self.config.verbose)
         t0 = time.time()
+        self._last_kmeans = km                                 # its phase_seconds describe this training
         self._set_centroids(km.fit(vectors))
         if self.config.verbose:
             print(f"Training completed in {time.time() - t0:.2f}s")

@@ -32,6 +32,38 @@ class PQConfig(IndexConfig):                                # index/pq.py:26-48
         return 2 ** self.n_bits
 
 
+def train_subquantizers(vectors: np.ndarray, m: int, ksub: int, n_iter: int, rng: np.random.RandomState) -> np.ndarray:
+    """The sub-quantizer training shared by PQIndex (pq.py:132-180) and HybridIndex (hybrid.py:167-203):
+    per sub-space, start from ``rng.choice(n, k, replace=False)`` rows and run n_iter Lloyd steps.  The rows
+    are uploaded once; a trainer per sub-space works on its columns on the device in the reference's
+    arithmetic (fp32 in the first step, float64 afterwards, sums in sample order), and the float64
+    centroids are rounded to fp32 when they enter the codebook, as ``codebook[m] = centroids`` does."""
+    n, d = vectors.shape
+    ds = d // m
+    k = min(ksub, n)
+    book = np.zeros((m, ksub, ds), dtype=np.float32)
+    if n_iter <= 0:
+        for j in range(m):
+            book[j, :k] = vectors[rng.choice(n, k, replace=False), j * ds:(j + 1) * ds]
+        return book
+    store = N.RowStore(d)
+    try:
+        store.append(vectors)
+        for j in range(m):
+            trainer = N.KMeansTrainer(store, j * ds, ds, k)
+            try:
+                trainer.init_rows(rng.choice(n, k, replace=False))           # pq.py:150-151
+                for _ in range(n_iter):
+                    trainer.step(N.KMEANS_PQ)
+                    trainer.commit()
+                book[j, :k] = trainer.centroids()
+            finally:
+                trainer.close()
+    finally:
+        store.close()
+    return book
+
+
 class PQIndex(BaseIndex):
     """index/pq.py:51-436"""
 
@@ -74,19 +106,8 @@ class PQIndex(BaseIndex):
         replace=False)`` rows, n_iter Lloyd steps, empty clusters collapse to
         the zero vector, zero padding when n < 2**n_bits."""
         vectors = self._validate_vectors(vectors)
-        m, ds, ksub = self.config.n_subvectors, self._subvector_dim, self._n_centroids
-        book = np.zeros((m, ksub, ds), dtype=np.float32)
-        for j in range(m):
-            sub = np.ascontiguousarray(vectors[:, j * ds:(j + 1) * ds])
-            n = len(sub)
-            k = min(ksub, n)
-            cent = sub[self._rng.choice(n, k, replace=False)].copy()
-            for _ in range(self.config.n_iter):
-                assign, _ = N.assign(sub, cent, N.EUCLIDEAN_SQ)
-                sums, counts = N.kmeans_accumulate(sub, assign, k)
-                cent = (sums / np.maximum(counts, 1)[:, None]).astype(np.float32)
-            book[j, :k] = cent
-        self._set_codebook(book)
+        self._set_codebook(train_subquantizers(vectors, self.config.n_subvectors, self._n_centroids, self.config.n_iter,
+                                               self._rng))
 
     def _set_codebook(self, book: np.ndarray) -> None:
         self._codebook = N.f32(book)
