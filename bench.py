@@ -365,10 +365,11 @@ def bench_c1(dev, native, n=10_000, d=128, nq=100, k=10):
 def bench_ceilings(dev, native):
     """What this GPU reaches on the two limits the fractions are quoted against: a large device-to-device copy
     (read + write bytes per second) and register-only MFMA loops (no memory traffic at all)."""
-    copy_gbs, f32_tflops, bf16_tflops = native.measure_ceilings()
+    copy_gbs, f32_tflops, bf16_tflops, valu_tops = native.measure_ceilings()
     return {"copy_gbs_read_plus_write": round(copy_gbs, 1), "hbm_spec_gbs": HBM_PEAK_GBS,
             "mfma_f32_loop_tflops": round(f32_tflops, 1), "mfma_f32_spec_tflops": MFMA_F32_PEAK_TFLOPS,
-            "mfma_bf16_loop_tflops": round(bf16_tflops, 1), "mfma_bf16_spec_tflops": MFMA_BF16_PEAK_TFLOPS}
+            "mfma_bf16_loop_tflops": round(bf16_tflops, 1), "mfma_bf16_spec_tflops": MFMA_BF16_PEAK_TFLOPS,
+            "valu_direct_form_loop_tops": round(valu_tops, 1)}
 
 
 if __name__ == "__main__":

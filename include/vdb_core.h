@@ -85,8 +85,9 @@ int vdb_device_info(char* name, int name_len, int64_t* mem_total, int64_t* mem_f
 int vdb_synchronize(void);
 /* What this GPU reaches on the two limits the roofline fractions are quoted against (no counterpart in the
  * reference): a 1 GiB device-to-device copy in GB/s (bytes read + bytes written) and register-only
- * loops of v_mfma_f32_32x32x2_f32 / v_mfma_f32_32x32x16_bf16 in TFLOP/s.  Allocates 2 GiB while it runs. */
-int vdb_measure_ceilings(float* copy_gbs, float* mfma_f32_tflops, float* mfma_bf16_tflops);
+ * loops of v_mfma_f32_32x32x2_f32 / v_mfma_f32_32x32x16_bf16 in TFLOP/s, and of the subtract / multiply / add
+ * mix of the direct-form scans on the vector ALUs in 10^12 operations per second.  Allocates 2 GiB while it runs. */
+int vdb_measure_ceilings(float* copy_gbs, float* mfma_f32_tflops, float* mfma_bf16_tflops, float* valu_direct_tops);
 /* Kernel timing for roofline accounting (no counterpart in the reference; its
  * only timers are wall clocks around Collection.search, query/executor.py:255-272).
  * While enabled, every launch of a path's dominant kernel (the MFMA flat

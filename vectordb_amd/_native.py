@@ -48,7 +48,7 @@ SIGNATURES = {
     "vdb_last_error": (C.c_char_p, []),
     "vdb_device_info": (C.c_int, [C.c_char_p, C.c_int, c_i64_p, c_i64_p]),
     "vdb_synchronize": (C.c_int, []),
-    "vdb_measure_ceilings": (C.c_int, [c_float_p, c_float_p, c_float_p]),
+    "vdb_measure_ceilings": (C.c_int, [c_float_p, c_float_p, c_float_p, c_float_p]),
     "vdb_profile_enable": (C.c_int, [C.c_int]),
     "vdb_profile_read": (C.c_int, [c_float_p, C.POINTER(C.c_int)]),
     "vdb_rows_create": (C.c_int, [C.POINTER(C.c_void_p), C.c_int]),
@@ -213,11 +213,12 @@ def synchronize() -> None:
 
 
 def measure_ceilings():
-    """(device-to-device copy GB/s counting read + write, fp32 MFMA loop TFLOP/s, bf16 MFMA loop TFLOP/s)."""
+    """(device-to-device copy GB/s counting read + write, fp32 MFMA loop TFLOP/s, bf16 MFMA loop TFLOP/s,
+    vector-ALU subtract/multiply/add loop in 10^12 operations/s)."""
     init()
-    a, b, c = C.c_float(0.0), C.c_float(0.0), C.c_float(0.0)
-    check(load().vdb_measure_ceilings(C.byref(a), C.byref(b), C.byref(c)))
-    return a.value, b.value, c.value
+    a, b, c, d = C.c_float(0.0), C.c_float(0.0), C.c_float(0.0), C.c_float(0.0)
+    check(load().vdb_measure_ceilings(C.byref(a), C.byref(b), C.byref(c), C.byref(d)))
+    return a.value, b.value, c.value, d.value
 
 
 def profile_enable(on: bool) -> None:

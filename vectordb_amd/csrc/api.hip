@@ -771,11 +771,11 @@ int vdb_device_info(char* name, int name_len, int64_t* mem_total, int64_t* mem_f
     return VDB_OK;
 }
 
-int vdb_measure_ceilings(float* copy_gbs, float* mfma_f32_tflops, float* mfma_bf16_tflops) {
-    VDB_REQUIRE(copy_gbs && mfma_f32_tflops && mfma_bf16_tflops, "null argument");
+int vdb_measure_ceilings(float* copy_gbs, float* mfma_f32_tflops, float* mfma_bf16_tflops, float* valu_direct_tops) {
+    VDB_REQUIRE(copy_gbs && mfma_f32_tflops && mfma_bf16_tflops && valu_direct_tops, "null argument");
     ScopedHandle tmp;
     VDB_TRY(tmp.open());
-    return measure_ceilings(tmp.stream, copy_gbs, mfma_f32_tflops, mfma_bf16_tflops);
+    return measure_ceilings(tmp.stream, copy_gbs, mfma_f32_tflops, mfma_bf16_tflops, valu_direct_tops);
 }
 
 int vdb_profile_enable(int on) {

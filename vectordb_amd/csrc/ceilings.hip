@@ -37,6 +37,52 @@ __global__ __launch_bounds__(256) void mfma_loop_kernel(float* out, int iters) {
     out[(size_t)blockIdx.x * blockDim.x + threadIdx.x] = s;
 }
 
+// The arithmetic of the direct-form scans (sum (q - x)^2 in NumPy's rounding: subtract, multiply and add are
+// three separately rounded operations, no fma) on registers only: 16 independent packed accumulators per lane,
+// v_pk_add_f32 / v_pk_mul_f32 / v_pk_add_f32 per pair of elements.  What the vector ALUs reach on that mix is the
+// ceiling of the IVF list scan and of the batched Manhattan scan.
+typedef float pk2 __attribute__((ext_vector_type(2)));
+__global__ __launch_bounds__(256) void valu_direct_loop_kernel(float* out, int iters, float seed) {
+    pk2 acc[16], x[16];
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {
+        acc[i] = pk2{0.0f, 0.0f};
+        x[i] = pk2{seed * (float)(threadIdx.x + i), seed * (float)(i + 1)};
+    }
+    pk2 q = pk2{seed, -seed};
+    for (int it = 0; it < iters; ++it) {
+#pragma unroll
+        for (int i = 0; i < 16; ++i) {
+            const pk2 d = q - x[i];
+            acc[i] = acc[i] + d * d;
+        }
+        q = q + pk2{1e-3f, 1e-3f};
+    }
+    float s = 0.0f;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) s += acc[i].x + acc[i].y;
+    out[(size_t)blockIdx.x * blockDim.x + threadIdx.x] = s;
+}
+
+static int time_valu_loop(float* out, int blocks, int iters, hipStream_t s, float* tops) {
+    hipEvent_t e0, e1;
+    VDB_HIP(hipEventCreate(&e0));
+    VDB_HIP(hipEventCreate(&e1));
+    hipLaunchKernelGGL(valu_direct_loop_kernel, dim3(blocks), dim3(256), 0, s, out, 16, 0.5f);
+    VDB_HIP(hipEventRecord(e0, s));
+    hipLaunchKernelGGL(valu_direct_loop_kernel, dim3(blocks), dim3(256), 0, s, out, iters, 0.5f);
+    VDB_HIP(hipEventRecord(e1, s));
+    VDB_HIP(hipEventSynchronize(e1));
+    float ms = 0.0f;
+    VDB_HIP(hipEventElapsedTime(&ms, e0, e1));
+    (void)hipEventDestroy(e0);
+    (void)hipEventDestroy(e1);
+    // per iteration and lane: 16 accumulators x 2 elements x 3 operations
+    const double ops = (double)blocks * 256 * iters * 16.0 * 2.0 * 3.0;
+    *tops = (float)(ops / (ms * 1e-3) / 1e12);
+    return VDB_OK;
+}
+
 template <bool BF16>
 static int time_mfma_loop(float* out, int blocks, int iters, hipStream_t s, float* tflops) {
     hipEvent_t e0, e1;
@@ -58,7 +104,7 @@ static int time_mfma_loop(float* out, int blocks, int iters, hipStream_t s, floa
     return VDB_OK;
 }
 
-int measure_ceilings(hipStream_t s, float* copy_gbs, float* mfma_f32_tflops, float* mfma_bf16_tflops) {
+int measure_ceilings(hipStream_t s, float* copy_gbs, float* mfma_f32_tflops, float* mfma_bf16_tflops, float* valu_direct_tops) {
     const size_t bytes = (size_t)1 << 30;
     void *a = nullptr, *b = nullptr;
     VDB_HIP(hipMalloc(&a, bytes));
@@ -83,6 +129,7 @@ int measure_ceilings(hipStream_t s, float* copy_gbs, float* mfma_f32_tflops, flo
         const int blocks = ctx().num_cus * 2;                                                   // 8 waves per CU, 2 per SIMD
         VDB_TRY(time_mfma_loop<false>(reinterpret_cast<float*>(a), blocks, 4096, s, mfma_f32_tflops));
         VDB_TRY(time_mfma_loop<true>(reinterpret_cast<float*>(a), blocks, 16384, s, mfma_bf16_tflops));
+        VDB_TRY(time_valu_loop(reinterpret_cast<float*>(a), ctx().num_cus * 4, 4096, s, valu_direct_tops));   // 4 waves per SIMD
         return VDB_OK;
     };
     st = body();

@@ -128,27 +128,31 @@ template <int PER_STAGE> __device__ __forceinline__ void wait_loads(int stages_b
     }
 }
 
-// G queries per item, shared out over QS sets of 4 waves: thread t sums row (t & 255) of
-// the chunk against the G/QS queries of set (t >> 8).  More than one set keeps two or
-// more waves on every SIMD, so one wave's scalar work and waits hide behind another's
-// arithmetic.
+// G queries per item, shared out over QS sets of waves: a thread sums R rows of the chunk (rows
+// row0, row0 + 256/R, ...) against the G/QS queries of set (tid / (256/R)).  More than one set keeps
+// two or more waves on every SIMD, so one wave's scalar work and waits hide behind another's
+// arithmetic.  R = 2 halves what a (row, query) pair costs besides its arithmetic: a query value
+// read from LDS (a broadcast to the whole wave) serves two rows, and the per-item bookkeeping,
+// barriers and result stores are shared by twice as many pairs.
 // WHOLE: every leaf of the plan is a whole number of stages (dimensions such as 128, 256, 384,
 // 768, 1024): the group-by-group path for leaf ends inside a stage is compiled out, and with it
 // the register copies where the two paths meet.
-template <int OP, int G, int QS, bool WHOLE>
-__global__ __launch_bounds__(S_NT * QS) void stream_sums_kernel(const StreamParams p) {
+template <int OP, int G, int QS, bool WHOLE, int R>
+__global__ __launch_bounds__(S_NT / R * QS) void stream_sums_kernel(const StreamParams p) {
     extern __shared__ __align__(16) float smem[];
+    constexpr int TPS = S_NT / R;                 // threads per wave set
+    static_assert(TPS % 64 == 0, "a wave set is whole waves");
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int row = tid & (S_NT - 1);
+    const int row0 = tid % TPS;
     const int nbuf = p.nbuf;
     constexpr int GT = G / QS;                    // queries per thread
-    constexpr int H = GT >= 4 ? 4 : GT;           // queries per unit of the arithmetic loop
+    constexpr int H = R > 1 ? 2 : (GT >= 4 ? 4 : GT);   // queries per unit of the arithmetic loop (its values sit in registers twice)
     constexpr int U = GT / H;
-    constexpr int NW = 4 * QS;                    // waves
+    constexpr int NW = TPS * QS / 64;             // waves
     constexpr int ROW_GLDS = 32 / NW;             // row LDS-DMA instructions per wave and stage
     constexpr int PER_STAGE = ROW_GLDS + 1;
     constexpr int SLOT = S_STAGE + G * S_CK;      // floats per stage slot: 256 row pieces, then the G query pieces
-    const int qset = __builtin_amdgcn_readfirstlane(tid >> 8);
+    const int qset = __builtin_amdgcn_readfirstlane(tid / TPS);
     const int g_first = qset * GT;                // this thread's slots of the pending-sum stack
     // The group's queries are dealt to the wave sets unit by unit (H at a time), so a group that
     // is only partly filled keeps every set busy: local query g is group query gq(g).
@@ -171,10 +175,11 @@ __global__ __launch_bounds__(S_NT * QS) void stream_sums_kernel(const StreamPara
     const int piece = lane & 7;
     // query pieces: the stage's 32 floats of each of the group's queries are G*8 pieces of
     // 16 bytes; wave w fetches pieces [w*QL, (w+1)*QL) (piece s: query s >> 3, floats (s & 7)*4..)
-    constexpr int QL = (G * 8) / NW;              // lanes per wave that fetch query pieces: 2, 4, 8 or 16
-    static_assert(QL >= 1 && QL <= 16 && (QL & (QL - 1)) == 0, "query pieces must split evenly over the waves");
+    constexpr int QL = (G * 8) / NW;              // lanes per wave that fetch query pieces: 2, 4, 8, 16 or 32
+    static_assert(QL >= 1 && QL <= 32 && (QL & (QL - 1)) == 0, "query pieces must split evenly over the waves");
+    constexpr int QPW = QL > 8 ? QL / 8 : 1;      // queries a wave's pieces belong to
     const int sidx = wave * QL + (lane & (QL - 1));
-    const int ga = (wave * QL) >> 3;              // the wave's pieces belong to at most two queries
+    const int ga = (wave * QL) >> 3;              // the first of them
     const float* row_src[ROW_GLDS];               // this lane's row pieces of the item, at column 0
     int row_c4[ROW_GLDS];                         // 4 * (piece of the row this lane fetches)
     const float* q_src = p.q;
@@ -186,9 +191,13 @@ __global__ __launch_bounds__(S_NT * QS) void stream_sums_kernel(const StreamPara
             row_src[i] = p.data + (it.row0 + min(r, it.rows - 1)) * p.ld;
             row_c4[i] = (piece ^ ((r >> 1) & 7)) * 4;
         }
-        const int id0 = uload(p.sq_qid + it.qbeg + min(ga, it.qcnt - 1));
-        const int id1 = uload(p.sq_qid + it.qbeg + min(ga + 1, it.qcnt - 1));
-        q_src = p.q + (int64_t)(((sidx >> 3) != ga) ? id1 : id0) * p.ldq + (sidx & 7) * 4;
+        int id = uload(p.sq_qid + it.qbeg + min(ga, it.qcnt - 1));
+#pragma unroll
+        for (int j = 1; j < QPW; ++j) {
+            const int idj = uload(p.sq_qid + it.qbeg + min(ga + j, it.qcnt - 1));
+            if ((sidx >> 3) - ga == j) id = idj;
+        }
+        q_src = p.q + (int64_t)id * p.ldq + (sidx & 7) * 4;
     };
     begin_item();
     auto issue = [&]() {
@@ -221,16 +230,19 @@ __global__ __launch_bounds__(S_NT * QS) void stream_sums_kernel(const StreamPara
     int64_t c_item = first;
     int c_ks = 0, c_buf = 0;
     Item c_it{};
-    f2 acc[GT][4];
-    float res[GT];
+    f2 acc[R][GT][4];
+    float res[R][GT];
     int leaf = 0, in_leaf = 0, sp = 0, L = 0;
-    const int sw = (row >> 1) & 7;
+    const int sw = (row0 >> 1) & 7;               // the same for every row of the thread: TPS is a multiple of 16
 
     auto zero_acc = [&]() {
 #pragma unroll
-        for (int g = 0; g < GT; ++g) {
+        for (int rr = 0; rr < R; ++rr) {
 #pragma unroll
-            for (int j = 0; j < 4; ++j) acc[g][j] = f2{0.0f, 0.0f};
+            for (int g = 0; g < GT; ++g) {
+#pragma unroll
+                for (int j = 0; j < 4; ++j) acc[rr][g][j] = f2{0.0f, 0.0f};
+            }
         }
     };
     // a leaf is complete: res[] holds its sums
@@ -238,14 +250,22 @@ __global__ __launch_bounds__(S_NT * QS) void stream_sums_kernel(const StreamPara
         if (!one_leaf) {
             // push, then fold pending partial sums right into left
 #pragma unroll
-            for (int g = 0; g < GT; ++g) St[(sp * G + g_first + g) * S_NT + row] = res[g];
+            for (int rr = 0; rr < R; ++rr) {
+                const int row = row0 + rr * TPS;
+#pragma unroll
+                for (int g = 0; g < GT; ++g) St[(sp * G + g_first + g) * S_NT + row] = res[rr][g];
+            }
             ++sp;
             for (int f = 0; f < p.folds[leaf]; ++f) {
 #pragma unroll
-                for (int g = 0; g < GT; ++g) {
-                    const float b = St[((sp - 1) * G + g_first + g) * S_NT + row];
-                    const float a = St[((sp - 2) * G + g_first + g) * S_NT + row];
-                    St[((sp - 2) * G + g_first + g) * S_NT + row] = s_comb<OP>(a, b);
+                for (int rr = 0; rr < R; ++rr) {
+                    const int row = row0 + rr * TPS;
+#pragma unroll
+                    for (int g = 0; g < GT; ++g) {
+                        const float b = St[((sp - 1) * G + g_first + g) * S_NT + row];
+                        const float a = St[((sp - 2) * G + g_first + g) * S_NT + row];
+                        St[((sp - 2) * G + g_first + g) * S_NT + row] = s_comb<OP>(a, b);
+                    }
                 }
                 --sp;
             }
@@ -267,12 +287,15 @@ __global__ __launch_bounds__(S_NT * QS) void stream_sums_kernel(const StreamPara
             leaf = 0; in_leaf = 0; sp = 0; L = p.leaf_len[0];
         }
 
-        const float* xb = smem + c_buf * SLOT + row * S_CK;
+        const float* xb = smem + c_buf * SLOT + row0 * S_CK;
         const float* qb = smem + c_buf * SLOT + S_STAGE;
         if (++c_buf == nbuf) c_buf = 0;
-        float4 xv[8];
+        float4 xv[R][8];
 #pragma unroll
-        for (int c = 0; c < 8; ++c) xv[c] = *reinterpret_cast<const float4*>(xb + ((c ^ sw) << 2));
+        for (int rr = 0; rr < R; ++rr) {
+#pragma unroll
+            for (int c = 0; c < 8; ++c) xv[rr][c] = *reinterpret_cast<const float4*>(xb + rr * TPS * S_CK + ((c ^ sw) << 2));
+        }
 
         // the stage's query values, fetched one unit (8 floats of H queries) ahead of their use
         float4 qv[2][H][2];
@@ -284,8 +307,7 @@ __global__ __launch_bounds__(S_NT * QS) void stream_sums_kernel(const StreamPara
                 qv[buf][h][1] = *reinterpret_cast<const float4*>(src + h * S_CK + 4);
             }
         };
-        // a unit whose H queries are all padding (a group that is not full) is neither fetched nor summed: the
-        // broadcast reads of the query values are what the LDS return path is busy with in a batch scan
+        // a unit whose H queries are all padding (a group that is not full) is neither fetched nor summed
         auto unit_live = [&](int unit) { return gq((unit % U) * H) < c_it.qcnt; };
         if (unit_live(0)) load_q(0, 0);
 
@@ -297,14 +319,18 @@ __global__ __launch_bounds__(S_NT * QS) void stream_sums_kernel(const StreamPara
                 const int grp = unit / U, g0 = (unit % U) * H;
                 if (unit + 1 < (S_CK / 8) * U && unit_live(unit + 1)) load_q((unit + 1) & 1, unit + 1);
                 if (gq(g0) < c_it.qcnt) {               // units whose queries are all padding do no arithmetic
-                    const f2 x2[4] = {f2{xv[2 * grp].x, xv[2 * grp].y}, f2{xv[2 * grp].z, xv[2 * grp].w},
-                                      f2{xv[2 * grp + 1].x, xv[2 * grp + 1].y}, f2{xv[2 * grp + 1].z, xv[2 * grp + 1].w}};
 #pragma unroll
                     for (int h = 0; h < H; ++h) {
                         const float4 qa = qv[unit & 1][h][0], qc = qv[unit & 1][h][1];
                         const f2 q2[4] = {f2{qa.x, qa.y}, f2{qa.z, qa.w}, f2{qc.x, qc.y}, f2{qc.z, qc.w}};
 #pragma unroll
-                        for (int j = 0; j < 4; ++j) acc[g0 + h][j] = s_accum2<OP>(acc[g0 + h][j], x2[j], q2[j]);
+                        for (int rr = 0; rr < R; ++rr) {
+                            const f2 x2[4] = {f2{xv[rr][2 * grp].x, xv[rr][2 * grp].y}, f2{xv[rr][2 * grp].z, xv[rr][2 * grp].w},
+                                              f2{xv[rr][2 * grp + 1].x, xv[rr][2 * grp + 1].y},
+                                              f2{xv[rr][2 * grp + 1].z, xv[rr][2 * grp + 1].w}};
+#pragma unroll
+                            for (int j = 0; j < 4; ++j) acc[rr][g0 + h][j] = s_accum2<OP>(acc[rr][g0 + h][j], x2[j], q2[j]);
+                        }
                     }
                 }
                 __builtin_amdgcn_sched_barrier(0);      // keep the query reads one unit ahead, not all at the top
@@ -312,7 +338,10 @@ __global__ __launch_bounds__(S_NT * QS) void stream_sums_kernel(const StreamPara
             in_leaf += S_CK;
             if (in_leaf == L) {
 #pragma unroll
-                for (int g = 0; g < GT; ++g) res[g] = s_tree2<OP>(acc[g]);
+                for (int rr = 0; rr < R; ++rr) {
+#pragma unroll
+                    for (int g = 0; g < GT; ++g) res[rr][g] = s_tree2<OP>(acc[rr][g]);
+                }
                 end_leaf();
             }
         } else if constexpr (!WHOLE) {
@@ -320,27 +349,31 @@ __global__ __launch_bounds__(S_NT * QS) void stream_sums_kernel(const StreamPara
 #pragma unroll
             for (int grp = 0; grp < S_CK / 8; ++grp) {
                 if (col0 + grp * 8 < p.dim) {
-                    const f2 x2[4] = {f2{xv[2 * grp].x, xv[2 * grp].y}, f2{xv[2 * grp].z, xv[2 * grp].w},
-                                      f2{xv[2 * grp + 1].x, xv[2 * grp + 1].y}, f2{xv[2 * grp + 1].z, xv[2 * grp + 1].w}};
-                    const float xs[8] = {x2[0].x, x2[0].y, x2[1].x, x2[1].y, x2[2].x, x2[2].y, x2[3].x, x2[3].y};
                     const int cnt = min(8, L - in_leaf);
 #pragma unroll
                     for (int g = 0; g < GT; ++g) {
                         const float4 qa = *reinterpret_cast<const float4*>(qb + gq(g) * S_CK + grp * 8);
                         const float4 qc = *reinterpret_cast<const float4*>(qb + gq(g) * S_CK + grp * 8 + 4);
-                        if (cnt == 8) {
-                            const f2 q2[4] = {f2{qa.x, qa.y}, f2{qa.z, qa.w}, f2{qc.x, qc.y}, f2{qc.z, qc.w}};
 #pragma unroll
-                            for (int j = 0; j < 4; ++j) acc[g][j] = s_accum2<OP>(acc[g][j], x2[j], q2[j]);
-                            res[g] = s_tree2<OP>(acc[g]);
-                        } else {
-                            // sequential tail of the leaf (or a leaf shorter than 8)
-                            const float qs[8] = {qa.x, qa.y, qa.z, qa.w, qc.x, qc.y, qc.z, qc.w};
-                            float r = in_leaf == 0 ? 0.0f : s_tree2<OP>(acc[g]);
+                        for (int rr = 0; rr < R; ++rr) {
+                            const f2 x2[4] = {f2{xv[rr][2 * grp].x, xv[rr][2 * grp].y}, f2{xv[rr][2 * grp].z, xv[rr][2 * grp].w},
+                                              f2{xv[rr][2 * grp + 1].x, xv[rr][2 * grp + 1].y},
+                                              f2{xv[rr][2 * grp + 1].z, xv[rr][2 * grp + 1].w}};
+                            if (cnt == 8) {
+                                const f2 q2[4] = {f2{qa.x, qa.y}, f2{qa.z, qa.w}, f2{qc.x, qc.y}, f2{qc.z, qc.w}};
 #pragma unroll
-                            for (int j = 0; j < 8; ++j)
-                                if (j < cnt) r = s_comb<OP>(r, s_term<OP>(xs[j], qs[j]));
-                            res[g] = r;
+                                for (int j = 0; j < 4; ++j) acc[rr][g][j] = s_accum2<OP>(acc[rr][g][j], x2[j], q2[j]);
+                                res[rr][g] = s_tree2<OP>(acc[rr][g]);
+                            } else {
+                                // sequential tail of the leaf (or a leaf shorter than 8)
+                                const float xs[8] = {x2[0].x, x2[0].y, x2[1].x, x2[1].y, x2[2].x, x2[2].y, x2[3].x, x2[3].y};
+                                const float qs[8] = {qa.x, qa.y, qa.z, qa.w, qc.x, qc.y, qc.z, qc.w};
+                                float r = in_leaf == 0 ? 0.0f : s_tree2<OP>(acc[rr][g]);
+#pragma unroll
+                                for (int j = 0; j < 8; ++j)
+                                    if (j < cnt) r = s_comb<OP>(r, s_term<OP>(xs[j], qs[j]));
+                                res[rr][g] = r;
+                            }
                         }
                         __builtin_amdgcn_sched_barrier(0);
                     }
@@ -353,16 +386,20 @@ __global__ __launch_bounds__(S_NT * QS) void stream_sums_kernel(const StreamPara
         if (++c_ks == ksteps) {
             c_ks = 0;
             c_item += gridDim.x;
-            const int64_t chunk_off = c_it.out_rel + row;
-            const bool live = row < c_it.rows;
 #pragma unroll
-            for (int g = 0; g < GT; ++g) {
-                if (gq(g) < c_it.qcnt) {
-                    float v = one_leaf ? res[g] : St[(g_first + g) * S_NT + row];
-                    if (p.post == POST_SQRT) v = sqrtf(v);
-                    else if (p.post == POST_NEG) v = -v;
-                    const int64_t ob = uload(p.sq_out + c_it.qbeg + gq(g));
-                    if (live) p.out[ob + chunk_off] = v;
+            for (int rr = 0; rr < R; ++rr) {
+                const int row = row0 + rr * TPS;
+                const int64_t chunk_off = c_it.out_rel + row;
+                const bool live = row < c_it.rows;
+#pragma unroll
+                for (int g = 0; g < GT; ++g) {
+                    if (gq(g) < c_it.qcnt) {
+                        float v = one_leaf ? res[rr][g] : St[(g_first + g) * S_NT + row];
+                        if (p.post == POST_SQRT) v = sqrtf(v);
+                        else if (p.post == POST_NEG) v = -v;
+                        const int64_t ob = uload(p.sq_out + c_it.qbeg + gq(g));
+                        if (live) p.out[ob + chunk_off] = v;
+                    }
                 }
             }
         }
@@ -406,19 +443,23 @@ int launch_stream_sums(const StreamJob& j, hipStream_t s) {
     static const bool no_whole = getenv("VDB_NO_WHOLE") != nullptr;
     bool whole = !no_whole && j.dim == j.ld;
     for (int i = 0; i < j.plan.n_leaves; ++i) whole = whole && j.plan.leaf_len[i] % S_CK == 0;
+    // two rows per thread in the 8-query kernel (see the kernel's comment); VDB_STREAM_ROWS=1 keeps one, for A/B timing
+    static const int env_rows = getenv("VDB_STREAM_ROWS") ? atoi(getenv("VDB_STREAM_ROWS")) : 0;
+    const int rows_per_thread = env_rows == 1 ? 1 : 2;
     KernelTimer timer(s, j.timed);
-#define VDB_LAUNCH_STREAM(O, GG, QQ)                                                            \
+#define VDB_LAUNCH_STREAM(O, GG, QQ, RR)                                                        \
     {                                                                                            \
-        auto kern = whole ? stream_sums_kernel<O, GG, QQ, true> : stream_sums_kernel<O, GG, QQ, false>; \
-        VDB_TRY(raise_dynamic_lds(reinterpret_cast<const void*>(kern),                         \
-                                    lds));      \
-        hipLaunchKernelGGL(kern, dim3(grid), dim3(S_NT * QQ), lds, s, p);                        \
+        /* two rows per thread only where every leaf is whole stages: the general path needs too many registers */ \
+        auto kern = whole ? stream_sums_kernel<O, GG, QQ, true, RR> : stream_sums_kernel<O, GG, QQ, false, 1>; \
+        VDB_TRY(raise_dynamic_lds(reinterpret_cast<const void*>(kern), lds));                    \
+        hipLaunchKernelGGL(kern, dim3(grid), dim3(S_NT / (whole ? RR : 1) * QQ), lds, s, p);     \
     }
 #define VDB_LAUNCH_STREAM_OP(O)                                                                  \
     case O:                                                                                      \
-        if (j.group == 1) VDB_LAUNCH_STREAM(O, 1, 1)                                              \
-        else if (j.group == 8) VDB_LAUNCH_STREAM(O, 8, STREAM_QS)                                 \
-        else VDB_LAUNCH_STREAM(O, 16, STREAM_QS)                                                  \
+        if (j.group == 1) VDB_LAUNCH_STREAM(O, 1, 1, 1)                                           \
+        else if (j.group == 8 && rows_per_thread == 2) VDB_LAUNCH_STREAM(O, 8, STREAM_QS, 2)      \
+        else if (j.group == 8) VDB_LAUNCH_STREAM(O, 8, STREAM_QS, 1)                              \
+        else VDB_LAUNCH_STREAM(O, 16, STREAM_QS, 1)                                               \
         break;
     switch (j.op) {
         VDB_LAUNCH_STREAM_OP(OP_DOT)
@@ -428,7 +469,7 @@ int launch_stream_sums(const StreamJob& j, hipStream_t s) {
         VDB_LAUNCH_STREAM_OP(OP_NEQ)
         case OP_SQ:
             VDB_REQUIRE(j.group == 1, "squared norms run one row set at a time");
-            VDB_LAUNCH_STREAM(OP_SQ, 1, 1)
+            VDB_LAUNCH_STREAM(OP_SQ, 1, 1, 1)
             break;
         default: VDB_REQUIRE(false, "unknown streaming op %d", j.op);
     }

@@ -296,7 +296,7 @@ int launch_ivfpq_scan(const float* q, int ldq, int dim, int nq, const float* cen
                       int dsub, const SumPlan& plan, const uint8_t* codes, const int64_t* list_off, int n_lists,
                       const int* probes, int n_probe, const int64_t* cand_off, int64_t cand_stride, float* cand, hipStream_t s);
 // measured ceilings of this GPU (ceilings.hip): device-to-device copy GB/s (read + write), register-only MFMA loops
-int measure_ceilings(hipStream_t s, float* copy_gbs, float* mfma_f32_tflops, float* mfma_bf16_tflops);
+int measure_ceilings(hipStream_t s, float* copy_gbs, float* mfma_f32_tflops, float* mfma_bf16_tflops, float* valu_direct_tops);
 // k-means
 int launch_kmeans_accumulate(const float* x, int64_t n, int dim, int ldx, const int* assign, int n_clusters,
                              double* sums, unsigned long long* counts, hipStream_t s);

@@ -85,7 +85,7 @@ class KMeans:
             for redo in range(self.n_redo):
                 trainer = N.KMeansTrainer(store, 0, vectors.shape[1], self.n_clusters)
                 try:
-                    cent = self._fit_once(trainer, n)
+                    cent = self._fit_once(vectors, trainer)
                     if self.n_redo > 1 or self.verbose:
                         _, d = trainer.assignments(with_distances=True)       # ivf.py:150-153
                         inertia = float(np.sum(d.astype(np.float64) ** 2))
@@ -102,41 +102,67 @@ class KMeans:
         self.centroids = best
         return self.centroids
 
-    def _fit_once(self, trainer: "N.KMeansTrainer", n: int) -> np.ndarray:
+    def _with_trainer(self, vectors, trainer, body):
+        """Run body(trainer) on a trainer over `vectors`: the caller's, or one opened (and closed) here."""
+        if trainer is not None:
+            return body(trainer)
+        vectors = N.f32(vectors)
+        store = N.RowStore(vectors.shape[1])
+        try:
+            store.append(vectors)
+            own = N.KMeansTrainer(store, 0, vectors.shape[1], self.n_clusters)
+            try:
+                return body(own)
+            finally:
+                own.close()
+        finally:
+            store.close()
+
+    def _fit_once(self, vectors, trainer: Optional["N.KMeansTrainer"] = None) -> np.ndarray:
         """ivf.py:165-202 on resident rows.  Host side: the RandomState draws, in the reference's order
         (randint for the first centroid, one uniform per rng.choice of k-means++, randint per empty
         cluster in ascending cluster order), and the stopping test on one number per step."""
-        t0 = time.perf_counter()
-        self._init_centroids_pp(trainer, n)
-        t1 = time.perf_counter()
-        self.phase_seconds["init_pp"] += t1 - t0
-        try:
-            return self._lloyd(trainer, n)
-        finally:
-            self.phase_seconds["lloyd"] += time.perf_counter() - t1
+        n = len(vectors)
+        if not hasattr(self, "phase_seconds"):
+            self.phase_seconds = {"upload": 0.0, "init_pp": 0.0, "lloyd": 0.0, "lloyd_steps": 0}
 
-    def _lloyd(self, trainer: "N.KMeansTrainer", n: int) -> np.ndarray:
-        for it in range(self.n_iter):
-            self.phase_seconds["lloyd_steps"] += 1
-            counts, diff = trainer.step(N.KMEANS_IVF)
-            empty = np.flatnonzero(counts == 0)
-            if len(empty):                                                     # ivf.py:185-190
-                diff = trainer.reseed(empty, [self._rng.randint(n) for _ in empty])
-            trainer.commit()
-            if self.verbose and (it + 1) % 5 == 0:
-                print(f"    Iteration {it + 1}/{self.n_iter}: diff={diff:.6f}")
-            if diff < 1e-6:
-                break
-        return trainer.centroids()
+        def body(tr):
+            t0 = time.perf_counter()
+            self._init_centroids_pp(vectors, tr)
+            t1 = time.perf_counter()
+            self.phase_seconds["init_pp"] += t1 - t0
+            try:
+                for it in range(self.n_iter):
+                    self.phase_seconds["lloyd_steps"] += 1
+                    counts, diff = tr.step(N.KMEANS_IVF)
+                    empty = np.flatnonzero(counts == 0)
+                    if len(empty):                                             # ivf.py:185-190
+                        diff = tr.reseed(empty, [self._rng.randint(n) for _ in empty])
+                    tr.commit()
+                    if self.verbose and (it + 1) % 5 == 0:
+                        print(f"    Iteration {it + 1}/{self.n_iter}: diff={diff:.6f}")
+                    if diff < 1e-6:
+                        break
+                return tr.centroids()
+            finally:
+                self.phase_seconds["lloyd"] += time.perf_counter() - t1
 
-    def _init_centroids_pp(self, trainer: "N.KMeansTrainer", n: int) -> np.ndarray:
+        return self._with_trainer(vectors, trainer, body)
+
+    def _init_centroids_pp(self, vectors, trainer: Optional["N.KMeansTrainer"] = None) -> np.ndarray:
         """k-means++ (ivf.py:204-226) with the reference's draw order.  rng.choice(n, p=probs) draws one
         uniform number and takes the first row whose cumulative probability exceeds it, so the k - 1
         uniforms are drawn up front (same generator state afterwards) and the device keeps the running
         minimum of the squared distances and does every draw itself: no row of numbers comes back."""
-        first = self._rng.randint(n)
-        uniforms = self._rng.random_sample(self.n_clusters - 1)
-        return trainer.init_pp(first, uniforms)
+        n = len(vectors)
+
+        def body(tr):
+            first = self._rng.randint(n)
+            uniforms = self._rng.random_sample(self.n_clusters - 1)
+            tr.init_pp(first, uniforms)
+            return tr.centroids()
+
+        return self._with_trainer(vectors, trainer, body)
 
     def _assign(self, vectors, centroids) -> np.ndarray:
         idx, _ = N.assign(vectors, centroids, N.EUCLIDEAN)    # ivf.py:228-231
