@@ -320,7 +320,9 @@ static int rows_reserve(vdb_rows* h, int64_t n_total, hipStream_t s) {
     Rows& r = h->r;
     if (n_total <= r.cap) return VDB_OK;
     int64_t cap = std::max<int64_t>(n_total, r.cap + r.cap / 2);
-    cap = round_up64(std::max<int64_t>(cap, 1024), 256);    // whole 256-row tiles stay readable past the last row
+    // a 256-row chunk that starts at any stored row stays readable: the scans read whole chunks and drop what
+    // lies past the end of a list or of the store
+    cap = round_up64(std::max<int64_t>(cap, 1024) + 256, 256);
     if (r.bf16)
         VDB_TRY(h->data16.reserve_keep((size_t)cap * r.ld16 * 2, (size_t)r.n * r.ld16 * 2, s));
     else
@@ -400,9 +402,13 @@ static int cand_splits(int64_t tiles, int nq) {
     return (int)splits;
 }
 
-static int stream_flat_sums(Workspace& ws, const Rows& r, int metric, const float* q, int nq, float* out, hipStream_t s) {
+// leave_sqrt: direct-form Euclidean sums are stored without their square root (the selection that follows takes it)
+static int stream_flat_sums(Workspace& ws, const Rows& r, int metric, const float* q, int nq, float* out, hipStream_t s,
+                            bool leave_sqrt = false) {
     StreamPlanBufs b{};
-    const int group = nq == 1 ? 1 : 8;
+    // queries per row chunk: 16 for real batches (each staged chunk serves twice as many queries), 8 for a handful
+    static const int env_group = getenv("VDB_STREAM_GROUP") ? atoi(getenv("VDB_STREAM_GROUP")) : 0;
+    const int group = nq == 1 ? 1 : ((env_group == 8 || env_group == 16) ? env_group : (nq >= 16 ? 16 : 8));
     const int64_t items_cap = ((r.n + 255) / 256) * ((nq + group - 1) / group);
     // the plan buffers of a flat scan are its own (row norms and the IVF plans use the shared ones),
     // so a repeated search of the same shape skips the two planning launches
@@ -425,6 +431,7 @@ static int stream_flat_sums(Workspace& ws, const Rows& r, int metric, const floa
     StreamJob j{};
     j.data = r.data; j.ld = r.ld; j.dim = r.dim; j.plan = r.plan;
     j.op = op_of_metric(metric); j.post = post_of_metric(metric);
+    if (leave_sqrt && j.post == POST_SQRT) j.post = POST_NONE;
     j.q = q; j.ldq = r.ld; j.group = group; j.n_seg = 1;
     j.seg_row_off = b.seg_row_off; j.seg_q_off = b.seg_q_off; j.seg_item_off = b.seg_item_off;
     j.sq_qid = b.sq_qid; j.sq_out = b.sq_out; j.items = b.items; j.items_cap = b.items_cap; j.out = out; j.timed = true;
@@ -451,10 +458,11 @@ static int stream_flat_search(vdb_rows* h, Workspace& ws, int metric, const floa
         const int n_cand = splits * topk_cand_lists_per_split();
         VDB_TRY(ws.part_d.reserve((size_t)nb * n_cand * kmax * sizeof(float)));
         VDB_TRY(ws.part_i.reserve((size_t)nb * n_cand * kmax * sizeof(int)));
-        VDB_TRY(stream_flat_sums(ws, r, metric, q + (int64_t)q0 * r.ld, nb, ws.cand.as<float>(), s));
+        VDB_TRY(stream_flat_sums(ws, r, metric, q + (int64_t)q0 * r.ld, nb, ws.cand.as<float>(), s, true));
         for (int64_t done = 0; done < k_eff; done += KMAX_FUSED) {
             const int kk = (int)std::min<int64_t>(KMAX_FUSED, k_eff - done);
             CandJob c{};
+            c.sqrt_here = true;
             c.cand = ws.cand.as<float>(); c.cand_stride = r.n; c.nq = nb; c.n = r.n; c.mask = d_mask;
             c.metric = metric; c.q_sq = ws.q_sq.as<float>() + q0; c.q_nrm = ws.q_nrm.as<float>() + q0;
             c.row_sq = r.sq; c.row_nrm = r.nrm;
@@ -1513,9 +1521,10 @@ static int ivf_search_impl(vdb_ivf* h, const float* d_q, int nq, int k, int n_pr
     VDB_REQUIRE(cand_stride < (int64_t)0x7fffffff, "n_probe=%d lists can hold more than 2^31 rows", n_probe);
     const int q_block = (int)std::max<int64_t>(1, std::min<int64_t>(nq, CAND_BUDGET / (cand_stride * (int64_t)sizeof(float))));
     static const int env_group = getenv("VDB_STREAM_GROUP") ? atoi(getenv("VDB_STREAM_GROUP")) : 0;
-    // 16 queries per row chunk once a list is probed by ~8 queries or more on average
+    // queries per row chunk: 8 (VDB_STREAM_GROUP=16 selects the one-row-per-thread kernel with 16, for A/B timing)
     const int64_t per_list = (int64_t)nq * n_probe / std::max(1, h->n_lists);
-    const int group = nq == 1 ? 1 : (env_group > 0 ? env_group : (per_list >= 6 ? 16 : 8));
+    (void)per_list;
+    const int group = nq == 1 ? 1 : (env_group > 0 ? env_group : 8);      // 8: the two-rows-per-thread kernel
 
     VDB_TRY(ws.probes.reserve((size_t)nq * n_probe * sizeof(int)));
     VDB_TRY(ws.probe_d.reserve((size_t)nq * n_probe * sizeof(float)));
@@ -1547,6 +1556,7 @@ static int ivf_search_impl(vdb_ivf* h, const float* d_q, int nq, int k, int n_pr
         StreamJob j{};
         j.data = m->r.data; j.ld = m->r.ld; j.dim = m->r.dim; j.plan = m->r.plan;
         j.op = op_of_metric(sm); j.post = post_of_metric(sm);
+        if (j.post == POST_SQRT) j.post = POST_NONE;      // the selection below takes the root (CandJob::sqrt_here)
         j.q = q + (int64_t)q0 * m->r.ld; j.ldq = m->r.ld; j.group = group; j.n_seg = h->n_lists;
         j.seg_row_off = h->list_off.as<int64_t>(); j.seg_q_off = b.seg_q_off; j.seg_item_off = b.seg_item_off;
         j.sq_qid = b.sq_qid; j.sq_out = b.sq_out; j.items = b.items; j.items_cap = b.items_cap;
@@ -1564,6 +1574,7 @@ static int ivf_search_impl(vdb_ivf* h, const float* d_q, int nq, int k, int n_pr
             c.probes = probes; c.n_probe = n_probe; c.n_lists = h->n_lists; c.list_off = h->list_off.as<int64_t>();
             c.cand_off = ws.cand_off.as<int64_t>(); c.tile_off = ws.tile_off.as<int>();
             c.row_ids = h->row_ids.as<int>(); c.mask = d_mask;
+            c.sqrt_here = true;
             c.metric = sm; c.q_sq = ws.q_sq.as<float>() + q0; c.q_nrm = ws.q_nrm.as<float>() + q0;
             c.row_sq = m->r.sq; c.row_nrm = m->r.nrm;
             c.lb_d = done > 0 ? ws.lb_d.as<float>() : nullptr; c.lb_k = done > 0 ? ws.lb_k.as<int64_t>() : nullptr;

@@ -2,6 +2,8 @@
 // register-only matrix-core loops reach, for reporting beside the spec peaks that the roofline
 // fractions are quoted against.  Nothing on the search path calls this file.
 #include "flat_math.h"
+#include <algorithm>
+#include <cstdlib>
 
 namespace vdb {
 
@@ -129,7 +131,9 @@ int measure_ceilings(hipStream_t s, float* copy_gbs, float* mfma_f32_tflops, flo
         const int blocks = ctx().num_cus * 2;                                                   // 8 waves per CU, 2 per SIMD
         VDB_TRY(time_mfma_loop<false>(reinterpret_cast<float*>(a), blocks, 4096, s, mfma_f32_tflops));
         VDB_TRY(time_mfma_loop<true>(reinterpret_cast<float*>(a), blocks, 16384, s, mfma_bf16_tflops));
-        VDB_TRY(time_valu_loop(reinterpret_cast<float*>(a), ctx().num_cus * 4, 4096, s, valu_direct_tops));   // 4 waves per SIMD
+        // 4 waves per SIMD by default; VDB_CEIL_WAVES = 1 or 2 shows what fewer resident waves reach
+        static const int env_waves = getenv("VDB_CEIL_WAVES") ? atoi(getenv("VDB_CEIL_WAVES")) : 4;
+        VDB_TRY(time_valu_loop(reinterpret_cast<float*>(a), ctx().num_cus * std::max(1, env_waves), 4096, s, valu_direct_tops));
         return VDB_OK;
     };
     st = body();

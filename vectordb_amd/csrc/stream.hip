@@ -87,12 +87,43 @@ template <int OP> __device__ __forceinline__ f2 s_accum2(f2 r, f2 x, f2 q) {
     if (OP == OP_MAXABS) return f2{fmaxf(r.x, d.x), fmaxf(r.y, d.y)};
     return r + d;
 }
+// The staged form of s_accum2 for the operations whose pair costs more than one instruction: stage 1 on every
+// pair of a unit, then (squared differences) the squares, then stage 3.  |d| enters the last stage as a source
+// modifier of a one-element add or max; there is no packed fp32 abs or max.
+template <int OP> __device__ constexpr bool s_staged() { return OP == OP_SQDIFF || OP == OP_ABSDIFF || OP == OP_MAXABS || OP == OP_SQ; }
+template <int OP> __device__ __forceinline__ f2 s_stage1(f2 x, f2 q) {
+    if (OP == OP_SQDIFF) return q - x;
+    if (OP == OP_SQ) return x * x;
+    return x - q;
+}
+template <int OP> __device__ __forceinline__ f2 s_stage3(f2 r, f2 d) {
+    if (OP == OP_ABSDIFF) return f2{r.x + __builtin_fabsf(d.x), r.y + __builtin_fabsf(d.y)};
+    if (OP == OP_MAXABS) return f2{fmaxf(r.x, __builtin_fabsf(d.x)), fmaxf(r.y, __builtin_fabsf(d.y))};
+    return r + d;
+}
+// every value of d[] is computed before anything behind the fence starts
+template <int N> __device__ __forceinline__ void s_fence(f2* d) {
+    static_assert(N % 4 == 0, "pairs come in fours");
+    if constexpr (N % 8 == 0) {
+#pragma unroll
+        for (int i = 0; i < N; i += 8)
+            asm volatile("" : "+v"(d[i]), "+v"(d[i + 1]), "+v"(d[i + 2]), "+v"(d[i + 3]), "+v"(d[i + 4]), "+v"(d[i + 5]), "+v"(d[i + 6]), "+v"(d[i + 7]));
+    } else {
+#pragma unroll
+        for (int i = 0; i < N; i += 4) asm volatile("" : "+v"(d[i]), "+v"(d[i + 1]), "+v"(d[i + 2]), "+v"(d[i + 3]));
+    }
+}
 template <int OP> __device__ __forceinline__ float s_tree2(const f2* a) {
     return s_comb<OP>(s_comb<OP>(s_comb<OP>(a[0].x, a[0].y), s_comb<OP>(a[1].x, a[1].y)),
                       s_comb<OP>(s_comb<OP>(a[2].x, a[2].y), s_comb<OP>(a[3].x, a[3].y)));
 }
 
 typedef int i8v __attribute__((ext_vector_type(8)));
+// eight consecutive floats at any dword address through the scalar cache (one s_load_dwordx8)
+__device__ __forceinline__ i8v uload8(const float* p) {
+    typedef int i8v_u __attribute__((ext_vector_type(8), aligned(4)));
+    return *reinterpret_cast<const __attribute__((address_space(4))) i8v_u*>(reinterpret_cast<uintptr_t>(p));
+}
 struct Item {
     int64_t row0;        // first stored row of the chunk
     int64_t out_rel;     // chunk's first row relative to its segment's first row
@@ -114,14 +145,19 @@ __device__ __forceinline__ Item load_item(const StreamParams& p, int64_t item) {
 template <int PER_STAGE> __device__ __forceinline__ void wait_loads(int stages_behind) {
     // the wave's LDS-DMA loads retire in order: leaving `stages_behind` later stages
     // outstanding means the stage in front of them has landed
-    static_assert(PER_STAGE == 9 || PER_STAGE == 5 || PER_STAGE == 3, "add the immediates for this count");
+    static_assert(PER_STAGE == 9 || PER_STAGE == 8 || PER_STAGE == 5 || PER_STAGE == 4 || PER_STAGE == 3,
+                  "add the immediates for this count");
     if (stages_behind >= 2) {
         if (PER_STAGE == 9) asm volatile("s_waitcnt vmcnt(18)" ::: "memory");
+        else if (PER_STAGE == 8) asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
         else if (PER_STAGE == 5) asm volatile("s_waitcnt vmcnt(10)" ::: "memory");
+        else if (PER_STAGE == 4) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
         else asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
     } else if (stages_behind == 1) {
         if (PER_STAGE == 9) asm volatile("s_waitcnt vmcnt(9)" ::: "memory");
+        else if (PER_STAGE == 8) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
         else if (PER_STAGE == 5) asm volatile("s_waitcnt vmcnt(5)" ::: "memory");
+        else if (PER_STAGE == 4) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
         else asm volatile("s_waitcnt vmcnt(3)" ::: "memory");
     } else {
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -138,7 +174,7 @@ template <int PER_STAGE> __device__ __forceinline__ void wait_loads(int stages_b
 // 768, 1024): the group-by-group path for leaf ends inside a stage is compiled out, and with it
 // the register copies where the two paths meet.
 template <int OP, int G, int QS, bool WHOLE, int R>
-__global__ __launch_bounds__(S_NT / R * QS) void stream_sums_kernel(const StreamParams p) {
+__global__ __launch_bounds__(S_NT / R * QS, (G == 8 && R == 1 && WHOLE) ? 4 : 1) void stream_sums_kernel(const StreamParams p) {
     extern __shared__ __align__(16) float smem[];
     constexpr int TPS = S_NT / R;                 // threads per wave set
     static_assert(TPS % 64 == 0, "a wave set is whole waves");
@@ -146,11 +182,21 @@ __global__ __launch_bounds__(S_NT / R * QS) void stream_sums_kernel(const Stream
     const int row0 = tid % TPS;
     const int nbuf = p.nbuf;
     constexpr int GT = G / QS;                    // queries per thread
-    constexpr int H = R > 1 ? 2 : (GT >= 4 ? 4 : GT);   // queries per unit of the arithmetic loop (its values sit in registers twice)
+#ifndef VDB_STREAM_H1
+#define VDB_STREAM_H1 4
+#endif
+    // queries per unit of the arithmetic loop (a unit's values sit in registers twice: in use and prefetched)
+    constexpr int H = R > 1 ? 2 : ((G == 8 && WHOLE) ? 1 : (GT >= VDB_STREAM_H1 ? VDB_STREAM_H1 : GT));
     constexpr int U = GT / H;
     constexpr int NW = TPS * QS / 64;             // waves
     constexpr int ROW_GLDS = 32 / NW;             // row LDS-DMA instructions per wave and stage
-    constexpr int PER_STAGE = ROW_GLDS + 1;
+    // SQ: the query values do not pass through LDS at all.  They are the same for every lane, so they can come
+    // through the scalar cache into SGPRs and enter the packed operations as scalar operands (two s_load_dwordx8 per
+    // unit, issued one unit ahead).  Measured on the 10M x 128 list scan and the 1M x 128 Manhattan batch this is no
+    // faster than the LDS broadcast reads (2.61 vs 2.61 ms, 12.6 vs 12.0 ms): eight waves per CU ask the scalar
+    // cache for as many bytes as they would ask LDS for.  Left off.
+    constexpr bool SQ = false;
+    constexpr int PER_STAGE = ROW_GLDS + (SQ ? 0 : 1);
     constexpr int SLOT = S_STAGE + G * S_CK;      // floats per stage slot: 256 row pieces, then the G query pieces
     const int qset = __builtin_amdgcn_readfirstlane(tid / TPS);
     const int g_first = qset * GT;                // this thread's slots of the pending-sum stack
@@ -182,36 +228,63 @@ __global__ __launch_bounds__(S_NT / R * QS) void stream_sums_kernel(const Stream
     const int ga = (wave * QL) >> 3;              // the first of them
     const float* row_src[ROW_GLDS];               // this lane's row pieces of the item, at column 0
     int row_c4[ROW_GLDS];                         // 4 * (piece of the row this lane fetches)
+    // UBASE (the batch kernels, which only read row stores): a row piece is addressed as a
+    // wave-uniform base (first row of the chunk, current column) plus a byte offset that is fixed per lane for
+    // the whole launch, so a stage issues its loads without any vector-ALU work.  A chunk that ends before its
+    // 256th row reads on into the rows behind it (a row store keeps that many rows of slack behind its last
+    // row); those sums are never stored.
+    constexpr bool UBASE = WHOLE && G >= 8;
+    unsigned row_off[ROW_GLDS];
+    const float* item_base = p.data;
+#pragma unroll
+    for (int i = 0; i < ROW_GLDS; ++i) {
+        const int r = wave * (8 * ROW_GLDS) + i * 8 + (lane >> 3);
+        row_off[i] = (unsigned)((r * p.ld + (piece ^ ((r >> 1) & 7)) * 4) * (int)sizeof(float));
+    }
     const float* q_src = p.q;
     auto begin_item = [&]() {
         const Item it = load_item(p, p_item);
+        if constexpr (UBASE) {
+            item_base = p.data + it.row0 * p.ld;      // wave-uniform: the item comes from scalar loads
+        } else {
 #pragma unroll
-        for (int i = 0; i < ROW_GLDS; ++i) {
-            const int r = wave * (8 * ROW_GLDS) + i * 8 + (lane >> 3);
-            row_src[i] = p.data + (it.row0 + min(r, it.rows - 1)) * p.ld;
-            row_c4[i] = (piece ^ ((r >> 1) & 7)) * 4;
+            for (int i = 0; i < ROW_GLDS; ++i) {
+                const int r = wave * (8 * ROW_GLDS) + i * 8 + (lane >> 3);
+                row_src[i] = p.data + (it.row0 + min(r, it.rows - 1)) * p.ld;
+                row_c4[i] = (piece ^ ((r >> 1) & 7)) * 4;
+            }
         }
-        int id = uload(p.sq_qid + it.qbeg + min(ga, it.qcnt - 1));
+        if constexpr (!SQ) {
+            int id = uload(p.sq_qid + it.qbeg + min(ga, it.qcnt - 1));
 #pragma unroll
-        for (int j = 1; j < QPW; ++j) {
-            const int idj = uload(p.sq_qid + it.qbeg + min(ga + j, it.qcnt - 1));
-            if ((sidx >> 3) - ga == j) id = idj;
+            for (int j = 1; j < QPW; ++j) {
+                const int idj = uload(p.sq_qid + it.qbeg + min(ga + j, it.qcnt - 1));
+                if ((sidx >> 3) - ga == j) id = idj;
+            }
+            q_src = p.q + (int64_t)id * p.ldq + (sidx & 7) * 4;
         }
-        q_src = p.q + (int64_t)id * p.ldq + (sidx & 7) * 4;
     };
     begin_item();
     auto issue = [&]() {
         const unsigned slot = (unsigned)(uintptr_t)(smem + p_buf * SLOT);
         const unsigned base = __builtin_amdgcn_readfirstlane(slot + wave * (8 * ROW_GLDS) * S_CK * (unsigned)sizeof(float));
         const int col0 = p_ks * S_CK;
-        if (lane < QL) {
+        if (!SQ && lane < QL) {
             const float* src = (col0 + (sidx & 7) * 4 < p.ld) ? q_src + col0 : p.zeros;
             glds16(src, __builtin_amdgcn_readfirstlane(slot + (S_STAGE + wave * QL * 4) * (unsigned)sizeof(float)));
         }
+        if constexpr (UBASE) {
+            const uint64_t b = (uint64_t)(uintptr_t)(item_base + col0);
+            const uint32_t lo = __builtin_amdgcn_readfirstlane((uint32_t)b), hi = __builtin_amdgcn_readfirstlane((uint32_t)(b >> 32));
+            const void* sb = reinterpret_cast<const void*>(((uint64_t)hi << 32) | lo);
 #pragma unroll
-        for (int i = 0; i < ROW_GLDS; ++i) {
-            const float* src = (col0 + row_c4[i] < p.ld) ? row_src[i] + col0 + row_c4[i] : p.zeros;
-            glds16(src, base + i * 8 * S_CK * (unsigned)sizeof(float));
+            for (int i = 0; i < ROW_GLDS; ++i) glds16_s(sb, row_off[i], base + i * 8 * S_CK * (unsigned)sizeof(float));
+        } else {
+#pragma unroll
+            for (int i = 0; i < ROW_GLDS; ++i) {
+                const float* src = (col0 + row_c4[i] < p.ld) ? row_src[i] + col0 + row_c4[i] : p.zeros;
+                glds16(src, base + i * 8 * S_CK * (unsigned)sizeof(float));
+            }
         }
         ++pn;
         if (++p_buf == nbuf) p_buf = 0;
@@ -232,6 +305,7 @@ __global__ __launch_bounds__(S_NT / R * QS) void stream_sums_kernel(const Stream
     Item c_it{};
     f2 acc[R][GT][4];
     float res[R][GT];
+    const float* qp[GT];                          // SQ: this thread's queries of the item (wave-uniform addresses)
     int leaf = 0, in_leaf = 0, sp = 0, L = 0;
     const int sw = (row0 >> 1) & 7;               // the same for every row of the thread: TPS is a multiple of 16
 
@@ -285,6 +359,11 @@ __global__ __launch_bounds__(S_NT / R * QS) void stream_sums_kernel(const Stream
             c_it = load_item(p, c_item);
             zero_acc();
             leaf = 0; in_leaf = 0; sp = 0; L = p.leaf_len[0];
+            if constexpr (SQ) {
+#pragma unroll
+                for (int g = 0; g < GT; ++g)
+                    qp[g] = p.q + (int64_t)uload(p.sq_qid + c_it.qbeg + min(gq(g), c_it.qcnt - 1)) * p.ldq;
+            }
         }
 
         const float* xb = smem + c_buf * SLOT + row0 * S_CK;
@@ -298,39 +377,97 @@ __global__ __launch_bounds__(S_NT / R * QS) void stream_sums_kernel(const Stream
         }
 
         // the stage's query values, fetched one unit (8 floats of H queries) ahead of their use
+        const int col0 = c_ks * S_CK;
         float4 qv[2][H][2];
+        i8v qs[2][H];
         auto load_q = [&](int buf, int unit) {
-            const float* src = qb + gq((unit % U) * H) * S_CK + (unit / U) * 8;
+            if constexpr (SQ) {
 #pragma unroll
-            for (int h = 0; h < H; ++h) {
-                qv[buf][h][0] = *reinterpret_cast<const float4*>(src + h * S_CK);
-                qv[buf][h][1] = *reinterpret_cast<const float4*>(src + h * S_CK + 4);
+                for (int h = 0; h < H; ++h)
+                    qs[buf][h] = uload8(qp[(unit % U) * H + h] + col0 + (unit / U) * 8);
+            } else {
+                const float* src = qb + gq((unit % U) * H) * S_CK + (unit / U) * 8;
+#pragma unroll
+                for (int h = 0; h < H; ++h) {
+                    qv[buf][h][0] = *reinterpret_cast<const float4*>(src + h * S_CK);
+                    qv[buf][h][1] = *reinterpret_cast<const float4*>(src + h * S_CK + 4);
+                }
             }
         };
         // a unit whose H queries are all padding (a group that is not full) is neither fetched nor summed
         auto unit_live = [&](int unit) { return gq((unit % U) * H) < c_it.qcnt; };
-        if (unit_live(0)) load_q(0, 0);
+        if (SQ || unit_live(0)) load_q(0, 0);
 
-        const int col0 = c_ks * S_CK;
         if (WHOLE || L - in_leaf >= S_CK) {
             // the whole stage lies inside one leaf: four full groups of 8, no control flow
 #pragma unroll
             for (int unit = 0; unit < (S_CK / 8) * U; ++unit) {
                 const int grp = unit / U, g0 = (unit % U) * H;
-                if (unit + 1 < (S_CK / 8) * U && unit_live(unit + 1)) load_q((unit + 1) & 1, unit + 1);
+                if constexpr (SQ) {
+                    // Scalar loads return in any order, so the only wait there is for them is "all of them".  Taking
+                    // that wait here, before the next unit's loads go out, makes it a wait for loads that were issued
+                    // a whole unit of arithmetic ago; taken at the first use below, it would wait for the loads
+                    // issued just above it as well.
+#pragma unroll
+                    for (int h = 0; h < H; ++h) asm volatile("" :: "s"(qs[unit & 1][h]));
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+                // (scalar loads are issued for padded units too, from the group's last query: branches around them
+                // would only blur which loads are still in flight where the paths meet)
+                if (unit + 1 < (S_CK / 8) * U && (SQ || unit_live(unit + 1))) load_q((unit + 1) & 1, unit + 1);
+                if constexpr (SQ) __builtin_amdgcn_sched_barrier(0);
                 if (gq(g0) < c_it.qcnt) {               // units whose queries are all padding do no arithmetic
+                    f2 q2[H][4], x2[R][4];
 #pragma unroll
                     for (int h = 0; h < H; ++h) {
-                        const float4 qa = qv[unit & 1][h][0], qc = qv[unit & 1][h][1];
-                        const f2 q2[4] = {f2{qa.x, qa.y}, f2{qa.z, qa.w}, f2{qc.x, qc.y}, f2{qc.z, qc.w}};
+                        if constexpr (SQ) {
+                            const i8v w = qs[unit & 1][h];
 #pragma unroll
-                        for (int rr = 0; rr < R; ++rr) {
-                            const f2 x2[4] = {f2{xv[rr][2 * grp].x, xv[rr][2 * grp].y}, f2{xv[rr][2 * grp].z, xv[rr][2 * grp].w},
-                                              f2{xv[rr][2 * grp + 1].x, xv[rr][2 * grp + 1].y},
-                                              f2{xv[rr][2 * grp + 1].z, xv[rr][2 * grp + 1].w}};
-#pragma unroll
-                            for (int j = 0; j < 4; ++j) acc[rr][g0 + h][j] = s_accum2<OP>(acc[rr][g0 + h][j], x2[j], q2[j]);
+                            for (int j = 0; j < 4; ++j) q2[h][j] = f2{__int_as_float(w[2 * j]), __int_as_float(w[2 * j + 1])};
+                        } else {
+                            const float4 qa = qv[unit & 1][h][0], qc = qv[unit & 1][h][1];
+                            q2[h][0] = f2{qa.x, qa.y}; q2[h][1] = f2{qa.z, qa.w}; q2[h][2] = f2{qc.x, qc.y}; q2[h][3] = f2{qc.z, qc.w};
                         }
+                    }
+#pragma unroll
+                    for (int rr = 0; rr < R; ++rr) {
+                        x2[rr][0] = f2{xv[rr][2 * grp].x, xv[rr][2 * grp].y}; x2[rr][1] = f2{xv[rr][2 * grp].z, xv[rr][2 * grp].w};
+                        x2[rr][2] = f2{xv[rr][2 * grp + 1].x, xv[rr][2 * grp + 1].y};
+                        x2[rr][3] = f2{xv[rr][2 * grp + 1].z, xv[rr][2 * grp + 1].w};
+                    }
+                    if constexpr (s_staged<OP>()) {
+                        // The unit's H*R*4 packed pairs go through the operation stage by stage (all differences, then
+                        // all squares, then all additions): an instruction that consumes the result of the one before
+                        // it waits out the pipeline, and a wave's neighbours are often in their LDS reads instead of
+                        // filling that gap.  Same operations on the same values: the sums are unchanged.
+                        constexpr int NE = H * R * 4;
+                        f2 d[NE];
+#pragma unroll
+                        for (int h = 0; h < H; ++h)
+#pragma unroll
+                            for (int rr = 0; rr < R; ++rr)
+#pragma unroll
+                                for (int j = 0; j < 4; ++j) d[(h * R + rr) * 4 + j] = s_stage1<OP>(x2[rr][j], q2[h][j]);
+                        s_fence<NE>(d);
+                        if constexpr (OP == OP_SQDIFF) {
+#pragma unroll
+                            for (int e = 0; e < NE; ++e) d[e] = d[e] * d[e];
+                            s_fence<NE>(d);
+                        }
+#pragma unroll
+                        for (int h = 0; h < H; ++h)
+#pragma unroll
+                            for (int rr = 0; rr < R; ++rr)
+#pragma unroll
+                                for (int j = 0; j < 4; ++j)
+                                    acc[rr][g0 + h][j] = s_stage3<OP>(acc[rr][g0 + h][j], d[(h * R + rr) * 4 + j]);
+                    } else {
+#pragma unroll
+                        for (int h = 0; h < H; ++h)
+#pragma unroll
+                            for (int rr = 0; rr < R; ++rr)
+#pragma unroll
+                                for (int j = 0; j < 4; ++j) acc[rr][g0 + h][j] = s_accum2<OP>(acc[rr][g0 + h][j], x2[rr][j], q2[h][j]);
                     }
                 }
                 __builtin_amdgcn_sched_barrier(0);      // keep the query reads one unit ahead, not all at the top
@@ -435,17 +572,19 @@ int launch_stream_sums(const StreamJob& j, hipStream_t s) {
     // eight queries: arithmetic-bound, two independent blocks per CU (two stage buffers each),
     // so that one block's loads, waits and barriers hide behind the other's arithmetic.
     static const int env_nbuf = getenv("VDB_STREAM_NBUF") ? atoi(getenv("VDB_STREAM_NBUF")) : 0;
-    const int want_nbuf = env_nbuf > 0 ? env_nbuf : (j.group == 1 ? 4 : 2);
+    static const int env_rows = getenv("VDB_STREAM_ROWS") ? atoi(getenv("VDB_STREAM_ROWS")) : 0;
+    const int rows_per_thread = env_rows == 1 ? 1 : 2;
+    static const bool no_whole = getenv("VDB_NO_WHOLE") != nullptr;
+    bool whole = !no_whole && j.dim == j.ld;
+    for (int i = 0; i < j.plan.n_leaves; ++i) whole = whole && j.plan.leaf_len[i] % S_CK == 0;
+    // 16 queries per row chunk, two rows per thread: one block of eight waves per CU with four stages in flight
+    // (half the global->LDS traffic per (row, query) pair of the 8-query form)
+    const bool g16r2 = j.group == 16 && rows_per_thread == 2 && whole;
+    const int want_nbuf = env_nbuf > 0 ? env_nbuf : ((j.group == 1 || g16r2) ? 4 : 2);
     p.nbuf = (int)std::max<size_t>(2, std::min<size_t>(want_nbuf, (budget - stack) / slot));
     const size_t lds = (size_t)p.nbuf * slot + stack;
     const int blocks_per_cu = (int)std::max<size_t>(1, std::min<size_t>(2, budget / lds));
     const int grid = ctx().num_cus * blocks_per_cu;   // blocks past the item count leave at once
-    static const bool no_whole = getenv("VDB_NO_WHOLE") != nullptr;
-    bool whole = !no_whole && j.dim == j.ld;
-    for (int i = 0; i < j.plan.n_leaves; ++i) whole = whole && j.plan.leaf_len[i] % S_CK == 0;
-    // two rows per thread in the 8-query kernel (see the kernel's comment); VDB_STREAM_ROWS=1 keeps one, for A/B timing
-    static const int env_rows = getenv("VDB_STREAM_ROWS") ? atoi(getenv("VDB_STREAM_ROWS")) : 0;
-    const int rows_per_thread = env_rows == 1 ? 1 : 2;
     KernelTimer timer(s, j.timed);
 #define VDB_LAUNCH_STREAM(O, GG, QQ, RR)                                                        \
     {                                                                                            \
@@ -459,6 +598,7 @@ int launch_stream_sums(const StreamJob& j, hipStream_t s) {
         if (j.group == 1) VDB_LAUNCH_STREAM(O, 1, 1, 1)                                           \
         else if (j.group == 8 && rows_per_thread == 2) VDB_LAUNCH_STREAM(O, 8, STREAM_QS, 2)      \
         else if (j.group == 8) VDB_LAUNCH_STREAM(O, 8, STREAM_QS, 1)                              \
+        else if (g16r2) VDB_LAUNCH_STREAM(O, 16, 4, 2)                                            \
         else VDB_LAUNCH_STREAM(O, 16, STREAM_QS, 1)                                               \
         break;
     switch (j.op) {
@@ -730,7 +870,9 @@ static constexpr int RUN_CHUNK = 256;      // probed lists whose ranges are stag
 // FIN: how a candidate value becomes a distance, fixed per launch so that the row terms of the
 // CAND_UNROLL tiles are fetched together instead of one dependent load per tile:
 // 0 = the value is the distance (direct forms, Manhattan, Chebyshev, Hamming, negated dot), 1 = the Euclidean
-// identity form, 2 = cosine of the matrix form, 3 = cosine of the pair form, 4 = the angle of the pair form.
+// identity form, 2 = cosine of the matrix form, 3 = cosine of the pair form, 4 = the angle of the pair form,
+// 5 = the square root of the streamed sum (direct-form Euclidean whose scan left the root to this kernel: one
+// correctly rounded sqrtf per candidate costs the scan, which is bound by its vector ALUs, more than it costs here).
 template <int FIN>
 __global__ __launch_bounds__(LIST_NT) void topk_cand_kernel(CandParams p) {
     extern __shared__ __align__(16) float smem[];
@@ -806,7 +948,7 @@ __global__ __launch_bounds__(LIST_NT) void topk_cand_kernel(CandParams p) {
             for (int u = 0; u < CAND_UNROLL; ++u) {
                 rt[u] = 1.0f;
                 if (FIN == 1 && ok[u]) rt[u] = p.fin.row_sq[pos[u]];
-                if (FIN >= 2 && ok[u]) rt[u] = p.fin.row_nrm[pos[u]];
+                if (FIN >= 2 && FIN <= 4 && ok[u]) rt[u] = p.fin.row_nrm[pos[u]];
             }
             float d[CAND_UNROLL];
 #pragma unroll
@@ -825,6 +967,8 @@ __global__ __launch_bounds__(LIST_NT) void topk_cand_kernel(CandParams p) {
                 } else if (FIN == 4) {
                     const float den = q_nrm * rt[u];                                            // metrics.py:535-538
                     v = angular_of(den < 1e-8f ? 0.0f : v / den);
+                } else if (FIN == 5) {
+                    v = sqrtf(v);                                                               // metrics.py:43
                 }
                 d[u] = ok[u] ? v : INFINITY;
             }
@@ -861,9 +1005,10 @@ int launch_topk_cand(const CandJob& j, hipStream_t s) {
     p.cand_off = j.cand_off; p.tile_off = j.tile_off;
     const size_t lds = (size_t)RUN_CHUNK * 24 + 8;
     const int fin = (j.metric == VDB_EUCLIDEAN || j.metric == VDB_EUCLIDEAN_SQ) ? 1
-                    : j.metric == VDB_COSINE ? 2 : j.metric == VDB_COSINE_PAIR ? 3 : j.metric == VDB_ANGULAR ? 4 : 0;
+                    : j.metric == VDB_COSINE ? 2 : j.metric == VDB_COSINE_PAIR ? 3 : j.metric == VDB_ANGULAR ? 4
+                    : (j.metric == VDB_EUCLIDEAN_DIRECT && j.sqrt_here) ? 5 : 0;
     auto kern = fin == 1 ? topk_cand_kernel<1> : fin == 2 ? topk_cand_kernel<2> : fin == 3 ? topk_cand_kernel<3>
-                : fin == 4 ? topk_cand_kernel<4> : topk_cand_kernel<0>;
+                : fin == 4 ? topk_cand_kernel<4> : fin == 5 ? topk_cand_kernel<5> : topk_cand_kernel<0>;
     VDB_TRY(raise_dynamic_lds(reinterpret_cast<const void*>(kern), lds));
     hipLaunchKernelGGL(kern, dim3(j.nq, j.splits), dim3(LIST_NT), lds, s, p);
     VDB_HIP(hipGetLastError());

@@ -24,6 +24,14 @@ __device__ __forceinline__ void glds16(const void* gsrc, unsigned lds_dst) {
                  : "=&s"(keep) : "v"(gsrc), "s"(lds_dst) : "memory");
 }
 
+// The same with the address split into a wave-uniform base (an SGPR pair) and a 32-bit byte offset per lane:
+// nothing of the address has to be computed on the vector ALU.
+__device__ __forceinline__ void glds16_s(const void* sbase, unsigned voff, unsigned lds_dst) {
+    unsigned keep;
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2\n\ts_mov_b32 m0, %0"
+                 : "=&s"(keep) : "v"(voff), "s"(sbase), "s"(lds_dst) : "memory");
+}
+
 // Insert (v, id) into the calling thread's ascending list (consecutive
 // positions are LIST_NT floats apart).  A thread sees ids in ascending order,
 // so an equal distance is placed behind the entries already present.

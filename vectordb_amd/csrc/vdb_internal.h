@@ -237,6 +237,7 @@ struct CandJob {
     int metric; const float* q_sq; const float* q_nrm; const float* row_sq; const float* row_nrm;
     const float* lb_d; const int64_t* lb_k; float radius; int use_radius;
     int k; int splits; float* part_d; int* part_i;
+    bool sqrt_here;                                   // VDB_EUCLIDEAN_DIRECT whose scan stored the sums without the root
 };
 int launch_topk_cand(const CandJob& j, hipStream_t s);
 // range search over the streamed sums of ONE query (candidate slot = stored row): count + scan of the rows inside
