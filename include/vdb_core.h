@@ -238,6 +238,19 @@ int vdb_ivf_build(vdb_ivf* h, const float* rows, int64_t n, const int32_t* list_
 /* explicit list layout: row numbers of every list in scan order, concatenated,
  * and n_lists+1 offsets (covers swap-removed lists, ivf.py:730-738) */
 int vdb_ivf_build_lists(vdb_ivf* h, const float* rows, int64_t n, const int64_t* list_rows, const int64_t* list_offsets);
+/* the same layout with rows already in list order and a row number of the caller's choice for every one of
+ * them (what searches return and what a mask is indexed by; any values below 2^31, e.g. slots of a host table
+ * that has gaps where rows were removed) */
+int vdb_ivf_build_numbered(vdb_ivf* h, const float* rows, int64_t n, const int64_t* row_numbers, const int64_t* list_offsets);
+/* IVFIndex.add / add_batch on a built index (ivf.py:478-542: `self._inverted_lists[cluster].append(entry)`):
+ * row i goes behind the last row of list lists[i].  Costs the new rows, plus, when a list has outgrown its
+ * place, one device-side move of that list to a place twice as large; the rest of the index is not touched. */
+int vdb_ivf_append(vdb_ivf* h, const float* rows, const int64_t* row_numbers, const int32_t* lists, int64_t count);
+/* IVFIndex.remove (ivf.py:708-745): the row at `position` of `list` is replaced by the list's last row */
+int vdb_ivf_remove_at(vdb_ivf* h, int32_t list, int64_t position);
+/* rows in lists, positions of the row buffer in use, and positions lost to places that lists have left (a caller
+ * rebuilds when the last is large) */
+int vdb_ivf_layout(vdb_ivf* h, int64_t* live_rows, int64_t* positions, int64_t* dead_positions);
 /* IVFIndex.search / search_batch (ivf.py:571-673).  mask is indexed by row
  * number (insertion position). */
 int vdb_ivf_search(vdb_ivf* h, const float* queries, int nq, int k, int n_probe,
@@ -295,6 +308,13 @@ int vdb_ivfpq_encode(vdb_ivfpq* h, const float* rows, int64_t n, int32_t* out_li
 /* lists in scan order: codes[n][m] by row number, the row numbers of every list
  * concatenated, n_lists+1 offsets (hybrid.py:262 appends, :405-409 removes in place) */
 int vdb_ivfpq_build(vdb_ivfpq* h, const uint8_t* codes, int64_t n, const int64_t* list_rows, const int64_t* list_offsets);
+/* codes already in list order, a row number of the caller's choice for each (as vdb_ivf_build_numbered) */
+int vdb_ivfpq_build_numbered(vdb_ivfpq* h, const uint8_t* codes, int64_t n, const int64_t* row_numbers, const int64_t* list_offsets);
+/* HybridIndex.add on a built index (hybrid.py:262 appends to the list), list by list as vdb_ivf_append, and
+ * remove (hybrid.py:396-400 filters the list: the codes behind the removed one move up in their order) */
+int vdb_ivfpq_append(vdb_ivfpq* h, const uint8_t* codes, const int64_t* row_numbers, const int32_t* lists, int64_t count);
+int vdb_ivfpq_remove_at(vdb_ivfpq* h, int32_t list, int64_t position);
+int vdb_ivfpq_layout(vdb_ivfpq* h, int64_t* live_rows, int64_t* positions, int64_t* dead_positions);
 int vdb_ivfpq_search(vdb_ivfpq* h, const float* queries, int nq, int k, int n_probe,
                      const uint32_t* mask, float* out_dist, int64_t* out_row);
 int vdb_ivfpq_search_dev(vdb_ivfpq* h, const float* d_queries, int nq, int k, int n_probe,

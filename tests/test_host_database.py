@@ -1,0 +1,75 @@
+"""Host-side pieces that need no GPU: the VectorDB file layout (core/database.py:313-416), Collection.to_dict /
+from_dict (core/collection.py:998-1055), recommend_index (index/__init__.py:99-170), bulk index loaders."""
+
+import json
+import pickle
+
+import numpy as np
+import pytest
+
+
+def test_vectordb_files_and_errors(tmp_path):
+    from vectordb_amd.core import VectorDB, Collection, StorageError, ValidationError
+    rng = np.random.RandomState(0)
+    db = VectorDB(data_dir=str(tmp_path / "d"))
+    c = db.create_collection("docs", dimension=4, metric="cosine", normalize=True, max_vectors=10)
+    for i in range(5):
+        c.add(f"r{i}", rng.randn(4).astype(np.float32), {"i": i})
+    c.delete("r1")
+    c.add("r0", np.ones(4, dtype=np.float32), {"i": 100}, overwrite=True)
+    db.save()
+    manifest = json.load(open(tmp_path / "d" / "manifest.json"))
+    assert manifest["version"] == "0.1.0" and manifest["collections"] == ["docs"]
+    data = pickle.load(open(tmp_path / "d" / "docs.collection", "rb"))
+    # the reference's record layout (core/vector.py:121-128) in dict order: an overwritten id keeps its place
+    assert [r["id"] for r in data["vectors"]] == ["r0", "r2", "r3", "r4"]
+    assert set(data["vectors"][0]) == {"id", "vector", "metadata", "timestamp"} and data["vectors"][0]["metadata"] == {"i": 100}
+    assert data["config"]["dimension"] == 4 and data["config"]["metric"] == "cosine" and data["config"]["normalize_vectors"] is True
+    back = VectorDB.load(str(tmp_path / "d"))["docs"]
+    assert list(back._vectors) == ["r0", "r2", "r3", "r4"] and back.normalize and back.max_vectors == 10
+    np.testing.assert_array_equal(np.stack(list(back._vectors.values())), np.stack(list(c._vectors.values())))
+    assert back._bulk is not None
+    # the matrix form
+    arr = Collection.from_dict(c.to_dict(arrays=True))
+    np.testing.assert_array_equal(arr._bulk, np.stack(list(c._vectors.values())))
+    assert arr.get("r2")["metadata"] == {"i": 2}
+    with pytest.raises(ValidationError):
+        db.create_collection("bad name!", dimension=4)
+    with pytest.raises(StorageError, match="Manifest"):
+        (tmp_path / "empty").mkdir()
+        VectorDB.load(str(tmp_path / "empty"))
+    st = c.stats().to_dict()
+    assert st["vector_count"] == 4 and st["index_type"] == "flat" and st["memory_usage_bytes"] > 4 * 4 * 4
+
+
+def test_recommend_index_table():
+    """The values of index/__init__.py:120-170."""
+    from vectordb_amd.index import recommend_index
+    assert recommend_index(9999, 128) == {"index_type": "flat", "params": {}, "reason": "Dataset small enough for exact search"}
+    assert recommend_index(10000, 128, "speed")["params"] == {"M": 12, "ef_construction": 100, "ef_search": 32}
+    assert recommend_index(50000, 128, "recall")["params"] == {"M": 32, "ef_construction": 400, "ef_search": 200}
+    assert recommend_index(99999, 128)["params"] == {"M": 16, "ef_construction": 200, "ef_search": 64}
+    assert recommend_index(1_000_000, 128, "speed") == {"index_type": "ivf", "params": {"n_clusters": 4000, "n_probe": 40},
+                                                        "reason": "IVF optimized for speed on large datasets"}
+    assert recommend_index(1_000_000, 128, "recall")["index_type"] == "hnsw"
+    assert recommend_index(1_000_000, 128)["params"] == {"n_clusters": 4000, "n_probe": 200}
+    assert recommend_index(100_000, 64, "speed")["params"] == {"n_clusters": 1264, "n_probe": 12}
+
+
+def test_bulk_loaders_keep_list_order():
+    from vectordb_amd.index import IVFIndex, HybridIndex
+    data = {"index_type": "ivf", "dimension": 2, "metric": "euclidean", "config": {"n_clusters": 3, "n_probe": 2},
+            "is_trained": True, "centroids": [[0, 0], [1, 1], [2, 2]],
+            "inverted_lists": {"0": [{"id": "a", "vector": [0, 0.5], "metadata": {"k": 1}}, {"id": "b", "vector": [0.1, 0], "metadata": {}}],
+                               "2": [{"id": "c", "vector": [2, 2], "metadata": {}}], "1": []}}
+    idx = IVFIndex.from_dict(data)
+    assert idx.size == 3 and idx.get_vectors_in_cluster(0) == ["a", "b"] and idx.get_vectors_in_cluster(2) == ["c"]
+    assert idx._id_to_position == {"a": 0, "b": 1, "c": 0} and idx._metadata["a"] == {"k": 1}
+    np.testing.assert_array_equal(idx.get("b")[0], np.array([0.1, 0], dtype=np.float32))
+    assert idx.to_dict()["inverted_lists"]["0"][1]["id"] == "b"
+    hd = {"index_type": "ivf_pq", "dimension": 4, "metric": "euclidean", "config": {"n_clusters": 2, "n_probe": 1, "n_subvectors": 2, "n_bits": 2},
+          "inverted_lists": {"1": [{"id": "x", "codes": [1, 2], "metadata": {"m": 1}}, {"id": "y", "codes": [3, 0], "metadata": {}}],
+                             "0": [{"id": "z", "codes": [0, 0], "metadata": {}}]}}
+    h = HybridIndex.from_dict(hd)
+    assert h.size == 3 and h._row_ids == ["x", "y", "z"] and h._list_of_row[:3].tolist() == [1, 1, 0]
+    np.testing.assert_array_equal(h._codes_arr[:3], np.array([[1, 2], [3, 0], [0, 0]], dtype=np.uint8))

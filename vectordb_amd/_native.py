@@ -88,6 +88,10 @@ SIGNATURES = {
     "vdb_ivf_set_centroids": (C.c_int, [C.c_void_p, c_float_p, C.c_int]),
     "vdb_ivf_build": (C.c_int, [C.c_void_p, c_float_p, C.c_int64, c_i32_p]),
     "vdb_ivf_build_lists": (C.c_int, [C.c_void_p, c_float_p, C.c_int64, c_i64_p, c_i64_p]),
+    "vdb_ivf_build_numbered": (C.c_int, [C.c_void_p, c_float_p, C.c_int64, c_i64_p, c_i64_p]),
+    "vdb_ivf_append": (C.c_int, [C.c_void_p, c_float_p, c_i64_p, c_i32_p, C.c_int64]),
+    "vdb_ivf_remove_at": (C.c_int, [C.c_void_p, C.c_int32, C.c_int64]),
+    "vdb_ivf_layout": (C.c_int, [C.c_void_p, c_i64_p, c_i64_p, c_i64_p]),
     "vdb_ivf_search": (C.c_int, [C.c_void_p, c_float_p, C.c_int, C.c_int, C.c_int, c_u32_p, c_float_p, c_i64_p]),
     "vdb_ivf_search_dev": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p,
                                      C.c_void_p, C.c_void_p]),
@@ -114,6 +118,10 @@ SIGNATURES = {
     "vdb_ivfpq_set_quantizers": (C.c_int, [C.c_void_p, c_float_p, C.c_int, c_float_p]),
     "vdb_ivfpq_encode": (C.c_int, [C.c_void_p, c_float_p, C.c_int64, c_i32_p, c_u8_p]),
     "vdb_ivfpq_build": (C.c_int, [C.c_void_p, c_u8_p, C.c_int64, c_i64_p, c_i64_p]),
+    "vdb_ivfpq_build_numbered": (C.c_int, [C.c_void_p, c_u8_p, C.c_int64, c_i64_p, c_i64_p]),
+    "vdb_ivfpq_append": (C.c_int, [C.c_void_p, c_u8_p, c_i64_p, c_i32_p, C.c_int64]),
+    "vdb_ivfpq_remove_at": (C.c_int, [C.c_void_p, C.c_int32, C.c_int64]),
+    "vdb_ivfpq_layout": (C.c_int, [C.c_void_p, c_i64_p, c_i64_p, c_i64_p]),
     "vdb_ivfpq_search": (C.c_int, [C.c_void_p, c_float_p, C.c_int, C.c_int, C.c_int, c_u32_p, c_float_p, c_i64_p]),
     "vdb_ivfpq_search_dev": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p,
                                        C.c_void_p, C.c_void_p]),
@@ -511,6 +519,33 @@ class IvfLists:
         check(self.lib.vdb_ivf_build_lists(self.h, fptr(rows), len(rows), lr.ctypes.data_as(c_i64_p),
                                            lo.ctypes.data_as(c_i64_p)))
 
+    def build_numbered(self, rows: np.ndarray, row_numbers: np.ndarray, list_offsets: np.ndarray) -> None:
+        """Rows already in list order; ``row_numbers[i]`` is what searches return for row i and what a mask is indexed by."""
+        rows = f32(rows).reshape(-1, self.dim)
+        rn = np.ascontiguousarray(row_numbers, dtype=np.int64)
+        lo = np.ascontiguousarray(list_offsets, dtype=np.int64)
+        check(self.lib.vdb_ivf_build_numbered(self.h, fptr(rows), len(rows), rn.ctypes.data_as(c_i64_p),
+                                              lo.ctypes.data_as(c_i64_p)))
+
+    def append(self, rows: np.ndarray, row_numbers, lists) -> None:
+        """New rows behind the last row of their lists; the rest of the index stays where it is."""
+        rows = f32(rows).reshape(-1, self.dim)
+        rn = np.ascontiguousarray(row_numbers, dtype=np.int64).reshape(-1)
+        ls = np.ascontiguousarray(lists, dtype=np.int32).reshape(-1)
+        if not (len(rows) == len(rn) == len(ls)):
+            raise ValueError("rows, row numbers and lists must have one entry per row")
+        check(self.lib.vdb_ivf_append(self.h, fptr(rows), rn.ctypes.data_as(c_i64_p), ls.ctypes.data_as(c_i32_p), len(rows)))
+
+    def remove_at(self, list_no: int, position: int) -> None:
+        """The list's last row takes the place of the row at ``position``."""
+        check(self.lib.vdb_ivf_remove_at(self.h, int(list_no), int(position)))
+
+    def layout(self):
+        """(rows in lists, positions in use, positions lost to places that lists have left)"""
+        a, b, c = C.c_int64(0), C.c_int64(0), C.c_int64(0)
+        check(self.lib.vdb_ivf_layout(self.h, C.byref(a), C.byref(b), C.byref(c)))
+        return a.value, b.value, c.value
+
     def search(self, queries: np.ndarray, k: int, n_probe: int, mask_words=None):
         q = f32(queries)
         if q.ndim == 1:
@@ -663,6 +698,32 @@ class IvfPqLists:
         lo = np.ascontiguousarray(list_offsets, dtype=np.int64)
         check(self.lib.vdb_ivfpq_build(self.h, c.ctypes.data_as(c_u8_p), len(c), lr.ctypes.data_as(c_i64_p),
                                        lo.ctypes.data_as(c_i64_p)))
+
+    def build_numbered(self, codes: np.ndarray, row_numbers: np.ndarray, list_offsets: np.ndarray) -> None:
+        """Codes already in list order, a row number of the caller's choice for each."""
+        c = np.ascontiguousarray(codes, dtype=np.uint8).reshape(-1, self.m)
+        rn = np.ascontiguousarray(row_numbers, dtype=np.int64)
+        lo = np.ascontiguousarray(list_offsets, dtype=np.int64)
+        check(self.lib.vdb_ivfpq_build_numbered(self.h, c.ctypes.data_as(c_u8_p), len(c), rn.ctypes.data_as(c_i64_p),
+                                                lo.ctypes.data_as(c_i64_p)))
+
+    def append(self, codes: np.ndarray, row_numbers, lists) -> None:
+        c = np.ascontiguousarray(codes, dtype=np.uint8).reshape(-1, self.m)
+        rn = np.ascontiguousarray(row_numbers, dtype=np.int64).reshape(-1)
+        ls = np.ascontiguousarray(lists, dtype=np.int32).reshape(-1)
+        if not (len(c) == len(rn) == len(ls)):
+            raise ValueError("codes, row numbers and lists must have one entry per row")
+        check(self.lib.vdb_ivfpq_append(self.h, c.ctypes.data_as(c_u8_p), rn.ctypes.data_as(c_i64_p),
+                                        ls.ctypes.data_as(c_i32_p), len(c)))
+
+    def remove_at(self, list_no: int, position: int) -> None:
+        """The codes behind ``position`` move up by one, in their order."""
+        check(self.lib.vdb_ivfpq_remove_at(self.h, int(list_no), int(position)))
+
+    def layout(self):
+        a, b, c = C.c_int64(0), C.c_int64(0), C.c_int64(0)
+        check(self.lib.vdb_ivfpq_layout(self.h, C.byref(a), C.byref(b), C.byref(c)))
+        return a.value, b.value, c.value
 
     def search(self, queries: np.ndarray, k: int, n_probe: int, mask_words=None):
         q = f32(queries)

@@ -128,6 +128,24 @@ class MetadataFilter:
         return True
 
 
+@dataclass
+class CollectionStats:                                     # core/collection.py:75-100
+    name: str
+    dimension: int
+    metric: str
+    vector_count: int
+    index_type: str
+    memory_usage_bytes: int
+    created_at: float
+    updated_at: float
+
+    def to_dict(self) -> Dict[str, Any]:
+        return {"name": self.name, "dimension": self.dimension, "metric": self.metric, "vector_count": self.vector_count,
+                "index_type": self.index_type, "memory_usage_bytes": self.memory_usage_bytes,
+                "memory_usage_mb": round(self.memory_usage_bytes / (1024 * 1024), 2),
+                "created_at": self.created_at, "updated_at": self.updated_at}
+
+
 class Collection:
     """core/collection.py:302-828 (search path).
 
@@ -155,9 +173,19 @@ class Collection:
         self.enable_metadata_index = enable_metadata_index
         self._vectors: Dict[str, np.ndarray] = {}          # insertion-ordered, like the reference's dict of records
         self._metadata: Dict[str, Dict[str, Any]] = {}
-        self._matrix_dirty = True
-        self._ids: List[str] = []
+        # Device mirror of the reference's dense matrix (core/collection.py:809-828).  Row order = insertion order
+        # of the dict.  A write does not rebuild it: a new id goes behind the last row (uploaded with the other
+        # new rows at the next search), an overwritten id keeps its row, a deleted id leaves a dead row that every
+        # search masks out.  The rows are packed again once a quarter of them is dead.
+        self._matrix_dirty = True                           # full rebuild wanted
+        self._ids: List[Optional[str]] = []                 # row -> id (None: dead)
+        self._row_of: Dict[str, int] = {}
+        self._synced = 0                                    # rows [0, _synced) are on the device
+        self._n_dead = 0
+        self._alive = np.zeros(0, dtype=bool)
         self._store: Optional[N.RowStore] = None
+        self._bulk: Optional[np.ndarray] = None             # rows of a loaded collection, in dict order, not yet uploaded
+        self._timestamps: Dict[str, float] = {}
         self._created_at = self._updated_at = time.time()
 
     def __len__(self) -> int:
@@ -179,8 +207,15 @@ class Collection:
         existed = id in self._vectors
         self._vectors[id] = vector
         self._metadata[id] = dict(metadata or {})
-        self._matrix_dirty = True
-        self._updated_at = time.time()
+        self._updated_at = self._timestamps[id] = time.time()
+        if not self._matrix_dirty:
+            if existed:                                     # the dict keeps the position of an existing key
+                row = self._row_of[id]
+                if row < self._synced:
+                    self._store.set_row(row, vector)
+            else:
+                self._row_of[id] = len(self._ids)
+                self._ids.append(id)
         if self._index is not None:
             try:
                 if existed:
@@ -215,7 +250,15 @@ class Collection:
         if id not in self._vectors:
             return False
         del self._vectors[id], self._metadata[id]
-        self._matrix_dirty = True
+        self._timestamps.pop(id, None)
+        if not self._matrix_dirty:
+            row = self._row_of.pop(id)
+            self._ids[row] = None
+            self._n_dead += 1
+            if row < len(self._alive):
+                self._alive[row] = False
+            if self._n_dead > max(1024, len(self._ids) // 4):
+                self._matrix_dirty = True                   # pack the rows again at the next search
         if self._index is not None:
             try:
                 self._index.remove(id)
@@ -225,7 +268,7 @@ class Collection:
 
     def clear(self) -> int:
         n = len(self._vectors)
-        self._vectors.clear(); self._metadata.clear()
+        self._vectors.clear(); self._metadata.clear(); self._timestamps.clear()
         self._matrix_dirty = True
         self._drop_index()
         return n
@@ -269,30 +312,54 @@ class Collection:
 
     # ------------------------------------------------------------ search
     def _ensure_matrix(self) -> None:
-        """core/collection.py:809-828: rebuild the dense matrix (here: the
-        device mirror) after any write; row order = insertion order."""
-        if not self._matrix_dirty and self._store is not None:
-            return
+        """Bring the device mirror up to date: everything after a rebuild request, otherwise only the rows added
+        since the last search."""
         if self._store is None:
             self._store = N.RowStore(self.dimension)
-        self._store.truncate(0)
-        self._ids = list(self._vectors.keys())
-        if self._ids:
-            self._store.append(np.stack([self._vectors[i] for i in self._ids]).astype(np.float32))
-        self._matrix_dirty = False
+            self._matrix_dirty = True
+        if self._matrix_dirty:
+            self._store.truncate(0)
+            self._ids = list(self._vectors.keys())
+            self._row_of = {id: r for r, id in enumerate(self._ids)}
+            self._synced = 0
+            self._n_dead = 0
+            self._alive = np.zeros(0, dtype=bool)
+            self._matrix_dirty = False
+        n = len(self._ids)
+        if self._synced < n:
+            # a row that was added and deleted between two searches goes up as zeros and stays masked
+            if self._synced == 0 and self._bulk is not None and len(self._bulk) == n and self._n_dead == 0:
+                tail = self._bulk                           # a loaded collection nobody has written to: its matrix as it is
+            else:
+                zero = np.zeros(self.dimension, dtype=np.float32)
+                tail = np.stack([self._vectors[i] if i is not None else zero
+                                 for i in self._ids[self._synced:]]).astype(np.float32)
+            self._bulk = None
+            self._store.append(tail)
+            alive = np.ones(n, dtype=bool)
+            alive[:len(self._alive)] = self._alive
+            for r in range(self._synced, n):
+                if self._ids[r] is None:
+                    alive[r] = False
+            self._alive = alive
+            self._synced = n
 
     def _search_device(self, queries: np.ndarray, k: int, filter: Optional[Dict[str, Any]]):
         if self.metric not in _QUERY_METRICS:
             raise ValueError(f"Unknown metric: {self.metric}")
         self._ensure_matrix()
-        words = None
+        mask = None
         if filter and self.enable_metadata_index:
             pred = MetadataFilter(filter)
-            mask = np.fromiter((pred(self._metadata[i]) for i in self._ids), dtype=bool, count=len(self._ids))
+            mask = np.fromiter((i is not None and pred(self._metadata[i]) for i in self._ids), dtype=bool, count=len(self._ids))
+        elif self._n_dead:
+            mask = self._alive
+        words = None
+        if mask is not None:
             if not mask.any():
                 return None
             words = N.pack_mask(mask)
-        k = min(k, len(self._ids))
+        k = min(k, len(self._vectors))
         return self._store.search(queries, k, _QUERY_METRICS[self.metric], words)
 
     def _results(self, dist_row, rows_row, include_vector: bool, include_metadata: bool) -> List[SearchResult]:
@@ -342,6 +409,71 @@ class Collection:
         if found is None:
             return [[] for _ in range(len(qs))]
         return [self._results(found[0][i], found[1][i], include_vector, True) for i in range(len(qs))]
+
+    # ------------------------------------------------------------ statistics and serialisation
+    def stats(self) -> CollectionStats:
+        """core/collection.py:953-976"""
+        memory = 0
+        if self._vectors:
+            memory += len(self._vectors) * self.dimension * 4
+            memory += sum(len(str(m)) for m in self._metadata.values())
+            memory += sum(len(i) for i in self._vectors.keys())
+        return CollectionStats(name=self.name, dimension=self.dimension, metric=self.metric, vector_count=len(self._vectors),
+                               index_type=self.index_type or "flat", memory_usage_bytes=memory,
+                               created_at=self._created_at, updated_at=self._updated_at)
+
+    def to_dict(self, arrays: bool = False) -> Dict[str, Any]:
+        """core/collection.py:998-1020: name, config, one record per row, timestamps.  With ``arrays=True`` the
+        records carry no ``"vector"`` lists; the rows are one float32 matrix under ``"matrix"`` instead (same
+        order), which is what a load hands to the device in one piece."""
+        ids = list(self._vectors.keys())
+        out = {"name": self.name,
+               "config": {"dimension": self.dimension, "metric": self.metric, "index_type": self.index_type or "flat",
+                          "normalize_vectors": self.normalize, "max_vectors": self.max_vectors,
+                          "enable_metadata_index": self.enable_metadata_index, "index_params": dict(self._index_params)},
+               "created_at": self._created_at, "updated_at": self._updated_at}
+        if arrays:
+            out["matrix"] = (np.stack([self._vectors[i] for i in ids]).astype(np.float32) if ids
+                             else np.zeros((0, self.dimension), dtype=np.float32))
+            out["vectors"] = [{"id": i, "metadata": self._metadata[i], "timestamp": self._timestamps.get(i, self._created_at)}
+                              for i in ids]
+        else:
+            out["vectors"] = [{"id": i, "vector": self._vectors[i].tolist(), "metadata": self._metadata[i],
+                               "timestamp": self._timestamps.get(i, self._created_at)} for i in ids]
+        return out
+
+    @classmethod
+    def from_dict(cls, data: Dict[str, Any]) -> "Collection":
+        """core/collection.py:1022-1055.  The rows become one matrix; the first search uploads it whole."""
+        config = data["config"]
+        index_type = config.get("index_type")
+        params = config.get("index_params") or {}
+        col = cls(name=data["name"], dimension=config["dimension"], metric=config["metric"],
+                  normalize=config.get("normalize_vectors", False), max_vectors=config.get("max_vectors"),
+                  enable_metadata_index=config.get("enable_metadata_index", True),
+                  index_type=index_type if (index_type and index_type != "flat") else None,
+                  index_params=params if (index_type and index_type != "flat") else None)
+        records = data.get("vectors", [])
+        if "matrix" in data:
+            matrix = np.ascontiguousarray(data["matrix"], dtype=np.float32).reshape(len(records), config["dimension"])
+        elif records:
+            matrix = np.array([r["vector"] for r in records], dtype=np.float32).reshape(len(records), config["dimension"])
+        else:
+            matrix = np.zeros((0, config["dimension"]), dtype=np.float32)
+        now = time.time()
+        for i, r in enumerate(records):
+            col._vectors[r["id"]] = matrix[i]
+            col._metadata[r["id"]] = dict(r.get("metadata") or {})
+            col._timestamps[r["id"]] = r.get("timestamp", now)
+        if len(col._vectors) == len(records):               # no duplicate ids: dict order is matrix order
+            col._bulk = matrix
+        col._matrix_dirty = True
+        col._created_at = data.get("created_at", now)
+        col._updated_at = data.get("updated_at", now)
+        return col
+
+    def __repr__(self) -> str:
+        return f"Collection(name='{self.name}', dimension={self.dimension}, count={len(self)}, metric='{self.metric}')"
 
     def __del__(self):
         store = getattr(self, "_store", None)

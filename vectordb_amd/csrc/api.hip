@@ -9,6 +9,7 @@
 #include <functional>
 #include <limits>
 #include <numeric>
+#include <unordered_map>
 
 namespace vdb {
 
@@ -667,27 +668,99 @@ static int with_host_io(Workspace& ws, const float* queries, int nq, int dim, in
     return VDB_OK;
 }
 
+// ============================================================== where inverted lists live
+// After a build the lists are packed one behind the other in list order.  A list that outgrows its place is moved to
+// the end of the position space with twice the room; the place it leaves is dead until the next build.  Appending a
+// row therefore touches one list (amortised: one row), never the whole index.
+struct ListMove { int64_t from, to, count; };
+struct ListLayout {
+    int n_lists = 0;
+    std::vector<int64_t> beg, len, cap;
+    int64_t tail = 0;           // positions handed out: rows, free room and dead places
+    int64_t live = 0;           // rows in lists
+    int64_t dead = 0;           // positions in abandoned places
+    int64_t row_limit = 0;      // 1 + the largest row number stored: the length of a filter mask
+    DevBuf dev;                 // int64 [2 * n_lists]: where every list begins, then where it ends
+    std::vector<int64_t> staged;
+    bool dev_stale = true;
+    std::vector<int64_t> len_desc;      // list lengths at the last sort, longest first
+    int64_t grown_since_sort = 0;
+
+    void reset(int n) {
+        n_lists = n;
+        beg.assign(n, 0); len.assign(n, 0); cap.assign(n, 0);
+        tail = live = dead = row_limit = 0;
+        dev_stale = true;
+        len_desc.clear();
+        grown_since_sort = 0;
+    }
+    void set_packed(const int64_t* offsets) {
+        for (int l = 0; l < n_lists; ++l) { beg[l] = offsets[l]; len[l] = cap[l] = offsets[l + 1] - offsets[l]; }
+        tail = live = offsets[n_lists];
+        dead = 0;
+        dev_stale = true;
+        len_desc.clear();
+        grown_since_sort = 0;
+    }
+    const int64_t* d_beg() const { return dev.as<int64_t>(); }
+    const int64_t* d_end() const { return dev.as<int64_t>() + n_lists; }
+    int sync(hipStream_t s) {
+        if (!dev_stale) return VDB_OK;
+        staged.resize((size_t)2 * n_lists);
+        for (int l = 0; l < n_lists; ++l) { staged[l] = beg[l]; staged[(size_t)n_lists + l] = beg[l] + len[l]; }
+        VDB_TRY(dev.reserve(staged.size() * sizeof(int64_t)));
+        VDB_HIP(hipMemcpyAsync(dev.p, staged.data(), staged.size() * sizeof(int64_t), hipMemcpyHostToDevice, s));
+        VDB_HIP(hipStreamSynchronize(s));      // `staged` is pageable and is rewritten by the next call
+        dev_stale = false;
+        return VDB_OK;
+    }
+    // an upper bound of the rows in the n_probe longest lists (the most candidates one query can have): exact at
+    // the last sort, plus everything appended since
+    int64_t probe_bound(int n_probe) {
+        if (len_desc.size() != (size_t)n_lists || grown_since_sort > std::max<int64_t>(4096, live / 16)) {
+            len_desc.assign(len.begin(), len.end());
+            std::sort(len_desc.begin(), len_desc.end(), std::greater<int64_t>());
+            grown_since_sort = 0;
+        }
+        int64_t t = grown_since_sort;
+        for (int i = 0; i < std::min(n_probe, n_lists); ++i) t += len_desc[i];
+        return t;
+    }
+    // positions for `count` new rows (dst[i] for the row that goes to lists[i]) and the lists that have to move first
+    int plan_append(const int32_t* lists, int64_t count, std::vector<int64_t>& dst, std::vector<ListMove>& moves) {
+        std::unordered_map<int, int64_t> need;
+        for (int64_t i = 0; i < count; ++i) {
+            VDB_REQUIRE(lists[i] >= 0 && lists[i] < n_lists, "list number %d out of range", lists[i]);
+            ++need[lists[i]];
+        }
+        for (const auto& kv : need) {
+            const int l = kv.first;
+            if (len[l] + kv.second <= cap[l]) continue;
+            const int64_t room = std::max<int64_t>(16, 2 * (len[l] + kv.second));
+            if (len[l] > 0) moves.push_back(ListMove{beg[l], tail, len[l]});
+            dead += cap[l];
+            beg[l] = tail; cap[l] = room;
+            tail += room;
+        }
+        dst.resize((size_t)count);
+        for (int64_t i = 0; i < count; ++i) dst[(size_t)i] = beg[lists[i]] + len[lists[i]]++;
+        live += count;
+        grown_since_sort += count;
+        dev_stale = true;
+        return VDB_OK;
+    }
+};
+
 // ============================================================== IVF handle
 struct vdb_ivf : Handle {
     int dim = 0, metric = 0;
     vdb_rows* centroids = nullptr;      // n_lists rows
-    vdb_rows* members = nullptr;        // all rows, stored in list order
-    DevBuf list_off;                    // int64 [n_lists + 1]
-    DevBuf row_ids;                     // int   [n]  row number of every stored position
-    std::vector<int64_t> h_list_off;
-    std::vector<int64_t> len_desc;      // list lengths, longest first
+    vdb_rows* members = nullptr;        // the rows of every list, at the positions `lay` names
+    ListLayout lay;
+    DevBuf row_ids;                     // int   [positions]  row number of every stored position
+    DevBuf app_rows, app_sq, app_nrm, app_dst, app_no;     // staging of appended rows
     int n_lists = 0;
-    // rows in the n_probe longest lists: the most candidates one query can have
-    int64_t probe_bound(int n_probe) {
-        if (len_desc.size() != (size_t)n_lists) {
-            len_desc.resize(n_lists);
-            for (int l = 0; l < n_lists; ++l) len_desc[l] = h_list_off[l + 1] - h_list_off[l];
-            std::sort(len_desc.begin(), len_desc.end(), std::greater<int64_t>());
-        }
-        int64_t t = 0;
-        for (int i = 0; i < std::min(n_probe, n_lists); ++i) t += len_desc[i];
-        return t;
-    }
+    int64_t probe_bound(int n_probe) { return lay.probe_bound(n_probe); }
     int64_t last_scan_rows = -1;
     int last_nq = 0, last_nprobe = 0;
     hipStream_t last_stream = nullptr;  // stream of the last search (its probe lists are read back for the statistics)
@@ -1402,7 +1475,8 @@ int vdb_ivf_destroy(vdb_ivf* h) {
         Entry g(h);
         (void)hipStreamSynchronize(h->stream);
         if (h->last_stream && h->last_stream != h->stream) (void)hipStreamSynchronize(h->last_stream);
-        h->list_off.release(); h->row_ids.release(); h->ws.release();
+        h->lay.dev.release(); h->row_ids.release(); h->ws.release();
+        h->app_rows.release(); h->app_sq.release(); h->app_nrm.release(); h->app_dst.release(); h->app_no.release();
     }
     vdb_rows_destroy(h->centroids);
     vdb_rows_destroy(h->members);
@@ -1417,44 +1491,52 @@ int vdb_ivf_set_centroids(vdb_ivf* h, const float* centroids, int n_lists) {
     VDB_TRY(vdb_rows_truncate(h->centroids, 0));
     VDB_TRY(vdb_rows_append(h->centroids, centroids, n_lists));
     h->n_lists = n_lists;
-    h->h_list_off.assign(n_lists + 1, 0);
-    h->len_desc.clear();
+    h->lay.reset(n_lists);
     VDB_TRY(vdb_rows_truncate(h->members, 0));
     return VDB_OK;
 }
 
-int vdb_ivf_build_lists(vdb_ivf* h, const float* rows, int64_t n, const int64_t* list_rows, const int64_t* list_offsets) {
+// rows[gather[i]] becomes the row at position i and answers to the row number numbers[i]
+static int ivf_build_impl(vdb_ivf* h, const float* rows, int64_t n, const int64_t* gather, int64_t n_src, const int64_t* numbers,
+                          const int64_t* list_offsets) {
     VDB_REQUIRE(h && h->n_lists >= 1, "centroids must be set before the lists are built");
-    VDB_REQUIRE(n >= 0 && (n == 0 || (rows && list_rows)) && list_offsets, "bad arguments to vdb_ivf_build_lists");
+    VDB_REQUIRE(n >= 0 && (n == 0 || (rows && numbers)) && list_offsets, "bad arguments to the list build");
     VDB_REQUIRE(list_offsets[0] == 0 && list_offsets[h->n_lists] == n, "list offsets do not cover %lld rows", (long long)n);
     VDB_REQUIRE(n < (int64_t)0x7fffffff, "at most 2^31-1 rows per device");
     for (int l = 0; l < h->n_lists; ++l)
         VDB_REQUIRE(list_offsets[l] <= list_offsets[l + 1], "list offsets must be non-decreasing");
-    std::vector<int> perm((size_t)n);
+    std::vector<int> perm((size_t)n), nums((size_t)n);
+    int64_t row_limit = 0;
     for (int64_t i = 0; i < n; ++i) {
-        VDB_REQUIRE(list_rows[i] >= 0 && list_rows[i] < n, "row number %lld out of range", (long long)list_rows[i]);
-        perm[(size_t)i] = (int)list_rows[i];
+        const int64_t g = gather ? gather[i] : i;
+        VDB_REQUIRE(g >= 0 && g < n_src, "row %lld out of range", (long long)g);
+        VDB_REQUIRE(numbers[i] >= 0 && numbers[i] < (int64_t)0x7fffffff, "row number %lld out of range", (long long)numbers[i]);
+        perm[(size_t)i] = (int)g;
+        nums[(size_t)i] = (int)numbers[i];
+        row_limit = std::max(row_limit, numbers[i] + 1);
     }
     Entry g(h);
     hipStream_t s = h->stream;
     vdb_rows* m = h->members;
     m->r.n = 0;
-    h->h_list_off.assign(list_offsets, list_offsets + h->n_lists + 1);
-    h->len_desc.clear();
-    VDB_TRY(h->list_off.reserve((size_t)(h->n_lists + 1) * sizeof(int64_t)));
-    VDB_HIP(hipMemcpyAsync(h->list_off.p, list_offsets, (size_t)(h->n_lists + 1) * sizeof(int64_t), hipMemcpyHostToDevice, s));
-    if (n == 0) { VDB_HIP(hipStreamSynchronize(s)); return VDB_OK; }
+    h->lay.set_packed(list_offsets);
+    h->lay.row_limit = row_limit;
+    VDB_TRY(h->lay.sync(s));
+    if (n == 0) return VDB_OK;
     VDB_TRY(h->row_ids.reserve((size_t)n * sizeof(int)));
-    VDB_HIP(hipMemcpyAsync(h->row_ids.p, perm.data(), (size_t)n * sizeof(int), hipMemcpyHostToDevice, s));
-    VDB_TRY(rows_reserve(m, n, s));
-    // rows up in insertion order, gathered into list order on the device
-    DevBuf raw;
-    int st = raw.reserve((size_t)n * h->dim * sizeof(float));
+    // a list's 256-row chunks start anywhere, so the buffer keeps 256 rows of room behind the last position
+    VDB_TRY(rows_reserve(m, n + 256, s));
+    // rows up in the caller's order, gathered into list order on the device
+    DevBuf raw, d_perm;
+    int st = raw.reserve((size_t)n_src * h->dim * sizeof(float));
+    if (st == VDB_OK) st = d_perm.reserve((size_t)n * sizeof(int));
     if (st == VDB_OK) {
         auto body = [&]() -> int {
-            VDB_HIP(hipMemcpyAsync(raw.p, rows, (size_t)n * h->dim * sizeof(float), hipMemcpyHostToDevice, s));
+            VDB_HIP(hipMemcpyAsync(h->row_ids.p, nums.data(), (size_t)n * sizeof(int), hipMemcpyHostToDevice, s));
+            VDB_HIP(hipMemcpyAsync(d_perm.p, perm.data(), (size_t)n * sizeof(int), hipMemcpyHostToDevice, s));
+            VDB_HIP(hipMemcpyAsync(raw.p, rows, (size_t)n_src * h->dim * sizeof(float), hipMemcpyHostToDevice, s));
             hipLaunchKernelGGL(pad_rows_kernel, dim3(grid_for(n * m->r.ld)), dim3(256), 0, s, raw.as<float>(), (int64_t)h->dim,
-                               h->dim, n, h->row_ids.as<int>(), m->r.data, m->r.ld);
+                               h->dim, n, d_perm.as<int>(), m->r.data, m->r.ld);
             VDB_HIP(hipGetLastError());
             VDB_TRY(row_norms(m->ws, m->r.data, m->r.ld, m->r.dim, n, m->r.plan, m->r.sq, m->r.nrm, s));
             VDB_HIP(hipStreamSynchronize(s));
@@ -1462,9 +1544,126 @@ int vdb_ivf_build_lists(vdb_ivf* h, const float* rows, int64_t n, const int64_t*
         };
         st = body();
     }
-    raw.release();
+    raw.release(); d_perm.release();
     if (st == VDB_OK) m->r.n = n;
     return st;
+}
+
+int vdb_ivf_build_lists(vdb_ivf* h, const float* rows, int64_t n, const int64_t* list_rows, const int64_t* list_offsets) {
+    VDB_REQUIRE(n == 0 || list_rows, "bad arguments to vdb_ivf_build_lists");
+    return ivf_build_impl(h, rows, n, list_rows, n, list_rows, list_offsets);
+}
+
+int vdb_ivf_build_numbered(vdb_ivf* h, const float* rows, int64_t n, const int64_t* row_numbers, const int64_t* list_offsets) {
+    return ivf_build_impl(h, rows, n, nullptr, n, row_numbers, list_offsets);
+}
+
+// one thread per float of the padded destination rows
+__global__ void ivf_scatter_rows_kernel(const float* __restrict__ src, int ld, int64_t count, const int64_t* __restrict__ dst,
+                                        const int* __restrict__ numbers, const float* __restrict__ sq, const float* __restrict__ nrm,
+                                        float* __restrict__ data, float* __restrict__ osq, float* __restrict__ onrm,
+                                        int* __restrict__ row_ids) {
+    const int64_t total = count * ld;
+    for (int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; t < total; t += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t i = t / ld;
+        const int c = (int)(t - i * ld);
+        const int64_t d = dst[i];
+        data[d * ld + c] = src[t];
+        if (c == 0) { osq[d] = sq[i]; onrm[d] = nrm[i]; row_ids[d] = numbers[i]; }
+    }
+}
+
+__global__ void ivf_move_rows_kernel(float* __restrict__ data, float* __restrict__ sq, float* __restrict__ nrm, int* __restrict__ row_ids,
+                                     int ld, int64_t from, int64_t to, int64_t count) {
+    const int64_t total = count * ld;
+    for (int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; t < total; t += (int64_t)gridDim.x * blockDim.x) {
+        data[to * ld + t] = data[from * ld + t];
+        if (t < count) { sq[to + t] = sq[from + t]; nrm[to + t] = nrm[from + t]; row_ids[to + t] = row_ids[from + t]; }
+    }
+}
+
+int vdb_ivf_append(vdb_ivf* h, const float* rows, const int64_t* row_numbers, const int32_t* lists, int64_t count) {
+    VDB_REQUIRE(h && h->n_lists >= 1, "centroids must be set before rows are appended");
+    VDB_REQUIRE(count >= 0 && (count == 0 || (rows && row_numbers && lists)), "bad arguments to vdb_ivf_append");
+    if (count == 0) return VDB_OK;
+    std::vector<int> nums((size_t)count);
+    int64_t row_limit = h->lay.row_limit;
+    for (int64_t i = 0; i < count; ++i) {
+        VDB_REQUIRE(row_numbers[i] >= 0 && row_numbers[i] < (int64_t)0x7fffffff, "row number %lld out of range", (long long)row_numbers[i]);
+        nums[(size_t)i] = (int)row_numbers[i];
+        row_limit = std::max(row_limit, row_numbers[i] + 1);
+    }
+    Entry g(h);
+    hipStream_t s = h->stream;
+    vdb_rows* m = h->members;
+    Rows& r = m->r;
+    ListLayout& lay = h->lay;
+    std::vector<int64_t> dst;
+    std::vector<ListMove> moves;
+    const int64_t old_tail = lay.tail;
+    VDB_TRY(lay.plan_append(lists, count, dst, moves));
+    VDB_REQUIRE(lay.tail < (int64_t)0x7fffffff, "at most 2^31-1 positions per device");
+    lay.row_limit = row_limit;
+    // room for every position handed out so far (the rows behind r.n are kept when the buffers grow)
+    r.n = old_tail;
+    VDB_TRY(rows_reserve(m, lay.tail + 256, s));     // 256 rows of room behind the last position, as after a build
+    VDB_TRY(h->row_ids.reserve_keep((size_t)r.cap * sizeof(int), (size_t)old_tail * sizeof(int), s));
+    r.n = lay.tail;
+    for (const ListMove& mv : moves) {
+        hipLaunchKernelGGL(ivf_move_rows_kernel, dim3(grid_for(mv.count * r.ld)), dim3(256), 0, s, r.data, r.sq, r.nrm,
+                           h->row_ids.as<int>(), r.ld, mv.from, mv.to, mv.count);
+    }
+    VDB_HIP(hipGetLastError());
+    // the new rows: padded copy, norms in the order every other row's norms were summed in, then into their places
+    Workspace& ws = h->ws;
+    VDB_TRY(ws.stage.reserve((size_t)count * h->dim * sizeof(float)));
+    VDB_TRY(h->app_rows.reserve((size_t)count * r.ld * sizeof(float)));
+    VDB_TRY(h->app_sq.reserve((size_t)count * sizeof(float)));
+    VDB_TRY(h->app_nrm.reserve((size_t)count * sizeof(float)));
+    VDB_TRY(h->app_dst.reserve((size_t)count * sizeof(int64_t)));
+    VDB_TRY(h->app_no.reserve((size_t)count * sizeof(int)));
+    VDB_HIP(hipMemcpyAsync(ws.stage.p, rows, (size_t)count * h->dim * sizeof(float), hipMemcpyHostToDevice, s));
+    VDB_HIP(hipMemcpyAsync(h->app_dst.p, dst.data(), (size_t)count * sizeof(int64_t), hipMemcpyHostToDevice, s));
+    VDB_HIP(hipMemcpyAsync(h->app_no.p, nums.data(), (size_t)count * sizeof(int), hipMemcpyHostToDevice, s));
+    hipLaunchKernelGGL(pad_rows_kernel, dim3(grid_for(count * r.ld)), dim3(256), 0, s, ws.stage.as<float>(), (int64_t)h->dim, h->dim,
+                       count, (const int*)nullptr, h->app_rows.as<float>(), r.ld);
+    VDB_HIP(hipGetLastError());
+    VDB_TRY(row_norms(m->ws, h->app_rows.as<float>(), r.ld, r.dim, count, r.plan, h->app_sq.as<float>(), h->app_nrm.as<float>(), s));
+    hipLaunchKernelGGL(ivf_scatter_rows_kernel, dim3(grid_for(count * r.ld)), dim3(256), 0, s, h->app_rows.as<float>(), r.ld, count,
+                       h->app_dst.as<int64_t>(), h->app_no.as<int>(), h->app_sq.as<float>(), h->app_nrm.as<float>(), r.data, r.sq,
+                       r.nrm, h->row_ids.as<int>());
+    VDB_HIP(hipGetLastError());
+    VDB_HIP(hipStreamSynchronize(s));          // the host vectors above are pageable
+    return VDB_OK;
+}
+
+int vdb_ivf_remove_at(vdb_ivf* h, int32_t list, int64_t position) {
+    VDB_REQUIRE(h && list >= 0 && list < h->n_lists, "bad list number");
+    Entry g(h);
+    ListLayout& lay = h->lay;
+    VDB_REQUIRE(position >= 0 && position < lay.len[list], "position %lld is not in list %d (%lld rows)", (long long)position, list,
+                (long long)lay.len[list]);
+    Rows& r = h->members->r;
+    const int64_t last = lay.len[list] - 1;
+    // the list's last row takes the place of the removed one (index/ivf.py:708-745)
+    if (position < last) {
+        hipLaunchKernelGGL(ivf_move_rows_kernel, dim3(1), dim3(256), 0, h->stream, r.data, r.sq, r.nrm, h->row_ids.as<int>(), r.ld,
+                           lay.beg[list] + last, lay.beg[list] + position, (int64_t)1);
+        VDB_HIP(hipGetLastError());
+    }
+    --lay.len[list];
+    --lay.live;
+    lay.dev_stale = true;
+    return VDB_OK;
+}
+
+int vdb_ivf_layout(vdb_ivf* h, int64_t* live_rows, int64_t* positions, int64_t* dead_positions) {
+    VDB_REQUIRE(h, "null handle");
+    Entry g(h);
+    if (live_rows) *live_rows = h->lay.live;
+    if (positions) *positions = h->lay.tail;
+    if (dead_positions) *dead_positions = h->lay.dead;
+    return VDB_OK;
 }
 
 int vdb_ivf_build(vdb_ivf* h, const float* rows, int64_t n, const int32_t* list_of_row) {
@@ -1510,9 +1709,10 @@ static int ivf_search_impl(vdb_ivf* h, const float* d_q, int nq, int k, int n_pr
     Workspace& ws = h->ws;
     VDB_TRY(fill_results(d_out_d, d_out_i, (int64_t)nq * k, s));
     if (d_out_order) VDB_TRY(fill_results(nullptr, d_out_order, (int64_t)nq * k, s));
-    if (m->r.n == 0) return VDB_OK;
+    if (h->lay.live == 0) return VDB_OK;
+    VDB_TRY(h->lay.sync(s));
 
-    const int64_t k_eff = std::min<int64_t>(k, m->r.n);
+    const int64_t k_eff = std::min<int64_t>(k, h->lay.live);
     const int kmax = (int)std::min<int64_t>(KMAX_FUSED, k_eff);
     const bool multi = k_eff > KMAX_FUSED;
     const int sm = scan_metric_of(h->metric);
@@ -1546,19 +1746,19 @@ static int ivf_search_impl(vdb_ivf* h, const float* d_q, int nq, int k, int n_pr
         VDB_TRY(ws.lb_d.reserve((size_t)q_block * sizeof(float)));
         VDB_TRY(ws.lb_k.reserve((size_t)q_block * sizeof(int64_t)));
     }
-    const int64_t avg_tiles = std::max<int64_t>(1, ((int64_t)n_probe * (m->r.n / std::max(1, h->n_lists)) + 255) / 256);
+    const int64_t avg_tiles = std::max<int64_t>(1, ((int64_t)n_probe * (h->lay.live / std::max(1, h->n_lists)) + 255) / 256);
 
     for (int q0 = 0; q0 < nq; q0 += q_block) {
         const int nb = std::min(q_block, nq - q0);
         const int* probes = ws.probes.as<int>() + (int64_t)q0 * n_probe;
-        VDB_TRY(launch_ivf_plan(probes, nb, n_probe, h->list_off.as<int64_t>(), h->n_lists, group, cand_stride,
+        VDB_TRY(launch_ivf_plan(probes, nb, n_probe, h->lay.d_beg(), h->lay.d_end(), h->n_lists, group, cand_stride,
                                 ws.list_cnt.as<int>(), ws.cursor.as<int>(), ws.cand_off.as<int64_t>(), ws.tile_off.as<int>(), b, s));
         StreamJob j{};
         j.data = m->r.data; j.ld = m->r.ld; j.dim = m->r.dim; j.plan = m->r.plan;
         j.op = op_of_metric(sm); j.post = post_of_metric(sm);
         if (j.post == POST_SQRT) j.post = POST_NONE;      // the selection below takes the root (CandJob::sqrt_here)
         j.q = q + (int64_t)q0 * m->r.ld; j.ldq = m->r.ld; j.group = group; j.n_seg = h->n_lists;
-        j.seg_row_off = h->list_off.as<int64_t>(); j.seg_q_off = b.seg_q_off; j.seg_item_off = b.seg_item_off;
+        j.seg_row_off = h->lay.d_beg(); j.seg_q_off = b.seg_q_off; j.seg_item_off = b.seg_item_off;
         j.sq_qid = b.sq_qid; j.sq_out = b.sq_out; j.items = b.items; j.items_cap = b.items_cap;
         j.out = ws.cand.as<float>(); j.timed = true;
         VDB_TRY(launch_stream_sums(j, s));
@@ -1571,7 +1771,7 @@ static int ivf_search_impl(vdb_ivf* h, const float* d_q, int nq, int k, int n_pr
             const int kk = (int)std::min<int64_t>(KMAX_FUSED, k_eff - done);
             CandJob c{};
             c.cand = ws.cand.as<float>(); c.cand_stride = cand_stride; c.nq = nb; c.n = 0;
-            c.probes = probes; c.n_probe = n_probe; c.n_lists = h->n_lists; c.list_off = h->list_off.as<int64_t>();
+            c.probes = probes; c.n_probe = n_probe; c.n_lists = h->n_lists; c.list_beg = h->lay.d_beg(); c.list_end = h->lay.d_end();
             c.cand_off = ws.cand_off.as<int64_t>(); c.tile_off = ws.tile_off.as<int>();
             c.row_ids = h->row_ids.as<int>(); c.mask = d_mask;
             c.sqrt_here = true;
@@ -1584,7 +1784,7 @@ static int ivf_search_impl(vdb_ivf* h, const float* d_q, int nq, int k, int n_pr
                         multi ? ws.lb_d.as<float>() : nullptr, multi ? ws.lb_k.as<int64_t>() : nullptr};
             VDB_TRY(launch_select(ws.part_d.as<float>(), ws.part_i.as<int>(), nb, n_cand, kk, 1 << 30, nullptr, 0, o, s, ws.mid));
             VDB_TRY(launch_ivf_rows(ws.slots.as<int>() + (int64_t)q0 * k, nb, kk, k, (int)done, probes, n_probe, h->n_lists,
-                                    ws.cand_off.as<int64_t>(), h->list_off.as<int64_t>(), h->row_ids.as<int>(),
+                                    ws.cand_off.as<int64_t>(), h->lay.d_beg(), h->row_ids.as<int>(),
                                     d_out_i + (int64_t)q0 * k, d_out_order ? d_out_order + (int64_t)q0 * k : nullptr, s));
         }
     }
@@ -1612,7 +1812,7 @@ int vdb_ivf_search(vdb_ivf* h, const float* queries, int nq, int k, int n_probe,
     Entry g(h);
     hipStream_t s = h->stream;
     const uint32_t* d_mask = nullptr;
-    VDB_TRY(upload_mask(h->ws, mask, h->members->r.n, &d_mask, s));
+    VDB_TRY(upload_mask(h->ws, mask, h->lay.row_limit, &d_mask, s));
     return with_host_io(h->members->ws, queries, nq, h->dim, k, out_dist, out_row, s,
                         [&](const float* dq, float* dd, int64_t* di) {
                             return ivf_search_impl(h, dq, nq, k, n_probe, d_mask, dd, di, nullptr, s);
@@ -1651,7 +1851,7 @@ int vdb_ivf_last_scan_rows(vdb_ivf* h, int64_t* rows_scanned) {
     VDB_HIP(hipStreamSynchronize(s));
     int64_t total = 0;
     for (int l : probes)
-        if (l >= 0 && l < h->n_lists) total += h->h_list_off[l + 1] - h->h_list_off[l];
+        if (l >= 0 && l < h->n_lists) total += h->lay.len[l];
     *rows_scanned = total;
     return VDB_OK;
 }
@@ -1882,25 +2082,15 @@ struct vdb_ivfpq : Handle {
     SumPlan plan;                       // over one sub-vector
     vdb_rows* centroids = nullptr;      // coarse centroids
     DevBuf book;                        // float [m][ksub][dsub]
-    DevBuf codes;                       // uint8 [n][m] in list order
-    DevBuf list_off;                    // int64 [n_lists + 1]
-    DevBuf row_ids;                     // int   [n]
-    std::vector<int64_t> h_list_off, len_desc;
+    DevBuf codes;                       // uint8 [positions][m], every list at the positions `lay` names
+    ListLayout lay;
+    DevBuf row_ids;                     // int   [positions]
+    DevBuf app_codes, app_dst, app_no;  // staging of appended codes
     int n_lists = 0;
-    int64_t n = 0;
     bool ready = false;
     hipStream_t last_stream = nullptr;  // stream of the last *_dev call
     Workspace ws, io;
-    int64_t probe_bound(int n_probe) {
-        if (len_desc.size() != (size_t)n_lists) {
-            len_desc.resize(n_lists);
-            for (int l = 0; l < n_lists; ++l) len_desc[l] = h_list_off[l + 1] - h_list_off[l];
-            std::sort(len_desc.begin(), len_desc.end(), std::greater<int64_t>());
-        }
-        int64_t t = 0;
-        for (int i = 0; i < std::min(n_probe, n_lists); ++i) t += len_desc[i];
-        return t;
-    }
+    int64_t probe_bound(int n_probe) { return lay.probe_bound(n_probe); }
 };
 
 int vdb_ivfpq_create(vdb_ivfpq** out, int dim, int m, int ksub) {
@@ -1924,7 +2114,8 @@ int vdb_ivfpq_destroy(vdb_ivfpq* h) {
         Entry g(h);
         (void)hipStreamSynchronize(h->stream);
         if (h->last_stream && h->last_stream != h->stream) (void)hipStreamSynchronize(h->last_stream);
-        h->book.release(); h->codes.release(); h->list_off.release(); h->row_ids.release(); h->ws.release(); h->io.release();
+        h->book.release(); h->codes.release(); h->lay.dev.release(); h->row_ids.release(); h->ws.release(); h->io.release();
+        h->app_codes.release(); h->app_dst.release(); h->app_no.release();
     }
     vdb_rows_destroy(h->centroids);
     h->close();
@@ -1943,9 +2134,7 @@ int vdb_ivfpq_set_quantizers(vdb_ivfpq* h, const float* centroids, int n_lists, 
     VDB_HIP(hipMemcpyAsync(h->book.p, codebook, bytes, hipMemcpyHostToDevice, s));
     VDB_HIP(hipStreamSynchronize(s));
     h->n_lists = n_lists;
-    h->h_list_off.assign(n_lists + 1, 0);
-    h->len_desc.clear();
-    h->n = 0;
+    h->lay.reset(n_lists);
     h->ready = true;
     return VDB_OK;
 }
@@ -1985,34 +2174,142 @@ int vdb_ivfpq_encode(vdb_ivfpq* h, const float* rows, int64_t n, int32_t* out_li
     return st;
 }
 
-int vdb_ivfpq_build(vdb_ivfpq* h, const uint8_t* codes, int64_t n, const int64_t* list_rows, const int64_t* list_offsets) {
+// codes[gather[i]] becomes the code at position i and answers to the row number numbers[i]
+static int ivfpq_build_impl(vdb_ivfpq* h, const uint8_t* codes, int64_t n, const int64_t* gather, const int64_t* numbers,
+                            const int64_t* list_offsets) {
     VDB_REQUIRE(h && h->ready, "quantizers must be set before the lists are built");
-    VDB_REQUIRE(n >= 0 && (n == 0 || (codes && list_rows)) && list_offsets, "bad arguments to vdb_ivfpq_build");
+    VDB_REQUIRE(n >= 0 && (n == 0 || (codes && numbers)) && list_offsets, "bad arguments to the list build");
     VDB_REQUIRE(list_offsets[0] == 0 && list_offsets[h->n_lists] == n, "list offsets do not cover %lld rows", (long long)n);
     VDB_REQUIRE(n < (int64_t)0x7fffffff, "at most 2^31-1 rows per device");
-    std::vector<int> perm((size_t)n);
+    std::vector<int> nums((size_t)n);
     std::vector<uint8_t> ordered((size_t)n * h->m);
     for (int l = 0; l < h->n_lists; ++l)
         VDB_REQUIRE(list_offsets[l] <= list_offsets[l + 1], "list offsets must be non-decreasing");
+    int64_t row_limit = 0;
     for (int64_t i = 0; i < n; ++i) {
-        VDB_REQUIRE(list_rows[i] >= 0 && list_rows[i] < n, "row number %lld out of range", (long long)list_rows[i]);
-        perm[(size_t)i] = (int)list_rows[i];
-        memcpy(&ordered[(size_t)i * h->m], codes + list_rows[i] * h->m, h->m);
+        const int64_t g = gather ? gather[i] : i;
+        VDB_REQUIRE(g >= 0 && g < n, "row %lld out of range", (long long)g);
+        VDB_REQUIRE(numbers[i] >= 0 && numbers[i] < (int64_t)0x7fffffff, "row number %lld out of range", (long long)numbers[i]);
+        nums[(size_t)i] = (int)numbers[i];
+        row_limit = std::max(row_limit, numbers[i] + 1);
+        memcpy(&ordered[(size_t)i * h->m], codes + g * h->m, h->m);
     }
     Entry g(h);
     hipStream_t s = h->stream;
-    h->h_list_off.assign(list_offsets, list_offsets + h->n_lists + 1);
-    h->len_desc.clear();
-    VDB_TRY(h->list_off.reserve((size_t)(h->n_lists + 1) * sizeof(int64_t)));
-    VDB_HIP(hipMemcpyAsync(h->list_off.p, list_offsets, (size_t)(h->n_lists + 1) * sizeof(int64_t), hipMemcpyHostToDevice, s));
+    h->lay.set_packed(list_offsets);
+    h->lay.row_limit = row_limit;
+    VDB_TRY(h->lay.sync(s));
     if (n > 0) {
         VDB_TRY(h->row_ids.reserve((size_t)n * sizeof(int)));
         VDB_TRY(h->codes.reserve((size_t)n * h->m));
-        VDB_HIP(hipMemcpyAsync(h->row_ids.p, perm.data(), (size_t)n * sizeof(int), hipMemcpyHostToDevice, s));
+        VDB_HIP(hipMemcpyAsync(h->row_ids.p, nums.data(), (size_t)n * sizeof(int), hipMemcpyHostToDevice, s));
         VDB_HIP(hipMemcpyAsync(h->codes.p, ordered.data(), (size_t)n * h->m, hipMemcpyHostToDevice, s));
     }
     VDB_HIP(hipStreamSynchronize(s));
-    h->n = n;
+    return VDB_OK;
+}
+
+int vdb_ivfpq_build(vdb_ivfpq* h, const uint8_t* codes, int64_t n, const int64_t* list_rows, const int64_t* list_offsets) {
+    VDB_REQUIRE(n == 0 || list_rows, "bad arguments to vdb_ivfpq_build");
+    return ivfpq_build_impl(h, codes, n, list_rows, list_rows, list_offsets);
+}
+
+int vdb_ivfpq_build_numbered(vdb_ivfpq* h, const uint8_t* codes, int64_t n, const int64_t* row_numbers, const int64_t* list_offsets) {
+    return ivfpq_build_impl(h, codes, n, nullptr, row_numbers, list_offsets);
+}
+
+__global__ void ivfpq_scatter_codes_kernel(const uint8_t* __restrict__ src, int m, int64_t count, const int64_t* __restrict__ dst,
+                                           const int* __restrict__ numbers, uint8_t* __restrict__ codes, int* __restrict__ row_ids) {
+    const int64_t total = count * m;
+    for (int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; t < total; t += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t i = t / m;
+        const int c = (int)(t - i * m);
+        const int64_t d = dst[i];
+        codes[d * m + c] = src[t];
+        if (c == 0) row_ids[d] = numbers[i];
+    }
+}
+
+__global__ void ivfpq_move_codes_kernel(uint8_t* __restrict__ codes, int* __restrict__ row_ids, int m, int64_t from, int64_t to,
+                                        int64_t count) {
+    const int64_t total = count * m;
+    for (int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; t < total; t += (int64_t)gridDim.x * blockDim.x) {
+        codes[to * m + t] = codes[from * m + t];
+        if (t < count) row_ids[to + t] = row_ids[from + t];
+    }
+}
+
+int vdb_ivfpq_append(vdb_ivfpq* h, const uint8_t* codes, const int64_t* row_numbers, const int32_t* lists, int64_t count) {
+    VDB_REQUIRE(h && h->ready, "quantizers must be set before rows are appended");
+    VDB_REQUIRE(count >= 0 && (count == 0 || (codes && row_numbers && lists)), "bad arguments to vdb_ivfpq_append");
+    if (count == 0) return VDB_OK;
+    std::vector<int> nums((size_t)count);
+    int64_t row_limit = h->lay.row_limit;
+    for (int64_t i = 0; i < count; ++i) {
+        VDB_REQUIRE(row_numbers[i] >= 0 && row_numbers[i] < (int64_t)0x7fffffff, "row number %lld out of range", (long long)row_numbers[i]);
+        nums[(size_t)i] = (int)row_numbers[i];
+        row_limit = std::max(row_limit, row_numbers[i] + 1);
+    }
+    Entry g(h);
+    hipStream_t s = h->stream;
+    ListLayout& lay = h->lay;
+    std::vector<int64_t> dst;
+    std::vector<ListMove> moves;
+    const int64_t old_tail = lay.tail;
+    VDB_TRY(lay.plan_append(lists, count, dst, moves));
+    VDB_REQUIRE(lay.tail < (int64_t)0x7fffffff, "at most 2^31-1 positions per device");
+    lay.row_limit = row_limit;
+    VDB_TRY(h->codes.reserve_keep((size_t)lay.tail * h->m, (size_t)old_tail * h->m, s));
+    VDB_TRY(h->row_ids.reserve_keep((size_t)lay.tail * sizeof(int), (size_t)old_tail * sizeof(int), s));
+    for (const ListMove& mv : moves)
+        hipLaunchKernelGGL(ivfpq_move_codes_kernel, dim3(grid_for(mv.count * h->m)), dim3(256), 0, s, h->codes.as<uint8_t>(),
+                           h->row_ids.as<int>(), h->m, mv.from, mv.to, mv.count);
+    VDB_HIP(hipGetLastError());
+    VDB_TRY(h->app_codes.reserve((size_t)count * h->m));
+    VDB_TRY(h->app_dst.reserve((size_t)count * sizeof(int64_t)));
+    VDB_TRY(h->app_no.reserve((size_t)count * sizeof(int)));
+    VDB_HIP(hipMemcpyAsync(h->app_codes.p, codes, (size_t)count * h->m, hipMemcpyHostToDevice, s));
+    VDB_HIP(hipMemcpyAsync(h->app_dst.p, dst.data(), (size_t)count * sizeof(int64_t), hipMemcpyHostToDevice, s));
+    VDB_HIP(hipMemcpyAsync(h->app_no.p, nums.data(), (size_t)count * sizeof(int), hipMemcpyHostToDevice, s));
+    hipLaunchKernelGGL(ivfpq_scatter_codes_kernel, dim3(grid_for(count * h->m)), dim3(256), 0, s, h->app_codes.as<uint8_t>(), h->m,
+                       count, h->app_dst.as<int64_t>(), h->app_no.as<int>(), h->codes.as<uint8_t>(), h->row_ids.as<int>());
+    VDB_HIP(hipGetLastError());
+    VDB_HIP(hipStreamSynchronize(s));          // the host vectors above are pageable
+    return VDB_OK;
+}
+
+int vdb_ivfpq_remove_at(vdb_ivfpq* h, int32_t list, int64_t position) {
+    VDB_REQUIRE(h && list >= 0 && list < h->n_lists, "bad list number");
+    Entry g(h);
+    ListLayout& lay = h->lay;
+    VDB_REQUIRE(position >= 0 && position < lay.len[list], "position %lld is not in list %d (%lld rows)", (long long)position, list,
+                (long long)lay.len[list]);
+    // the codes behind the removed one close the gap in their order (index/hybrid.py:396-400 filters the list)
+    const int64_t behind = lay.len[list] - 1 - position;
+    if (behind > 0) {
+        hipStream_t s = h->stream;
+        const int64_t at = lay.beg[list] + position;
+        VDB_TRY(h->app_codes.reserve((size_t)behind * h->m));
+        VDB_TRY(h->app_no.reserve((size_t)behind * sizeof(int)));
+        uint8_t* codes = h->codes.as<uint8_t>();
+        int* ids = h->row_ids.as<int>();
+        VDB_HIP(hipMemcpyAsync(h->app_codes.p, codes + (at + 1) * h->m, (size_t)behind * h->m, hipMemcpyDeviceToDevice, s));
+        VDB_HIP(hipMemcpyAsync(h->app_no.p, ids + at + 1, (size_t)behind * sizeof(int), hipMemcpyDeviceToDevice, s));
+        VDB_HIP(hipMemcpyAsync(codes + at * h->m, h->app_codes.p, (size_t)behind * h->m, hipMemcpyDeviceToDevice, s));
+        VDB_HIP(hipMemcpyAsync(ids + at, h->app_no.p, (size_t)behind * sizeof(int), hipMemcpyDeviceToDevice, s));
+    }
+    --lay.len[list];
+    --lay.live;
+    lay.dev_stale = true;
+    return VDB_OK;
+}
+
+int vdb_ivfpq_layout(vdb_ivfpq* h, int64_t* live_rows, int64_t* positions, int64_t* dead_positions) {
+    VDB_REQUIRE(h, "null handle");
+    Entry g(h);
+    if (live_rows) *live_rows = h->lay.live;
+    if (positions) *positions = h->lay.tail;
+    if (dead_positions) *dead_positions = h->lay.dead;
     return VDB_OK;
 }
 
@@ -2025,8 +2322,9 @@ static int ivfpq_search_impl(vdb_ivfpq* h, const float* d_q, int nq, int k, int 
     n_probe = std::min(n_probe, h->n_lists);
     Workspace& ws = h->ws;
     VDB_TRY(fill_results(d_out_d, d_out_i, (int64_t)nq * k, s));
-    if (h->n == 0) return VDB_OK;
-    const int64_t k_eff = std::min<int64_t>(k, h->n);
+    if (h->lay.live == 0) return VDB_OK;
+    VDB_TRY(h->lay.sync(s));
+    const int64_t k_eff = std::min<int64_t>(k, h->lay.live);
     const int kmax = (int)std::min<int64_t>(KMAX_FUSED, k_eff);
     const bool multi = k_eff > KMAX_FUSED;
     const int64_t cand_stride = round_up64(std::max<int64_t>(h->probe_bound(n_probe), 1), 64);
@@ -2059,15 +2357,15 @@ static int ivfpq_search_impl(vdb_ivfpq* h, const float* d_q, int nq, int k, int 
         VDB_TRY(ws.lb_d.reserve((size_t)q_block * sizeof(float)));
         VDB_TRY(ws.lb_k.reserve((size_t)q_block * sizeof(int64_t)));
     }
-    const int64_t avg_tiles = std::max<int64_t>(1, ((int64_t)n_probe * (h->n / std::max(1, h->n_lists)) + 255) / 256);
+    const int64_t avg_tiles = std::max<int64_t>(1, ((int64_t)n_probe * (h->lay.live / std::max(1, h->n_lists)) + 255) / 256);
     for (int q0 = 0; q0 < nq; q0 += q_block) {
         const int nb = std::min(q_block, nq - q0);
         const int* probes = ws.probes.as<int>() + (int64_t)q0 * n_probe;
-        VDB_TRY(launch_ivf_plan(probes, nb, n_probe, h->list_off.as<int64_t>(), h->n_lists, 8, cand_stride,
+        VDB_TRY(launch_ivf_plan(probes, nb, n_probe, h->lay.d_beg(), h->lay.d_end(), h->n_lists, 8, cand_stride,
                                 ws.list_cnt.as<int>(), ws.cursor.as<int>(), ws.cand_off.as<int64_t>(), ws.tile_off.as<int>(), b, s));
         VDB_TRY(launch_ivfpq_scan(d_q + (int64_t)q0 * h->dim, h->dim, h->dim, nb, h->centroids->r.data, h->centroids->r.ld,
                                   h->book.as<float>(), h->m, h->ksub, h->dsub, h->plan, h->codes.as<uint8_t>(),
-                                  h->list_off.as<int64_t>(), h->n_lists, probes, n_probe, ws.cand_off.as<int64_t>(),
+                                  h->lay.d_beg(), h->lay.d_end(), h->n_lists, probes, n_probe, ws.cand_off.as<int64_t>(),
                                   cand_stride, ws.cand.as<float>(), s));
         const int splits = cand_splits(avg_tiles, nb);
         const int n_cand = splits * topk_cand_lists_per_split();
@@ -2077,7 +2375,7 @@ static int ivfpq_search_impl(vdb_ivfpq* h, const float* d_q, int nq, int k, int 
             const int kk = (int)std::min<int64_t>(KMAX_FUSED, k_eff - done);
             CandJob c{};
             c.cand = ws.cand.as<float>(); c.cand_stride = cand_stride; c.nq = nb; c.n = 0;
-            c.probes = probes; c.n_probe = n_probe; c.n_lists = h->n_lists; c.list_off = h->list_off.as<int64_t>();
+            c.probes = probes; c.n_probe = n_probe; c.n_lists = h->n_lists; c.list_beg = h->lay.d_beg(); c.list_end = h->lay.d_end();
             c.cand_off = ws.cand_off.as<int64_t>(); c.tile_off = ws.tile_off.as<int>();
             c.row_ids = h->row_ids.as<int>(); c.mask = d_mask;
             c.metric = VDB_MANHATTAN;                 // the slots already hold final distances
@@ -2088,7 +2386,7 @@ static int ivfpq_search_impl(vdb_ivfpq* h, const float* d_q, int nq, int k, int 
                         multi ? ws.lb_d.as<float>() : nullptr, multi ? ws.lb_k.as<int64_t>() : nullptr};
             VDB_TRY(launch_select(ws.part_d.as<float>(), ws.part_i.as<int>(), nb, n_cand, kk, 1 << 30, nullptr, 0, o, s, ws.mid));
             VDB_TRY(launch_ivf_rows(ws.slots.as<int>() + (int64_t)q0 * k, nb, kk, k, (int)done, probes, n_probe, h->n_lists,
-                                    ws.cand_off.as<int64_t>(), h->list_off.as<int64_t>(), h->row_ids.as<int>(),
+                                    ws.cand_off.as<int64_t>(), h->lay.d_beg(), h->row_ids.as<int>(),
                                     d_out_i + (int64_t)q0 * k, nullptr, s));
         }
     }
@@ -2109,7 +2407,7 @@ int vdb_ivfpq_search(vdb_ivfpq* h, const float* queries, int nq, int k, int n_pr
     Entry g(h);
     hipStream_t s = h->stream;
     const uint32_t* d_mask = nullptr;
-    VDB_TRY(upload_mask(h->ws, mask, h->n, &d_mask, s));
+    VDB_TRY(upload_mask(h->ws, mask, h->lay.row_limit, &d_mask, s));
     return with_host_io(h->io, queries, nq, h->dim, k, out_dist, out_row, s,
                         [&](const float* dq, float* dd, int64_t* di) {
                             return ivfpq_search_impl(h, dq, nq, k, n_probe, d_mask, dd, di, s);

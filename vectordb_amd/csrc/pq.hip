@@ -265,7 +265,7 @@ struct IvfPqScanParams {
     const float* cent; int ldc;
     const float* book; int m; int ksub; int dsub; SumPlan plan;
     const uint8_t* codes;                       // [n][m] in list order
-    const int64_t* list_off; int n_lists;
+    const int64_t* list_beg; const int64_t* list_end; int n_lists;
     const int* probes; int n_probe;
     const int64_t* cand_off; int64_t cand_stride;
     float* cand;
@@ -280,8 +280,8 @@ __global__ __launch_bounds__(256) void ivfpq_scan_kernel(IvfPqScanParams p) {
     const int qi = unit / p.n_probe, pr = unit - qi * p.n_probe;
     const int l = p.probes[unit];
     if (l < 0 || l >= p.n_lists) return;
-    const int64_t pos0 = p.list_off[l];
-    const int64_t len = p.list_off[l + 1] - pos0;
+    const int64_t pos0 = p.list_beg[l];
+    const int64_t len = p.list_end[l] - pos0;
     if (len == 0) return;
     for (int i = tid; i < p.dim; i += 256) qres[i] = p.q[(int64_t)qi * p.ldq + i] - p.cent[(int64_t)l * p.ldc + i];
     __syncthreads();
@@ -299,10 +299,10 @@ __global__ __launch_bounds__(256) void ivfpq_scan_kernel(IvfPqScanParams p) {
 }
 
 int launch_ivfpq_scan(const float* q, int ldq, int dim, int nq, const float* cent, int ldc, const float* book, int m, int ksub,
-                      int dsub, const SumPlan& plan, const uint8_t* codes, const int64_t* list_off, int n_lists,
+                      int dsub, const SumPlan& plan, const uint8_t* codes, const int64_t* list_beg, const int64_t* list_end, int n_lists,
                       const int* probes, int n_probe, const int64_t* cand_off, int64_t cand_stride, float* cand, hipStream_t s) {
     if (nq <= 0) return VDB_OK;
-    IvfPqScanParams p{q, ldq, dim, cent, ldc, book, m, ksub, dsub, plan, codes, list_off, n_lists, probes, n_probe,
+    IvfPqScanParams p{q, ldq, dim, cent, ldc, book, m, ksub, dsub, plan, codes, list_beg, list_end, n_lists, probes, n_probe,
                       cand_off, cand_stride, cand};
     const size_t lds = ((size_t)m * ksub + dim) * sizeof(float);
     VDB_REQUIRE(lds <= 160 * 1024, "%d sub-spaces x %d codewords need %zu bytes of LDS", m, ksub, lds);

@@ -620,7 +620,8 @@ int launch_stream_sums(const StreamJob& j, hipStream_t s) {
 }
 
 // --------------------------------------------------------------------------
-static int launch_build_items(const StreamPlanBufs& b, const int64_t* seg_row_off, int n_seg, int group, hipStream_t s);
+static int launch_build_items(const StreamPlanBufs& b, const int64_t* seg_row_beg, const int64_t* seg_row_end, int n_seg, int group,
+                              hipStream_t s);
 
 // plan of a flat scan: one segment with every row and every query
 __global__ void flat_plan_kernel(int64_t n, int nq, int group, int64_t out_stride,
@@ -640,12 +641,14 @@ int launch_flat_plan(int64_t n, int nq, int group, int64_t out_stride, const Str
     hipLaunchKernelGGL(flat_plan_kernel, dim3((nq + 255) / 256), dim3(256), 0, s, n, nq, group, out_stride,
                        b.seg_row_off, b.seg_q_off, b.seg_item_off, b.sq_qid, b.sq_out);
     VDB_HIP(hipGetLastError());
-    return launch_build_items(b, b.seg_row_off, 1, group, s);
+    return launch_build_items(b, b.seg_row_off, b.seg_row_off + 1, 1, group, s);
 }
 
 
-// expands the per-segment item counts into the item table (one thread per item)
-__global__ void build_items_kernel(int n_seg, int group, const int64_t* __restrict__ seg_row_off,
+// expands the per-segment item counts into the item table (one thread per item).  Segment i holds the stored rows
+// [seg_row_beg[i], seg_row_end[i]); segments need not be adjacent or in order (lists that were moved to the end of
+// the row buffer when they outgrew their place).
+__global__ void build_items_kernel(int n_seg, int group, const int64_t* __restrict__ seg_row_beg, const int64_t* __restrict__ seg_row_end,
                                    const int* __restrict__ seg_q_off, const int64_t* __restrict__ seg_item_off,
                                    int64_t cap, StreamItem* __restrict__ items) {
     const int64_t total = min(seg_item_off[n_seg], cap);
@@ -661,7 +664,7 @@ __global__ void build_items_kernel(int n_seg, int group, const int64_t* __restri
         const int groups = (nqs + group - 1) / group;
         const int64_t chunk = local / groups;
         const int grp = (int)(local - chunk * groups);
-        const int64_t r0 = seg_row_off[lo], r1 = seg_row_off[lo + 1];
+        const int64_t r0 = seg_row_beg[lo], r1 = seg_row_end[lo];
         StreamItem it;
         it.out_rel = chunk * S_NT;
         it.row0 = r0 + it.out_rel;
@@ -673,9 +676,10 @@ __global__ void build_items_kernel(int n_seg, int group, const int64_t* __restri
     }
 }
 
-static int launch_build_items(const StreamPlanBufs& b, const int64_t* seg_row_off, int n_seg, int group, hipStream_t s) {
+static int launch_build_items(const StreamPlanBufs& b, const int64_t* seg_row_beg, const int64_t* seg_row_end, int n_seg, int group,
+                              hipStream_t s) {
     const int grid = (int)std::max<int64_t>(1, std::min<int64_t>((b.items_cap + 255) / 256, 4096));
-    hipLaunchKernelGGL(build_items_kernel, dim3(grid), dim3(256), 0, s, n_seg, group, seg_row_off, b.seg_q_off,
+    hipLaunchKernelGGL(build_items_kernel, dim3(grid), dim3(256), 0, s, n_seg, group, seg_row_beg, seg_row_end, b.seg_q_off,
                        b.seg_item_off, b.items_cap, b.items);
     VDB_HIP(hipGetLastError());
     return VDB_OK;
@@ -689,8 +693,8 @@ static int launch_build_items(const StreamPlanBufs& b, const int64_t* seg_row_of
 // A probe entry outside [0, n_lists) (a query whose centroid distances are all NaN has
 // no ranking) stands for an empty list.
 __global__ void ivf_plan_count_kernel(const int* __restrict__ probes, int nq, int n_probe, int n_lists,
-                                      const int64_t* __restrict__ list_off, int* __restrict__ list_cnt,
-                                      int64_t* __restrict__ cand_off, int* __restrict__ tile_off) {
+                                      const int64_t* __restrict__ list_beg, const int64_t* __restrict__ list_end,
+                                      int* __restrict__ list_cnt, int64_t* __restrict__ cand_off, int* __restrict__ tile_off) {
     const int q = blockIdx.x * blockDim.x + threadIdx.x;
     if (q >= nq) return;
     int64_t run = 0;
@@ -700,7 +704,7 @@ __global__ void ivf_plan_count_kernel(const int* __restrict__ probes, int nq, in
         cand_off[(int64_t)q * (n_probe + 1) + pr] = run;
         tile_off[(int64_t)q * (n_probe + 1) + pr] = tiles;
         if (l < 0 || l >= n_lists) continue;
-        const int64_t len = list_off[l + 1] - list_off[l];
+        const int64_t len = list_end[l] - list_beg[l];
         run += len;
         tiles += (int)((len + LIST_NT - 1) / LIST_NT);
         atomicAdd(&list_cnt[l], 1);
@@ -710,7 +714,8 @@ __global__ void ivf_plan_count_kernel(const int* __restrict__ probes, int nq, in
 }
 
 // exclusive scans over the lists: query entries and items (single block)
-__global__ __launch_bounds__(1024) void ivf_plan_scan_kernel(const int* __restrict__ list_cnt, const int64_t* __restrict__ list_off,
+__global__ __launch_bounds__(1024) void ivf_plan_scan_kernel(const int* __restrict__ list_cnt, const int64_t* __restrict__ list_beg,
+                                                             const int64_t* __restrict__ list_end,
                                                              int n_lists, int group, int* __restrict__ seg_q_off,
                                                              int64_t* __restrict__ seg_item_off, int* __restrict__ cursor) {
     __shared__ int64_t sh_items[1024];
@@ -726,7 +731,7 @@ __global__ __launch_bounds__(1024) void ivf_plan_scan_kernel(const int* __restri
         int64_t items = 0;
         if (l < n_lists) {
             c = list_cnt[l];
-            const int64_t len = list_off[l + 1] - list_off[l];
+            const int64_t len = list_end[l] - list_beg[l];
             items = ((len + S_NT - 1) / S_NT) * ((c + group - 1) / group);
         }
         sh_cnt[tid] = c;
@@ -766,19 +771,19 @@ __global__ void ivf_plan_fill_kernel(const int* __restrict__ probes, int nq, int
     sq_out[slot] = (int64_t)q * cand_stride + cand_off[(int64_t)q * (n_probe + 1) + pr];
 }
 
-int launch_ivf_plan(const int* probes, int nq, int n_probe, const int64_t* list_off, int n_lists, int group,
+int launch_ivf_plan(const int* probes, int nq, int n_probe, const int64_t* list_beg, const int64_t* list_end, int n_lists, int group,
                     int64_t cand_stride, int* list_cnt, int* cursor, int64_t* cand_off, int* tile_off,
                     const StreamPlanBufs& b, hipStream_t s) {
     VDB_HIP(hipMemsetAsync(list_cnt, 0, (size_t)n_lists * sizeof(int), s));
     hipLaunchKernelGGL(ivf_plan_count_kernel, dim3((nq + 255) / 256), dim3(256), 0, s, probes, nq, n_probe, n_lists,
-                       list_off, list_cnt, cand_off, tile_off);
-    hipLaunchKernelGGL(ivf_plan_scan_kernel, dim3(1), dim3(1024), 0, s, list_cnt, list_off, n_lists, group, b.seg_q_off,
+                       list_beg, list_end, list_cnt, cand_off, tile_off);
+    hipLaunchKernelGGL(ivf_plan_scan_kernel, dim3(1), dim3(1024), 0, s, list_cnt, list_beg, list_end, n_lists, group, b.seg_q_off,
                        b.seg_item_off, cursor);
     const int64_t total = (int64_t)nq * n_probe;
     hipLaunchKernelGGL(ivf_plan_fill_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, probes, nq, n_probe,
                        n_lists, cand_stride, cand_off, cursor, b.sq_qid, b.sq_out);
     VDB_HIP(hipGetLastError());
-    return launch_build_items(b, list_off, n_lists, group, s);
+    return launch_build_items(b, list_beg, list_end, n_lists, group, s);
 }
 
 // --------------------------------------------------------------------------
@@ -852,7 +857,7 @@ struct CandParams {
     const float* cand; int64_t cand_stride;      // query q owns cand[q*cand_stride ...]
     int64_t n;                                   // flat: candidates per query (slot = stored row)
     const int* probes; int n_probe; int n_lists; // lists: probed lists of every query, or null
-    const int64_t* list_off;
+    const int64_t* list_beg; const int64_t* list_end;
     const int64_t* cand_off; const int* tile_off; // lists: [nq][n_probe+1] slots / 256-slot tiles before every probe
     const int* row_ids;                          // stored position -> row number (null = identity)
     const uint32_t* mask;                        // by row number
@@ -905,9 +910,9 @@ __global__ __launch_bounds__(LIST_NT) void topk_cand_kernel(CandParams p) {
             for (int i = tid; i < nr; i += LIST_NT) {
                 const int l = p.probes[(int64_t)qi * p.n_probe + c0 + i];
                 const bool ok = l >= 0 && l < p.n_lists;
-                const int64_t pos0 = ok ? p.list_off[l] : 0;
+                const int64_t pos0 = ok ? p.list_beg[l] : 0;
                 R_pos0[i] = pos0;
-                R_len[i] = ok ? p.list_off[l + 1] - pos0 : 0;
+                R_len[i] = ok ? p.list_end[l] - pos0 : 0;
                 R_slot0[i] = (int)p.cand_off[qo + i];
             }
             for (int i = tid; i <= nr; i += LIST_NT) R_tile[i] = p.tile_off[qo + i];
@@ -997,7 +1002,7 @@ int launch_topk_cand(const CandJob& j, hipStream_t s) {
     VDB_REQUIRE(j.k >= 1 && j.k <= 64, "candidate selection supports k <= 64, got %d", j.k);
     CandParams p{};
     p.cand = j.cand; p.cand_stride = j.cand_stride; p.n = j.n; p.probes = j.probes; p.n_probe = j.n_probe; p.n_lists = j.n_lists;
-    p.list_off = j.list_off; p.row_ids = j.row_ids; p.mask = j.mask;
+    p.list_beg = j.list_beg; p.list_end = j.list_end; p.row_ids = j.row_ids; p.mask = j.mask;
     p.fin = Finish{j.metric, j.q_sq, j.q_nrm, j.row_sq, j.row_nrm, 1e-8f};
     p.lb_d = j.lb_d; p.lb_k = j.lb_k; p.radius = j.radius; p.use_radius = j.use_radius;
     p.k = j.k; p.splits = j.splits; p.part_d = j.part_d; p.part_i = j.part_i;
@@ -1218,7 +1223,7 @@ int launch_range_collect(const RangeJob& j, const int64_t* block_off, int64_t ca
 // candidate slot -> row number for the results of a list scan
 __global__ void ivf_rows_kernel(const int* __restrict__ slots, int nq, int k, int out_stride, int out_off,
                                 const int* __restrict__ probes, int n_probe, int n_lists, const int64_t* __restrict__ cand_off,
-                                const int64_t* __restrict__ list_off, const int* __restrict__ row_ids,
+                                const int64_t* __restrict__ list_beg, const int* __restrict__ row_ids,
                                 int64_t* __restrict__ out_rows, int64_t* __restrict__ out_order) {
     const int t = blockIdx.x * blockDim.x + threadIdx.x;
     if (t >= nq * k) return;
@@ -1233,17 +1238,17 @@ __global__ void ivf_rows_kernel(const int* __restrict__ slots, int nq, int k, in
         if (co[mid] <= slot) lo = mid; else hi = mid;
     }
     const int l = probes[(int64_t)q * n_probe + lo];
-    out_rows[at] = (l >= 0 && l < n_lists) ? (int64_t)row_ids[list_off[l] + (slot - co[lo])] : -1;
+    out_rows[at] = (l >= 0 && l < n_lists) ? (int64_t)row_ids[list_beg[l] + (slot - co[lo])] : -1;
     // visiting order of the reference's scan (ivf.py:619-628): probe rank, then position in the list
     if (out_order) out_order[at] = ((int64_t)lo << 32) | (int64_t)(slot - co[lo]);
 }
 
 int launch_ivf_rows(const int* slots, int nq, int k, int out_stride, int out_off, const int* probes, int n_probe, int n_lists,
-                    const int64_t* cand_off, const int64_t* list_off, const int* row_ids, int64_t* out_rows,
+                    const int64_t* cand_off, const int64_t* list_beg, const int* row_ids, int64_t* out_rows,
                     int64_t* out_order, hipStream_t s) {
     if (nq <= 0 || k <= 0) return VDB_OK;
     hipLaunchKernelGGL(ivf_rows_kernel, dim3((nq * k + 255) / 256), dim3(256), 0, s, slots, nq, k, out_stride, out_off,
-                       probes, n_probe, n_lists, cand_off, list_off, row_ids, out_rows, out_order);
+                       probes, n_probe, n_lists, cand_off, list_beg, row_ids, out_rows, out_order);
     VDB_HIP(hipGetLastError());
     return VDB_OK;
 }

@@ -219,7 +219,7 @@ int launch_stream_sums(const StreamJob& j, hipStream_t s);
 int launch_row_norms(const float* data, int ld, int dim, int64_t n, const SumPlan& plan, const StreamPlanBufs& b,
                      float* sq, float* nrm, hipStream_t s);
 int launch_flat_plan(int64_t n, int nq, int group, int64_t out_stride, const StreamPlanBufs& b, hipStream_t s);
-int launch_ivf_plan(const int* probes, int nq, int n_probe, const int64_t* list_off, int n_lists, int group,
+int launch_ivf_plan(const int* probes, int nq, int n_probe, const int64_t* list_beg, const int64_t* list_end, int n_lists, int group,
                     int64_t cand_stride, int* list_cnt, int* cursor, int64_t* cand_off, int* tile_off,
                     const StreamPlanBufs& b, hipStream_t s);
 // in-place distance finish of a [nq][n] matrix of streamed sums (identity-form L2 and cosine only)
@@ -231,7 +231,7 @@ int topk_cand_lists_per_split();
 struct CandJob {
     const float* cand; int64_t cand_stride; int nq;
     int64_t n;                                        // flat: candidates per query (slot = stored row)
-    const int* probes; int n_probe; int n_lists; const int64_t* list_off;   // lists (probes == null: flat)
+    const int* probes; int n_probe; int n_lists; const int64_t* list_beg; const int64_t* list_end;   // lists (probes == null: flat)
     const int64_t* cand_off; const int* tile_off;     // lists: [nq][n_probe+1] from launch_ivf_plan
     const int* row_ids; const uint32_t* mask;
     int metric; const float* q_sq; const float* q_nrm; const float* row_sq; const float* row_nrm;
@@ -253,7 +253,7 @@ int launch_range_count(const RangeJob& j, int* block_counts, int64_t* block_off,
 int launch_range_collect(const RangeJob& j, const int64_t* block_off, int64_t cap, int64_t m, uint64_t* keys,
                          float* out_d, int64_t* out_row, hipStream_t s);
 int launch_ivf_rows(const int* slots, int nq, int k, int out_stride, int out_off, const int* probes, int n_probe, int n_lists,
-                    const int64_t* cand_off, const int64_t* list_off, const int* row_ids, int64_t* out_rows,
+                    const int64_t* cand_off, const int64_t* list_beg, const int* row_ids, int64_t* out_rows,
                     int64_t* out_order, hipStream_t s);
 
 // final selection: per query, the k best of n_cand ascending candidate lists of k,
@@ -294,7 +294,7 @@ int launch_pq_scan(const uint8_t* codes, int64_t n, int m, int ksub, const float
 int launch_residual(const float* x, int64_t ldx, const float* cent, int ldc, const int* list, int dim, int64_t n,
                     float* out, hipStream_t s);
 int launch_ivfpq_scan(const float* q, int ldq, int dim, int nq, const float* cent, int ldc, const float* book, int m, int ksub,
-                      int dsub, const SumPlan& plan, const uint8_t* codes, const int64_t* list_off, int n_lists,
+                      int dsub, const SumPlan& plan, const uint8_t* codes, const int64_t* list_beg, const int64_t* list_end, int n_lists,
                       const int* probes, int n_probe, const int64_t* cand_off, int64_t cand_stride, float* cand, hipStream_t s);
 // measured ceilings of this GPU (ceilings.hip): device-to-device copy GB/s (read + write), register-only MFMA loops
 int measure_ceilings(hipStream_t s, float* copy_gbs, float* mfma_f32_tflops, float* mfma_bf16_tflops, float* valu_direct_tops);

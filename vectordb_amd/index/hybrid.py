@@ -57,9 +57,11 @@ class HybridIndex(BaseIndex):
         self._size = 0
         self._rng = np.random.RandomState(seed)
         self._build_start = time.time()
+        # Device mirror: a device row number is a host row.  `_dirty` asks for a full build of the lists; otherwise
+        # host rows [_synced, len(_row_ids)) are waiting to be appended to the tails of their lists.
         self._dev: Optional[N.IvfPqLists] = None
         self._dirty = True
-        self._live_rows = np.zeros(0, dtype=np.int64)      # device row -> host row
+        self._synced = 0
 
     @property
     def index_type(self) -> IndexType:
@@ -147,7 +149,6 @@ class HybridIndex(BaseIndex):
                 self._ids.append(id)
                 self._metadata[id] = (metadata[i] if metadata else None) or {}
             self._size += n
-            self._dirty = True
         return n
 
     def remove(self, id: str) -> bool:
@@ -156,12 +157,15 @@ class HybridIndex(BaseIndex):
             if id not in self._row_of:
                 return False
             r = self._row_of.pop(id)
+            if not self._dirty and r < self._synced:
+                # its place on the device: rows of a list sit there in insertion order
+                l = int(self._list_of_row[r])
+                self._dev.remove_at(l, int(np.count_nonzero(self._list_of_row[:r] == l)))
             self._list_of_row[r] = -1
             self._row_ids[r] = None
             self._ids.remove(id)
             self._metadata.pop(id, None)
             self._size -= 1
-            self._dirty = True
             return True
 
     def remove_batch(self, ids: List[str]) -> int:
@@ -176,24 +180,31 @@ class HybridIndex(BaseIndex):
 
     # ------------------------------------------------------------ device lists
     def _sync(self) -> None:
-        if not self._dirty:
-            return
         n_rows = len(self._row_ids)
         lists = self._list_of_row[:n_rows]
-        live = np.flatnonzero(lists >= 0)
-        order = live[np.argsort(lists[live], kind="stable")]                      # grouped by list, insertion order inside
-        offs = np.searchsorted(lists[order], np.arange(self.config.n_clusters + 1))
-        compact = np.full(n_rows, -1, dtype=np.int64)
-        compact[live] = np.arange(len(live))
-        self._dev.build(self._codes_arr[live], compact[order], offs)
-        self._live_rows = live
-        self._dirty = False
+        if self._dirty:
+            live = np.flatnonzero(lists >= 0)
+            order = live[np.argsort(lists[live], kind="stable")]                  # grouped by list, insertion order inside
+            offs = np.searchsorted(lists[order], np.arange(self.config.n_clusters + 1))
+            self._dev.build_numbered(self._codes_arr[order], order, offs)
+            self._dirty = False
+        elif self._synced < n_rows:
+            # rows added since the last search go behind the last codes of their lists (hybrid.py:262); rows that
+            # were removed again before they were ever uploaded are skipped
+            new = np.arange(self._synced, n_rows, dtype=np.int64)
+            new = new[lists[new] >= 0]
+            if len(new):
+                self._dev.append(self._codes_arr[new], new, lists[new])
+                live, _positions, dead = self._dev.layout()
+                if dead > live + 4096:      # more abandoned places than rows: pack the lists again at the next search
+                    self._dirty = True
+        self._synced = n_rows
 
     def _mask_words(self, filter_fn: Optional[FilterFunction]):
         if filter_fn is None:
             return None
-        mask = np.fromiter((bool(filter_fn(self._row_ids[r], self._metadata.get(self._row_ids[r], {})))
-                            for r in self._live_rows), dtype=bool, count=len(self._live_rows))
+        mask = np.fromiter((i is not None and bool(filter_fn(i, self._metadata.get(i, {}))) for i in self._row_ids),
+                           dtype=bool, count=len(self._row_ids))
         return N.pack_mask(mask)
 
     # ------------------------------------------------------------ search
@@ -202,7 +213,7 @@ class HybridIndex(BaseIndex):
         for d, r in zip(dist_row, rows_row):
             if r < 0:
                 break
-            id = self._row_ids[int(self._live_rows[r])]
+            id = self._row_ids[int(r)]
             out.append(SearchResult(id=id, distance=d, score=1.0 / (1.0 + d),                    # hybrid.py:342-348
                                     vector=self._reconstruct(id) if include_vectors else None,
                                     metadata=self._metadata.get(id, {}) if include_metadata else None))
@@ -285,17 +296,20 @@ class HybridIndex(BaseIndex):
         if data.get("coarse_centroids") and data.get("pq_codebook"):
             index._set_quantizers(np.array(data["coarse_centroids"], dtype=np.float32),
                                   np.array(data["pq_codebook"], dtype=np.float32))
+        ids, meta, lists, codes = [], [], [], []
         for l_str, entries in data.get("inverted_lists", {}).items():
             for e in entries:
-                r = len(index._row_ids)
-                index._reserve(r + 1)
-                index._list_of_row[r] = int(l_str)
-                index._codes_arr[r] = np.array(e["codes"], dtype=np.uint8)
-                index._row_of[e["id"]] = r
-                index._row_ids.append(e["id"])
-                index._ids.append(e["id"])
-                index._metadata[e["id"]] = e.get("metadata", {})
-                index._size += 1
+                ids.append(e["id"]); meta.append(e.get("metadata", {})); lists.append(int(l_str)); codes.append(e["codes"])
+        n = len(ids)
+        if n:
+            index._reserve(n)
+            index._list_of_row[:n] = np.asarray(lists, dtype=np.int32)
+            index._codes_arr[:n] = np.array(codes, dtype=np.uint8).reshape(n, index.config.n_subvectors)
+            index._row_of = dict(zip(ids, range(n)))
+            index._row_ids = list(ids)
+            index._ids = list(ids)
+            index._metadata = dict(zip(ids, meta))
+            index._size = n
         index._dirty = True
         return index
 

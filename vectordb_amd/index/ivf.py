@@ -198,9 +198,12 @@ class IVFIndex(BaseIndex):
         self._build_start = time.time()
         self._n_distance_computations = 0
         self._rng = np.random.RandomState(seed)
+        # Device mirror.  A device row number is a slot of the host table.  After the first build, adds go to the
+        # tails of their lists (`_pending` until the next search) and removes swap inside one list, as the host
+        # lists do; `_dev_dirty` asks for a full rebuild (new centroids, clear, or too many abandoned places).
         self._dev: Optional[N.IvfLists] = None
         self._dev_dirty = True
-        self._dev_ids: List[str] = []                          # device row number -> id
+        self._pending: List[int] = []                          # slots added since the device was last brought up to date
 
     # ------------------------------------------------------------ properties
     @property
@@ -277,7 +280,8 @@ class IVFIndex(BaseIndex):
         self._id_to_cluster[id] = cluster
         self._id_to_position[id] = len(self._lists[cluster])
         self._lists[cluster].append(slot)
-        self._dev_dirty = True
+        if not self._dev_dirty:
+            self._pending.append(slot)
 
     def add(self, id: str, vector, metadata: Optional[Dict[str, Any]] = None) -> None:
         if not self.is_trained():
@@ -339,17 +343,32 @@ class IVFIndex(BaseIndex):
             np.cumsum(sizes, out=offsets[1:])
             order = np.fromiter((s for c in range(k) for s in self._lists[c]), dtype=np.int64, count=int(offsets[-1]))
             rows = self._vectors[order] if len(order) else np.zeros((0, self._dimension), np.float32)
-            self._dev.build_lists(rows, np.arange(len(order), dtype=np.int64), offsets)
-            self._dev_ids = [self._slot_id[s] for s in order]
+            self._dev.build_numbered(rows, order, offsets)
+            self._pending = []
             self._dev_dirty = False
+        else:
+            self._flush_pending()
         return self._dev
+
+    def _flush_pending(self) -> None:
+        """Rows added since the last search go behind the last rows of their lists on the device (ivf.py:478-542
+        appends to the Python list); nothing else of the index is uploaded again."""
+        if not self._pending or self._dev is None or self._dev_dirty:
+            return
+        slots = np.asarray(self._pending, dtype=np.int64)
+        lists = np.fromiter((self._id_to_cluster[self._slot_id[s]] for s in self._pending), dtype=np.int32, count=len(slots))
+        self._dev.append(self._vectors[slots], slots, lists)
+        self._pending = []
+        live, _positions, dead = self._dev.layout()
+        if dead > live + 4096:              # more abandoned places than rows: pack the lists again at the next search
+            self._dev_dirty = True
 
     # ------------------------------------------------------------ search
     def _mask_words(self, filter_fn: Optional[FilterFunction]):
         if filter_fn is None:
             return None
-        mask = np.fromiter((bool(filter_fn(i, self._metadata.get(i, {}))) for i in self._dev_ids), dtype=bool,
-                           count=len(self._dev_ids))
+        mask = np.fromiter((i is not None and bool(filter_fn(i, self._metadata.get(i, {}))) for i in self._slot_id),
+                           dtype=bool, count=len(self._slot_id))
         return N.pack_mask(mask)
 
     def _results(self, dist_row, rows_row, include_vectors: bool, include_metadata: bool) -> List[SearchResult]:
@@ -357,7 +376,7 @@ class IVFIndex(BaseIndex):
         for d, r in zip(dist_row, rows_row):
             if r < 0:
                 break
-            id = self._dev_ids[r]
+            id = self._slot_id[r]
             d = float(d)
             out.append(SearchResult(id=id, distance=d, score=1.0 / (1.0 + d),
                                     vector=self._vectors[self._slot_of[id]].copy() if include_vectors else None,
@@ -417,13 +436,16 @@ class IVFIndex(BaseIndex):
                 return False
             cluster, pos = self._id_to_cluster[id], self._id_to_position[id]
             lst = self._lists[cluster]
+            if self._dev is not None and not self._dev_dirty:
+                self._flush_pending()                  # the device list must hold the row before it can swap it out
+                if not self._dev_dirty:
+                    self._dev.remove_at(cluster, pos)
             if pos < len(lst) - 1:
                 lst[pos] = lst[-1]
                 self._id_to_position[self._slot_id[lst[pos]]] = pos
             lst.pop()
             self._slot_id[self._slot_of[id]] = None
             del self._slot_of[id], self._metadata[id], self._id_to_cluster[id], self._id_to_position[id]
-            self._dev_dirty = True
             return True
 
     def remove_batch(self, ids: List[str]) -> int:
@@ -507,10 +529,40 @@ class IVFIndex(BaseIndex):
         if data.get("centroids") is not None:
             index._set_centroids(np.array(data["centroids"], dtype=np.float32))
             index._is_trained = data.get("is_trained", True)
+        # every list's entries in one pass: one matrix for the rows, one call for the bookkeeping
+        ids, meta, clusters, vecs = [], [], [], []
         for c_str, entries in data.get("inverted_lists", {}).items():
             for e in entries:
-                index._append(e["id"], np.array(e["vector"], dtype=np.float32), e.get("metadata", {}), int(c_str))
+                ids.append(e["id"]); meta.append(e.get("metadata", {})); clusters.append(int(c_str)); vecs.append(e["vector"])
+        if ids:
+            index._bulk_load(ids, np.array(vecs, dtype=np.float32).reshape(len(ids), data["dimension"]), meta,
+                             np.asarray(clusters, dtype=np.int64))
         return index
+
+    def _bulk_load(self, ids: List[str], vectors: np.ndarray, metadata: List[Dict[str, Any]], clusters: np.ndarray) -> None:
+        """Rows whose lists are known (a saved index): the host table takes the matrix as it is and every list gets
+        its slots in the order given, without a pass through ``_append`` per row."""
+        n = len(ids)
+        with self._lock:
+            base = self._n_slots
+            if base + n > len(self._vectors):
+                grown = np.zeros((max(2 * len(self._vectors), base + n), self._dimension), dtype=np.float32)
+                grown[:base] = self._vectors[:base]
+                self._vectors = grown
+            self._vectors[base:base + n] = vectors
+            self._n_slots = base + n
+            self._slot_id.extend(ids)
+            slots = range(base, base + n)
+            self._slot_of.update(zip(ids, slots))
+            self._metadata.update(zip(ids, metadata))
+            cl = clusters.tolist()
+            self._id_to_cluster.update(zip(ids, cl))
+            for id, slot, c in zip(ids, slots, cl):
+                lst = self._lists[c]
+                self._id_to_position[id] = len(lst)
+                lst.append(slot)
+            self._dev_dirty = True
+            self._pending = []
 
     def iter_ids(self) -> Iterator[str]:
         return iter(list(self._slot_of))

@@ -291,9 +291,9 @@ class PQIndex(BaseIndex):
         ids = list(data.get("ids", []))
         codes = data.get("codes", {})
         index._reserve(len(ids))
-        for r, id in enumerate(ids):
-            index._codes_arr[r] = np.array(codes[id], dtype=np.uint8)
-            index._row_of[id] = r
+        if ids:
+            index._codes_arr[:len(ids)] = np.array([codes[id] for id in ids], dtype=np.uint8).reshape(len(ids), -1)
+        index._row_of = dict(zip(ids, range(len(ids))))
         index._ids = ids
         index._metadata = dict(data.get("metadata", {}))
         index._synced = -1
