@@ -122,29 +122,39 @@ static constexpr int PQ_WAVES = 4;
 // M > 0: compile-time number of sub-spaces (multiple of 4); 0: run-time.
 // Q queries share one pass over the codes: their tables are interleaved in LDS,
 // T[(j * ksub + c) * Q + q], so one LDS read of Q floats serves all of them.
-template <int M, int Q>
+// KSUB > 0: compile-time codewords per sub-space (256 for 8-bit codes): a sub-space's table offset becomes the
+// immediate offset of the LDS read instead of an addition per row.
+template <int M, int Q, int KSUB = 0>
 __global__ __launch_bounds__(256) void pq_scan_kernel(PqScanParams p) {
     extern __shared__ __align__(16) float sm[];
     const int m = M > 0 ? M : p.m;
+    const int ksub = KSUB > 0 ? KSUB : p.ksub;
     float* T = sm;                                  // [m][ksub][Q]
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int split = blockIdx.x, q0 = blockIdx.y * Q;
     const int qcnt = min(Q, p.nq - q0);
     const int k = p.k;
 
-    for (int i = tid; i < m * p.ksub; i += 256) {
+    for (int i = tid; i < m * ksub; i += 256) {
 #pragma unroll
-        for (int q = 0; q < Q; ++q) T[i * Q + q] = p.lut[(int64_t)(q0 + min(q, qcnt - 1)) * m * p.ksub + i];
+        for (int q = 0; q < Q; ++q) T[i * Q + q] = p.lut[(int64_t)(q0 + min(q, qcnt - 1)) * m * ksub + i];
     }
     WaveTopK best[Q];
     float lbd[Q];
     int64_t lbk[Q];
+    // A row can only enter a list if sqrt(sum) <= the list's k-th distance.  thr2 is a bound on the SUM that no such
+    // row exceeds (the square of the k-th distance, a few ulps up; never below the square of the smallest distance
+    // whose own square still is a normal number), so the correctly rounded root, ten instructions per row and
+    // query, is only taken for the rare tile in which some lane passes it.
+    float thr2[Q];
 #pragma unroll
     for (int q = 0; q < Q; ++q) {
         best[q].init(k > 0 ? k : 1);
         lbd[q] = -INFINITY; lbk[q] = -1;
+        thr2[q] = INFINITY;
         if (p.lb_d && q < qcnt) { lbd[q] = p.lb_d[q0 + q]; lbk[q] = p.lb_k[q0 + q]; }
     }
+    const bool roots_always = p.dist_out != nullptr || p.lb_d != nullptr;      // wave-uniform
     __syncthreads();
 
     const int64_t ntiles = (p.n + 255) / 256;
@@ -189,13 +199,26 @@ __global__ __launch_bounds__(256) void pq_scan_kernel(PqScanParams p) {
         for (int u = 0; u < PQ_UNROLL; ++u) {
             const int64_t row = (tb + u) * 256 + tid;
             float acc[Q];
-            if (M > 0) {
+            if (M > 0 && Q == 4) {
+                // the four queries' entries are one 16-byte read; two packed adds per sub-space (each element is
+                // still its own sequential fp32 sum in sub-space order)
+                typedef float pq_f2 __attribute__((ext_vector_type(2)));
+                const float4 t0v = *reinterpret_cast<const float4*>(T + (w[u][0] & 0xff) * Q);
+                pq_f2 a01 = pq_f2{t0v.x, t0v.y}, a23 = pq_f2{t0v.z, t0v.w};
+#pragma unroll
+                for (int j = 1; j < M; ++j) {
+                    const float4 tv = *reinterpret_cast<const float4*>(T + (j * ksub + ((w[u][j >> 2] >> (8 * (j & 3))) & 0xff)) * Q);
+                    a01 = a01 + pq_f2{tv.x, tv.y};
+                    a23 = a23 + pq_f2{tv.z, tv.w};
+                }
+                acc[0] = a01.x; acc[1 % Q] = a01.y; acc[2 % Q] = a23.x; acc[3 % Q] = a23.y;
+            } else if (M > 0) {
                 const float* t0p = T + (w[u][0] & 0xff) * Q;
 #pragma unroll
                 for (int q = 0; q < Q; ++q) acc[q] = t0p[q];
 #pragma unroll
                 for (int j = 1; j < M; ++j) {
-                    const float* tp = T + (j * p.ksub + ((w[u][j >> 2] >> (8 * (j & 3))) & 0xff)) * Q;
+                    const float* tp = T + (j * ksub + ((w[u][j >> 2] >> (8 * (j & 3))) & 0xff)) * Q;
 #pragma unroll
                     for (int q = 0; q < Q; ++q) acc[q] = acc[q] + tp[q];
                 }
@@ -205,7 +228,7 @@ __global__ __launch_bounds__(256) void pq_scan_kernel(PqScanParams p) {
 #pragma unroll
                 for (int q = 0; q < Q; ++q) acc[q] = t0p[q];
                 for (int j = 1; j < m; ++j) {
-                    const float* tp = T + (j * p.ksub + src[j]) * Q;
+                    const float* tp = T + (j * ksub + src[j]) * Q;
 #pragma unroll
                     for (int q = 0; q < Q; ++q) acc[q] = acc[q] + tp[q];
                 }
@@ -213,11 +236,18 @@ __global__ __launch_bounds__(256) void pq_scan_kernel(PqScanParams p) {
             const bool pass = ok[u] && ((mw[u] >> (row & 31)) & 1u);
 #pragma unroll
             for (int q = 0; q < Q; ++q) {
-                const float d = sqrtf(acc[q]);
-                if (p.dist_out && ok[u] && q < qcnt) p.dist_out[(int64_t)(q0 + q) * p.n + row] = d;
-                if (k > 0) {
-                    const bool above = (d > lbd[q]) || (d == lbd[q] && row > lbk[q]);
-                    best[q].template offer<false>(pass && above, d, (int)row, lane);
+                if (roots_always) {
+                    const float d = sqrtf(acc[q]);
+                    if (p.dist_out && ok[u] && q < qcnt) p.dist_out[(int64_t)(q0 + q) * p.n + row] = d;
+                    if (k > 0) {
+                        const bool above = (d > lbd[q]) || (d == lbd[q] && row > lbk[q]);
+                        best[q].template offer<false>(pass && above, d, (int)row, lane);
+                    }
+                } else if (__ballot(pass && acc[q] <= thr2[q]) != 0ull) {
+                    const float d = sqrtf(acc[q]);
+                    best[q].template offer<false>(pass, d, (int)row, lane);
+                    const float t = best[q].thr;
+                    thr2[q] = fmaxf(__fmaf_rn(t * t, 4e-7f, t * t), 1e-36f);
                 }
             }
         }
@@ -369,7 +399,7 @@ int launch_pq_scan(const uint8_t* codes, int64_t n, int m, int ksub, const float
     KernelTimer timer(s);
 #define VDB_LAUNCH_PQ(MM, QQ)                                                                  \
     {                                                                                          \
-        auto kern = pq_scan_kernel<MM, QQ>;                                                    \
+        auto kern = ksub == 256 ? pq_scan_kernel<MM, QQ, 256> : pq_scan_kernel<MM, QQ, 0>;     \
         VDB_TRY(raise_dynamic_lds(reinterpret_cast<const void*>(kern),                       \
                                     lds));    \
         hipLaunchKernelGGL(kern, grid, dim3(256), lds, s, p);                                  \
