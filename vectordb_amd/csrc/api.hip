@@ -235,6 +235,8 @@ struct Workspace {
     PinBuf pin_in, pin_out;             // host ends of the small transfers of the host-pointer entry points
     DevBuf q_buf, q_sq, q_nrm, part_d, part_i, lb_d, lb_k, thr_d, thr_k, mask, out_d, out_i, dist, probes, probe_d, lut, stage;
     DevBuf queue, queue_cnt, flag, mins;
+    DevBuf ticket;                      // one int per query, zero between launches (topk_cand's last-block merge)
+    void* ticket_zeroed = nullptr;      // the allocation that has been cleared
     DevBuf mid[4];                      // intermediate levels of a hierarchical list merge (launch_select)
     // item table of the last flat scan, kept between calls: it depends on (rows, queries, group) only
     DevBuf fp_seg_row_off, fp_seg_q_off, fp_seg_item_off, fp_sq_qid, fp_sq_out, fp_items;
@@ -244,12 +246,13 @@ struct Workspace {
         DevBuf* all[] = {&q_buf, &q_sq, &q_nrm, &part_d, &part_i, &lb_d, &lb_k, &thr_d, &thr_k, &mask, &out_d, &out_i, &dist,
                          &probes, &probe_d, &lut, &stage, &round32, &q16, &cand, &seg_row_off, &seg_q_off, &seg_item_off, &sq_qid, &sq_out,
                          &cand_off, &tile_off, &list_cnt, &cursor, &slots, &items,
-                         &queue, &queue_cnt, &flag, &mins, &mid[0], &mid[1], &mid[2], &mid[3],
+                         &queue, &queue_cnt, &flag, &mins, &ticket, &mid[0], &mid[1], &mid[2], &mid[3],
                          &fp_seg_row_off, &fp_seg_q_off, &fp_seg_item_off, &fp_sq_qid, &fp_sq_out, &fp_items};
         for (DevBuf* b : all) f(b);
     }
     void release() {
         fp_n = -1;
+        ticket_zeroed = nullptr;
         each([](DevBuf* b) { b->release(); });
         pin_in.release(); pin_out.release();
     }
@@ -1699,6 +1702,82 @@ static int ivf_probe_impl(vdb_ivf* h, const float* q_pad_unused, const float* d_
     return VDB_OK;
 }
 
+// One query: four launches.  Centroid sums (the streaming scan over the centroid rows) -> one block that takes the
+// query's norms, ranks the centroids and lays out the scan (launch_ivf_one_plan) -> list scan -> selection whose
+// last block merges and maps slots to rows.  Same values and the same order as the batch path, which spends
+// fifteen launches on a single query.
+static bool ivf_one_query_ok(const vdb_ivf* h, int nq, int k, int n_probe) {
+    static const bool off = getenv("VDB_IVF_NO_ONE") != nullptr;
+    const Rows& m = h->members->r;
+    const Rows& c = h->centroids->r;
+    return !off && nq == 1 && k <= KMAX_FUSED && n_probe <= 64 && m.ld == m.dim && m.dim % 8 == 0 && !m.bf16 && !c.bf16 &&
+           h->n_lists <= (1 << 20);
+}
+
+static int ivf_search_one(vdb_ivf* h, const float* d_q, int k, int n_probe, const uint32_t* d_mask,
+                          float* d_out_d, int64_t* d_out_i, int64_t* d_out_order, hipStream_t s) {
+    vdb_rows* m = h->members;
+    vdb_rows* c = h->centroids;
+    Workspace& ws = h->ws;
+    const int sm = scan_metric_of(h->metric);
+    const int64_t k_eff = std::min<int64_t>(k, h->lay.live);
+    const int64_t cand_stride = round_up64(std::max<int64_t>(h->probe_bound(n_probe), 1), 64);
+    VDB_REQUIRE(cand_stride < (int64_t)0x7fffffff, "n_probe=%d lists can hold more than 2^31 rows", n_probe);
+    h->last_nq = 1; h->last_nprobe = n_probe; h->last_scan_rows = -1; h->last_stream = s;
+
+    // 1: the query against every centroid
+    VDB_TRY(ws.dist.reserve((size_t)h->n_lists * sizeof(float)));
+    VDB_TRY(stream_flat_sums(c->ws, c->r, sm, d_q, 1, ws.dist.as<float>(), s));
+    // 2: norms, ranking, layout of the scan
+    StreamPlanBufs b{};
+    const int64_t items_cap = cand_stride / 256 + n_probe;
+    VDB_TRY(reserve_stream_plan(ws, 1, n_probe, items_cap, &b));
+    VDB_TRY(ws.probes.reserve((size_t)n_probe * sizeof(int)));
+    VDB_TRY(ws.probe_d.reserve((size_t)n_probe * sizeof(float)));
+    VDB_TRY(ws.q_sq.reserve(sizeof(float)));
+    VDB_TRY(ws.q_nrm.reserve(sizeof(float)));
+    VDB_TRY(ws.cand.reserve((size_t)cand_stride * sizeof(float)));
+    VDB_TRY(ws.cand_off.reserve((size_t)(n_probe + 1) * sizeof(int64_t)));
+    VDB_TRY(ws.tile_off.reserve((size_t)(n_probe + 1) * sizeof(int)));
+    VDB_TRY(launch_ivf_one_plan(ws.dist.as<float>(), sm, c->r.sq, c->r.nrm, c->r.cos_eps, d_q, m->r.plan, h->n_lists, n_probe,
+                                h->lay.d_beg(), h->lay.d_end(), ws.q_sq.as<float>(), ws.q_nrm.as<float>(), ws.probes.as<int>(),
+                                ws.probe_d.as<float>(), ws.cand_off.as<int64_t>(), ws.tile_off.as<int>(), b, s));
+    // 3: the probed lists
+    StreamJob j{};
+    j.data = m->r.data; j.ld = m->r.ld; j.dim = m->r.dim; j.plan = m->r.plan;
+    j.op = op_of_metric(sm); j.post = post_of_metric(sm);
+    if (j.post == POST_SQRT) j.post = POST_NONE;          // the selection takes the root (CandJob::sqrt_here)
+    j.q = d_q; j.ldq = m->r.ld; j.group = 1; j.n_seg = 1;
+    j.seg_row_off = nullptr; j.seg_q_off = nullptr; j.seg_item_off = b.seg_item_off;
+    j.sq_qid = b.sq_qid; j.sq_out = b.sq_out; j.items = b.items; j.items_cap = b.items_cap;
+    j.out = ws.cand.as<float>(); j.timed = true;
+    VDB_TRY(launch_stream_sums(j, s));
+    // 4: the k best, merged and mapped to rows by the block that finishes last
+    const int64_t avg_tiles = std::max<int64_t>(1, ((int64_t)n_probe * (h->lay.live / std::max(1, h->n_lists)) + 255) / 256);
+    const int splits = cand_splits(avg_tiles, 1);
+    const int n_cand = splits * topk_cand_lists_per_split();
+    const int kk = (int)std::max<int64_t>(k_eff, 1);
+    VDB_TRY(ws.part_d.reserve((size_t)n_cand * kk * sizeof(float)));
+    VDB_TRY(ws.part_i.reserve((size_t)n_cand * kk * sizeof(int)));
+    VDB_TRY(ws.ticket.reserve(sizeof(int)));
+    if (ws.ticket_zeroed != ws.ticket.p) {
+        VDB_HIP(hipMemsetAsync(ws.ticket.p, 0, sizeof(int), s));
+        ws.ticket_zeroed = ws.ticket.p;
+    }
+    CandJob cj{};
+    cj.cand = ws.cand.as<float>(); cj.cand_stride = cand_stride; cj.nq = 1; cj.n = 0;
+    cj.probes = ws.probes.as<int>(); cj.n_probe = n_probe; cj.n_lists = h->n_lists;
+    cj.list_beg = h->lay.d_beg(); cj.list_end = h->lay.d_end();
+    cj.cand_off = ws.cand_off.as<int64_t>(); cj.tile_off = ws.tile_off.as<int>();
+    cj.row_ids = h->row_ids.as<int>(); cj.mask = d_mask;
+    cj.sqrt_here = true;
+    cj.metric = sm; cj.q_sq = ws.q_sq.as<float>(); cj.q_nrm = ws.q_nrm.as<float>();
+    cj.row_sq = m->r.sq; cj.row_nrm = m->r.nrm;
+    cj.k = kk; cj.splits = splits; cj.part_d = ws.part_d.as<float>(); cj.part_i = ws.part_i.as<int>();
+    cj.ticket = ws.ticket.as<int>(); cj.k_out = k; cj.fin_d = d_out_d; cj.fin_rows = d_out_i; cj.fin_order = d_out_order;
+    return launch_topk_cand(cj, s);
+}
+
 static int ivf_search_impl(vdb_ivf* h, const float* d_q, int nq, int k, int n_probe, const uint32_t* d_mask,
                            float* d_out_d, int64_t* d_out_i, int64_t* d_out_order, hipStream_t s) {
     VDB_REQUIRE(h->n_lists >= 1, "index is not trained");
@@ -1707,6 +1786,10 @@ static int ivf_search_impl(vdb_ivf* h, const float* d_q, int nq, int k, int n_pr
     n_probe = std::min(n_probe, h->n_lists);
     vdb_rows* m = h->members;
     Workspace& ws = h->ws;
+    if (h->lay.live > 0 && ivf_one_query_ok(h, nq, k, n_probe)) {
+        VDB_TRY(h->lay.sync(s));
+        return ivf_search_one(h, d_q, k, n_probe, d_mask, d_out_d, d_out_i, d_out_order, s);     // writes all k results
+    }
     VDB_TRY(fill_results(d_out_d, d_out_i, (int64_t)nq * k, s));
     if (d_out_order) VDB_TRY(fill_results(nullptr, d_out_order, (int64_t)nq * k, s));
     if (h->lay.live == 0) return VDB_OK;

@@ -866,6 +866,10 @@ struct CandParams {
     float radius; int use_radius;
     int k; int splits;
     float* part_d; int* part_i;                  // [nq][splits][k], idx = candidate slot
+    // One launch for selection, merge and row lookup (lists only): the block that finishes last for a query
+    // (ticket[q] counts them and is left at zero again) merges every block's lists and writes the k_out results.
+    int* ticket; int k_out;
+    float* fin_d; int64_t* fin_rows; int64_t* fin_order;
 };
 
 static constexpr int CAND_WAVES = LIST_NT / 64;   // candidate lists one block writes
@@ -994,6 +998,49 @@ __global__ __launch_bounds__(LIST_NT) void topk_cand_kernel(CandParams p) {
     // one candidate list per wave
     const int64_t list = ((int64_t)qi * p.splits + split) * CAND_WAVES + wave;
     best.store(p.part_d + list * k, p.part_i + list * k, lane);
+    if (p.ticket == nullptr) return;
+
+    __shared__ int s_last;
+    __threadfence();                            // this block's lists are visible device-wide before its ticket
+    __syncthreads();
+    if (tid == 0) s_last = atomicAdd(p.ticket + qi, 1) == p.splits - 1;
+    __syncthreads();
+    if (!s_last || wave != 0) return;
+    __threadfence();                            // and the other blocks' lists are visible to this one
+    WaveTopK fin;
+    fin.init(k);
+    const int total = p.splits * CAND_WAVES * k;
+    const float* pd = p.part_d + (int64_t)qi * total;
+    const int* pi = p.part_i + (int64_t)qi * total;
+    for (int c0 = 0; c0 < total; c0 += 64) {
+        const int c = c0 + lane;
+        const bool have = c < total;
+        const float d = have ? pd[c] : INFINITY;
+        const int id = have ? pi[c] : EMPTY_IDX;
+        fin.offer(have && id != EMPTY_IDX, d, id, lane);
+    }
+    if (lane < p.k_out) {
+        const int64_t at = (int64_t)qi * p.k_out + lane;
+        float d = INFINITY;
+        int64_t row = -1, order = -1;
+        if (lane < k && fin.eid != EMPTY_IDX) {
+            const int slot = fin.eid;
+            const int64_t* co = p.cand_off + (int64_t)qi * (p.n_probe + 1);
+            int lo = 0, hi = p.n_probe;         // co[lo] <= slot < co[hi]
+            while (hi - lo > 1) {
+                const int mid = (lo + hi) >> 1;
+                if (co[mid] <= slot) lo = mid; else hi = mid;
+            }
+            const int l = p.probes[(int64_t)qi * p.n_probe + lo];
+            d = fin.e;
+            row = p.row_ids[p.list_beg[l] + (slot - co[lo])];
+            order = ((int64_t)lo << 32) | (int64_t)(slot - co[lo]);   // the reference's visiting order (ivf.py:619-628)
+        }
+        p.fin_d[at] = d;
+        p.fin_rows[at] = row;
+        if (p.fin_order) p.fin_order[at] = order;
+    }
+    if (lane == 0) p.ticket[qi] = 0;
 }
 
 int topk_cand_lists_per_split() { return CAND_WAVES; }
@@ -1006,6 +1053,9 @@ int launch_topk_cand(const CandJob& j, hipStream_t s) {
     p.fin = Finish{j.metric, j.q_sq, j.q_nrm, j.row_sq, j.row_nrm, 1e-8f};
     p.lb_d = j.lb_d; p.lb_k = j.lb_k; p.radius = j.radius; p.use_radius = j.use_radius;
     p.k = j.k; p.splits = j.splits; p.part_d = j.part_d; p.part_i = j.part_i;
+    p.ticket = j.ticket; p.k_out = j.k_out; p.fin_d = j.fin_d; p.fin_rows = j.fin_rows; p.fin_order = j.fin_order;
+    VDB_REQUIRE(j.ticket == nullptr || (j.probes && j.row_ids && j.fin_d && j.fin_rows && j.k_out >= j.k && j.k_out <= 64),
+                "the one-launch selection serves list candidates with k <= 64");
     VDB_REQUIRE(j.probes == nullptr || (j.cand_off && j.tile_off), "list candidates need their slot and tile offsets");
     p.cand_off = j.cand_off; p.tile_off = j.tile_off;
     const size_t lds = (size_t)RUN_CHUNK * 24 + 8;
@@ -1267,11 +1317,7 @@ __global__ void sqrt_kernel(const float* __restrict__ sq, float* __restrict__ nr
 // folded right into left (np.sum of a contiguous fp32 run; distance/metrics.py:455-456,469-470).
 struct SmallNormPlan { int n_leaves; short leaf_len[SumPlan::MAX_LEAVES]; unsigned char folds[SumPlan::MAX_LEAVES]; };
 
-__global__ void small_norms_kernel(const float* __restrict__ data, int ld, int64_t n, SmallNormPlan plan,
-                                   float* __restrict__ sq, float* __restrict__ nrm) {
-    const int64_t row = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (row >= n) return;
-    const float* x = data + row * ld;
+__device__ static float small_norm_of(const float* __restrict__ x, const SmallNormPlan& plan) {
     float stack[8];
     int sp = 0, off = 0;
     for (int l = 0; l < plan.n_leaves; ++l) {
@@ -1300,9 +1346,128 @@ __global__ void small_norms_kernel(const float* __restrict__ data, int ld, int64
             stack[sp++] = a + b;
         }
     }
-    const float total = stack[0];
+    return stack[0];
+}
+
+__global__ void small_norms_kernel(const float* __restrict__ data, int ld, int64_t n, SmallNormPlan plan,
+                                   float* __restrict__ sq, float* __restrict__ nrm) {
+    const int64_t row = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (row >= n) return;
+    const float total = small_norm_of(data + row * ld, plan);
     sq[row] = total;
     nrm[row] = sqrtf(total);
+}
+
+// --------------------------------------------------------------------------
+// One query against an IVF index: everything between the centroid sums and the list scan in one block.
+//   query norms (NumPy order) -> distance to every centroid -> the n_probe nearest in (distance, list) order
+//   (index/ivf.py:611-614) -> slot and tile offsets of the probed lists, the scan's items, its query entries.
+// Replaces, for a single query, the selection and merge launches of the probe, the norm launches and the four
+// planning launches of the batch path.
+struct IvfOneParams {
+    const float* sums; Finish fin;               // streamed sums against the centroids; their metric and norms
+    const float* q; SmallNormPlan qplan;
+    int n_lists; int n_probe;
+    const int64_t* list_beg; const int64_t* list_end;
+    float* q_sq; float* q_nrm;                   // out: the query's norms, for the finish of the list scan
+    int* probes; float* probe_d;                 // out [n_probe]
+    int64_t* cand_off; int* tile_off;            // out [n_probe + 1]
+    int* sq_qid; int64_t* sq_out;                // out [n_probe]
+    int64_t* seg_item_off;                       // out [2]
+    StreamItem* items; int64_t items_cap;
+};
+static constexpr int ONE_NT = 1024;
+
+__global__ __launch_bounds__(ONE_NT) void ivf_one_plan_kernel(IvfOneParams p) {
+    __shared__ float s_q[2];
+    __shared__ float Ld[ONE_NT / 64][64];
+    __shared__ int Li[ONE_NT / 64][64];
+    __shared__ int64_t s_len[64], s_co[65], s_io[65];
+    __shared__ int s_list[64], s_to[65];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int np = p.n_probe;
+    if (tid == 0) {
+        const float sq = small_norm_of(p.q, p.qplan);
+        s_q[0] = sq; s_q[1] = sqrtf(sq);
+        p.q_sq[0] = sq; p.q_nrm[0] = s_q[1];
+    }
+    __syncthreads();
+    const float q_sq = s_q[0], q_nrm = s_q[1];
+    WaveTopK best;
+    best.init(np);
+    for (int base = wave * 64; base < p.n_lists; base += ONE_NT) {
+        const int i = base + lane;
+        const bool ok = i < p.n_lists;
+        const float d = ok ? finish_value(p.fin, p.sums[i], q_sq, q_nrm, i) : INFINITY;
+        best.offer(ok, d, i, lane);
+    }
+    Ld[wave][lane] = best.e; Li[wave][lane] = best.eid;       // lanes >= n_probe hold what the list pushed out
+    __syncthreads();
+    if (wave == 0) {
+        WaveTopK fin;
+        fin.init(np);
+        for (int w = 0; w < ONE_NT / 64; ++w) {
+            const int id = Li[w][lane];
+            fin.offer(lane < np && id != EMPTY_IDX, Ld[w][lane], id, lane);
+        }
+        if (lane < np) {
+            const int l = fin.eid;
+            const bool ok = l != EMPTY_IDX;
+            p.probes[lane] = ok ? l : -1;         // no ranking (every distance NaN): an empty list
+            if (p.probe_d) p.probe_d[lane] = ok ? fin.e : INFINITY;
+            s_list[lane] = ok ? l : -1;
+            s_len[lane] = ok ? p.list_end[l] - p.list_beg[l] : 0;
+        }
+    }
+    __syncthreads();
+    if (tid == 0) {
+        int64_t co = 0, io = 0;
+        int to = 0;
+        for (int i = 0; i < np; ++i) {
+            s_co[i] = co; s_to[i] = to; s_io[i] = io;
+            const int64_t chunks = (s_len[i] + S_NT - 1) / S_NT;
+            co += s_len[i]; to += (int)chunks; io += chunks;
+        }
+        s_co[np] = co; s_to[np] = to; s_io[np] = io;
+        p.seg_item_off[0] = 0; p.seg_item_off[1] = io;
+    }
+    __syncthreads();
+    if (tid <= np) { p.cand_off[tid] = s_co[tid]; p.tile_off[tid] = s_to[tid]; }
+    if (tid < np) { p.sq_qid[tid] = 0; p.sq_out[tid] = s_co[tid]; }
+    // items: chunk c of probe pr; one thread per item
+    const int64_t total = min(s_io[np], p.items_cap);
+    for (int64_t it = tid; it < total; it += ONE_NT) {
+        int lo = 0, hi = np;                      // s_io[lo] <= it < s_io[hi]
+        while (hi - lo > 1) {
+            const int mid = (lo + hi) >> 1;
+            if (s_io[mid] <= it) lo = mid; else hi = mid;
+        }
+        const int64_t c = it - s_io[lo];
+        StreamItem item;
+        item.out_rel = c * S_NT;
+        item.row0 = p.list_beg[s_list[lo]] + item.out_rel;
+        item.rows = (int)min<int64_t>(S_NT, s_len[lo] - item.out_rel);
+        item.qbeg = lo; item.qcnt = 1; item.pad = 0;
+        p.items[it] = item;
+    }
+}
+
+int launch_ivf_one_plan(const float* sums, int metric, const float* cent_sq, const float* cent_nrm, float cos_eps, const float* q,
+                        const SumPlan& plan, int n_lists, int n_probe, const int64_t* list_beg, const int64_t* list_end,
+                        float* q_sq, float* q_nrm, int* probes, float* probe_d, int64_t* cand_off, int* tile_off,
+                        const StreamPlanBufs& b, hipStream_t s) {
+    VDB_REQUIRE(n_probe >= 1 && n_probe <= 64, "the one-query plan ranks at most 64 lists");
+    IvfOneParams p{};
+    p.sums = sums; p.fin = Finish{metric, nullptr, nullptr, cent_sq, cent_nrm, cos_eps};
+    p.q = q;
+    p.qplan.n_leaves = plan.n_leaves;
+    for (int i = 0; i < plan.n_leaves; ++i) { p.qplan.leaf_len[i] = plan.leaf_len[i]; p.qplan.folds[i] = plan.folds[i]; }
+    p.n_lists = n_lists; p.n_probe = n_probe; p.list_beg = list_beg; p.list_end = list_end;
+    p.q_sq = q_sq; p.q_nrm = q_nrm; p.probes = probes; p.probe_d = probe_d; p.cand_off = cand_off; p.tile_off = tile_off;
+    p.sq_qid = b.sq_qid; p.sq_out = b.sq_out; p.seg_item_off = b.seg_item_off; p.items = b.items; p.items_cap = b.items_cap;
+    hipLaunchKernelGGL(ivf_one_plan_kernel, dim3(1), dim3(ONE_NT), 0, s, p);
+    VDB_HIP(hipGetLastError());
+    return VDB_OK;
 }
 
 // A batch of rows (up to a few thousand queries): eight lanes per row, lane j keeps the strided

@@ -238,7 +238,15 @@ struct CandJob {
     const float* lb_d; const int64_t* lb_k; float radius; int use_radius;
     int k; int splits; float* part_d; int* part_i;
     bool sqrt_here;                                   // VDB_EUCLIDEAN_DIRECT whose scan stored the sums without the root
+    // lists only: one launch for selection, merge and row lookup (the last block of a query merges); ticket = one
+    // zeroed int per query, k_out = results per query (>= k; the rest is filled with INFINITY / -1)
+    int* ticket; int k_out; float* fin_d; int64_t* fin_rows; int64_t* fin_order;
 };
+// one query against an IVF index: norms, centroid ranking, slot/tile offsets and scan items in one block
+int launch_ivf_one_plan(const float* sums, int metric, const float* cent_sq, const float* cent_nrm, float cos_eps, const float* q,
+                        const SumPlan& plan, int n_lists, int n_probe, const int64_t* list_beg, const int64_t* list_end,
+                        float* q_sq, float* q_nrm, int* probes, float* probe_d, int64_t* cand_off, int* tile_off,
+                        const StreamPlanBufs& b, hipStream_t s);
 int launch_topk_cand(const CandJob& j, hipStream_t s);
 // range search over the streamed sums of ONE query (candidate slot = stored row): count + scan of the rows inside
 // the radius, then the first `cap` of them in row order as sorted (distance, row) results
