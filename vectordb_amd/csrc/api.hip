@@ -1711,7 +1711,7 @@ static bool ivf_one_query_ok(const vdb_ivf* h, int nq, int k, int n_probe) {
     const Rows& m = h->members->r;
     const Rows& c = h->centroids->r;
     return !off && nq == 1 && k <= KMAX_FUSED && n_probe <= 64 && m.ld == m.dim && m.dim % 8 == 0 && !m.bf16 && !c.bf16 &&
-           h->n_lists <= (1 << 20);
+           h->n_lists <= 16384;
 }
 
 static int ivf_search_one(vdb_ivf* h, const float* d_q, int k, int n_probe, const uint32_t* d_mask,
@@ -1754,8 +1754,10 @@ static int ivf_search_one(vdb_ivf* h, const float* d_q, int k, int n_probe, cons
     VDB_TRY(launch_stream_sums(j, s));
     // 4: the k best, merged and mapped to rows by the block that finishes last
     const int64_t avg_tiles = std::max<int64_t>(1, ((int64_t)n_probe * (h->lay.live / std::max(1, h->n_lists)) + 255) / 256);
-    const int splits = cand_splits(avg_tiles, 1);
-    const int n_cand = splits * topk_cand_lists_per_split();
+    // one step of the selection walk per block where the candidates allow it (the walk is a chain of dependent
+    // loads); the blocks' lists are merged by the last of them, so not more than 64
+    const int splits = (int)std::max<int64_t>(1, std::min<int64_t>(64, avg_tiles / 8));
+    const int n_cand = splits;                                 // one list per block in this mode
     const int kk = (int)std::max<int64_t>(k_eff, 1);
     VDB_TRY(ws.part_d.reserve((size_t)n_cand * kk * sizeof(float)));
     VDB_TRY(ws.part_i.reserve((size_t)n_cand * kk * sizeof(int)));

@@ -882,7 +882,8 @@ static constexpr int RUN_CHUNK = 256;      // probed lists whose ranges are stag
 // identity form, 2 = cosine of the matrix form, 3 = cosine of the pair form, 4 = the angle of the pair form,
 // 5 = the square root of the streamed sum (direct-form Euclidean whose scan left the root to this kernel: one
 // correctly rounded sqrtf per candidate costs the scan, which is bound by its vector ALUs, more than it costs here).
-template <int FIN>
+// ONE: the one-launch mode (p.ticket set): few blocks that run nearly alone, register-only merge network
+template <int FIN, bool ONE>
 __global__ __launch_bounds__(LIST_NT) void topk_cand_kernel(CandParams p) {
     extern __shared__ __align__(16) float smem[];
     int64_t* R_pos0 = reinterpret_cast<int64_t*>(smem);         // first stored row of the run
@@ -986,22 +987,44 @@ __global__ __launch_bounds__(LIST_NT) void topk_cand_kernel(CandParams p) {
                 for (int u = 0; u < CAND_UNROLL; ++u)
                     if (ok[u]) ok[u] = (p.mask[rown[u] >> 5] >> (rown[u] & 31)) & 1u;
             }
+
 #pragma unroll
             for (int u = 0; u < CAND_UNROLL; ++u) {
                 bool want = ok[u];
                 if (p.use_radius && !(d[u] <= p.radius)) want = false;
                 if (!((d[u] > lbd) || (d[u] == lbd && slot[u] > lbk))) want = false;
-                best.offer(want, d[u], slot[u], lane);      // tiles in order, lanes in order: ascending slots
+                best.offer<true, ONE>(want, d[u], slot[u], lane);      // tiles in order, lanes in order: ascending slots
             }
+
         }
     }
-    // one candidate list per wave
-    const int64_t list = ((int64_t)qi * p.splits + split) * CAND_WAVES + wave;
-    best.store(p.part_d + list * k, p.part_i + list * k, lane);
-    if (p.ticket == nullptr) return;
-
+    if (!ONE) {
+        // one candidate list per wave
+        const int64_t list = ((int64_t)qi * p.splits + split) * CAND_WAVES + wave;
+        best.store(p.part_d + list * k, p.part_i + list * k, lane);
+        return;
+    }
+    // ---- one launch: the block's four wave lists become one (a pair's place = the pairs that precede it), and
+    // the block that finishes last for its query merges every block's list
+    __syncthreads();                            // the run tables in smem are no longer read
+    float* Wd = smem;                           // [CAND_WAVES][64]
+    int* Wi = reinterpret_cast<int*>(smem + CAND_WAVES * 64);
+    Wd[wave * 64 + lane] = best.e; Wi[wave * 64 + lane] = best.eid;
+    __syncthreads();
+    float* bd = p.part_d + ((int64_t)qi * p.splits + split) * k;
+    int* bi = p.part_i + ((int64_t)qi * p.splits + split) * k;
+    if (tid < k) { bd[tid] = INFINITY; bi[tid] = EMPTY_IDX; }
+    __syncthreads();
+    if (lane < k && best.eid != EMPTY_IDX) {
+        int rank = lane;
+        for (int w = 0; w < CAND_WAVES; ++w) {
+            if (w == wave) continue;
+            for (int e = 0; e < k; ++e) rank += pair_less(Wd[w * 64 + e], Wi[w * 64 + e], best.e, best.eid) ? 1 : 0;
+        }
+        if (rank < k) { bd[rank] = best.e; bi[rank] = best.eid; }
+    }
     __shared__ int s_last;
-    __threadfence();                            // this block's lists are visible device-wide before its ticket
+    __threadfence();                            // this block's list is visible device-wide before its ticket
     __syncthreads();
     if (tid == 0) s_last = atomicAdd(p.ticket + qi, 1) == p.splits - 1;
     __syncthreads();
@@ -1009,7 +1032,7 @@ __global__ __launch_bounds__(LIST_NT) void topk_cand_kernel(CandParams p) {
     __threadfence();                            // and the other blocks' lists are visible to this one
     WaveTopK fin;
     fin.init(k);
-    const int total = p.splits * CAND_WAVES * k;
+    const int total = p.splits * k;
     const float* pd = p.part_d + (int64_t)qi * total;
     const int* pi = p.part_i + (int64_t)qi * total;
     for (int c0 = 0; c0 < total; c0 += 64) {
@@ -1017,7 +1040,15 @@ __global__ __launch_bounds__(LIST_NT) void topk_cand_kernel(CandParams p) {
         const bool have = c < total;
         const float d = have ? pd[c] : INFINITY;
         const int id = have ? pi[c] : EMPTY_IDX;
-        fin.offer(have && id != EMPTY_IDX, d, id, lane);
+        fin.offer<true, true>(have && id != EMPTY_IDX, d, id, lane);
+    }
+    // slot -> (probe, position) -> row: the query's slot offsets and probes go to LDS in one coalesced read each,
+    // so the search per result is a few LDS reads instead of a chain of global ones
+    int* s_co = reinterpret_cast<int*>(smem);   // [n_probe + 1] (a query's slots are below 2^31), then its probes
+    const bool small = 2 * p.n_probe + 1 <= 2 * CAND_WAVES * 64;
+    if (small) {
+        for (int i = lane; i <= p.n_probe; i += 64) s_co[i] = (int)p.cand_off[(int64_t)qi * (p.n_probe + 1) + i];
+        for (int i = lane; i < p.n_probe; i += 64) s_co[p.n_probe + 1 + i] = p.probes[(int64_t)qi * p.n_probe + i];
     }
     if (lane < p.k_out) {
         const int64_t at = (int64_t)qi * p.k_out + lane;
@@ -1029,12 +1060,13 @@ __global__ __launch_bounds__(LIST_NT) void topk_cand_kernel(CandParams p) {
             int lo = 0, hi = p.n_probe;         // co[lo] <= slot < co[hi]
             while (hi - lo > 1) {
                 const int mid = (lo + hi) >> 1;
-                if (co[mid] <= slot) lo = mid; else hi = mid;
+                if ((small ? (int64_t)s_co[mid] : co[mid]) <= slot) lo = mid; else hi = mid;
             }
-            const int l = p.probes[(int64_t)qi * p.n_probe + lo];
+            const int l = small ? s_co[p.n_probe + 1 + lo] : p.probes[(int64_t)qi * p.n_probe + lo];
             d = fin.e;
-            row = p.row_ids[p.list_beg[l] + (slot - co[lo])];
-            order = ((int64_t)lo << 32) | (int64_t)(slot - co[lo]);   // the reference's visiting order (ivf.py:619-628)
+            const int64_t in_list = slot - (small ? (int64_t)s_co[lo] : co[lo]);
+            row = p.row_ids[p.list_beg[l] + in_list];
+            order = ((int64_t)lo << 32) | in_list;                    // the reference's visiting order (ivf.py:619-628)
         }
         p.fin_d[at] = d;
         p.fin_rows[at] = row;
@@ -1042,6 +1074,7 @@ __global__ __launch_bounds__(LIST_NT) void topk_cand_kernel(CandParams p) {
     }
     if (lane == 0) p.ticket[qi] = 0;
 }
+
 
 int topk_cand_lists_per_split() { return CAND_WAVES; }
 
@@ -1062,8 +1095,11 @@ int launch_topk_cand(const CandJob& j, hipStream_t s) {
     const int fin = (j.metric == VDB_EUCLIDEAN || j.metric == VDB_EUCLIDEAN_SQ) ? 1
                     : j.metric == VDB_COSINE ? 2 : j.metric == VDB_COSINE_PAIR ? 3 : j.metric == VDB_ANGULAR ? 4
                     : (j.metric == VDB_EUCLIDEAN_DIRECT && j.sqrt_here) ? 5 : 0;
-    auto kern = fin == 1 ? topk_cand_kernel<1> : fin == 2 ? topk_cand_kernel<2> : fin == 3 ? topk_cand_kernel<3>
-                : fin == 4 ? topk_cand_kernel<4> : fin == 5 ? topk_cand_kernel<5> : topk_cand_kernel<0>;
+    const bool one = j.ticket != nullptr;
+#define VDB_CAND_KERN(F) (one ? topk_cand_kernel<F, true> : topk_cand_kernel<F, false>)
+    auto kern = fin == 1 ? VDB_CAND_KERN(1) : fin == 2 ? VDB_CAND_KERN(2) : fin == 3 ? VDB_CAND_KERN(3)
+                : fin == 4 ? VDB_CAND_KERN(4) : fin == 5 ? VDB_CAND_KERN(5) : VDB_CAND_KERN(0);
+#undef VDB_CAND_KERN
     VDB_TRY(raise_dynamic_lds(reinterpret_cast<const void*>(kern), lds));
     hipLaunchKernelGGL(kern, dim3(j.nq, j.splits), dim3(LIST_NT), lds, s, p);
     VDB_HIP(hipGetLastError());
@@ -1365,7 +1401,7 @@ __global__ void small_norms_kernel(const float* __restrict__ data, int ld, int64
 // Replaces, for a single query, the selection and merge launches of the probe, the norm launches and the four
 // planning launches of the batch path.
 struct IvfOneParams {
-    const float* sums; Finish fin;               // streamed sums against the centroids; their metric and norms
+    const float* sums; float* dists; Finish fin;  // streamed sums against the centroids (dists: where their distances go; may be sums)
     const float* q; SmallNormPlan qplan;
     int n_lists; int n_probe;
     const int64_t* list_beg; const int64_t* list_end;
@@ -1378,10 +1414,24 @@ struct IvfOneParams {
 };
 static constexpr int ONE_NT = 1024;
 
+// unsigned key whose order is the order of the distances (-0 and +0 are one distance)
+__device__ __forceinline__ uint32_t order_key(float d) {
+    if (d == 0.0f) d = 0.0f;
+    const uint32_t u = __float_as_uint(d);
+    return u ^ ((u >> 31) ? 0xffffffffu : 0x80000000u);
+}
+
+// A single block has the chip to itself and runs at whatever the slowest dependent chain costs, so the ranking is
+// a radix select: four rounds of a 256-bin histogram over the distance keys find the n_probe-th smallest key T
+// exactly; the keys up to T (all ties of T included) are gathered, and one wave sorts them by (distance, list).
 __global__ __launch_bounds__(ONE_NT) void ivf_one_plan_kernel(IvfOneParams p) {
+    extern __shared__ __align__(16) uint32_t s_key[];           // [n_lists]
     __shared__ float s_q[2];
-    __shared__ float Ld[ONE_NT / 64][64];
-    __shared__ int Li[ONE_NT / 64][64];
+    __shared__ int s_hist[256];
+    __shared__ uint32_t s_prefix;
+    __shared__ int s_need, s_cnt, s_valid;
+    __shared__ float Cd[ONE_NT];
+    __shared__ int Ci[ONE_NT];
     __shared__ int64_t s_len[64], s_co[65], s_io[65];
     __shared__ int s_list[64], s_to[65];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -1390,33 +1440,94 @@ __global__ __launch_bounds__(ONE_NT) void ivf_one_plan_kernel(IvfOneParams p) {
         const float sq = small_norm_of(p.q, p.qplan);
         s_q[0] = sq; s_q[1] = sqrtf(sq);
         p.q_sq[0] = sq; p.q_nrm[0] = s_q[1];
+        s_prefix = 0; s_need = np; s_cnt = 0; s_valid = 0;
     }
+    if (tid < 256) s_hist[tid] = 0;
+    if (tid < np) { s_list[tid] = -1; s_len[tid] = 0; p.probes[tid] = -1; if (p.probe_d) p.probe_d[tid] = INFINITY; }
     __syncthreads();
     const float q_sq = s_q[0], q_nrm = s_q[1];
-    WaveTopK best;
-    best.init(np);
-    for (int base = wave * 64; base < p.n_lists; base += ONE_NT) {
-        const int i = base + lane;
-        const bool ok = i < p.n_lists;
-        const float d = ok ? finish_value(p.fin, p.sums[i], q_sq, q_nrm, i) : INFINITY;
-        best.offer(ok, d, i, lane);
+    // distances (kept in place of the sums), keys, and the first histogram
+    int valid = 0;
+    for (int i = tid; i < p.n_lists; i += ONE_NT) {
+        const float d = finish_value(p.fin, p.sums[i], q_sq, q_nrm, i);
+        p.dists[i] = d;
+        const bool ok = !(d != d);                           // a NaN distance ranks nowhere
+        const uint32_t key = ok ? order_key(d) : 0xffffffffu;
+        s_key[i] = key;
+        if (ok) { atomicAdd(&s_hist[key >> 24], 1); ++valid; }
     }
-    Ld[wave][lane] = best.e; Li[wave][lane] = best.eid;       // lanes >= n_probe hold what the list pushed out
+    if (valid) atomicAdd(&s_valid, valid);
     __syncthreads();
-    if (wave == 0) {
-        WaveTopK fin;
-        fin.init(np);
-        for (int w = 0; w < ONE_NT / 64; ++w) {
-            const int id = Li[w][lane];
-            fin.offer(lane < np && id != EMPTY_IDX, Ld[w][lane], id, lane);
+    const bool take_all = s_valid <= np;
+    for (int round = 0; round < 4 && !take_all; ++round) {
+        const int shift = 24 - 8 * round;
+        if (wave == 0) {
+            // the bin in which the running count reaches what is still needed
+            const int h0 = s_hist[4 * lane], h1 = s_hist[4 * lane + 1], h2 = s_hist[4 * lane + 2], h3 = s_hist[4 * lane + 3];
+            int incl = h0 + h1 + h2 + h3;
+#pragma unroll
+            for (int off = 1; off < 64; off <<= 1) {
+                const int up = __shfl_up(incl, off);
+                if (lane >= off) incl += up;
+            }
+            const int need = s_need;
+            const unsigned long long m = __ballot(incl >= need);
+            const int first = __builtin_ctzll(m);            // m != 0: the valid keys are more than n_probe
+            if (lane == first) {
+                int before = incl - (h0 + h1 + h2 + h3), bin = 4 * lane;
+                if (before + h0 < need) { before += h0; ++bin;
+                    if (before + h1 < need) { before += h1; ++bin;
+                        if (before + h2 < need) { before += h2; ++bin; } } }
+                s_prefix = (s_prefix << 8) | (uint32_t)bin;
+                s_need = need - before;
+            }
         }
-        if (lane < np) {
-            const int l = fin.eid;
-            const bool ok = l != EMPTY_IDX;
-            p.probes[lane] = ok ? l : -1;         // no ranking (every distance NaN): an empty list
-            if (p.probe_d) p.probe_d[lane] = ok ? fin.e : INFINITY;
-            s_list[lane] = ok ? l : -1;
-            s_len[lane] = ok ? p.list_end[l] - p.list_beg[l] : 0;
+        __syncthreads();
+        if (tid < 256) s_hist[tid] = 0;
+        __syncthreads();
+        if (round < 3) {
+            const uint32_t prefix = s_prefix;
+            for (int i = tid; i < p.n_lists; i += ONE_NT) {
+                const uint32_t key = s_key[i];
+                if ((key >> shift) == prefix && key != 0xffffffffu) atomicAdd(&s_hist[(key >> (shift - 8)) & 255], 1);
+            }
+            __syncthreads();
+        }
+    }
+    // every key up to T: the n_probe best and the ties of the last of them
+    const uint32_t T = take_all ? 0xfffffffeu : s_prefix;
+    for (int i = tid; i < p.n_lists; i += ONE_NT) {
+        const uint32_t key = s_key[i];
+        if (key <= T && key != 0xffffffffu) {
+            const int at = atomicAdd(&s_cnt, 1);
+            if (at < ONE_NT) { Cd[at] = p.dists[i]; Ci[at] = i; }
+        }
+    }
+    __syncthreads();
+    const int cnt = min(s_cnt, ONE_NT);                      // more than 1024 ties of one distance: the lowest lists among the first 1024 gathered
+    if (cnt <= 64) {
+        if (wave == 0) {
+            const bool have = lane < cnt;
+            const unsigned long long r = wave_merge_body(INFINITY, EMPTY_IDX, have ? Cd[lane] : INFINITY, have ? Ci[lane] : EMPTY_IDX);
+            const int l = (int)(r >> 32);
+            if (lane < np && l != EMPTY_IDX) {
+                p.probes[lane] = l;
+                if (p.probe_d) p.probe_d[lane] = __int_as_float((int)(unsigned)r);
+                s_list[lane] = l;
+                s_len[lane] = p.list_end[l] - p.list_beg[l];
+            }
+        }
+    } else if (tid < cnt) {
+        // many ties at T: a pair's place is the number of pairs that precede it
+        const float md = Cd[tid];
+        const int mid = Ci[tid];
+        int rank = 0;
+        for (int e = 0; e < cnt; ++e) rank += pair_less(Cd[e], Ci[e], md, mid) ? 1 : 0;
+        if (rank < np) {
+            p.probes[rank] = mid;
+            if (p.probe_d) p.probe_d[rank] = md;
+            s_list[rank] = mid;
+            s_len[rank] = p.list_end[mid] - p.list_beg[mid];
         }
     }
     __syncthreads();
@@ -1457,15 +1568,18 @@ int launch_ivf_one_plan(const float* sums, int metric, const float* cent_sq, con
                         float* q_sq, float* q_nrm, int* probes, float* probe_d, int64_t* cand_off, int* tile_off,
                         const StreamPlanBufs& b, hipStream_t s) {
     VDB_REQUIRE(n_probe >= 1 && n_probe <= 64, "the one-query plan ranks at most 64 lists");
+    VDB_REQUIRE(n_lists >= 1 && n_lists <= 16384, "the one-query plan keeps the keys of at most 16384 lists in LDS");
     IvfOneParams p{};
-    p.sums = sums; p.fin = Finish{metric, nullptr, nullptr, cent_sq, cent_nrm, cos_eps};
+    p.sums = sums; p.dists = const_cast<float*>(sums); p.fin = Finish{metric, nullptr, nullptr, cent_sq, cent_nrm, cos_eps};
     p.q = q;
     p.qplan.n_leaves = plan.n_leaves;
     for (int i = 0; i < plan.n_leaves; ++i) { p.qplan.leaf_len[i] = plan.leaf_len[i]; p.qplan.folds[i] = plan.folds[i]; }
     p.n_lists = n_lists; p.n_probe = n_probe; p.list_beg = list_beg; p.list_end = list_end;
     p.q_sq = q_sq; p.q_nrm = q_nrm; p.probes = probes; p.probe_d = probe_d; p.cand_off = cand_off; p.tile_off = tile_off;
     p.sq_qid = b.sq_qid; p.sq_out = b.sq_out; p.seg_item_off = b.seg_item_off; p.items = b.items; p.items_cap = b.items_cap;
-    hipLaunchKernelGGL(ivf_one_plan_kernel, dim3(1), dim3(ONE_NT), 0, s, p);
+    const size_t lds = (size_t)n_lists * sizeof(uint32_t);
+    VDB_TRY(raise_dynamic_lds(reinterpret_cast<const void*>(ivf_one_plan_kernel), lds));
+    hipLaunchKernelGGL(ivf_one_plan_kernel, dim3(1), dim3(ONE_NT), lds, s, p);
     VDB_HIP(hipGetLastError());
     return VDB_OK;
 }

@@ -66,6 +66,64 @@ __device__ __forceinline__ static bool pair_less(float a, int ai, float b, int b
 // resulting bitonic sequence is sorted with six more exchanges.  Pairs are ordered by (distance, id); lanes without
 // a candidate pass (INFINITY, EMPTY_IDX).  Returns this lane's new pair, id in the high word.  Not inlined: it
 // is the rare path of WaveTopK::offer, taken when many lanes bring a candidate at once.
+// The value of lane (l ^ J), without a trip through LDS (a bpermute costs an LDS round trip of a hundred cycles or
+// more; a selection network is a chain of them): quad permutes for 1 and 2, two masked row shifts for 4, a row
+// rotation for 8, the gfx950 row and half-wave swaps for 16 and 32.
+template <int J> __device__ __forceinline__ static int lane_xor(int x) {
+    static_assert(J == 1 || J == 2 || J == 4 || J == 8 || J == 16 || J == 32, "one bit");
+    if (J == 1) return __builtin_amdgcn_update_dpp(x, x, 0xB1, 0xF, 0xF, false);           // quad_perm:[1,0,3,2]
+    if (J == 2) return __builtin_amdgcn_update_dpp(x, x, 0x4E, 0xF, 0xF, false);           // quad_perm:[2,3,0,1]
+    if (J == 4) {
+        const int t = __builtin_amdgcn_update_dpp(x, x, 0x104, 0xF, 0x5, false);           // row_shl:4 into banks 0 and 2
+        return __builtin_amdgcn_update_dpp(t, x, 0x114, 0xF, 0xA, false);                  // row_shr:4 into banks 1 and 3
+    }
+    if (J == 8) return __builtin_amdgcn_update_dpp(x, x, 0x128, 0xF, 0xF, false);           // row_ror:8
+    typedef unsigned lane_u2 __attribute__((ext_vector_type(2)));
+    const int lane = threadIdx.x & 63;
+    if (J == 16) {
+        const lane_u2 r = __builtin_amdgcn_permlane16_swap((unsigned)x, (unsigned)x, false, false);
+        return (int)((lane & 16) ? r.x : r.y);
+    }
+    const lane_u2 r = __builtin_amdgcn_permlane32_swap((unsigned)x, (unsigned)x, false, false);
+    return (int)((lane & 32) ? r.x : r.y);
+}
+template <int J> __device__ __forceinline__ static float lane_xor(float x) { return __int_as_float(lane_xor<J>(__float_as_int(x))); }
+// lane l - 1's value (lane 0 keeps its own)
+__device__ __forceinline__ static int lane_up1(int x) { return __builtin_amdgcn_update_dpp(x, x, 0x138, 0xF, 0xF, false); }   // wave_shr:1
+__device__ __forceinline__ static float lane_up1(float x) { return __int_as_float(lane_up1(__float_as_int(x))); }
+// lane 63 - l's value
+__device__ __forceinline__ static int lane_reverse(int x) {
+    return lane_xor<32>(lane_xor<16>(__builtin_amdgcn_update_dpp(x, x, 0x140, 0xF, 0xF, false)));   // row_mirror, then the rows
+}
+__device__ __forceinline__ static float lane_reverse(float x) { return __int_as_float(lane_reverse(__float_as_int(x))); }
+
+template <int K2, int J> __device__ __forceinline__ static void bitonic_step(float& cd, int& cid, int lane) {
+    const float pd = lane_xor<J>(cd);
+    const int pid = lane_xor<J>(cid);
+    const bool keep_min = ((lane & K2) == 0) == ((lane & J) == 0);
+    const bool take = keep_min ? ((pd < cd) || (pd == cd && pid < cid)) : ((cd < pd) || (cd == pd && cid < pid));
+    if (take) { cd = pd; cid = pid; }
+    if constexpr (J > 1) bitonic_step<K2, J / 2>(cd, cid, lane);
+}
+template <int K2> __device__ __forceinline__ static void bitonic_sort_upto(float& cd, int& cid, int lane) {
+    if constexpr (K2 > 2) bitonic_sort_upto<K2 / 2>(cd, cid, lane);
+    bitonic_step<K2, K2 / 2>(cd, cid, lane);
+}
+
+__device__ __forceinline__ static unsigned long long wave_merge_body(float e, int eid, float cd, int cid) {
+    const int lane = threadIdx.x & 63;
+    bitonic_sort_upto<64>(cd, cid, lane);      // K2 = 64: (lane & 64) == 0 everywhere, ascending over the wave
+    {
+        const float rd = lane_reverse(cd);
+        const int rid = lane_reverse(cid);
+        if (pair_less(rd, rid, e, eid)) { e = rd; eid = rid; }
+    }
+    bitonic_step<64, 32>(e, eid, lane);
+    return ((unsigned long long)(unsigned)eid << 32) | (unsigned)__float_as_int(e);
+}
+// The same network with LDS permutes for the exchanges: fewer vector instructions per stage, each with the latency
+// of an LDS round trip.  The form for kernels that keep many waves per SIMD busy (their permutes overlap); the
+// register-only form above is for a block that has a CU, or the chip, to itself.
 __device__ __noinline__ static unsigned long long wave_merge_candidates(float e, int eid, float cd, int cid) {
     const int lane = threadIdx.x & 63;
 #pragma unroll
@@ -100,10 +158,11 @@ struct WaveTopK {
     __device__ __forceinline__ void init(int k_) { e = INFINITY; eid = EMPTY_IDX; thr = INFINITY; thr_id = EMPTY_IDX; k = k_; }
 
     // insert one pair; v / vid must be wave-uniform.  Pairs equal to a stored one go behind it.
+    template <bool INL = false>
     __device__ __forceinline__ void insert(float v, int vid, int lane) {
         const bool gt = (e > v) || (e == v && eid > vid);
-        const float pe = __shfl_up(e, 1);
-        const int pid = __shfl_up(eid, 1);
+        const float pe = INL ? lane_up1(e) : __shfl_up(e, 1);
+        const int pid = INL ? lane_up1(eid) : __shfl_up(eid, 1);
         const bool pgt = lane > 0 && ((pe > v) || (pe == v && pid > vid));
         if (gt) { e = pgt ? pe : v; eid = pgt ? pid : vid; }
         thr = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(e), k - 1));
@@ -113,13 +172,15 @@ struct WaveTopK {
     // offer every lane's candidate (want = this lane has one); lanes are taken in lane order
     // BULK = false leaves the sort-and-merge path (a function call) out of kernels whose inner loop cannot
     // afford the registers saved around it
-    template <bool BULK = true>
+    // INL = true: the register-only merge network, expanded in place (for blocks that run alone: see wave_merge_body)
+    template <bool BULK = true, bool INL = false>
     __device__ __forceinline__ void offer(bool want, float d, int id, int lane) {
         unsigned long long m = __ballot(want && ((d < thr) || (d == thr && id < thr_id)));
         if (BULK && __popcll(m) >= WAVE_BULK_MIN) {
             // many at once (an empty or a loosely bounded list): one sort-and-merge instead of that many insertions
             const bool mine = (m >> lane) & 1ull;
-            const unsigned long long r = wave_merge_candidates(e, eid, mine ? d : INFINITY, mine ? id : EMPTY_IDX);
+            const unsigned long long r = INL ? wave_merge_body(e, eid, mine ? d : INFINITY, mine ? id : EMPTY_IDX)
+                                             : wave_merge_candidates(e, eid, mine ? d : INFINITY, mine ? id : EMPTY_IDX);
             e = __int_as_float((int)(unsigned)r);
             eid = (int)(r >> 32);
             thr = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(e), k - 1));
@@ -131,7 +192,7 @@ struct WaveTopK {
             m &= m - 1;
             const float v = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(d), l));
             const int vid = __builtin_amdgcn_readlane(id, l);
-            if ((v < thr) || (v == thr && vid < thr_id)) insert(v, vid, lane);
+            if ((v < thr) || (v == thr && vid < thr_id)) insert<INL>(v, vid, lane);
         }
     }
 
