@@ -50,6 +50,8 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--only", default="flat1,l1,c3,bf16,ivf,ivfpq,pq,assign,encode,train,l1batch")
     ap.add_argument("--scale", type=float, default=1.0, help="scale the row counts (1.0 = BASELINE sizes)")
+    ap.add_argument("--cpu", action="store_true",
+                    help="also time the NumPy restatement of the reference (oracle/) on a stated down-scaled sample of C3, C4 and C5")
     args = ap.parse_args()
     only = set(args.only.split(","))
     from vectordb_amd import _native as N
@@ -108,6 +110,20 @@ def main():
                         "frac": round(flop / kern / 1e12 / MFMA_F32_PEAK, 4), "flop_per_launch": flop}
             emit("c3", workload=f"Flat dot {n}x{d} fp32 (one of 8 shards of 10M), batch {nq}, k=10",
                  qps=round(nq / wall, 1), ms_per_batch=round(wall * 1e3, 4), kernel_ms=round(kern * 1e3, 4), roofline=roof)
+        if args.cpu:
+            # the reference's batch path for dot (distance/metrics.py:376-391 then a stable sort per row) on 1/10 of a shard
+            from oracle import ref_numpy as R
+            ns, nqs = n // 10, 64
+            xs = randn(ns, d, 42).cpu().numpy()
+            qs = randn(nqs, d, 123).cpu().numpy()
+            t0 = time.perf_counter()
+            dm = R.pairwise_dot(qs, xs)
+            for i in range(nqs):
+                R.topk_stable(dm[i], 10)
+            dt = time.perf_counter() - t0
+            emit("cpu", config="C3", sample=f"Flat dot {ns}x{d} fp32, {nqs} queries as one batch, k=10 (1/10 of one shard)",
+                 cores=os.cpu_count(), ms_per_query_at_sample=round(dt / nqs * 1e3, 4),
+                 ms_per_query_full_shard_linear=round(dt / nqs * 1e3 * n / ns, 3), kind="port")
         store.close()
         torch.cuda.empty_cache()
 
@@ -233,6 +249,22 @@ def main():
                            "per_query_bytes_times_queries": nbytes,
                            "note": "bytes HBM must deliver once (every probed list and the centroids, shared by the batch) "
                                    "/ whole-batch wall time (probe + scan + select); per-query bytes x queries is listed beside it"})
+        if args.cpu:
+            # IVFIndex.search as the reference runs it (ivf.py:607-632), on the lists the first million rows fall into
+            from oracle import ref_numpy as R
+            ns, nqs = min(n, 1_000_000), 8
+            sub_lists = R.ivf_build_lists(assign[:ns].tolist(), nlist)
+            qs = randn(nqs, d, 123).cpu().numpy()
+            t0 = time.perf_counter()
+            scanned_cpu = 0
+            for i in range(nqs):
+                R.ivf_search(qs[i], x[:ns], cent, sub_lists, 10, nprobe, "euclidean")
+                scanned_cpu += sum(len(sub_lists[c]) for c in R.ivf_probe_order(qs[i], cent, "euclidean", nprobe))
+            dt = time.perf_counter() - t0
+            emit("cpu", config="C4", sample=f"IVF nlist={nlist} nprobe={nprobe} over the first {ns} of {n} rows, {nqs} single queries, k=10",
+                 cores=os.cpu_count(), ms_per_query_at_sample=round(dt / nqs * 1e3, 3), rows_scanned_per_query=scanned_cpu // nqs,
+                 ms_per_query_full_linear_in_rows_scanned=round(dt / nqs * 1e3 * n / ns, 2), kind="port",
+                 note="vectorised NumPy restatement; the reference itself loops in Python over every member (about 7 us per row)")
         lists.close()
         del x
         torch.cuda.empty_cache()
@@ -302,6 +334,22 @@ def main():
                      qps=round(nq / wall, 2), ms_per_batch=round(wall * 1e3, 4), kernel_ms=round(kern * 1e3, 4),
                      roofline={"bound": "hbm", "achieved": round(nbytes / kern / 1e9, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                                "frac": round(nbytes / kern / 1e9 / HBM_PEAK_GBS, 4), "bytes_per_launch": nbytes})
+        if args.cpu:
+            # PQIndex.search (pq.py:268-301): table, sequential fp32 sum over the sub-spaces, sqrt, stable top-k; 2M codes
+            from oracle import ref_numpy as R
+            ns, nqs = min(n, 2_000_000), 4
+            rng_c = np.random.default_rng(11)
+            codes_s = rng_c.integers(0, 256, size=(ns, m), dtype=np.uint8)
+            book = np.random.default_rng(7).standard_normal((m, 256, d // m), dtype=np.float32)
+            qs = randn(nqs, d, 123).cpu().numpy()
+            t0 = time.perf_counter()
+            for i in range(nqs):
+                R.pq_search(qs[i], book, codes_s, 10)
+            dt = time.perf_counter() - t0
+            emit("cpu", config="C5", sample=f"PQ m={m} nbits=8 ADC scan over {ns} of {n} codes, {nqs} single queries, k=10",
+                 cores=os.cpu_count(), ms_per_query_at_sample=round(dt / nqs * 1e3, 3),
+                 ms_per_query_full_linear=round(dt / nqs * 1e3 * n / ns, 1), kind="port",
+                 note="vectorised NumPy restatement; the reference's own scan is a Python loop (about 7 us per row)")
         pq.close()
         torch.cuda.empty_cache()
 

@@ -123,6 +123,8 @@ class MetadataFilter:
         for key, cond in self.filters.items():
             if key not in metadata:
                 return False
+            if isinstance(metadata[key], list) and not metadata[key]:
+                return False            # nothing is indexed for an empty list (core/collection.py:138-153): as if absent
             if not self._field_matches(metadata[key], cond):
                 return False
         return True

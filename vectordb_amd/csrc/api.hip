@@ -327,17 +327,18 @@ static int rows_reserve(vdb_rows* h, int64_t n_total, hipStream_t s) {
     // a 256-row chunk that starts at any stored row stays readable: the scans read whole chunks and drop what
     // lies past the end of a list or of the store
     cap = round_up64(std::max<int64_t>(cap, 1024) + 256, 256);
-    if (r.bf16)
-        VDB_TRY(h->data16.reserve_keep((size_t)cap * r.ld16 * 2, (size_t)r.n * r.ld16 * 2, s));
-    else
-        VDB_TRY(h->data.reserve_keep((size_t)cap * r.ld * sizeof(float), (size_t)r.n * r.ld * sizeof(float), s));
-    VDB_TRY(h->sq.reserve_keep((size_t)cap * sizeof(float), (size_t)r.n * sizeof(float), s));
-    VDB_TRY(h->nrm.reserve_keep((size_t)cap * sizeof(float), (size_t)r.n * sizeof(float), s));
-    r.cap = cap;
+    // the view is refreshed after every buffer that moved, and the capacity only once all of them have room: a
+    // failure half way leaves pointers that are valid and a capacity that every buffer still covers
+    int st = r.bf16 ? h->data16.reserve_keep((size_t)cap * r.ld16 * 2, (size_t)r.n * r.ld16 * 2, s)
+                    : h->data.reserve_keep((size_t)cap * r.ld * sizeof(float), (size_t)r.n * r.ld * sizeof(float), s);
     r.data = h->data.as<float>();
     r.data16 = h->data16.as<uint16_t>();
+    if (st == VDB_OK) st = h->sq.reserve_keep((size_t)cap * sizeof(float), (size_t)r.n * sizeof(float), s);
     r.sq = h->sq.as<float>();
+    if (st == VDB_OK) st = h->nrm.reserve_keep((size_t)cap * sizeof(float), (size_t)r.n * sizeof(float), s);
     r.nrm = h->nrm.as<float>();
+    if (st != VDB_OK) return st;
+    r.cap = cap;
     return VDB_OK;
 }
 
@@ -1548,7 +1549,12 @@ static int ivf_build_impl(vdb_ivf* h, const float* rows, int64_t n, const int64_
         st = body();
     }
     raw.release(); d_perm.release();
-    if (st == VDB_OK) m->r.n = n;
+    if (st == VDB_OK) {
+        m->r.n = n;
+    } else {
+        h->lay.reset(h->n_lists);       // no rows went in: the lists are empty, not half described
+        m->r.n = 0;
+    }
     return st;
 }
 

@@ -14,6 +14,8 @@ from __future__ import annotations
 
 from typing import Optional
 
+import threading
+
 import numpy as np
 
 from .. import _native as N
@@ -115,12 +117,26 @@ def query_distances_matrix(vectors, metric: str = "euclidean") -> np.ndarray:
 # ---------------------------------------------------------------- per-pair functions
 # distance/metrics.py:24-265.  One pair is one query against a one-row store.
 
+_pair_stores: dict = {}                    # dimension -> a one-row store kept between calls
+_pair_lock = threading.Lock()
+
+
 def _pair(a, b, code: int) -> float:
     a = N.f32(np.asarray(a)).reshape(1, -1)
     b = N.f32(np.asarray(b)).reshape(1, -1)
     if a.shape != b.shape:
         raise ValueError(f"shape mismatch: {a.shape} vs {b.shape}")
-    return float(_distances(a, b, code)[0, 0])
+    # one pair = one query against a one-row store; the store (its stream and buffers) is reused, so a scalar call
+    # costs a row upload and a launch, not an allocation
+    with _pair_lock:
+        store = _pair_stores.get(a.shape[1])
+        if store is None:
+            if len(_pair_stores) >= 16:
+                _pair_stores.popitem()[1].close()
+            store = _pair_stores[a.shape[1]] = N.RowStore(a.shape[1])
+        store.truncate(0)
+        store.append(b)
+        return float(store.distances(a, code)[0, 0])
 
 
 def euclidean(a, b) -> float:
