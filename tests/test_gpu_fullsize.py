@@ -214,6 +214,77 @@ def test_pq_100m_codes_with_filter(nat):
     pq.close()
 
 
+# ---------------------------------------------------------------- PQ scan behind a sample bound (5M codes: every query checked in full)
+@pytest.mark.parametrize("m", [16, 8])
+def test_pq_5m_bound_pass_complete(nat, m):
+    """Code sets of 4M rows and more are scanned behind a bound taken from their first rows, and lanes leave a row's
+    table sum as soon as it passes the bound.  The oracle scans all rows for every query: equal rows in equal
+    order, equal bits, for 1, 2, 3 and 5 queries per call, k = 10 and k = 32, an unselective filter, a filter that
+    leaves the sampled prefix without k passing rows, ties (every code row stored twice) and the best rows at the
+    very end of the set."""
+    n_half, d = 2_600_000, 128
+    n = 2 * n_half
+    rng = np.random.default_rng(31)
+    book = rng.standard_normal((m, 256, d // m), dtype=np.float32)
+    g = torch.Generator(device="cuda")
+    g.manual_seed(5)
+    c = torch.randint(0, 256, (n_half, m), device="cuda", dtype=torch.uint8, generator=g)
+    q = randn(5, d, 23)
+    qh = q.cpu().numpy()
+    half = c.cpu().numpy()
+    # the rows nearest to query 0: its best codeword in every sub-space, stored last (after both copies)
+    lut0 = R.pq_lut(qh[0], book)
+    best_code = lut0.argmin(axis=1).astype(np.uint8)
+    tail = np.tile(best_code, (7, 1))
+    tail[1:, 0] = np.arange(1, 7, dtype=np.uint8) ^ best_code[0]          # six near misses
+    host_codes = np.concatenate([half, half, tail])
+    n_all = host_codes.shape[0]
+    pq = nat.PqCodes(d, m, 256)
+    pq.set_codebook(book)
+    dev_codes = torch.from_numpy(host_codes).cuda()
+    pq.append_codes_device(dev_codes.data_ptr(), n_all, 0)
+    torch.cuda.synchronize()
+    assert len(pq) == n_all
+
+    keep_half = rng.random(n_all) < 0.5
+    keep_late = np.zeros(n_all, bool)
+    keep_late[n_all - 400_000:] = rng.random(400_000) < 0.3               # nothing passes in the sampled prefix
+    masks = {None: None, "half": keep_half, "late": keep_late}
+    words = {name: (None if v is None else torch.from_numpy(nat.pack_mask(v).view(np.int32)).cuda()) for name, v in masks.items()}
+
+    dist_all = []
+    for qi in range(5):
+        lut = R.pq_lut(qh[qi], book)
+        acc = lut[0, host_codes[:, 0]].copy()
+        for j in range(1, m):
+            acc += lut[j, host_codes[:, j]]          # sequential fp32 sum over the sub-spaces, as pq.py:291-294
+        dist_all.append(np.sqrt(acc))
+
+    def oracle(qi, k, keep):
+        dall = dist_all[qi]
+        if keep is None:
+            rows = topk_big(dall, k)
+        else:
+            kept = np.flatnonzero(keep)
+            rows = kept[topk_big(dall[kept], k)]
+        return rows, dall[rows]
+
+    ref = {(qi, k, name): oracle(qi, k, masks[name]) for qi in range(5) for k in (10, 32) for name in masks}
+    for name in masks:
+        mp = 0 if words[name] is None else words[name].data_ptr()
+        fn = lambda qp, nn, kk, dp, rp: pq.search_device(qp, nn, kk, dp, rp, mask_ptr=mp)
+        for k in (10, 32):
+            for lo, hi in ((0, 1), (1, 3), (0, 3), (0, 5)):
+                dist, rows = search_dev(fn, q[lo:hi].contiguous(), k)
+                for i, qi in enumerate(range(lo, hi)):
+                    want_rows, want_d = ref[(qi, k, name)]
+                    assert np.array_equal(rows[i], want_rows), (name, k, lo, hi, qi)
+                    assert np.array_equal(dist[i], want_d), (name, k, lo, hi, qi)
+    # the planted rows are found: the exact match first (lowest of equal rows wins: there is only one)
+    assert ref[(0, 10, None)][0][0] == n_all - 7
+    pq.close()
+
+
 # ---------------------------------------------------------------- Flat dot 10M x 768 over 8 shards (configs[2])
 def _bf16_round_t(t):
     return t.to(torch.bfloat16).to(torch.float32)

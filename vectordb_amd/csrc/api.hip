@@ -2112,6 +2112,11 @@ int vdb_pq_lut(vdb_pq* h, const float* query, float* out_lut) {
     return VDB_OK;
 }
 
+// bound pass of the PQ scan: blocks, tiles of 256 rows per block at most, smallest code set that gets one
+static constexpr int PQ_BOUND_SPLITS = 192;
+static constexpr int64_t PQ_BOUND_TILES_PER_BLOCK = 8;
+static constexpr int64_t PQ_BOUND_MIN_TILES = 16384;
+
 static int pq_search_impl(vdb_pq* h, const float* d_q, int nq, int k, const uint32_t* d_mask,
                           float* d_out_d, int64_t* d_out_i, hipStream_t s) {
     VDB_REQUIRE(h->trained, "index is not trained");
@@ -2123,7 +2128,9 @@ static int pq_search_impl(vdb_pq* h, const float* d_q, int nq, int k, const uint
     if (k_eff < k) VDB_TRY(fill_results(d_out_d, d_out_i, (int64_t)nq * k, s));
     if (h->n == 0) return VDB_OK;
     VDB_TRY(ws.lut.reserve((size_t)nq * h->m * h->ksub * sizeof(float)));
-    VDB_TRY(launch_pq_lut(d_q, h->dim, nq, h->book.as<float>(), h->m, h->ksub, h->dsub, h->plan, ws.lut.as<float>(), s));
+    VDB_TRY(ws.queue_cnt.reserve((size_t)nq * sizeof(int)));
+    int* qlen = ws.queue_cnt.as<int>();          // entries in every query's packed candidate area; the table kernel clears it
+    VDB_TRY(launch_pq_lut(d_q, h->dim, nq, h->book.as<float>(), h->m, h->ksub, h->dsub, h->plan, ws.lut.as<float>(), s, qlen));
     const int64_t ntiles = (h->n + 255) / 256;
     const int splits = (int)std::max<int64_t>(1, std::min<int64_t>((ntiles + 15) / 16, (8 * ctx().num_cus + nq - 1) / nq));
     const int n_cand = splits * pq_scan_lists_per_split();
@@ -2135,14 +2142,38 @@ static int pq_search_impl(vdb_pq* h, const float* d_q, int nq, int k, const uint
         VDB_TRY(ws.lb_d.reserve((size_t)nq * sizeof(float)));
         VDB_TRY(ws.lb_k.reserve((size_t)nq * sizeof(int64_t)));
     }
+    // Bound pass (one to three queries over a large code set, k results in one pass): a few blocks scan the first
+    // rows of the set and every wave reports its best row; the k-th smallest of those (different rows, so k rows
+    // are at most that far) is at least the query's k-th best over the whole set, and the full scan drops every row
+    // whose running sum passes it (pq_scan_kernel).  Any subset gives a valid bound; a looser one only makes the
+    // scan slower, never different.  Behind the bound nearly all wave lists of the full scan stay empty, so the
+    // waves pack what they hold into the front of the query's candidate area and one block per query picks the k
+    // best.  (Four queries per pass: a lane stays while any of its four sums is in reach, so a bound removes
+    // little and its pass costs what it saves; they keep one list per wave and the list merge.)
+    const float* bound_d = nullptr;
+    static const bool no_bound = getenv("VDB_PQ_NO_BOUND") != nullptr;
+    const bool bounded = !multi && !no_bound && nq < 4 && ntiles >= PQ_BOUND_MIN_TILES;
+    if (bounded) {
+        const int bsplits = (int)std::min<int64_t>(PQ_BOUND_SPLITS, splits);
+        const int64_t n_s = std::min<int64_t>(h->n, PQ_BOUND_TILES_PER_BLOCK * bsplits * 256);
+        const int area = bsplits * pq_scan_lists_per_split();
+        if (area >= 4 * kmax) {
+            VDB_TRY(launch_pq_scan(h->codes.as<uint8_t>(), n_s, h->m, h->ksub, ws.lut.as<float>(), nq, 1, d_mask, nullptr, nullptr,
+                                   bsplits, ws.part_d.as<float>(), ws.part_i.as<int>(), nullptr, s, nullptr, 0, false, qlen));
+            SelectOut o{d_out_d, d_out_i, nullptr, k, 0, nullptr, nullptr};
+            VDB_TRY(launch_select_packed(ws.part_d.as<float>(), ws.part_i.as<int>(), nq, area, kmax, o, s, qlen));
+            bound_d = d_out_d + (kmax - 1);
+        }
+    }
     for (int64_t done = 0; done < k_eff; done += KMAX_FUSED) {
         const int kk = (int)std::min<int64_t>(KMAX_FUSED, k_eff - done);
         VDB_TRY(launch_pq_scan(h->codes.as<uint8_t>(), h->n, h->m, h->ksub, ws.lut.as<float>(), nq, kk, d_mask,
                                done > 0 ? ws.lb_d.as<float>() : nullptr, done > 0 ? ws.lb_k.as<int64_t>() : nullptr, splits,
-                               ws.part_d.as<float>(), ws.part_i.as<int>(), nullptr, s));
+                               ws.part_d.as<float>(), ws.part_i.as<int>(), nullptr, s, bound_d, k, true, bound_d ? qlen : nullptr));
         SelectOut o{d_out_d, d_out_i, nullptr, k, (int)done,
                     multi ? ws.lb_d.as<float>() : nullptr, multi ? ws.lb_k.as<int64_t>() : nullptr};
-        VDB_TRY(launch_select(ws.part_d.as<float>(), ws.part_i.as<int>(), nq, n_cand, kk, 1 << 30, nullptr, 0, o, s, ws.mid));
+        if (bound_d) VDB_TRY(launch_select_packed(ws.part_d.as<float>(), ws.part_i.as<int>(), nq, n_cand * kk, kk, o, s, qlen));
+        else VDB_TRY(launch_select(ws.part_d.as<float>(), ws.part_i.as<int>(), nq, n_cand, kk, 1 << 30, nullptr, 0, o, s, ws.mid));
     }
     return VDB_OK;
 }

@@ -11,6 +11,7 @@
 //
 // All three reproduce the reference's fp32 results bit for bit: the sums over
 // a sub-vector follow NumPy's pairwise order and nothing is contracted to fma.
+#include <type_traits>
 #include "vdb_internal.h"
 #include "vdb_device.h"
 
@@ -57,9 +58,10 @@ __device__ static float np_sum_sqdiff(const float* a, const float* b, int n, con
 // ---------------------------------------------------------------- tables
 __global__ __launch_bounds__(256) void pq_lut_kernel(const float* __restrict__ q, int ldq,
                                                      const float* __restrict__ book, int m, int ksub, int dsub,
-                                                     SumPlan plan, float* __restrict__ lut) {
+                                                     SumPlan plan, float* __restrict__ lut, int* __restrict__ zero_counts) {
     extern __shared__ __align__(16) float qs[];
     const int sub = blockIdx.x, qi = blockIdx.y;
+    if (zero_counts && sub == 0 && threadIdx.x == 0) zero_counts[qi] = 0;    // the scan's per-query queue lengths
     for (int i = threadIdx.x; i < dsub; i += blockDim.x) qs[i] = q[(int64_t)qi * ldq + sub * dsub + i];
     __syncthreads();
     for (int c = threadIdx.x; c < ksub; c += blockDim.x) {
@@ -112,19 +114,22 @@ struct PqScanParams {
     const uint32_t* mask;
     const float* lb_d; const int64_t* lb_k;
     int k; int splits;
-    float* part_d; int* part_i;      // [nq][splits * PQ_WAVES][k]
+    float* part_d; int* part_i;      // [nq][splits * PQ_WAVES][k]: one list per wave, or (queue_len) a query's entries packed
+    int* queue_len;                  // optional [nq]: a wave appends its list's entries at part_*[q][queue_len[q]...]
     float* dist_out;                 // optional [nq][n]
+    const float* bound_d; int64_t bound_stride;   // optional: query q's k-th best is not above bound_d[q * bound_stride]
 };
 
-static constexpr int PQ_UNROLL = 4;      // row tiles whose code loads are in flight together
-static constexpr int PQ_WAVES = 4;
+static constexpr int PQ_WAVES = 4;       // waves of a split: one candidate list each
 
 // M > 0: compile-time number of sub-spaces (multiple of 4); 0: run-time.
 // Q queries share one pass over the codes: their tables are interleaved in LDS,
 // T[(j * ksub + c) * Q + q], so one LDS read of Q floats serves all of them.
 // KSUB > 0: compile-time codewords per sub-space (256 for 8-bit codes): a sub-space's table offset becomes the
 // immediate offset of the LDS read instead of an addition per row.
-template <int M, int Q, int KSUB = 0>
+// PQ_UNROLL: row tiles whose code loads are in flight together (measured on 100M codes: 4 beats 2 and 8; blocks of
+// eight waves that share the tables of a four-query pass are slower than blocks of four).
+template <int M, int Q, int KSUB = 0, int PQ_UNROLL = 4>
 __global__ __launch_bounds__(256) void pq_scan_kernel(PqScanParams p) {
     extern __shared__ __align__(16) float sm[];
     const int m = M > 0 ? M : p.m;
@@ -146,12 +151,19 @@ __global__ __launch_bounds__(256) void pq_scan_kernel(PqScanParams p) {
     // row exceeds (the square of the k-th distance, a few ulps up; never below the square of the smallest distance
     // whose own square still is a normal number), so the correctly rounded root, ten instructions per row and
     // query, is only taken for the rare tile in which some lane passes it.
-    float thr2[Q];
+    // thr2g: the same kind of bound from a distance that is known not to be below the query's k-th best over ALL
+    // rows (the k-th best of a sample of the rows, p.bound_d): it holds from the first tile on and for every wave.
+    float thr2[Q], thr2g[Q];
 #pragma unroll
     for (int q = 0; q < Q; ++q) {
         best[q].init(k > 0 ? k : 1);
         lbd[q] = -INFINITY; lbk[q] = -1;
-        thr2[q] = INFINITY;
+        thr2g[q] = INFINITY;
+        if (p.bound_d) {
+            const float t = p.bound_d[(int64_t)(q0 + min(q, qcnt - 1)) * p.bound_stride];
+            thr2g[q] = fmaxf(__fmaf_rn(t * t, 4e-7f, t * t), 1e-36f);
+        }
+        thr2[q] = thr2g[q];
         if (p.lb_d && q < qcnt) { lbd[q] = p.lb_d[q0 + q]; lbk[q] = p.lb_k[q0 + q]; }
     }
     const bool roots_always = p.dist_out != nullptr || p.lb_d != nullptr;      // wave-uniform
@@ -159,60 +171,150 @@ __global__ __launch_bounds__(256) void pq_scan_kernel(PqScanParams p) {
 
     const int64_t ntiles = (p.n + 255) / 256;
     const int64_t per = (ntiles + p.splits - 1) / p.splits;
-    const int64_t t0 = split * per, t1 = min(t0 + per, ntiles);
+    const int64_t t0 = min((int64_t)split * per, ntiles), t1 = min(t0 + per, ntiles);
+    // the codes (and filter words) of the PQ_UNROLL tiles from tile tbx on
+    constexpr int WN = M > 0 ? M / 4 : 1;
+    // Rows past the end of the set (or of this block's range) are read from the last row instead: the loads stay
+    // free of branches, so nothing waits for them before their first use a step later.
+    const uint32_t* mask_src = p.mask ? p.mask : reinterpret_cast<const uint32_t*>(p.codes);
+    auto fetch = [&](int64_t tbx, uint32_t (&wx)[PQ_UNROLL][WN], uint32_t (&mwx)[PQ_UNROLL]) {
+#pragma unroll
+        for (int u = 0; u < PQ_UNROLL; ++u) {
+            const int64_t row = min((tbx + u) * 256 + tid, p.n - 1);
+            if (M > 0) {
+                if (M % 16 == 0) {
+                    const uint4* src = reinterpret_cast<const uint4*>(p.codes + row * M);
+#pragma unroll
+                    for (int i = 0; i < M / 16; ++i) {
+                        const uint4 v = src[i];
+                        wx[u][4 * i] = v.x; wx[u][4 * i + 1] = v.y; wx[u][4 * i + 2] = v.z; wx[u][4 * i + 3] = v.w;
+                    }
+                } else if (M % 8 == 0) {
+                    const uint2* src = reinterpret_cast<const uint2*>(p.codes + row * M);
+#pragma unroll
+                    for (int i = 0; i < M / 8; ++i) { const uint2 v = src[i]; wx[u][2 * i] = v.x; wx[u][2 * i + 1] = v.y; }
+                } else {
+                    const uint32_t* src = reinterpret_cast<const uint32_t*>(p.codes + row * M);
+#pragma unroll
+                    for (int i = 0; i < M / 4; ++i) wx[u][i] = src[i];
+                }
+            }
+            mwx[u] = mask_src[p.mask ? (row >> 5) : 0];
+        }
+    };
+    // one step ahead: the codes of the coming step are on their way from HBM while this one's table sums are taken
+    uint32_t wn[PQ_UNROLL][WN], mwn[PQ_UNROLL];
+    fetch(min(t0, ntiles - 1), wn, mwn);
     for (int64_t tb = t0; tb < t1; tb += PQ_UNROLL) {
-        // ---- the rows' codes (and filter words), all tiles of the step first
-        uint32_t w[PQ_UNROLL][M > 0 ? M / 4 : 1];
+        uint32_t w[PQ_UNROLL][WN];
         uint32_t mw[PQ_UNROLL];
         bool ok[PQ_UNROLL];
 #pragma unroll
         for (int u = 0; u < PQ_UNROLL; ++u) {
-            const int64_t row = (tb + u) * 256 + tid;
-            ok[u] = (tb + u) < t1 && row < p.n;
-            mw[u] = 0xffffffffu;
-            if (M > 0) {
+            ok[u] = (tb + u) < t1 && (tb + u) * 256 + tid < p.n;
+            mw[u] = p.mask ? mwn[u] : 0xffffffffu;
 #pragma unroll
-                for (int i = 0; i < M / 4; ++i) w[u][i] = 0;
-                if (ok[u]) {
-                    if (M % 16 == 0) {
-                        const uint4* src = reinterpret_cast<const uint4*>(p.codes + row * M);
+            for (int i = 0; i < WN; ++i) w[u][i] = wn[u][i];
+        }
+        fetch(tb + PQ_UNROLL, wn, mwn);                 // past the last step: the last row again, unused
+        // ---- table sums in sub-space order, then the selection
+        if constexpr (M >= 4) if (!roots_always) {
+            // The entries are squares, so a row's running sum only grows: once it is above the bound of every query
+            // of the pass the row is out, and its lane sits out the remaining gathers.  The scan is bound by LDS
+            // bank conflicts between the lanes of a gather, so every lane that leaves makes the gathers of the
+            // others cheaper, and a tile whose lanes have all left skips them.  First half of the sub-spaces for
+            // every tile of the step (all gathers in flight together), then two sub-spaces per test.
+            constexpr int MM = M > 0 ? M : 4;
+            constexpr int JA = MM / 2;
+            typedef float pq_f2 __attribute__((ext_vector_type(2)));
+            float acc[PQ_UNROLL][Q];
+            pq_f2 a01[PQ_UNROLL], a23[PQ_UNROLL];          // Q == 4: the four sums as two packed pairs
+            auto entry = [&](int u, int jj) { return (jj * ksub + ((w[u][jj >> 2] >> (8 * (jj & 3))) & 0xff)) * Q; };
+            auto add = [&](int u, int jj) {
+                if constexpr (Q == 4) {
+                    const float4 tv = *reinterpret_cast<const float4*>(T + entry(u, jj));
+                    a01[u] = a01[u] + pq_f2{tv.x, tv.y};
+                    a23[u] = a23[u] + pq_f2{tv.z, tv.w};
+                } else {
+                    const float* tp = T + entry(u, jj);
 #pragma unroll
-                        for (int i = 0; i < M / 16; ++i) {
-                            const uint4 v = src[i];
-                            w[u][4 * i] = v.x; w[u][4 * i + 1] = v.y; w[u][4 * i + 2] = v.z; w[u][4 * i + 3] = v.w;
-                        }
-                    } else if (M % 8 == 0) {
-                        const uint2* src = reinterpret_cast<const uint2*>(p.codes + row * M);
+                    for (int q = 0; q < Q; ++q) acc[u][q] = acc[u][q] + tp[q];
+                }
+            };
+            auto sum_of = [&](int u, int q) -> float {
+                if constexpr (Q == 4) return q == 0 ? a01[u].x : q == 1 ? a01[u].y : q == 2 ? a23[u].x : a23[u].y;
+                else return acc[u][q];
+            };
+            auto in_reach = [&](int u) {
+                bool r = false;
 #pragma unroll
-                        for (int i = 0; i < M / 8; ++i) { const uint2 v = src[i]; w[u][2 * i] = v.x; w[u][2 * i + 1] = v.y; }
+                for (int q = 0; q < Q; ++q) r = r || (sum_of(u, q) <= thr2[q]);
+                return r;
+            };
+#pragma unroll
+            for (int u = 0; u < PQ_UNROLL; ++u) {
+                if constexpr (Q == 4) {
+                    const float4 tv = *reinterpret_cast<const float4*>(T + entry(u, 0));
+                    a01[u] = pq_f2{tv.x, tv.y}; a23[u] = pq_f2{tv.z, tv.w};
+                } else {
+                    const float* tp = T + entry(u, 0);
+#pragma unroll
+                    for (int q = 0; q < Q; ++q) acc[u][q] = tp[q];
+                }
+#pragma unroll
+                for (int jj = 1; jj < JA; ++jj) add(u, jj);
+            }
+            bool alive[PQ_UNROLL];
+#pragma unroll
+            for (int u = 0; u < PQ_UNROLL; ++u) {
+                const int64_t row = (tb + u) * 256 + tid;
+                alive[u] = ok[u] && ((mw[u] >> (row & 31)) & 1u) && in_reach(u);
+            }
+            // Two more sub-spaces at a time for all tiles of the step.  A lane that has left keeps reading, but entry
+            // 0 of the table: lanes that read one address are served together, so it no longer collides with
+            // anyone, and the step stays free of divergent branches.  Its sums are not used again.
+#pragma unroll
+            for (int jj = JA; jj < MM; jj += 2) {
+                bool any = false;
+#pragma unroll
+                for (int u = 0; u < PQ_UNROLL; ++u) any = any || alive[u];
+                if (__ballot(any) == 0ull) break;                       // wave-uniform: nothing left in reach
+#pragma unroll
+                for (int u = 0; u < PQ_UNROLL; ++u) {
+                    const int e0 = alive[u] ? entry(u, jj) : 0, e1 = alive[u] ? entry(u, jj + 1) : 0;
+                    if constexpr (Q == 4) {
+                        const float4 t0 = *reinterpret_cast<const float4*>(T + e0), t1 = *reinterpret_cast<const float4*>(T + e1);
+                        a01[u] = (a01[u] + pq_f2{t0.x, t0.y}) + pq_f2{t1.x, t1.y};
+                        a23[u] = (a23[u] + pq_f2{t0.z, t0.w}) + pq_f2{t1.z, t1.w};
                     } else {
-                        const uint32_t* src = reinterpret_cast<const uint32_t*>(p.codes + row * M);
 #pragma unroll
-                        for (int i = 0; i < M / 4; ++i) w[u][i] = src[i];
+                        for (int q = 0; q < Q; ++q) acc[u][q] = (acc[u][q] + T[e0 + q]) + T[e1 + q];
+                    }
+                }
+#pragma unroll
+                for (int u = 0; u < PQ_UNROLL; ++u) alive[u] = alive[u] && in_reach(u);
+            }
+#pragma unroll
+            for (int u = 0; u < PQ_UNROLL; ++u) {
+                const int64_t row = (tb + u) * 256 + tid;
+#pragma unroll
+                for (int q = 0; q < Q; ++q) {
+                    const float a = sum_of(u, q);
+                    if (__ballot(alive[u] && a <= thr2[q]) != 0ull) {
+                        const float d = sqrtf(a);
+                        best[q].template offer<false>(alive[u], d, (int)row, lane);
+                        const float t = best[q].thr;
+                        thr2[q] = fminf(thr2g[q], fmaxf(__fmaf_rn(t * t, 4e-7f, t * t), 1e-36f));
                     }
                 }
             }
-            if (ok[u] && p.mask) mw[u] = p.mask[row >> 5];
+            continue;
         }
-        // ---- table sums in sub-space order, then the selection, tile by tile
 #pragma unroll
         for (int u = 0; u < PQ_UNROLL; ++u) {
             const int64_t row = (tb + u) * 256 + tid;
             float acc[Q];
-            if (M > 0 && Q == 4) {
-                // the four queries' entries are one 16-byte read; two packed adds per sub-space (each element is
-                // still its own sequential fp32 sum in sub-space order)
-                typedef float pq_f2 __attribute__((ext_vector_type(2)));
-                const float4 t0v = *reinterpret_cast<const float4*>(T + (w[u][0] & 0xff) * Q);
-                pq_f2 a01 = pq_f2{t0v.x, t0v.y}, a23 = pq_f2{t0v.z, t0v.w};
-#pragma unroll
-                for (int j = 1; j < M; ++j) {
-                    const float4 tv = *reinterpret_cast<const float4*>(T + (j * ksub + ((w[u][j >> 2] >> (8 * (j & 3))) & 0xff)) * Q);
-                    a01 = a01 + pq_f2{tv.x, tv.y};
-                    a23 = a23 + pq_f2{tv.z, tv.w};
-                }
-                acc[0] = a01.x; acc[1 % Q] = a01.y; acc[2 % Q] = a23.x; acc[3 % Q] = a23.y;
-            } else if (M > 0) {
+            if (M > 0) {
                 const float* t0p = T + (w[u][0] & 0xff) * Q;
 #pragma unroll
                 for (int q = 0; q < Q; ++q) acc[q] = t0p[q];
@@ -247,18 +349,30 @@ __global__ __launch_bounds__(256) void pq_scan_kernel(PqScanParams p) {
                     const float d = sqrtf(acc[q]);
                     best[q].template offer<false>(pass, d, (int)row, lane);
                     const float t = best[q].thr;
-                    thr2[q] = fmaxf(__fmaf_rn(t * t, 4e-7f, t * t), 1e-36f);
+                    thr2[q] = fminf(thr2g[q], fmaxf(__fmaf_rn(t * t, 4e-7f, t * t), 1e-36f));
                 }
             }
         }
     }
     if (k == 0) return;
-    // one candidate list per wave
+    // one candidate list per wave; behind a bound most lists are empty, so with queue_len the waves pack what they
+    // hold into the front of the query's area (in any order: the merge that follows does not need sorted input)
 #pragma unroll
     for (int q = 0; q < Q; ++q) {
         if (q < qcnt) {
-            const int64_t list = ((int64_t)(q0 + q) * p.splits + split) * PQ_WAVES + wave;
-            best[q].store(p.part_d + list * k, p.part_i + list * k, lane);
+            if (p.queue_len) {
+                const int cnt = __popcll(__ballot(lane < k && best[q].eid != EMPTY_IDX));     // the list's first cnt lanes
+                if (cnt > 0) {
+                    int at = 0;
+                    if (lane == 0) at = atomicAdd(p.queue_len + q0 + q, cnt);
+                    at = __builtin_amdgcn_readfirstlane(at);
+                    const int64_t base = (int64_t)(q0 + q) * p.splits * PQ_WAVES * k + at;
+                    if (lane < cnt) { p.part_d[base + lane] = best[q].e; p.part_i[base + lane] = best[q].eid; }
+                }
+            } else {
+                const int64_t list = ((int64_t)(q0 + q) * p.splits + split) * PQ_WAVES + wave;
+                best[q].store(p.part_d + list * k, p.part_i + list * k, lane);
+            }
         }
     }
 }
@@ -346,10 +460,10 @@ int launch_ivfpq_scan(const float* q, int ldq, int dim, int nq, const float* cen
 
 // ---------------------------------------------------------------- launchers
 int launch_pq_lut(const float* q, int ldq, int nq, const float* book, int m, int ksub, int dsub,
-                  const SumPlan& plan, float* lut, hipStream_t s) {
+                  const SumPlan& plan, float* lut, hipStream_t s, int* zero_counts) {
     if (nq <= 0) return VDB_OK;
     hipLaunchKernelGGL(pq_lut_kernel, dim3(m, nq), dim3(256), (size_t)dsub * sizeof(float), s,
-                       q, ldq, book, m, ksub, dsub, plan, lut);
+                       q, ldq, book, m, ksub, dsub, plan, lut, zero_counts);
     VDB_HIP(hipGetLastError());
     return VDB_OK;
 }
@@ -382,10 +496,11 @@ int launch_pq_encode(const float* x, int64_t n, int ldx, const float* book, int 
 
 int launch_pq_scan(const uint8_t* codes, int64_t n, int m, int ksub, const float* lut, int nq, int k,
                    const uint32_t* mask, const float* lb_d, const int64_t* lb_k, int splits,
-                   float* part_d, int* part_i, float* dist_out, hipStream_t s) {
+                   float* part_d, int* part_i, float* dist_out, hipStream_t s, const float* bound_d, int64_t bound_stride,
+                   bool timed, int* queue_len) {
     VDB_REQUIRE(k >= 0 && k <= 64, "scan supports k <= 64, got %d", k);
     VDB_REQUIRE(n < (int64_t)0x7fffffff, "at most 2^31-1 codes per device");
-    PqScanParams p{codes, n, m, ksub, lut, nq, mask, lb_d, lb_k, k, splits, part_d, part_i, dist_out};
+    PqScanParams p{codes, n, m, ksub, lut, nq, mask, lb_d, lb_k, k, splits, part_d, part_i, queue_len, dist_out, bound_d, bound_stride};
     const size_t table = (size_t)m * ksub * sizeof(float);
     VDB_REQUIRE(table <= 160 * 1024, "%d sub-spaces x %d codewords need %zu bytes of LDS", m, ksub, table);
     // queries per pass: as many tables as fit while two blocks still share a CU
@@ -396,12 +511,11 @@ int launch_pq_scan(const uint8_t* codes, int64_t n, int m, int ksub, const float
     if (!fixed_m) Q = 1;
     const size_t lds = table * Q;
     const dim3 grid(splits, (nq + Q - 1) / Q);
-    KernelTimer timer(s);
+    KernelTimer timer(s, timed);
 #define VDB_LAUNCH_PQ(MM, QQ)                                                                  \
     {                                                                                          \
         auto kern = ksub == 256 ? pq_scan_kernel<MM, QQ, 256> : pq_scan_kernel<MM, QQ, 0>;     \
-        VDB_TRY(raise_dynamic_lds(reinterpret_cast<const void*>(kern),                       \
-                                    lds));    \
+        VDB_TRY(raise_dynamic_lds(reinterpret_cast<const void*>(kern), lds));                  \
         hipLaunchKernelGGL(kern, grid, dim3(256), lds, s, p);                                  \
     }
 #define VDB_LAUNCH_PQ_M(MM)                                                                    \

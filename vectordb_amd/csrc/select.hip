@@ -233,11 +233,21 @@ __global__ __launch_bounds__(256) void merge_wave_kernel(const float* __restrict
     const int* iq = idx + (int64_t)q * total;
     WaveTopK top;
     top.init(k);
-    for (int i0 = 0; i0 < total; i0 += 64) {
-        const int i = i0 + lane;
-        const float v = i < total ? dq[i] : INFINITY;
-        const int id = i < total ? iq[i] : EMPTY_IDX;
-        top.offer(id != EMPTY_IDX, v, id, lane);
+    // eight loads per lane in flight: the walk is a chain of global-memory round trips otherwise
+    constexpr int MW_AHEAD = 8;
+    for (int i0 = 0; i0 < total; i0 += 64 * MW_AHEAD) {
+        float v[MW_AHEAD];
+        int id[MW_AHEAD];
+#pragma unroll
+        for (int a = 0; a < MW_AHEAD; ++a) {
+            const int i = i0 + a * 64 + lane;
+            v[a] = i < total ? dq[i] : INFINITY;
+            id[a] = i < total ? iq[i] : EMPTY_IDX;
+        }
+#pragma unroll
+        for (int a = 0; a < MW_AHEAD; ++a) {
+            if (i0 + a * 64 < total) top.offer(id[a] != EMPTY_IDX, v[a], id[a], lane);
+        }
     }
     if (lane < k) {
         const bool empty = top.eid == EMPTY_IDX;
@@ -292,6 +302,74 @@ int launch_select(const float* part_d, const int* part_i, int nq, int n_cand, in
     }
     hipLaunchKernelGGL(merge_lists_kernel<true>, dim3(nq, 1), dim3(256), lds, s, cur_d, cur_i, n, k,
                        (float*)nullptr, (int*)nullptr, idx_map, idx_offset, o);
+    VDB_HIP(hipGetLastError());
+    return VDB_OK;
+}
+
+// One block of up to sixteen waves per query picks the k best of the query's packed candidate area (queue_len[q]
+// entries of `area`, in any order): the waves share out the entries 64 at a time (256 entries or more per wave, so a
+// short queue keeps few waves busy), each keeps its k best in registers, and wave 0 merges the waves' lists through
+// LDS.  For a few queries, where one wave per query would walk the entries as a chain of global-memory round trips.
+static constexpr int MB_WAVES = 16;
+__global__ __launch_bounds__(64 * MB_WAVES) void merge_block_kernel(const float* __restrict__ d, const int* __restrict__ idx,
+                                                                    int area, int k, SelectOut o, int* __restrict__ queue_len) {
+    __shared__ float sh_d[MB_WAVES * 64];
+    __shared__ int sh_i[MB_WAVES * 64];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int q = blockIdx.x;
+    const int total = queue_len ? min(__builtin_amdgcn_readfirstlane(queue_len[q]), area) : area;
+    const int waves = max(1, min(MB_WAVES, (total + 255) / 256));
+    const float* dq = d + (int64_t)q * area;
+    const int* iq = idx + (int64_t)q * area;
+    WaveTopK top;
+    top.init(k);
+    constexpr int AHEAD = 8;
+    if (wave < waves) {
+        for (int i0 = wave * 64; i0 < total; i0 += 64 * waves * AHEAD) {
+            float v[AHEAD];
+            int id[AHEAD];
+#pragma unroll
+            for (int a = 0; a < AHEAD; ++a) {
+                const int i = i0 + a * 64 * waves + lane;
+                v[a] = i < total ? dq[i] : INFINITY;
+                id[a] = i < total ? iq[i] : EMPTY_IDX;
+            }
+#pragma unroll
+            for (int a = 0; a < AHEAD; ++a) {
+                if (i0 + a * 64 * waves < total) top.template offer<true, true>(id[a] != EMPTY_IDX, v[a], id[a], lane);
+            }
+        }
+        // the waves' lists packed end to end (k entries each)
+        if (lane < k) { sh_d[wave * k + lane] = top.e; sh_i[wave * k + lane] = top.eid; }
+    }
+    __syncthreads();
+    if (wave != 0) return;
+    if (queue_len && lane == 0) queue_len[q] = 0;          // every wave has read it (the barrier above)
+    for (int i0 = k; i0 < waves * k; i0 += 64) {           // from wave 1's list on: wave 0's own is in `top` already
+        const int i = i0 + lane;
+        const float v = i < waves * k ? sh_d[i] : INFINITY;
+        const int id = i < waves * k ? sh_i[i] : EMPTY_IDX;
+        top.template offer<true, true>(id != EMPTY_IDX, v, id, lane);
+    }
+    if (lane < k) {
+        const bool empty = top.eid == EMPTY_IDX;
+        const int64_t row = empty ? -1 : (int64_t)top.eid;
+        const int64_t at = (int64_t)q * o.out_stride + o.out_off + lane;
+        if (o.out_d) o.out_d[at] = empty ? INFINITY : top.e;
+        if (o.out_i) o.out_i[at] = row;
+        if (o.out_i32) o.out_i32[at] = (int)row;
+        if (lane == k - 1 && o.last_d) {
+            o.last_d[q] = empty ? INFINITY : top.e;
+            o.last_key[q] = empty ? INT64_MAX : (int64_t)top.eid;
+        }
+    }
+}
+
+int launch_select_packed(const float* part_d, const int* part_i, int nq, int area, int k, const SelectOut& o, hipStream_t s,
+                         int* queue_len) {
+    if (nq <= 0) return VDB_OK;
+    VDB_REQUIRE(k >= 1 && k <= 64 && queue_len, "packed selection: k in 1..64 and a queue length per query");
+    hipLaunchKernelGGL(merge_block_kernel, dim3(nq), dim3(64 * MB_WAVES), 0, s, part_d, part_i, area, k, o, queue_len);
     VDB_HIP(hipGetLastError());
     return VDB_OK;
 }

@@ -278,6 +278,10 @@ struct SelectOut {
 // than one block's worth of lists has to be merged hierarchically.
 int launch_select(const float* part_d, const int* part_i, int nq, int n_cand, int k, int tie_group,
                   const int* idx_map, int64_t idx_offset, const SelectOut& o, hipStream_t s, DevBuf* mid);
+// a few queries: the k best of every query's packed candidate area (queue_len[q] of `area` entries, any order),
+// one block per query; sets queue_len[q] back to zero
+int launch_select_packed(const float* part_d, const int* part_i, int nq, int area, int k, const SelectOut& o, hipStream_t s,
+                         int* queue_len);
 // lists laid out [n_lists][nq][k] with int64 ids (negative = empty), ordered by (distance, id);
 // with a payload of the same layout the payload of every selected entry is written instead of its id.
 // List l of the distances starts at d + l * stride_d, of the ids and the payload at i + l * stride_i
@@ -290,14 +294,15 @@ int launch_row_sort_topk(const float* dist, int nq, int n, int k, float* out_d, 
 
 // PQ
 int launch_pq_lut(const float* q, int ldq, int nq, const float* book, int m, int ksub, int dsub,
-                  const SumPlan& plan, float* lut, hipStream_t s);
+                  const SumPlan& plan, float* lut, hipStream_t s, int* zero_counts = nullptr);
 int launch_pq_encode(const float* x, int64_t n, int ldx, const float* book, int m, int ksub, int dsub,
                      const SumPlan& plan, uint8_t* codes, hipStream_t s);
 // candidate lists come out as [nq][splits * pq_scan_lists_per_split()][k]
 int pq_scan_lists_per_split();
 int launch_pq_scan(const uint8_t* codes, int64_t n, int m, int ksub, const float* lut, int nq, int k,
                    const uint32_t* mask, const float* lb_d, const int64_t* lb_k, int splits,
-                   float* part_d, int* part_i, float* dist_out, hipStream_t s);
+                   float* part_d, int* part_i, float* dist_out, hipStream_t s, const float* bound_d = nullptr,
+                   int64_t bound_stride = 0, bool timed = true, int* queue_len = nullptr);
 // IVF-PQ (index/hybrid.py): residuals, and the per-(query, probe) table + list scan into candidate slots
 int launch_residual(const float* x, int64_t ldx, const float* cent, int ldc, const int* list, int dim, int64_t n,
                     float* out, hipStream_t s);
