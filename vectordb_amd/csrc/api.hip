@@ -412,8 +412,7 @@ static int stream_flat_sums(Workspace& ws, const Rows& r, int metric, const floa
                             bool leave_sqrt = false) {
     StreamPlanBufs b{};
     // queries per row chunk: 16 for real batches (each staged chunk serves twice as many queries), 8 for a handful
-    static const int env_group = getenv("VDB_STREAM_GROUP") ? atoi(getenv("VDB_STREAM_GROUP")) : 0;
-    const int group = nq == 1 ? 1 : ((env_group == 8 || env_group == 16) ? env_group : (nq >= 16 ? 16 : 8));
+    const int group = nq == 1 ? 1 : stream_batch_group(r.dim, r.ld, r.plan, op_of_metric(metric), nq, r.n);
     const int64_t items_cap = ((r.n + 255) / 256) * ((nq + group - 1) / group);
     // the plan buffers of a flat scan are its own (row norms and the IVF plans use the shared ones),
     // so a repeated search of the same shape skips the two planning launches
@@ -1811,11 +1810,8 @@ static int ivf_search_impl(vdb_ivf* h, const float* d_q, int nq, int k, int n_pr
     const int64_t cand_stride = round_up64(std::max<int64_t>(h->probe_bound(n_probe), 1), 64);
     VDB_REQUIRE(cand_stride < (int64_t)0x7fffffff, "n_probe=%d lists can hold more than 2^31 rows", n_probe);
     const int q_block = (int)std::max<int64_t>(1, std::min<int64_t>(nq, CAND_BUDGET / (cand_stride * (int64_t)sizeof(float))));
-    static const int env_group = getenv("VDB_STREAM_GROUP") ? atoi(getenv("VDB_STREAM_GROUP")) : 0;
-    // queries per row chunk: 8 (VDB_STREAM_GROUP=16 selects the one-row-per-thread kernel with 16, for A/B timing)
-    const int64_t per_list = (int64_t)nq * n_probe / std::max(1, h->n_lists);
-    (void)per_list;
-    const int group = nq == 1 ? 1 : (env_group > 0 ? env_group : 8);      // 8: the two-rows-per-thread kernel
+    // queries per row chunk: 8, or up to 128 with the row-resident kernel (VDB_STREAM_GROUP=8 or 16 for A/B timing)
+    const int group = nq == 1 ? 1 : stream_batch_group(m->r.dim, m->r.ld, m->r.plan, op_of_metric(sm), 8, -1);
 
     VDB_TRY(ws.probes.reserve((size_t)nq * n_probe * sizeof(int)));
     VDB_TRY(ws.probe_d.reserve((size_t)nq * n_probe * sizeof(float)));

@@ -207,7 +207,11 @@ __global__ __launch_bounds__(S_NT / R * QS, (G == 8 && R == 1 && WHOLE) ? 4 : 1)
 
     const int ksteps = (p.ld + S_CK - 1) / S_CK;
     const int64_t total_items = min(uload(p.seg_item_off + p.n_seg), p.items_cap);
-    const int64_t first = blockIdx.x;
+    // Blocks b, b + 8, b + 16, ... share an XCD and its L2.  Consecutive items are the query groups of one row chunk
+    // (then the next chunk of the list), so a run of gridDim/8 consecutive items goes to the blocks of one XCD: the
+    // chunk leaves HBM once for all of its groups instead of once per XCD that happens to hold one of them.
+    const int per_xcd = gridDim.x >> 3;
+    const int64_t first = (gridDim.x & 7) == 0 ? (int64_t)(blockIdx.x & 7) * per_xcd + (blockIdx.x >> 3) : (int64_t)blockIdx.x;
     if (first >= total_items) return;
     const int my_items = (int)((total_items - first + gridDim.x - 1) / gridDim.x);
     const int n_stages = my_items * ksteps;
@@ -544,6 +548,275 @@ __global__ __launch_bounds__(S_NT / R * QS, (G == 8 && R == 1 && WHOLE) ? 4 : 1)
 }
 
 // --------------------------------------------------------------------------
+// Row-resident form of the batch sums, for rows of D = 32, 64 or 128 floats that are one leaf of the summation
+// plan: a thread holds its row of the chunk in registers and sums it against every query of the item, up to
+// RR_GROUP of them, instead of re-reading staged row pieces from LDS for every group of 8 or 16 queries and meeting
+// the block at a barrier after every 32 columns.
+//   Rows: a wave brings its 64 rows in through LDS in slabs of 16 columns (LDS-DMA, 64 consecutive bytes per row, so
+// the loads are whole half lines; a thread that fetched its own row 16 bytes at a time would touch 64 lines per
+// instruction and the kernel would be bound by the address path of the vector cache).  Piece c of row r sits at
+// position c ^ ((r >> 2) & 3) of the row's 64-byte slot (swizzled on the source side), which makes the
+// one-row-per-lane 16-byte reads conflict free.  The ring of RR_NB slabs is private to the wave: no barrier.  The
+// first RR_NB slabs of the NEXT item are fetched while this item is summed; the rest of a row (D = 128) follows
+// when the first have been moved to registers.
+//   Queries: through LDS, RR_TQ at a time, double buffered, one barrier per RR_TQ queries; every lane reads the same
+// values (broadcast reads), one unit of 8 columns ahead of their use.
+//   Items are the (row chunk, query group) records of stream_sums_kernel with groups of up to RR_GROUP queries,
+// walked as one sequence of (item, query tile) steps.  Sums are taken exactly as there: eight strided accumulators as
+// four packed pairs, then the tree.
+static constexpr int RR_TQ = 8;
+static constexpr int RR_GROUP = 128;
+static constexpr int RR_NB = 4;                     // ring buffers per wave, one slab of 64 rows x 16 floats each
+static constexpr size_t rowreg_lds_bytes(int D) { return (size_t)(S_NT / 64) * RR_NB * 64 * 16 * 4 + 2 * RR_TQ * (size_t)D * 4; }
+
+template <int OP, int D>
+__global__ __launch_bounds__(S_NT, 2) void rowreg_sums_kernel(const StreamParams p) {
+    static_assert(D % 16 == 0 && D <= 128, "one leaf of whole slabs");
+    constexpr int H = 2;                            // queries summed side by side
+    extern __shared__ __align__(16) float smem[];
+    float* ring_all = smem;                                         // [waves][RR_NB][64][16]
+    float (*qs)[RR_TQ][D] = reinterpret_cast<float (*)[RR_TQ][D]>(smem + (S_NT / 64) * RR_NB * 64 * 16);   // [2][RR_TQ][D]
+    constexpr int C4 = D / 4;                       // 16-byte pieces of a row
+    constexpr int SL = D / 16;                      // slabs of a row
+    constexpr int QF4 = RR_TQ * C4;                 // 16-byte pieces of a query tile
+    constexpr int NP = (QF4 + S_NT - 1) / S_NT;     // of which a thread stages this many
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int64_t total_items = min(uload(p.seg_item_off + p.n_seg), p.items_cap);
+    const int per_xcd = gridDim.x >> 3;             // runs of consecutive items per XCD, as in stream_sums_kernel
+    const int64_t first = (gridDim.x & 7) == 0 ? (int64_t)(blockIdx.x & 7) * per_xcd + (blockIdx.x >> 3) : (int64_t)blockIdx.x;
+    if (first >= total_items) return;
+
+    float* ring = ring_all + wave * (RR_NB * 64 * 16);
+    const unsigned ring_addr = (unsigned)(uintptr_t)ring;
+    // slab sl of item jt's rows into ring buffer b: four instructions of 16 rows x 64 bytes
+    auto issue_slab = [&](const Item& jt, int sl, int b) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int r = i * 16 + (lane >> 2);
+            const int c = (lane & 3) ^ ((r >> 2) & 3);
+            const float* src = p.data + (jt.row0 + wave * 64 + r) * p.ld + sl * 16 + c * 4;
+            glds16(src, __builtin_amdgcn_readfirstlane(ring_addr + (unsigned)(b * 4096 + i * 1024)));
+        }
+    };
+    float4 x[C4];
+    auto take_slab = [&](int sl, int b) {
+        const float* base = ring + b * 1024 + lane * 16;
+        const int sw = (lane >> 2) & 3;
+#pragma unroll
+        for (int c = 0; c < 4; ++c) x[4 * sl + c] = *reinterpret_cast<const float4*>(base + ((c ^ sw) << 2));
+    };
+
+    int64_t item = first;
+    Item it = load_item(p, item);
+    int tile = 0;
+    int ids[NP];
+    // the query numbers of the pieces this thread stages for (item jt, tile t) ...
+    auto load_ids = [&](const Item& jt, int t) {
+#pragma unroll
+        for (int i = 0; i < NP; ++i) {
+            const int f = tid + S_NT * i;
+            const int jq = min(t * RR_TQ + f / C4, jt.qcnt - 1);       // slots past the group repeat its last query
+            ids[i] = p.sq_qid[jt.qbeg + jq];
+        }
+    };
+    // ... and the pieces themselves, global memory -> LDS without passing through registers (a wave's 64 pieces are
+    // 1 KiB of the tile in lane order); awaited with vmcnt(0) before the barrier that publishes the tile
+    auto dma_q = [&](int b) {
+#pragma unroll
+        for (int i = 0; i < NP; ++i) {
+            const int f = tid + S_NT * i;
+            if (NP * S_NT == QF4 || f < QF4) {          // whole waves: QF4 is a multiple of 64
+                const float* src = p.q + (int64_t)ids[i] * p.ldq + (f % C4) * 4;
+                const unsigned dst = (unsigned)(uintptr_t)(&qs[b][0][0]) + (unsigned)(f - lane) * 16u;
+                glds16(src, __builtin_amdgcn_readfirstlane(dst));
+            }
+        }
+    };
+    load_ids(it, 0);
+#pragma unroll
+    for (int sl = 0; sl < (SL < RR_NB ? SL : RR_NB); ++sl) issue_slab(it, sl, sl);
+    dma_q(0);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    int buf = 0;
+    for (;;) {
+        // the step after this one
+        Item nit = it;
+        int ntile = tile + 1;
+        int64_t nitem = item;
+        bool has_next = true;
+        if (ntile * RR_TQ >= it.qcnt) {
+            nitem = item + gridDim.x;
+            ntile = 0;
+            has_next = nitem < total_items;
+            if (has_next) nit = load_item(p, nitem);
+        }
+        bool rest_pending = false;                  // D = 128: the second half of the rows is still on its way
+        if (tile == 0) {
+            // this item's rows: the first slabs are in the ring (fetched while the item before was summed; rows
+            // past the chunk's end come from the rows behind it, a row store keeps 256 rows of slack, and their
+            // sums are not stored)
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#pragma unroll
+            for (int sl = 0; sl < (SL < RR_NB ? SL : RR_NB); ++sl) take_slab(sl, sl);
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");             // the ring is free again
+            if constexpr (SL > RR_NB) {
+                // the other slabs are asked for now and taken when the first query pair reaches their columns
+#pragma unroll
+                for (int sl = RR_NB; sl < SL; ++sl) issue_slab(it, sl, sl - RR_NB);
+                rest_pending = true;
+            } else if (item + gridDim.x < total_items) {
+                const Item pit = load_item(p, item + gridDim.x);           // the block's next item, whatever its tiles
+#pragma unroll
+                for (int sl = 0; sl < SL; ++sl) issue_slab(pit, sl, sl);
+            }
+        }
+        if (has_next) load_ids(nit, ntile);
+        const int live = min(RR_TQ, it.qcnt - tile * RR_TQ);
+        const int pairs = (live + H - 1) / H;
+        // the H queries' values for columns 8c .. 8c+7 of the row, read one unit ahead of their use (every lane reads
+        // the same address); a pair's first unit is read while the pair before it is finished and stored
+        float4 qv[2][H][2];
+        auto load_qv = [&](const float* qa, int b, int c) {
+#pragma unroll
+            for (int h = 0; h < H; ++h) {
+                qv[b][h][0] = *reinterpret_cast<const float4*>(qa + h * D + c * 8);
+                qv[b][h][1] = *reinterpret_cast<const float4*>(qa + h * D + c * 8 + 4);
+            }
+        };
+        load_qv(&qs[buf][0][0], 0, 0);
+        for (int pr = 0; pr < pairs; ++pr) {
+            const float* qa = &qs[buf][H * pr][0];
+            // where the pair's results go: asked for now, needed when the row has been summed
+            int64_t ob[H];
+#pragma unroll
+            for (int h = 0; h < H; ++h) ob[h] = uload(p.sq_out + it.qbeg + min(tile * RR_TQ + H * pr + h, it.qcnt - 1));
+            __builtin_amdgcn_sched_barrier(0);
+            f2 acc[H][4];
+#pragma unroll
+            for (int h = 0; h < H; ++h)
+#pragma unroll
+                for (int j = 0; j < 4; ++j) acc[h][j] = f2{0.0f, 0.0f};
+#pragma unroll
+            for (int c = 0; c < D / 8; ++c) {
+                if constexpr (SL > RR_NB) {
+                    if (c == 2 * RR_NB && rest_pending) {
+                        // columns 16 * RR_NB onwards: the rest of the rows has had half a query pair to arrive
+                        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#pragma unroll
+                        for (int sl = RR_NB; sl < SL; ++sl) take_slab(sl, sl - RR_NB);
+                        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                        if (item + gridDim.x < total_items) {
+                            const Item pit = load_item(p, item + gridDim.x);
+#pragma unroll
+                            for (int sl = 0; sl < RR_NB; ++sl) issue_slab(pit, sl, sl);
+                        }
+                        rest_pending = false;
+                    }
+                }
+                if (c + 1 < D / 8) load_qv(qa, (c + 1) & 1, c + 1);
+                else if (pr + 1 < pairs) load_qv(qa + H * D, 0, 0);        // D / 8 is even: the next pair starts in buffer 0
+                f2 q2[H][4], x2[4];
+#pragma unroll
+                for (int h = 0; h < H; ++h) {
+                    const float4 a = qv[c & 1][h][0], b = qv[c & 1][h][1];
+                    q2[h][0] = f2{a.x, a.y}; q2[h][1] = f2{a.z, a.w}; q2[h][2] = f2{b.x, b.y}; q2[h][3] = f2{b.z, b.w};
+                }
+                x2[0] = f2{x[2 * c].x, x[2 * c].y}; x2[1] = f2{x[2 * c].z, x[2 * c].w};
+                x2[2] = f2{x[2 * c + 1].x, x[2 * c + 1].y}; x2[3] = f2{x[2 * c + 1].z, x[2 * c + 1].w};
+                if constexpr (s_staged<OP>()) {
+                    f2 d[H * 4];
+#pragma unroll
+                    for (int h = 0; h < H; ++h)
+#pragma unroll
+                        for (int j = 0; j < 4; ++j) d[h * 4 + j] = s_stage1<OP>(x2[j], q2[h][j]);
+                    s_fence<H * 4>(d);
+                    if constexpr (OP == OP_SQDIFF) {
+#pragma unroll
+                        for (int e = 0; e < H * 4; ++e) d[e] = d[e] * d[e];
+                        s_fence<H * 4>(d);
+                    }
+#pragma unroll
+                    for (int h = 0; h < H; ++h)
+#pragma unroll
+                        for (int j = 0; j < 4; ++j) acc[h][j] = s_stage3<OP>(acc[h][j], d[h * 4 + j]);
+                } else {
+#pragma unroll
+                    for (int h = 0; h < H; ++h)
+#pragma unroll
+                        for (int j = 0; j < 4; ++j) acc[h][j] = s_accum2<OP>(acc[h][j], x2[j], q2[h][j]);
+                }
+                // the running sums are taken here, not collected at the end of the row (the compiler would otherwise
+                // keep every unit's terms alive until then, in registers the row needs)
+                s_fence<H * 4>(&acc[0][0]);
+                __builtin_amdgcn_sched_barrier(0);
+            }
+#pragma unroll
+            for (int h = 0; h < H; ++h) {
+                const int gq = tile * RR_TQ + H * pr + h;              // the query's place in the group
+                if (gq < it.qcnt) {
+                    float v = s_tree2<OP>(acc[h]);
+                    if (p.post == POST_SQRT) v = sqrtf(v);
+                    else if (p.post == POST_NEG) v = -v;
+                    if (tid < it.rows) p.out[ob[h] + it.out_rel + tid] = v;
+                }
+            }
+            // the coming step's query values into the other buffer: their numbers were asked for a pair of queries ago
+            if (pr == 0 && has_next) dma_q(buf ^ 1);
+        }
+        if (!has_next) break;
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        buf ^= 1;
+        it = nit; tile = ntile; item = nitem;
+    }
+}
+
+static bool rowreg_fits(const StreamJob& j) {
+    const bool op_ok = j.op == OP_SQDIFF || j.op == OP_ABSDIFF || j.op == OP_MAXABS || j.op == OP_DOT;
+    return op_ok && j.dim == j.ld && j.ld == j.ldq && j.plan.n_leaves == 1 && (j.dim == 128 || j.dim == 64 || j.dim == 32);
+}
+// the query group width a batch job over these rows should be planned with.  n_rows < 0: many row chunks (an IVF list
+// scan).  A small row set (centroids) keeps the 16-query items: with groups of 128 there would be fewer items than
+// blocks.
+int stream_batch_group(int dim, int ld, const SumPlan& plan, int op, int nq, int64_t n_rows) {
+    static const int env_group = getenv("VDB_STREAM_GROUP") ? atoi(getenv("VDB_STREAM_GROUP")) : 0;
+    if (env_group == 8 || env_group == 16) return env_group;
+    StreamJob j{};
+    j.dim = dim; j.ld = ld; j.ldq = ld; j.plan = plan; j.op = op;
+    const int64_t items = n_rows < 0 ? INT64_MAX : ((n_rows + S_NT - 1) / S_NT) * ((nq + RR_GROUP - 1) / RR_GROUP);
+    if (rowreg_fits(j) && items >= 8 * (int64_t)ctx().num_cus) return RR_GROUP;
+    return nq >= 16 ? 16 : 8;
+}
+
+static int launch_rowreg_sums(const StreamJob& j, const StreamParams& p, hipStream_t s) {
+    const int grid = ctx().num_cus * 2;
+    const size_t lds = rowreg_lds_bytes(j.dim);
+    KernelTimer timer(s, j.timed);
+#define VDB_LAUNCH_RR_D(O, DD)                                                                  \
+    {                                                                                            \
+        auto kern = rowreg_sums_kernel<O, DD>;                                                   \
+        VDB_TRY(raise_dynamic_lds(reinterpret_cast<const void*>(kern), lds));                    \
+        hipLaunchKernelGGL(kern, dim3(grid), dim3(S_NT), lds, s, p);                             \
+    }
+#define VDB_LAUNCH_RR(O)                                                                         \
+    case O:                                                                                      \
+        if (j.dim == 128) VDB_LAUNCH_RR_D(O, 128) else if (j.dim == 64) VDB_LAUNCH_RR_D(O, 64) else VDB_LAUNCH_RR_D(O, 32) \
+        break;
+    switch (j.op) {
+        VDB_LAUNCH_RR(OP_DOT)
+        VDB_LAUNCH_RR(OP_SQDIFF)
+        VDB_LAUNCH_RR(OP_ABSDIFF)
+        VDB_LAUNCH_RR(OP_MAXABS)
+        default: VDB_REQUIRE(false, "row-resident sums: unsupported op %d", j.op);
+    }
+#undef VDB_LAUNCH_RR
+#undef VDB_LAUNCH_RR_D
+    VDB_HIP(hipGetLastError());
+    return VDB_OK;
+}
+
+// --------------------------------------------------------------------------
 static int stream_depth(const SumPlan& plan) {
     int sp = 0, depth = 0;
     for (int i = 0; i < plan.n_leaves; ++i) {
@@ -555,7 +828,8 @@ static int stream_depth(const SumPlan& plan) {
 }
 
 int launch_stream_sums(const StreamJob& j, hipStream_t s) {
-    VDB_REQUIRE(j.group == 1 || j.group == 8 || j.group == 16, "query group must be 1, 8 or 16");
+    VDB_REQUIRE(j.group == 1 || j.group == 8 || j.group == 16 || (j.group == RR_GROUP && rowreg_fits(j)),
+                "query group must be 1, 8 or 16 (or %d for rows that fit the row-resident kernel)", RR_GROUP);
     VDB_REQUIRE(j.ld % 4 == 0 && j.ld >= j.dim, "stored rows must be padded to a multiple of 4 floats");
     StreamParams p{};
     p.data = j.data; p.ld = j.ld; p.dim = j.dim; p.post = j.post;
@@ -564,6 +838,7 @@ int launch_stream_sums(const StreamJob& j, hipStream_t s) {
     p.q = j.q; p.ldq = j.ldq; p.zeros = ctx().zeros;
     p.n_seg = j.n_seg; p.seg_row_off = j.seg_row_off; p.seg_q_off = j.seg_q_off; p.seg_item_off = j.seg_item_off;
     p.sq_qid = j.sq_qid; p.sq_out = j.sq_out; p.out = j.out; p.items = j.items; p.items_cap = j.items_cap;
+    if (j.group == RR_GROUP) return launch_rowreg_sums(j, p, s);
     const size_t stack = (size_t)stream_depth(j.plan) * j.group * S_NT * sizeof(float);
     const size_t budget = 160 * 1024;
     const size_t slot = (size_t)(S_STAGE + j.group * S_CK) * sizeof(float);

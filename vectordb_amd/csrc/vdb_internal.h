@@ -206,7 +206,7 @@ struct StreamJob {
     const float* data; int ld; int dim; SumPlan plan;
     int op; int post;
     const float* q; int ldq;        // query rows; readable up to 8 floats past the last row
-    int group;                      // queries per item: 1 or 8
+    int group;                      // queries per item: 1, 8, 16 or 128 (stream_batch_group)
     int n_seg;
     const int64_t* seg_row_off; const int* seg_q_off; const int64_t* seg_item_off;
     const int* sq_qid; const int64_t* sq_out;
@@ -215,6 +215,10 @@ struct StreamJob {
     bool timed;
 };
 int launch_stream_sums(const StreamJob& j, hipStream_t s);
+// queries per item a batch job (nq > 1) over rows of this shape is planned with: 8 or 16, or 128 where the
+// row-resident kernel applies (rows of 32, 64 or 128 floats that are one leaf of the summation plan, and enough
+// row chunks to give every block several items; n_rows < 0: an IVF list scan)
+int stream_batch_group(int dim, int ld, const SumPlan& plan, int op, int nq, int64_t n_rows);
 // row norms in NumPy order: sq[i] = np.sum(row_i**2), nrm[i] = sqrt(sq[i]); b needs ceil(n/256) items
 int launch_row_norms(const float* data, int ld, int dim, int64_t n, const SumPlan& plan, const StreamPlanBufs& b,
                      float* sq, float* nrm, hipStream_t s);
