@@ -28,14 +28,14 @@ case = skipped = 0
 def ivf_case():
     global skipped
     n = int(rng.choice([50, 300, 3000, 20000, 60000]))
-    d = int(rng.choice([4, 16, 32, 100, 128]))
+    d = int(rng.choice([4, 16, 32, 64, 100, 128]))
     nlist = int(min(n, rng.choice([1, 3, 17, 64, 300, 1024, 1500])))
     metric = str(rng.choice(["euclidean", "cosine", "manhattan"]))
     x = rng.standard_normal((n, d), dtype=np.float32)
     cent = x[rng.choice(n, nlist, replace=False)].copy()
     assign = R.ivf_assign_batch(x, cent, metric)
     lists_ref = R.ivf_build_lists(assign, nlist)
-    nq = int(rng.choice([1, 2, 8, 9, 33]))
+    nq = int(rng.choice([1, 2, 8, 9, 33, 150, 300]))
     q = rng.standard_normal((nq, d), dtype=np.float32)
     k = int(rng.choice([1, 5, 10, 40, 100]))
     n_probe = int(min(nlist, rng.choice([1, 2, 8, 32, 33, 70])))

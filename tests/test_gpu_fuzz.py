@@ -1,0 +1,42 @@
+"""Short runs of the randomised parity soaks (tests/fuzz_*.py) inside the GPU suite: each script draws random
+shapes, metrics, filters and batch sizes for a few seconds, compares every case with the CPU oracle and stops at
+the first difference.  The long soaks are run by hand with more seconds and other seeds."""
+
+import os
+import subprocess
+import sys
+
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+
+
+def run_soak(script, seconds, seed, env=None):
+    e = dict(os.environ)
+    e.update(env or {})
+    r = subprocess.run([sys.executable, os.path.join(HERE, script), "--seconds", str(seconds), "--seed", str(seed)],
+                       capture_output=True, text=True, timeout=600, env=e)
+    tail = "\n".join((r.stdout + r.stderr).splitlines()[-15:])
+    assert r.returncode == 0, f"{script} seed {seed} failed:\n{tail}"
+    assert "no failure" in r.stdout, tail
+    return r.stdout
+
+
+def test_flat_soak(native):
+    run_soak("fuzz_flat.py", 12, 101)
+
+
+def test_flat_soak_row_resident_kernel(native):
+    # VDB_RR_MIN_ITEMS=1: batched Manhattan / Chebyshev over rows of 32, 64 or 128 floats take the row-resident
+    # kernel at every size instead of only from a few thousand row chunks on
+    run_soak("fuzz_flat.py", 12, 102, env={"VDB_RR_MIN_ITEMS": "1"})
+
+
+def test_ivf_pq_soak(native):
+    run_soak("fuzz_ivf_pq.py", 15, 103)
+
+
+def test_bf16_soak(native):
+    run_soak("fuzz_bf16.py", 10, 104)

@@ -785,7 +785,9 @@ int stream_batch_group(int dim, int ld, const SumPlan& plan, int op, int nq, int
     StreamJob j{};
     j.dim = dim; j.ld = ld; j.ldq = ld; j.plan = plan; j.op = op;
     const int64_t items = n_rows < 0 ? INT64_MAX : ((n_rows + S_NT - 1) / S_NT) * ((nq + RR_GROUP - 1) / RR_GROUP);
-    if (rowreg_fits(j) && items >= 8 * (int64_t)ctx().num_cus) return RR_GROUP;
+    // VDB_RR_MIN_ITEMS: the item count from which the row-resident kernel is taken (tests run it on small row sets)
+    static const int64_t min_items = getenv("VDB_RR_MIN_ITEMS") ? atoll(getenv("VDB_RR_MIN_ITEMS")) : 8 * (int64_t)ctx().num_cus;
+    if (rowreg_fits(j) && items >= min_items) return RR_GROUP;
     return nq >= 16 ? 16 : 8;
 }
 
