@@ -31,7 +31,8 @@ def test_flat_soak(native):
 def test_flat_soak_row_resident_kernel(native):
     # VDB_RR_MIN_ITEMS=1: batched Manhattan / Chebyshev over rows of 32, 64 or 128 floats take the row-resident
     # kernel at every size instead of only from a few thousand row chunks on
-    run_soak("fuzz_flat.py", 12, 102, env={"VDB_RR_MIN_ITEMS": "1"})
+    # VDB_FLAT_BOUND_MIN_ROWS: the bounded form of those batches (sample bound + per-query queues) from 4096 rows on
+    run_soak("fuzz_flat.py", 12, 102, env={"VDB_RR_MIN_ITEMS": "1", "VDB_FLAT_BOUND_MIN_ROWS": "4096"})
 
 
 def test_ivf_pq_soak(native):

@@ -408,8 +408,11 @@ static int cand_splits(int64_t tiles, int nq) {
 }
 
 // leave_sqrt: direct-form Euclidean sums are stored without their square root (the selection that follows takes it)
+// `more`: the fields of a StreamJob beyond the plain sums (run_if, the bounded form), or null.  own_plan: plan this
+// scan in the shared plan buffers instead of the cached flat plan (a scan over a prefix of the rows must not evict the
+// plan of the whole set).
 static int stream_flat_sums(Workspace& ws, const Rows& r, int metric, const float* q, int nq, float* out, hipStream_t s,
-                            bool leave_sqrt = false) {
+                            bool leave_sqrt = false, const StreamJob* more = nullptr, bool own_plan = false) {
     StreamPlanBufs b{};
     // queries per row chunk: 16 for real batches (each staged chunk serves twice as many queries), 8 for a handful
     const int group = nq == 1 ? 1 : stream_batch_group(r.dim, r.ld, r.plan, op_of_metric(metric), nq, r.n);
@@ -419,20 +422,26 @@ static int stream_flat_sums(Workspace& ws, const Rows& r, int metric, const floa
     DevBuf* bufs[] = {&ws.fp_seg_row_off, &ws.fp_seg_q_off, &ws.fp_seg_item_off, &ws.fp_sq_qid, &ws.fp_sq_out, &ws.fp_items};
     const size_t need[] = {2 * sizeof(int64_t), 2 * sizeof(int), 2 * sizeof(int64_t), (size_t)std::max(nq, 1) * sizeof(int),
                            (size_t)std::max(nq, 1) * sizeof(int64_t), (size_t)std::max<int64_t>(items_cap, 1) * sizeof(StreamItem)};
-    bool moved = false;
-    for (int i = 0; i < 6; ++i) {
-        void* before = bufs[i]->p;
-        VDB_TRY(bufs[i]->reserve(need[i]));
-        moved = moved || bufs[i]->p != before;
-    }
-    b.seg_row_off = ws.fp_seg_row_off.as<int64_t>(); b.seg_q_off = ws.fp_seg_q_off.as<int>();
-    b.seg_item_off = ws.fp_seg_item_off.as<int64_t>(); b.sq_qid = ws.fp_sq_qid.as<int>(); b.sq_out = ws.fp_sq_out.as<int64_t>();
-    b.items = ws.fp_items.as<StreamItem>(); b.items_cap = items_cap;
-    if (moved || ws.fp_n != r.n || ws.fp_nq != nq || ws.fp_group != group) {
+    if (own_plan) {
+        VDB_TRY(reserve_stream_plan(ws, 1, nq, items_cap, &b));
         VDB_TRY(launch_flat_plan(r.n, nq, group, r.n, b, s));
-        ws.fp_n = r.n; ws.fp_nq = nq; ws.fp_group = group;
+    } else {
+        bool moved = false;
+        for (int i = 0; i < 6; ++i) {
+            void* before = bufs[i]->p;
+            VDB_TRY(bufs[i]->reserve(need[i]));
+            moved = moved || bufs[i]->p != before;
+        }
+        b.seg_row_off = ws.fp_seg_row_off.as<int64_t>(); b.seg_q_off = ws.fp_seg_q_off.as<int>();
+        b.seg_item_off = ws.fp_seg_item_off.as<int64_t>(); b.sq_qid = ws.fp_sq_qid.as<int>(); b.sq_out = ws.fp_sq_out.as<int64_t>();
+        b.items = ws.fp_items.as<StreamItem>(); b.items_cap = items_cap;
+        if (moved || ws.fp_n != r.n || ws.fp_nq != nq || ws.fp_group != group) {
+            VDB_TRY(launch_flat_plan(r.n, nq, group, r.n, b, s));
+            ws.fp_n = r.n; ws.fp_nq = nq; ws.fp_group = group;
+        }
     }
     StreamJob j{};
+    if (more) j = *more;
     j.data = r.data; j.ld = r.ld; j.dim = r.dim; j.plan = r.plan;
     j.op = op_of_metric(metric); j.post = post_of_metric(metric);
     if (leave_sqrt && j.post == POST_SQRT) j.post = POST_NONE;
@@ -441,6 +450,8 @@ static int stream_flat_sums(Workspace& ws, const Rows& r, int metric, const floa
     j.sq_qid = b.sq_qid; j.sq_out = b.sq_out; j.items = b.items; j.items_cap = b.items_cap; j.out = out; j.timed = true;
     return launch_stream_sums(j, s);
 }
+
+static constexpr int FLAT_BOUND_QUEUE = 4096;     // (distance, row) entries per query in the bounded form
 
 // streamed search of a flat row set (any metric): per block of queries, sums -> candidate buffer -> k best
 static int stream_flat_search(vdb_rows* h, Workspace& ws, int metric, const float* q, int nq, int k, int64_t k_eff,
@@ -455,6 +466,32 @@ static int stream_flat_search(vdb_rows* h, Workspace& ws, int metric, const floa
         VDB_TRY(ws.lb_d.reserve((size_t)q_block * sizeof(float)));
         VDB_TRY(ws.lb_k.reserve((size_t)q_block * sizeof(int64_t)));
     }
+    // Bounded form (batches over a large row set with the row-resident kernel, direct-form metrics, k results in one
+    // pass): the k best of the first rows of the set go through the plain pipeline; their k-th distance is not below
+    // the query's k-th best over all rows, so the scan of the whole set keeps only the (row, query) pairs within it,
+    // in per-query queues, and one block per query picks the k best of its queue.  The [queries][rows] candidate
+    // buffer is neither written nor read.  A queue that fills up (rows ordered so that the first ones are the
+    // farthest) sets a device flag, and the plain pipeline below then runs behind that flag; otherwise its launches
+    // return at once.  Either way the results are those of the plain pipeline.
+    static const int64_t bound_min_rows = getenv("VDB_FLAT_BOUND_MIN_ROWS") ? atoll(getenv("VDB_FLAT_BOUND_MIN_ROWS")) : 262144;
+    const int op = op_of_metric(metric);
+    // (decided once for the call: a last, smaller block of queries must get the row-resident kernel too)
+    const int last_nb = nq % q_block ? nq % q_block : std::min(nq, q_block);
+    const bool bounded = nq >= 2 && last_nb >= 2 && !multi && r.n >= bound_min_rows &&
+                         (op == OP_SQDIFF || op == OP_ABSDIFF || op == OP_MAXABS) &&
+                         stream_batch_group(r.dim, r.ld, r.plan, op, std::min(nq, q_block), r.n) > 16 &&
+                         stream_batch_group(r.dim, r.ld, r.plan, op, last_nb, r.n) > 16;
+    const int64_t n_s = round_up64(std::max<int64_t>(r.n / 64, bound_min_rows / 16), 256);
+    const int* run_if = nullptr;
+    if (bounded) {
+        VDB_TRY(ws.thr_d.reserve((size_t)q_block * sizeof(float)));
+        VDB_TRY(ws.thr_k.reserve((size_t)q_block * sizeof(int64_t)));
+        VDB_TRY(ws.queue.reserve((size_t)q_block * FLAT_BOUND_QUEUE * (sizeof(float) + sizeof(int))));
+        VDB_TRY(ws.queue_cnt.reserve((size_t)q_block * sizeof(int)));
+        VDB_TRY(ws.flag.reserve(sizeof(int)));
+        VDB_HIP(hipMemsetAsync(ws.flag.p, 0, sizeof(int), s));
+        run_if = ws.flag.as<int>();
+    }
     for (int q0 = 0; q0 < nq; q0 += q_block) {
         const int nb = std::min(q_block, nq - q0);
         // enough blocks to fill the chip, at least 8 tiles each
@@ -462,10 +499,45 @@ static int stream_flat_search(vdb_rows* h, Workspace& ws, int metric, const floa
         const int n_cand = splits * topk_cand_lists_per_split();
         VDB_TRY(ws.part_d.reserve((size_t)nb * n_cand * kmax * sizeof(float)));
         VDB_TRY(ws.part_i.reserve((size_t)nb * n_cand * kmax * sizeof(int)));
-        VDB_TRY(stream_flat_sums(ws, r, metric, q + (int64_t)q0 * r.ld, nb, ws.cand.as<float>(), s, true));
+        if (bounded) {
+            // 1: the k-th best of the first n_s rows -> ws.thr_d
+            Rows rs = r;
+            rs.n = n_s;
+            const int64_t s_tiles = (n_s + 255) / 256;
+            const int s_splits = cand_splits(s_tiles, nb);
+            const int s_cand = s_splits * topk_cand_lists_per_split();
+            VDB_TRY(ws.part_d.reserve((size_t)nb * s_cand * kmax * sizeof(float)));
+            VDB_TRY(ws.part_i.reserve((size_t)nb * s_cand * kmax * sizeof(int)));
+            VDB_TRY(stream_flat_sums(ws, rs, metric, q + (int64_t)q0 * r.ld, nb, ws.cand.as<float>(), s, true, nullptr, true));
+            CandJob c{};
+            c.sqrt_here = true;
+            c.cand = ws.cand.as<float>(); c.cand_stride = n_s; c.nq = nb; c.n = n_s; c.mask = d_mask;
+            c.metric = metric; c.q_sq = ws.q_sq.as<float>() + q0; c.q_nrm = ws.q_nrm.as<float>() + q0;
+            c.row_sq = r.sq; c.row_nrm = r.nrm;
+            c.k = kmax; c.splits = s_splits; c.part_d = ws.part_d.as<float>(); c.part_i = ws.part_i.as<int>();
+            VDB_TRY(launch_topk_cand(c, s));
+            SelectOut ob{nullptr, nullptr, nullptr, kmax, 0, ws.thr_d.as<float>(), ws.thr_k.as<int64_t>()};
+            VDB_TRY(launch_select(ws.part_d.as<float>(), ws.part_i.as<int>(), nb, s_cand, kmax, 1 << 30, nullptr, 0, ob, s, ws.mid));
+            // 2: all rows, pairs within the bound -> queues
+            VDB_HIP(hipMemsetAsync(ws.queue_cnt.p, 0, (size_t)nb * sizeof(int), s));
+            StreamJob more{};
+            more.bound = ws.thr_d.as<float>(); more.bound_sqrt = metric == VDB_EUCLIDEAN_DIRECT; more.mask = d_mask;
+            more.queue_len = ws.queue_cnt.as<int>(); more.queue_d = ws.queue.as<float>();
+            more.queue_i = reinterpret_cast<int*>(ws.queue.as<float>() + (size_t)q_block * FLAT_BOUND_QUEUE);
+            more.queue_cap = FLAT_BOUND_QUEUE; more.overflow = ws.flag.as<int>();
+            VDB_TRY(stream_flat_sums(ws, r, metric, q + (int64_t)q0 * r.ld, nb, nullptr, s, true, &more));
+            // 3: the k best of every queue
+            SelectOut o{d_out_d ? d_out_d + (int64_t)q0 * k : nullptr, d_out_i ? d_out_i + (int64_t)q0 * k : nullptr,
+                        d_out_i32 ? d_out_i32 + (int64_t)q0 * k : nullptr, k, 0, nullptr, nullptr};
+            VDB_TRY(launch_select_packed(more.queue_d, more.queue_i, nb, FLAT_BOUND_QUEUE, kmax, o, s, more.queue_len));
+        }
+        StreamJob guard{};
+        guard.run_if = run_if;
+        VDB_TRY(stream_flat_sums(ws, r, metric, q + (int64_t)q0 * r.ld, nb, ws.cand.as<float>(), s, true, bounded ? &guard : nullptr));
         for (int64_t done = 0; done < k_eff; done += KMAX_FUSED) {
             const int kk = (int)std::min<int64_t>(KMAX_FUSED, k_eff - done);
             CandJob c{};
+            c.run_if = run_if;
             c.sqrt_here = true;
             c.cand = ws.cand.as<float>(); c.cand_stride = r.n; c.nq = nb; c.n = r.n; c.mask = d_mask;
             c.metric = metric; c.q_sq = ws.q_sq.as<float>() + q0; c.q_nrm = ws.q_nrm.as<float>() + q0;
@@ -475,7 +547,7 @@ static int stream_flat_search(vdb_rows* h, Workspace& ws, int metric, const floa
             VDB_TRY(launch_topk_cand(c, s));
             SelectOut o{d_out_d ? d_out_d + (int64_t)q0 * k : nullptr, d_out_i ? d_out_i + (int64_t)q0 * k : nullptr,
                         d_out_i32 ? d_out_i32 + (int64_t)q0 * k : nullptr, k, (int)done,
-                        multi ? ws.lb_d.as<float>() : nullptr, multi ? ws.lb_k.as<int64_t>() : nullptr};
+                        multi ? ws.lb_d.as<float>() : nullptr, multi ? ws.lb_k.as<int64_t>() : nullptr, run_if};
             VDB_TRY(launch_select(ws.part_d.as<float>(), ws.part_i.as<int>(), nb, n_cand, kk, 1 << 30, nullptr, 0, o, s, ws.mid));
         }
     }

@@ -56,6 +56,14 @@ struct StreamParams {
     const int* sq_qid;                // query number
     const int64_t* sq_out;            // where that query's value for the segment's row 0 goes
     float* out;
+    const int* run_if;                // optional device flag: the launch does nothing while it is zero
+    // Bounded form (row-resident kernel, flat row sets): instead of storing every sum, a (row, query) pair whose
+    // value is within the query's bound and whose row passes the filter is appended to the query's queue.
+    const float* bound;               // [queries] a distance that is not below the query's k-th best, or null
+    int bound_sqrt;                   // the sums are squares of the distances the bound is given in
+    const uint32_t* mask;             // filter bits by row number, or null
+    int* queue_len; float* queue_d; int* queue_i; int queue_cap;   // per query: entries so far, (distance, row) pairs
+    int* overflow;                    // set when a queue is full: the caller repeats the search without the bound
 };
 
 template <int OP> __device__ __forceinline__ float s_term(float x, float q) {
@@ -205,6 +213,7 @@ __global__ __launch_bounds__(S_NT / R * QS, (G == 8 && R == 1 && WHOLE) ? 4 : 1)
     auto gq = [&](int g) { return ((g / H) * QS + qset) * H + (g % H); };
     float* St = smem + nbuf * SLOT;               // [depth][G][256] pending partial sums (more than one leaf only)
 
+    if (p.run_if && uload(p.run_if) == 0) return;
     const int ksteps = (p.ld + S_CK - 1) / S_CK;
     const int64_t total_items = min(uload(p.seg_item_off + p.n_seg), p.items_cap);
     // Blocks b, b + 8, b + 16, ... share an XCD and its L2.  Consecutive items are the query groups of one row chunk
@@ -569,7 +578,7 @@ static constexpr int RR_GROUP = 128;
 static constexpr int RR_NB = 4;                     // ring buffers per wave, one slab of 64 rows x 16 floats each
 static constexpr size_t rowreg_lds_bytes(int D) { return (size_t)(S_NT / 64) * RR_NB * 64 * 16 * 4 + 2 * RR_TQ * (size_t)D * 4; }
 
-template <int OP, int D>
+template <int OP, int D, bool BOUNDED>
 __global__ __launch_bounds__(S_NT, 2) void rowreg_sums_kernel(const StreamParams p) {
     static_assert(D % 16 == 0 && D <= 128, "one leaf of whole slabs");
     constexpr int H = 2;                            // queries summed side by side
@@ -581,6 +590,7 @@ __global__ __launch_bounds__(S_NT, 2) void rowreg_sums_kernel(const StreamParams
     constexpr int QF4 = RR_TQ * C4;                 // 16-byte pieces of a query tile
     constexpr int NP = (QF4 + S_NT - 1) / S_NT;     // of which a thread stages this many
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    if (p.run_if && uload(p.run_if) == 0) return;
     const int64_t total_items = min(uload(p.seg_item_off + p.n_seg), p.items_cap);
     const int per_xcd = gridDim.x >> 3;             // runs of consecutive items per XCD, as in stream_sums_kernel
     const int64_t first = (gridDim.x & 7) == 0 ? (int64_t)(blockIdx.x & 7) * per_xcd + (blockIdx.x >> 3) : (int64_t)blockIdx.x;
@@ -687,10 +697,22 @@ __global__ __launch_bounds__(S_NT, 2) void rowreg_sums_kernel(const StreamParams
         load_qv(&qs[buf][0][0], 0, 0);
         for (int pr = 0; pr < pairs; ++pr) {
             const float* qa = &qs[buf][H * pr][0];
-            // where the pair's results go: asked for now, needed when the row has been summed
+            // where the pair's results go (or, bounded form, the queries' numbers and bounds): asked for now, needed
+            // when the row has been summed
             int64_t ob[H];
+            int qn[H];
+            float thr[H];
 #pragma unroll
-            for (int h = 0; h < H; ++h) ob[h] = uload(p.sq_out + it.qbeg + min(tile * RR_TQ + H * pr + h, it.qcnt - 1));
+            for (int h = 0; h < H; ++h) {
+                const int e = it.qbeg + min(tile * RR_TQ + H * pr + h, it.qcnt - 1);
+                ob[h] = 0; qn[h] = 0; thr[h] = 0.0f;
+                if constexpr (BOUNDED) {
+                    qn[h] = uload(p.sq_qid + e);
+                    thr[h] = uload(p.bound + qn[h]);
+                } else {
+                    ob[h] = uload(p.sq_out + e);
+                }
+            }
             __builtin_amdgcn_sched_barrier(0);
             f2 acc[H][4];
 #pragma unroll
@@ -758,7 +780,32 @@ __global__ __launch_bounds__(S_NT, 2) void rowreg_sums_kernel(const StreamParams
                     float v = s_tree2<OP>(acc[h]);
                     if (p.post == POST_SQRT) v = sqrtf(v);
                     else if (p.post == POST_NEG) v = -v;
-                    if (tid < it.rows) p.out[ob[h] + it.out_rel + tid] = v;
+                    if constexpr (BOUNDED) {
+                        // in reach of the query's k best?  (squares: the bound squared, a few ulps up, as no row within
+                        // the bound exceeds; rows equal to the bound stay in: ties are settled by row number later)
+                        float lim = thr[h];
+                        if (p.bound_sqrt) lim = fmaxf(__fmaf_rn(lim * lim, 4e-7f, lim * lim), 1e-36f);
+                        const int64_t row = it.row0 + tid;
+                        bool in = tid < it.rows && v <= lim;
+                        if (in && p.mask) in = (p.mask[row >> 5] >> (row & 31)) & 1u;
+                        const unsigned long long m = __ballot(in);
+                        if (m != 0ull) {
+                            int base = 0;
+                            if (lane == 0) base = atomicAdd(p.queue_len + qn[h], __popcll(m));
+                            base = __builtin_amdgcn_readfirstlane(base);
+                            const int at = base + __popcll(m & ((1ull << lane) - 1ull));
+                            if (in) {
+                                if (at < p.queue_cap) {
+                                    p.queue_d[(int64_t)qn[h] * p.queue_cap + at] = p.bound_sqrt ? sqrtf(v) : v;
+                                    p.queue_i[(int64_t)qn[h] * p.queue_cap + at] = (int)row;
+                                } else {
+                                    *p.overflow = 1;
+                                }
+                            }
+                        }
+                    } else if (tid < it.rows) {
+                        p.out[ob[h] + it.out_rel + tid] = v;
+                    }
                 }
             }
             // the coming step's query values into the other buffer: their numbers were asked for a pair of queries ago
@@ -795,11 +842,16 @@ static int launch_rowreg_sums(const StreamJob& j, const StreamParams& p, hipStre
     const int grid = ctx().num_cus * 2;
     const size_t lds = rowreg_lds_bytes(j.dim);
     KernelTimer timer(s, j.timed);
-#define VDB_LAUNCH_RR_D(O, DD)                                                                  \
+#define VDB_LAUNCH_RR_K(KERN)                                                                     \
     {                                                                                            \
-        auto kern = rowreg_sums_kernel<O, DD>;                                                   \
+        auto kern = KERN;                                                                        \
         VDB_TRY(raise_dynamic_lds(reinterpret_cast<const void*>(kern), lds));                    \
         hipLaunchKernelGGL(kern, dim3(grid), dim3(S_NT), lds, s, p);                             \
+    }
+#define VDB_LAUNCH_RR_D(O, DD)                                                                   \
+    {                                                                                            \
+        if (p.bound) VDB_LAUNCH_RR_K((rowreg_sums_kernel<O, DD, true>))                          \
+        else VDB_LAUNCH_RR_K((rowreg_sums_kernel<O, DD, false>))                                 \
     }
 #define VDB_LAUNCH_RR(O)                                                                         \
     case O:                                                                                      \
@@ -814,6 +866,7 @@ static int launch_rowreg_sums(const StreamJob& j, const StreamParams& p, hipStre
     }
 #undef VDB_LAUNCH_RR
 #undef VDB_LAUNCH_RR_D
+#undef VDB_LAUNCH_RR_K
     VDB_HIP(hipGetLastError());
     return VDB_OK;
 }
@@ -840,6 +893,11 @@ int launch_stream_sums(const StreamJob& j, hipStream_t s) {
     p.q = j.q; p.ldq = j.ldq; p.zeros = ctx().zeros;
     p.n_seg = j.n_seg; p.seg_row_off = j.seg_row_off; p.seg_q_off = j.seg_q_off; p.seg_item_off = j.seg_item_off;
     p.sq_qid = j.sq_qid; p.sq_out = j.sq_out; p.out = j.out; p.items = j.items; p.items_cap = j.items_cap;
+    p.run_if = j.run_if;
+    VDB_REQUIRE(j.bound == nullptr || (j.group == RR_GROUP && j.queue_len && j.queue_d && j.queue_i && j.queue_cap > 0 && j.overflow),
+                "the bounded form belongs to the row-resident kernel and needs its queues");
+    p.bound = j.bound; p.bound_sqrt = j.bound_sqrt ? 1 : 0; p.mask = j.mask; p.queue_len = j.queue_len; p.queue_d = j.queue_d;
+    p.queue_i = j.queue_i; p.queue_cap = j.queue_cap; p.overflow = j.overflow;
     if (j.group == RR_GROUP) return launch_rowreg_sums(j, p, s);
     const size_t stack = (size_t)stream_depth(j.plan) * j.group * S_NT * sizeof(float);
     const size_t budget = 160 * 1024;
@@ -1147,6 +1205,7 @@ struct CandParams {
     // (ticket[q] counts them and is left at zero again) merges every block's lists and writes the k_out results.
     int* ticket; int k_out;
     float* fin_d; int64_t* fin_rows; int64_t* fin_order;
+    const int* run_if;                           // optional device flag: the launch does nothing while it is zero
 };
 
 static constexpr int CAND_WAVES = LIST_NT / 64;   // candidate lists one block writes
@@ -1171,6 +1230,7 @@ __global__ __launch_bounds__(LIST_NT) void topk_cand_kernel(CandParams p) {
     const int qi = blockIdx.x, split = blockIdx.y;
     const int k = p.k;
     const int lane = tid & 63, wave = tid >> 6;
+    if (p.run_if && *p.run_if == 0) return;
     WaveTopK best;
     best.init(k);
     const float q_sq = p.fin.q_sq ? p.fin.q_sq[qi] : 0.0f;
@@ -1364,6 +1424,7 @@ int launch_topk_cand(const CandJob& j, hipStream_t s) {
     p.lb_d = j.lb_d; p.lb_k = j.lb_k; p.radius = j.radius; p.use_radius = j.use_radius;
     p.k = j.k; p.splits = j.splits; p.part_d = j.part_d; p.part_i = j.part_i;
     p.ticket = j.ticket; p.k_out = j.k_out; p.fin_d = j.fin_d; p.fin_rows = j.fin_rows; p.fin_order = j.fin_order;
+    p.run_if = j.run_if;
     VDB_REQUIRE(j.ticket == nullptr || (j.probes && j.row_ids && j.fin_d && j.fin_rows && j.k_out >= j.k && j.k_out <= 64),
                 "the one-launch selection serves list candidates with k <= 64");
     VDB_REQUIRE(j.probes == nullptr || (j.cand_off && j.tile_off), "list candidates need their slot and tile offsets");

@@ -213,6 +213,11 @@ struct StreamJob {
     const StreamItem* items; int64_t items_cap;
     float* out;
     bool timed;
+    const int* run_if;              // optional device flag: the launch does nothing while it is zero
+    // bounded form (group 128, flat row sets): pairs within bound[query] whose row passes `mask` go to per-query
+    // queues of queue_cap (distance, row) entries instead of `out`; *overflow is set when a queue is full
+    const float* bound; bool bound_sqrt; const uint32_t* mask;
+    int* queue_len; float* queue_d; int* queue_i; int queue_cap; int* overflow;
 };
 int launch_stream_sums(const StreamJob& j, hipStream_t s);
 // queries per item a batch job (nq > 1) over rows of this shape is planned with: 8 or 16, or 128 where the
@@ -245,6 +250,7 @@ struct CandJob {
     // lists only: one launch for selection, merge and row lookup (the last block of a query merges); ticket = one
     // zeroed int per query, k_out = results per query (>= k; the rest is filled with INFINITY / -1)
     int* ticket; int k_out; float* fin_d; int64_t* fin_rows; int64_t* fin_order;
+    const int* run_if;                                // optional device flag: the launch does nothing while it is zero
 };
 // one query against an IVF index: norms, centroid ranking, slot/tile offsets and scan items in one block
 int launch_ivf_one_plan(const float* sums, int metric, const float* cent_sq, const float* cent_nrm, float cos_eps, const float* q,
