@@ -567,7 +567,11 @@ __global__ __launch_bounds__(S_NT / R * QS, (G == 8 && R == 1 && WHOLE) ? 4 : 1)
 // position c ^ ((r >> 2) & 3) of the row's 64-byte slot (swizzled on the source side), which makes the
 // one-row-per-lane 16-byte reads conflict free.  The ring of RR_NB slabs is private to the wave: no barrier.  The
 // first RR_NB slabs of the NEXT item are fetched while this item is summed; the rest of a row (D = 128) follows
-// when the first have been moved to registers.
+// when the first have been moved to registers.  (Measured per item and wave at 10M x 128, 13 queries per item:
+// 29 k cycles summing, 3.3 k issuing the second half's sixteen DMA instructions, 2 k waiting for it, 3 k issuing
+// the next item's first half, 0.6 k moving slabs to registers, 1.3 k at the step ends.  Starting the first query
+// pair before the second half has arrived, staging through registers instead of DMA, and handing the row registers
+// over to the next item's loads during the last pair were each no faster or slower.)
 //   Queries: through LDS, RR_TQ at a time, double buffered, one barrier per RR_TQ queries; every lane reads the same
 // values (broadcast reads), one unit of 8 columns ahead of their use.
 //   Items are the (row chunk, query group) records of stream_sums_kernel with groups of up to RR_GROUP queries,
@@ -598,15 +602,23 @@ __global__ __launch_bounds__(S_NT, 2) void rowreg_sums_kernel(const StreamParams
 
     float* ring = ring_all + wave * (RR_NB * 64 * 16);
     const unsigned ring_addr = (unsigned)(uintptr_t)ring;
-    // slab sl of item jt's rows into ring buffer b: four instructions of 16 rows x 64 bytes
-    auto issue_slab = [&](const Item& jt, int sl, int b) {
+    // slab sl of item jt's rows into ring buffer b: four instructions of 16 rows x 64 bytes.  The address is a
+    // wave-uniform base (the item's first row of this wave, the slab's first column) plus a byte offset per lane that
+    // is fixed for the launch, so issuing a slab costs no vector-ALU work.
+    unsigned row_off[4];
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            const int r = i * 16 + (lane >> 2);
-            const int c = (lane & 3) ^ ((r >> 2) & 3);
-            const float* src = p.data + (jt.row0 + wave * 64 + r) * p.ld + sl * 16 + c * 4;
-            glds16(src, __builtin_amdgcn_readfirstlane(ring_addr + (unsigned)(b * 4096 + i * 1024)));
-        }
+    for (int i = 0; i < 4; ++i) {
+        const int r = i * 16 + (lane >> 2);
+        const int c = (lane & 3) ^ ((r >> 2) & 3);
+        row_off[i] = (unsigned)((r * p.ld + c * 4) * (int)sizeof(float));
+    }
+    auto issue_slab = [&](const Item& jt, int sl, int b) {
+        const uint64_t base = (uint64_t)(uintptr_t)(p.data + (jt.row0 + wave * 64) * p.ld + sl * 16);
+        const uint32_t lo = __builtin_amdgcn_readfirstlane((uint32_t)base), hi = __builtin_amdgcn_readfirstlane((uint32_t)(base >> 32));
+        const void* sb = reinterpret_cast<const void*>(((uint64_t)hi << 32) | lo);
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+            glds16_s(sb, row_off[i], __builtin_amdgcn_readfirstlane(ring_addr + (unsigned)(b * 4096 + i * 1024)));
     };
     float4 x[C4];
     auto take_slab = [&](int sl, int b) {
@@ -661,7 +673,6 @@ __global__ __launch_bounds__(S_NT, 2) void rowreg_sums_kernel(const StreamParams
             has_next = nitem < total_items;
             if (has_next) nit = load_item(p, nitem);
         }
-        bool rest_pending = false;                  // D = 128: the second half of the rows is still on its way
         if (tile == 0) {
             // this item's rows: the first slabs are in the ring (fetched while the item before was summed; rows
             // past the chunk's end come from the rows behind it, a row store keeps 256 rows of slack, and their
@@ -671,14 +682,17 @@ __global__ __launch_bounds__(S_NT, 2) void rowreg_sums_kernel(const StreamParams
             for (int sl = 0; sl < (SL < RR_NB ? SL : RR_NB); ++sl) take_slab(sl, sl);
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");             // the ring is free again
             if constexpr (SL > RR_NB) {
-                // the other slabs are asked for now and taken when the first query pair reaches their columns
 #pragma unroll
                 for (int sl = RR_NB; sl < SL; ++sl) issue_slab(it, sl, sl - RR_NB);
-                rest_pending = true;
-            } else if (item + gridDim.x < total_items) {
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#pragma unroll
+                for (int sl = RR_NB; sl < SL; ++sl) take_slab(sl, sl - RR_NB);
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            }
+            if (item + gridDim.x < total_items) {
                 const Item pit = load_item(p, item + gridDim.x);           // the block's next item, whatever its tiles
 #pragma unroll
-                for (int sl = 0; sl < SL; ++sl) issue_slab(pit, sl, sl);
+                for (int sl = 0; sl < (SL < RR_NB ? SL : RR_NB); ++sl) issue_slab(pit, sl, sl);
             }
         }
         if (has_next) load_ids(nit, ntile);
@@ -721,21 +735,6 @@ __global__ __launch_bounds__(S_NT, 2) void rowreg_sums_kernel(const StreamParams
                 for (int j = 0; j < 4; ++j) acc[h][j] = f2{0.0f, 0.0f};
 #pragma unroll
             for (int c = 0; c < D / 8; ++c) {
-                if constexpr (SL > RR_NB) {
-                    if (c == 2 * RR_NB && rest_pending) {
-                        // columns 16 * RR_NB onwards: the rest of the rows has had half a query pair to arrive
-                        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-#pragma unroll
-                        for (int sl = RR_NB; sl < SL; ++sl) take_slab(sl, sl - RR_NB);
-                        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-                        if (item + gridDim.x < total_items) {
-                            const Item pit = load_item(p, item + gridDim.x);
-#pragma unroll
-                            for (int sl = 0; sl < RR_NB; ++sl) issue_slab(pit, sl, sl);
-                        }
-                        rest_pending = false;
-                    }
-                }
                 if (c + 1 < D / 8) load_qv(qa, (c + 1) & 1, c + 1);
                 else if (pr + 1 < pairs) load_qv(qa + H * D, 0, 0);        // D / 8 is even: the next pair starts in buffer 0
                 f2 q2[H][4], x2[4];
