@@ -1930,9 +1930,17 @@ static int ivf_search_impl(vdb_ivf* h, const float* d_q, int nq, int k, int n_pr
             const int kk = (int)std::min<int64_t>(KMAX_FUSED, k_eff - done);
             CandJob c{};
             c.cand = ws.cand.as<float>(); c.cand_stride = cand_stride; c.nq = nb; c.n = 0;
-            c.probes = probes; c.n_probe = n_probe; c.n_lists = h->n_lists; c.list_beg = h->lay.d_beg(); c.list_end = h->lay.d_end();
-            c.cand_off = ws.cand_off.as<int64_t>(); c.tile_off = ws.tile_off.as<int>();
-            c.row_ids = h->row_ids.as<int>(); c.mask = d_mask;
+            const bool row_terms = !(sm == VDB_EUCLIDEAN_DIRECT || sm == VDB_EUCLIDEAN_SQ_DIRECT || sm == VDB_MANHATTAN ||
+                                     sm == VDB_CHEBYSHEV || sm == VDB_HAMMING);        // cosine forms divide by the row's norm
+            if (d_mask || row_terms) {
+                c.probes = probes; c.n_probe = n_probe; c.n_lists = h->n_lists; c.list_beg = h->lay.d_beg(); c.list_end = h->lay.d_end();
+                c.cand_off = ws.cand_off.as<int64_t>(); c.tile_off = ws.tile_off.as<int>();
+                c.row_ids = h->row_ids.as<int>(); c.mask = d_mask;
+            } else {
+                // no filter, no row term: a query's slots are one contiguous run (probe after probe), and nothing about
+                // the lists behind them is needed before the k results are mapped to rows
+                c.n = cand_stride; c.n_of_query = ws.cand_off.as<int64_t>() + n_probe; c.n_stride = n_probe + 1;
+            }
             c.sqrt_here = true;
             c.metric = sm; c.q_sq = ws.q_sq.as<float>() + q0; c.q_nrm = ws.q_nrm.as<float>() + q0;
             c.row_sq = m->r.sq; c.row_nrm = m->r.nrm;

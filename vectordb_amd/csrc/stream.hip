@@ -1205,6 +1205,7 @@ struct CandParams {
     int* ticket; int k_out;
     float* fin_d; int64_t* fin_rows; int64_t* fin_order;
     const int* run_if;                           // optional device flag: the launch does nothing while it is zero
+    const int64_t* n_of_query; int n_stride;     // flat: candidates of query q = n_of_query[q * n_stride] instead of n
 };
 
 static constexpr int CAND_WAVES = LIST_NT / 64;   // candidate lists one block writes
@@ -1258,8 +1259,9 @@ __global__ __launch_bounds__(LIST_NT) void topk_cand_kernel(CandParams p) {
             }
             for (int i = tid; i <= nr; i += LIST_NT) R_tile[i] = p.tile_off[qo + i];
         } else if (tid == 0) {
-            R_pos0[0] = 0; R_len[0] = p.n; R_slot0[0] = 0;
-            R_tile[0] = 0; R_tile[1] = (int)((p.n + LIST_NT - 1) / LIST_NT);
+            const int64_t nq_ = p.n_of_query ? p.n_of_query[(int64_t)qi * p.n_stride] : p.n;
+            R_pos0[0] = 0; R_len[0] = nq_; R_slot0[0] = 0;
+            R_tile[0] = 0; R_tile[1] = (int)((nq_ + LIST_NT - 1) / LIST_NT);
         }
         __syncthreads();
         const int t_begin = R_tile[0], t_end = R_tile[nr];
@@ -1423,7 +1425,7 @@ int launch_topk_cand(const CandJob& j, hipStream_t s) {
     p.lb_d = j.lb_d; p.lb_k = j.lb_k; p.radius = j.radius; p.use_radius = j.use_radius;
     p.k = j.k; p.splits = j.splits; p.part_d = j.part_d; p.part_i = j.part_i;
     p.ticket = j.ticket; p.k_out = j.k_out; p.fin_d = j.fin_d; p.fin_rows = j.fin_rows; p.fin_order = j.fin_order;
-    p.run_if = j.run_if;
+    p.run_if = j.run_if; p.n_of_query = j.n_of_query; p.n_stride = j.n_stride;
     VDB_REQUIRE(j.ticket == nullptr || (j.probes && j.row_ids && j.fin_d && j.fin_rows && j.k_out >= j.k && j.k_out <= 64),
                 "the one-launch selection serves list candidates with k <= 64");
     VDB_REQUIRE(j.probes == nullptr || (j.cand_off && j.tile_off), "list candidates need their slot and tile offsets");

@@ -251,6 +251,9 @@ struct CandJob {
     // zeroed int per query, k_out = results per query (>= k; the rest is filled with INFINITY / -1)
     int* ticket; int k_out; float* fin_d; int64_t* fin_rows; int64_t* fin_order;
     const int* run_if;                                // optional device flag: the launch does nothing while it is zero
+    // flat candidates whose count differs per query (the slots of an IVF query are one contiguous run when no filter
+    // needs the rows behind them): query q has n_of_query[q * n_stride] candidates
+    const int64_t* n_of_query; int n_stride;
 };
 // one query against an IVF index: norms, centroid ranking, slot/tile offsets and scan items in one block
 int launch_ivf_one_plan(const float* sums, int metric, const float* cent_sq, const float* cent_nrm, float cos_eps, const float* q,
