@@ -78,9 +78,9 @@ def pq_case():
     codes = rng.integers(0, 256, size=(n, m)).astype(np.uint8)
     if n > 20:
         codes[rng.integers(0, n, 5)] = codes[rng.integers(0, n, 5)]       # equal distances
-    nq = int(rng.choice([1, 3, 4, 5, 8, 9]))
+    nq = int(rng.choice([1, 2, 3, 4, 5, 8, 9]))
     q = rng.standard_normal((nq, d), dtype=np.float32)
-    k = int(rng.choice([1, 10, 33, 64, 100]))
+    k = int(rng.choice([1, 5, 10, 32, 33, 64, 100]))
     mask = (rng.random(n) < 0.4) if rng.random() < 0.4 else None
     label = f"pq n={n} m={m} dsub={dsub} nq={nq} k={k} mask={'none' if mask is None else int(mask.sum())}"
     pq = nat.PqCodes(d, m, 256)

@@ -39,5 +39,11 @@ def test_ivf_pq_soak(native):
     run_soak("fuzz_ivf_pq.py", 15, 103)
 
 
+def test_ivf_pq_soak_pq_bound_pass_on_small_sets(native):
+    # VDB_PQ_BOUND_MIN_TILES=8: PQ scans of one to three queries take their bound pass and the packed candidate
+    # queues from 2048 codes on instead of from 4M
+    run_soak("fuzz_ivf_pq.py", 12, 105, env={"VDB_PQ_BOUND_MIN_TILES": "8"})
+
+
 def test_bf16_soak(native):
     run_soak("fuzz_bf16.py", 10, 104)

@@ -2228,7 +2228,9 @@ static int pq_search_impl(vdb_pq* h, const float* d_q, int nq, int k, const uint
     // little and its pass costs what it saves; they keep one list per wave and the list merge.)
     const float* bound_d = nullptr;
     static const bool no_bound = getenv("VDB_PQ_NO_BOUND") != nullptr;
-    const bool bounded = !multi && !no_bound && nq < 4 && ntiles >= PQ_BOUND_MIN_TILES;
+    // VDB_PQ_BOUND_MIN_TILES: the smallest code set (in tiles of 256 rows) that gets a bound pass (tests lower it)
+    static const int64_t bound_min_tiles = getenv("VDB_PQ_BOUND_MIN_TILES") ? atoll(getenv("VDB_PQ_BOUND_MIN_TILES")) : PQ_BOUND_MIN_TILES;
+    const bool bounded = !multi && !no_bound && nq < 4 && ntiles >= bound_min_tiles;
     if (bounded) {
         const int bsplits = (int)std::min<int64_t>(PQ_BOUND_SPLITS, splits);
         const int64_t n_s = std::min<int64_t>(h->n, PQ_BOUND_TILES_PER_BLOCK * bsplits * 256);
