@@ -1416,6 +1416,50 @@ __global__ __launch_bounds__(LIST_NT) void topk_cand_kernel(CandParams p) {
 
 int topk_cand_lists_per_split() { return CAND_WAVES; }
 
+// The plain case of the selection above, as its own kernel: one run of candidates per query (slot = index), the value
+// is the distance or its square (SQRT), no filter, no radius, no lower bound.  Nothing but the loads, one compare and
+// one ballot per 64 candidates is left on the common path; the square root is taken only in tiles where some value
+// is within the square of the list's k-th distance (a few ulps up, as in the PQ scan).  Same lists out.
+template <bool SQRT>
+__global__ __launch_bounds__(LIST_NT) void topk_plain_kernel(CandParams p) {
+    if (p.run_if && *p.run_if == 0) return;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int qi = blockIdx.x, split = blockIdx.y;
+    const int k = p.k;
+    const int64_t n = p.n_of_query ? p.n_of_query[(int64_t)qi * p.n_stride] : p.n;
+    const float* cq = p.cand + (int64_t)qi * p.cand_stride;
+    WaveTopK best;
+    best.init(k);
+    float thr2 = INFINITY;
+    const int ntiles = (int)((n + LIST_NT - 1) / LIST_NT);
+    for (int t = split; t < ntiles; t += p.splits * CAND_UNROLL) {
+        float v[CAND_UNROLL];
+        int slot[CAND_UNROLL];
+        bool ok[CAND_UNROLL];
+#pragma unroll
+        for (int u = 0; u < CAND_UNROLL; ++u) {
+            const int tu = t + u * p.splits;
+            slot[u] = tu * LIST_NT + tid;
+            ok[u] = tu < ntiles && slot[u] < n;
+            v[u] = ok[u] ? cq[slot[u]] : INFINITY;
+        }
+#pragma unroll
+        for (int u = 0; u < CAND_UNROLL; ++u) {
+            if (SQRT) {
+                if (__ballot(ok[u] && v[u] <= thr2) != 0ull) {
+                    best.offer<true, false>(ok[u], sqrtf(v[u]), slot[u], lane);                  // metrics.py:43
+                    const float th = best.thr;
+                    thr2 = fmaxf(__fmaf_rn(th * th, 4e-7f, th * th), 1e-36f);
+                }
+            } else {
+                best.offer<true, false>(ok[u], v[u], slot[u], lane);
+            }
+        }
+    }
+    const int64_t list = ((int64_t)qi * p.splits + split) * CAND_WAVES + wave;
+    best.store(p.part_d + list * k, p.part_i + list * k, lane);
+}
+
 int launch_topk_cand(const CandJob& j, hipStream_t s) {
     VDB_REQUIRE(j.k >= 1 && j.k <= 64, "candidate selection supports k <= 64, got %d", j.k);
     CandParams p{};
@@ -1435,6 +1479,13 @@ int launch_topk_cand(const CandJob& j, hipStream_t s) {
                     : j.metric == VDB_COSINE ? 2 : j.metric == VDB_COSINE_PAIR ? 3 : j.metric == VDB_ANGULAR ? 4
                     : (j.metric == VDB_EUCLIDEAN_DIRECT && j.sqrt_here) ? 5 : 0;
     const bool one = j.ticket != nullptr;
+    if ((fin == 0 || fin == 5) && !one && j.probes == nullptr && j.mask == nullptr && !j.use_radius && j.lb_d == nullptr &&
+        (int64_t)((j.n + LIST_NT - 1) / LIST_NT) * LIST_NT < (int64_t)0x7fffffff) {
+        if (fin == 5) hipLaunchKernelGGL(topk_plain_kernel<true>, dim3(j.nq, j.splits), dim3(LIST_NT), 0, s, p);
+        else hipLaunchKernelGGL(topk_plain_kernel<false>, dim3(j.nq, j.splits), dim3(LIST_NT), 0, s, p);
+        VDB_HIP(hipGetLastError());
+        return VDB_OK;
+    }
 #define VDB_CAND_KERN(F) (one ? topk_cand_kernel<F, true> : topk_cand_kernel<F, false>)
     auto kern = fin == 1 ? VDB_CAND_KERN(1) : fin == 2 ? VDB_CAND_KERN(2) : fin == 3 ? VDB_CAND_KERN(3)
                 : fin == 4 ? VDB_CAND_KERN(4) : fin == 5 ? VDB_CAND_KERN(5) : VDB_CAND_KERN(0);
