@@ -496,7 +496,10 @@ static int stream_flat_search(vdb_rows* h, Workspace& ws, int metric, const floa
         const int nb = std::min(q_block, nq - q0);
         // enough blocks to fill the chip, at least 8 tiles each
         const int splits = cand_splits(ntiles, nb);
-        const int n_cand = splits * topk_cand_lists_per_split();
+        // a handful of queries: the lists are merged by one block per query, which is a chain of inserts per list; the
+        // selection blocks hand over one list each instead of one per wave
+        const bool block_list = nb <= 8;
+        const int n_cand = splits * (block_list ? 1 : topk_cand_lists_per_split());
         VDB_TRY(ws.part_d.reserve((size_t)nb * n_cand * kmax * sizeof(float)));
         VDB_TRY(ws.part_i.reserve((size_t)nb * n_cand * kmax * sizeof(int)));
         if (bounded) {
@@ -544,6 +547,7 @@ static int stream_flat_search(vdb_rows* h, Workspace& ws, int metric, const floa
             c.row_sq = r.sq; c.row_nrm = r.nrm;
             c.lb_d = done > 0 ? ws.lb_d.as<float>() : nullptr; c.lb_k = done > 0 ? ws.lb_k.as<int64_t>() : nullptr;
             c.k = kk; c.splits = splits; c.part_d = ws.part_d.as<float>(); c.part_i = ws.part_i.as<int>();
+            c.block_list = block_list;
             VDB_TRY(launch_topk_cand(c, s));
             SelectOut o{d_out_d ? d_out_d + (int64_t)q0 * k : nullptr, d_out_i ? d_out_i + (int64_t)q0 * k : nullptr,
                         d_out_i32 ? d_out_i32 + (int64_t)q0 * k : nullptr, k, (int)done,

@@ -263,6 +263,10 @@ __global__ __launch_bounds__(256) void merge_wave_kernel(const float* __restrict
     }
 }
 
+__global__ void merge_block_kernel(const float* __restrict__ d, const int* __restrict__ idx, int area, int k, SelectOut o,
+                                   int* __restrict__ queue_len);
+static constexpr int MB_WAVES = 16;
+
 int launch_select(const float* part_d, const int* part_i, int nq, int n_cand, int k, int tie_group,
                   const int* idx_map, int64_t idx_offset, const SelectOut& o, hipStream_t s, DevBuf* mid) {
     if (nq <= 0) return VDB_OK;
@@ -277,6 +281,13 @@ int launch_select(const float* part_d, const int* part_i, int nq, int n_cand, in
     if (n_cand <= FEW_LISTS) {
         hipLaunchKernelGGL(merge_few_kernel, dim3((nq + 255) / 256), dim3(256), 0, s, part_d, part_i, nq, n_cand, k,
                            idx_map, idx_offset, o);
+        VDB_HIP(hipGetLastError());
+        return VDB_OK;
+    }
+    if (nq <= 8 && idx_map == nullptr && idx_offset == 0 && (int64_t)n_cand * k <= (1 << 17)) {
+        // a handful of queries: one block of sixteen waves per query walks the lists as one run of entries, instead of
+        // two or three dependent launches of list merges
+        hipLaunchKernelGGL(merge_block_kernel, dim3(nq), dim3(64 * MB_WAVES), 0, s, part_d, part_i, n_cand * k, k, o, (int*)nullptr);
         VDB_HIP(hipGetLastError());
         return VDB_OK;
     }
@@ -310,13 +321,13 @@ int launch_select(const float* part_d, const int* part_i, int nq, int n_cand, in
 // entries of `area`, in any order): the waves share out the entries 64 at a time (256 entries or more per wave, so a
 // short queue keeps few waves busy), each keeps its k best in registers, and wave 0 merges the waves' lists through
 // LDS.  For a few queries, where one wave per query would walk the entries as a chain of global-memory round trips.
-static constexpr int MB_WAVES = 16;
 __global__ __launch_bounds__(64 * MB_WAVES) void merge_block_kernel(const float* __restrict__ d, const int* __restrict__ idx,
                                                                     int area, int k, SelectOut o, int* __restrict__ queue_len) {
     __shared__ float sh_d[MB_WAVES * 64];
     __shared__ int sh_i[MB_WAVES * 64];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int q = blockIdx.x;
+    if (o.run_if && *o.run_if == 0) return;
     const int total = queue_len ? min(__builtin_amdgcn_readfirstlane(queue_len[q]), area) : area;
     const int waves = max(1, min(MB_WAVES, (total + 255) / 256));
     const float* dq = d + (int64_t)q * area;

@@ -1206,11 +1206,29 @@ struct CandParams {
     float* fin_d; int64_t* fin_rows; int64_t* fin_order;
     const int* run_if;                           // optional device flag: the launch does nothing while it is zero
     const int64_t* n_of_query; int n_stride;     // flat: candidates of query q = n_of_query[q * n_stride] instead of n
+    int block_list;                              // the block's wave lists leave as one list: part_* is [nq][splits][k]
 };
 
 static constexpr int CAND_WAVES = LIST_NT / 64;   // candidate lists one block writes
 static constexpr int CAND_UNROLL = 4;       // tiles whose loads are in flight together
 static constexpr int RUN_CHUNK = 256;      // probed lists whose ranges are staged in LDS at a time
+
+// The block's CAND_WAVES wave lists as one list of k: an entry's place is the number of entries that precede it, its own
+// list's (it is sorted) and the other lists' (counted).  Wd / Wi: CAND_WAVES * 64 values each, no longer read by anyone.
+__device__ __forceinline__ void store_block_list(const WaveTopK& best, int k, float* Wd, int* Wi, float* bd, int* bi) {
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    Wd[wave * 64 + lane] = best.e; Wi[wave * 64 + lane] = best.eid;
+    if (tid < k) { bd[tid] = INFINITY; bi[tid] = EMPTY_IDX; }
+    __syncthreads();
+    if (lane < k && best.eid != EMPTY_IDX) {
+        int rank = lane;
+        for (int w = 0; w < CAND_WAVES; ++w) {
+            if (w == wave) continue;
+            for (int e = 0; e < k; ++e) rank += pair_less(Wd[w * 64 + e], Wi[w * 64 + e], best.e, best.eid) ? 1 : 0;
+        }
+        if (rank < k) { bd[rank] = best.e; bi[rank] = best.eid; }
+    }
+}
 
 // FIN: how a candidate value becomes a distance, fixed per launch so that the row terms of the
 // CAND_UNROLL tiles are fetched together instead of one dependent load per tile:
@@ -1337,6 +1355,12 @@ __global__ __launch_bounds__(LIST_NT) void topk_cand_kernel(CandParams p) {
         }
     }
     if (!ONE) {
+        if (p.block_list) {
+            __syncthreads();                    // the run tables in smem are no longer read
+            const int64_t list = (int64_t)qi * p.splits + split;
+            store_block_list(best, k, smem, reinterpret_cast<int*>(smem + CAND_WAVES * 64), p.part_d + list * k, p.part_i + list * k);
+            return;
+        }
         // one candidate list per wave
         const int64_t list = ((int64_t)qi * p.splits + split) * CAND_WAVES + wave;
         best.store(p.part_d + list * k, p.part_i + list * k, lane);
@@ -1456,6 +1480,13 @@ __global__ __launch_bounds__(LIST_NT) void topk_plain_kernel(CandParams p) {
             }
         }
     }
+    if (p.block_list) {
+        __shared__ float Wd[CAND_WAVES * 64];
+        __shared__ int Wi[CAND_WAVES * 64];
+        const int64_t list = (int64_t)qi * p.splits + split;
+        store_block_list(best, k, Wd, Wi, p.part_d + list * k, p.part_i + list * k);
+        return;
+    }
     const int64_t list = ((int64_t)qi * p.splits + split) * CAND_WAVES + wave;
     best.store(p.part_d + list * k, p.part_i + list * k, lane);
 }
@@ -1470,6 +1501,8 @@ int launch_topk_cand(const CandJob& j, hipStream_t s) {
     p.k = j.k; p.splits = j.splits; p.part_d = j.part_d; p.part_i = j.part_i;
     p.ticket = j.ticket; p.k_out = j.k_out; p.fin_d = j.fin_d; p.fin_rows = j.fin_rows; p.fin_order = j.fin_order;
     p.run_if = j.run_if; p.n_of_query = j.n_of_query; p.n_stride = j.n_stride;
+    p.block_list = j.block_list ? 1 : 0;
+    VDB_REQUIRE(!(j.block_list && j.ticket), "the one-launch selection writes its own lists");
     VDB_REQUIRE(j.ticket == nullptr || (j.probes && j.row_ids && j.fin_d && j.fin_rows && j.k_out >= j.k && j.k_out <= 64),
                 "the one-launch selection serves list candidates with k <= 64");
     VDB_REQUIRE(j.probes == nullptr || (j.cand_off && j.tile_off), "list candidates need their slot and tile offsets");

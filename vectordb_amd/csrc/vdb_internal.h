@@ -254,6 +254,7 @@ struct CandJob {
     // flat candidates whose count differs per query (the slots of an IVF query are one contiguous run when no filter
     // needs the rows behind them): query q has n_of_query[q * n_stride] candidates
     const int64_t* n_of_query; int n_stride;
+    bool block_list;                                  // one list per block instead of one per wave: part_* is [nq][splits][k]
 };
 // one query against an IVF index: norms, centroid ranking, slot/tile offsets and scan items in one block
 int launch_ivf_one_plan(const float* sums, int metric, const float* cent_sq, const float* cent_nrm, float cos_eps, const float* q,
