@@ -124,6 +124,18 @@ int vdb_rows_norms(vdb_rows* h, float* sqnorm_out, float* norm_out);      /* tes
  * cosine distance MATRIX of this handle (vdb_flat_distances*); searches keep the fixed 1e-8 of
  * query_distances (metrics.py:469-477), which has no such argument.  Default 1e-8. */
 int vdb_rows_set_cosine_eps(vdb_rows* h, float eps);
+/* Batched searches of an fp32 handle (euclidean, euclidean_squared, cosine, dot; the contraction of
+ * distance/metrics.py:453-484) behind a bf16 filter pass.  No counterpart in the reference, and no change of
+ * results: with VDB_PREFILTER_BF16 the handle keeps a bf16 copy of its rows beside them (half their size again,
+ * converted on the first search and after every write), the pass over all rows runs on the bf16 matrix cores with
+ * its bound loosened by the largest error rounding to bf16 can cause, and the fp32 dot product of every row that
+ * can still be among the k best is recomputed with the instruction sequence of the fp32 kernel.  Distances, rows
+ * and their order are bit for bit those of VDB_PREFILTER_NONE (tests/test_gpu_prefilter.py).  Applies where the
+ * dimension rounded up to 8 is a multiple of 64 and k <= 32; other shapes, vdb_flat_search_static_dev and values
+ * whose products could overflow take the fp32 kernels.  The environment variable VDB_PREFILTER=1 makes it the
+ * default of new fp32 handles. */
+enum vdb_prefilter { VDB_PREFILTER_NONE = 0, VDB_PREFILTER_BF16 = 1 };
+int vdb_rows_set_prefilter(vdb_rows* h, int mode);
 
 /* FlatIndex.search / search_batch (index/flat.py:288-460), the search part of
  * Collection.search (core/collection.py:733-758) and
@@ -150,7 +162,8 @@ int vdb_flat_search_static_dev(vdb_rows* h, int metric, const float* d_queries, 
 
 /* Diagnostics of the last vdb_flat_search* call on this handle (no counterpart in the reference;
  * the analogue of IVFIndex's distance_computations counter, index/ivf.py:626,838):
- * *used_queue = 1 when the batch ran the candidate-queue kernel behind a sampled bound,
+ * *used_queue = 1 when the batch ran the candidate-queue kernel behind a sampled bound (2 when that was the
+ * bf16 filter pass of vdb_rows_set_prefilter),
  * *overflowed = 1 when a queue was too small and the list kernel repeated the search.
  * Waits for the handle's stream. */
 int vdb_flat_search_stats(vdb_rows* h, int* used_queue, int* overflowed);

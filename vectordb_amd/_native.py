@@ -61,6 +61,7 @@ SIGNATURES = {
     "vdb_rows_size": (C.c_int, [C.c_void_p, c_i64_p]),
     "vdb_rows_norms": (C.c_int, [C.c_void_p, c_float_p, c_float_p]),
     "vdb_rows_set_cosine_eps": (C.c_int, [C.c_void_p, C.c_float]),
+    "vdb_rows_set_prefilter": (C.c_int, [C.c_void_p, C.c_int]),
     "vdb_flat_search_stats": (C.c_int, [C.c_void_p, C.POINTER(C.c_int), C.POINTER(C.c_int)]),
     "vdb_flat_search": (C.c_int, [C.c_void_p, C.c_int, c_float_p, C.c_int, C.c_int, c_u32_p, c_float_p, c_i64_p]),
     "vdb_flat_search_dev": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p,
@@ -317,6 +318,18 @@ class RowStore:
     def set_cosine_eps(self, eps: float) -> None:
         """Norm threshold of the cosine distance MATRIX of this store (pairwise_cosine's eps); searches keep 1e-8."""
         check(self.lib.vdb_rows_set_cosine_eps(self.h, float(eps)))
+
+    def set_prefilter(self, mode: Optional[str]) -> None:
+        """Batched searches behind a bf16 filter pass ("bf16") or on the fp32 kernels alone (None): same results."""
+        if mode not in (None, "bf16"):
+            raise ValueError(f"prefilter must be None or 'bf16', got {mode!r}")
+        check(self.lib.vdb_rows_set_prefilter(self.h, 1 if mode == "bf16" else 0))
+
+    def used_prefilter(self) -> bool:
+        """True when the last search on this store ran the bf16 filter pass."""
+        a, b = C.c_int(0), C.c_int(0)
+        check(self.lib.vdb_flat_search_stats(self.h, C.byref(a), C.byref(b)))
+        return a.value == 2
 
     def norms(self):
         n = len(self)

@@ -315,6 +315,12 @@ struct vdb_rows : Handle {
     Rows r;
     DevBuf data, data16, sq, nrm;
     Workspace ws;
+    // Exact search behind a bf16 filter (vdb_rows_set_prefilter): a bf16 copy of the fp32 rows, kept in step with
+    // them lazily (rows [0, shadow_n) are converted), and the largest row norm seen (a device float)
+    int prefilter = 0;
+    DevBuf shadow16, max_nrm, slack;
+    int64_t shadow_n = 0, shadow_cap = 0;
+    bool last_used_prefilter = false;
     bool last_used_queue = false;       // diagnostics of the last flat search
     hipStream_t last_stream = nullptr;
     const int* last_flag = nullptr;     // overflow flag of that search (device)
@@ -346,6 +352,7 @@ static int rows_append_dev_impl(vdb_rows* h, const float* d_rows, int64_t n, int
     Rows& r = h->r;
     if (n <= 0) return VDB_OK;
     h->last_stream = s;
+    h->shadow_n = std::min(h->shadow_n, r.n);       // rows past a truncation are new rows
     VDB_TRY(rows_reserve(h, r.n + n, s));
     if (r.bf16) {
         // in chunks: round, store bf16, norms of the rounded values
@@ -558,6 +565,30 @@ static int stream_flat_search(vdb_rows* h, Workspace& ws, int metric, const floa
     return VDB_OK;
 }
 
+// bf16 copy of the fp32 rows for the filter pass: rows [shadow_n, n) are converted now
+static int shadow_sync(vdb_rows* h, hipStream_t s) {
+    Rows& r = h->r;
+    h->shadow_n = std::min(h->shadow_n, r.n);
+    if (!h->max_nrm.p) {
+        VDB_TRY(h->max_nrm.reserve(sizeof(float)));
+        VDB_HIP(hipMemsetAsync(h->max_nrm.p, 0, sizeof(float), s));
+        h->shadow_n = 0;
+    }
+    if (h->shadow_cap < r.cap) {
+        VDB_TRY(h->shadow16.reserve_keep((size_t)r.cap * r.ld16 * 2, (size_t)h->shadow_n * r.ld16 * 2, s));
+        h->shadow_cap = r.cap;
+    }
+    if (h->shadow_n < r.n) {
+        const int64_t c = r.n - h->shadow_n;
+        hipLaunchKernelGGL(round_bf16_kernel, dim3(grid_for(c * r.ld16)), dim3(256), 0, s, r.data + h->shadow_n * r.ld, (int64_t)r.ld,
+                           r.dim, c, h->shadow16.as<uint16_t>() + h->shadow_n * r.ld16, r.ld16, (float*)nullptr, 0);
+        VDB_HIP(hipGetLastError());
+        VDB_TRY(launch_max_norm(r.nrm, h->shadow_n, r.n, h->max_nrm.as<float>(), s));
+        h->shadow_n = r.n;
+    }
+    return VDB_OK;
+}
+
 // ---- flat search on device pointers ------------------------------------
 // `ws_in` replaces the handle's own workspace (the no-allocation entry point passes one bound to the static scratch)
 static int flat_search_impl(vdb_rows* h, int metric, const float* d_q, int nq, int k, const uint32_t* d_mask,
@@ -565,6 +596,7 @@ static int flat_search_impl(vdb_rows* h, int metric, const float* d_q, int nq, i
     Rows& r = h->r;
     Workspace& ws = ws_in ? *ws_in : h->ws;
     h->last_used_queue = false;
+    h->last_used_prefilter = false;
     h->last_stream = s;
     h->last_flag = nullptr;
     VDB_REQUIRE(valid_metric(metric), "unknown metric code %d", metric);
@@ -647,19 +679,39 @@ static int flat_search_impl(vdb_rows* h, int metric, const float* d_q, int nq, i
         h->last_used_queue = true;
         h->last_flag = ws.flag.as<int>();
         if (!flag_cleared) VDB_HIP(hipMemsetAsync(ws.flag.p, 0, sizeof(int), s));
-        const char* qb = reinterpret_cast<const char*>(q);
-        const size_t q_pitch = r.bf16 ? (size_t)r.ld16 * 2 : (size_t)r.ld * 4;
+        // Filter pass on bf16 copies, exact selection in fp32 (vdb_rows_set_prefilter): only where the 256 x 256 bf16
+        // kernel can read the copy, and never from the entry point that must not allocate (the copy is allocated here)
+        Rows rf = r;
+        rf.bf16 = true;
+        bool prefilter = h->prefilter == VDB_PREFILTER_BF16 && !r.bf16 && ws_in == nullptr && queue_use_wide(rf);
+        if (prefilter) {
+            VDB_TRY(shadow_sync(h, s));
+            rf.data16 = h->shadow16.as<uint16_t>();
+            VDB_TRY(ws.q16.reserve((size_t)nq * r.ld16 * 2));
+            hipLaunchKernelGGL(round_bf16_kernel, dim3(grid_for((int64_t)nq * r.ld16)), dim3(256), 0, s,
+                               reinterpret_cast<const float*>(q), (int64_t)r.ld, r.dim, (int64_t)nq, ws.q16.as<uint16_t>(), r.ld16,
+                               (float*)nullptr, 0);
+            VDB_HIP(hipGetLastError());
+            VDB_TRY(h->slack.reserve((size_t)nq * sizeof(float)));
+            VDB_TRY(launch_prefilter_slack(metric, ws.q_nrm.as<float>(), h->max_nrm.as<float>(), nq, r.dim, h->slack.as<float>(),
+                                           ws.flag.as<int>(), s));
+        }
+        h->last_used_prefilter = prefilter;
+        const Rows& rq = prefilter ? rf : r;
+        const char* qb = prefilter ? ws.q16.as<char>() : reinterpret_cast<const char*>(q);
+        const size_t q_pitch = rq.bf16 ? (size_t)r.ld16 * 2 : (size_t)r.ld * 4;
         for (int q0 = 0; q0 < nq; q0 += QUEUE_Q_BLOCK) {
             const int nb = std::min(QUEUE_Q_BLOCK, nq - q0);
             int n_slabs = 0, cap = 0;
-            VDB_TRY(flat_queue_plan(r, nb, kmax, sample_stride, &n_slabs, &cap));
+            VDB_TRY(flat_queue_plan(rq, nb, kmax, sample_stride, &n_slabs, &cap));
             VDB_TRY(ws.queue.reserve((size_t)nb * n_slabs * cap * 8));
             VDB_TRY(ws.queue_cnt.reserve((size_t)nb * n_slabs * sizeof(int)));
-            VDB_TRY(launch_flat_queue(r, metric, qb + (size_t)q0 * q_pitch, ws.q_sq.as<float>() + q0, ws.q_nrm.as<float>() + q0,
+            PrefilterArgs pf{r.data, r.ld, reinterpret_cast<const float*>(q) + (size_t)q0 * r.ld, r.ld, h->slack.as<float>() + q0};
+            VDB_TRY(launch_flat_queue(rq, metric, qb + (size_t)q0 * q_pitch, ws.q_sq.as<float>() + q0, ws.q_nrm.as<float>() + q0,
                                       nb, kmax, d_mask, thr_init + q0, n_slabs, cap, ws.queue.p, ws.queue_cnt.as<int>(),
                                       ws.flag.as<int>(), d_out_d ? d_out_d + (int64_t)q0 * k : nullptr,
                                       d_out_i ? d_out_i + (int64_t)q0 * k : nullptr,
-                                      d_out_i32 ? d_out_i32 + (int64_t)q0 * k : nullptr, s));
+                                      d_out_i32 ? d_out_i32 + (int64_t)q0 * k : nullptr, s, prefilter ? &pf : nullptr));
         }
         run_if = ws.flag.as<int>();
     }
@@ -983,6 +1035,8 @@ int vdb_rows_create_typed(vdb_rows** out, int dim, int storage) {
     h->r.ld = round_up(dim, 4);
     h->r.bf16 = storage == VDB_STORE_BF16;
     h->r.ld16 = round_up(dim, 8);
+    static const bool prefilter_default = getenv("VDB_PREFILTER") != nullptr && atoi(getenv("VDB_PREFILTER")) != 0;
+    if (prefilter_default && !h->r.bf16) h->prefilter = VDB_PREFILTER_BF16;
     int st = make_sum_plan(dim, &h->r.plan);
     if (st == VDB_OK) st = h->open();
     if (st != VDB_OK) { delete h; return st; }
@@ -998,6 +1052,7 @@ int vdb_rows_destroy(vdb_rows* h) {
         (void)hipStreamSynchronize(h->stream);
         if (h->last_stream && h->last_stream != h->stream) (void)hipStreamSynchronize(h->last_stream);
         h->data.release(); h->data16.release(); h->sq.release(); h->nrm.release(); h->ws.release();
+        h->shadow16.release(); h->max_nrm.release(); h->slack.release();
     }
     h->close();
     delete h;
@@ -1010,6 +1065,7 @@ int vdb_rows_append(vdb_rows* h, const float* rows, int64_t n) {
     Entry g(h);
     hipStream_t s = h->stream;
     Rows& r = h->r;
+    h->shadow_n = std::min(h->shadow_n, r.n);
     VDB_TRY(rows_reserve(h, r.n + n, s));
     if (r.ld == r.dim && !r.bf16) {
         float* dst = r.data + r.n * r.ld;
@@ -1054,6 +1110,7 @@ int vdb_rows_set(vdb_rows* h, int64_t row, const float* vec) {
         return VDB_OK;
     }
     float* dst = r.data + row * r.ld;
+    h->shadow_n = std::min(h->shadow_n, row);       // the bf16 copy is rebuilt from this row on
     VDB_HIP(hipMemcpyAsync(dst, vec, (size_t)r.dim * sizeof(float), hipMemcpyHostToDevice, s));   // padding stays zero
     VDB_TRY(row_norms(h->ws, dst, r.ld, r.dim, 1, r.plan, r.sq + row, r.nrm + row, s));
     VDB_HIP(hipStreamSynchronize(s));
@@ -1064,6 +1121,20 @@ int vdb_rows_truncate(vdb_rows* h, int64_t n) {
     VDB_REQUIRE(h && n >= 0 && n <= h->r.n, "cannot truncate %lld rows to %lld", h ? (long long)h->r.n : 0LL, (long long)n);
     Entry g(h);
     h->r.n = n;
+    h->shadow_n = std::min(h->shadow_n, n);
+    return VDB_OK;
+}
+
+int vdb_rows_set_prefilter(vdb_rows* h, int mode) {
+    VDB_REQUIRE(h && (mode == VDB_PREFILTER_NONE || mode == VDB_PREFILTER_BF16), "unknown prefilter mode %d", mode);
+    Entry g(h);
+    VDB_REQUIRE(mode == VDB_PREFILTER_NONE || !h->r.bf16, "a bf16 filter pass needs fp32 storage");
+    h->prefilter = mode;
+    if (mode == VDB_PREFILTER_NONE) {
+        (void)hipStreamSynchronize(h->stream);
+        if (h->last_stream && h->last_stream != h->stream) (void)hipStreamSynchronize(h->last_stream);
+        h->shadow16.release(); h->shadow_n = 0; h->shadow_cap = 0;
+    }
     return VDB_OK;
 }
 
@@ -1132,7 +1203,7 @@ int vdb_flat_search_static_dev(vdb_rows* h, int metric, const float* d_queries, 
 int vdb_flat_search_stats(vdb_rows* h, int* used_queue, int* overflowed) {
     VDB_REQUIRE(h && used_queue && overflowed, "null argument");
     Entry g(h);
-    *used_queue = h->last_used_queue ? 1 : 0;
+    *used_queue = h->last_used_queue ? (h->last_used_prefilter ? 2 : 1) : 0;
     *overflowed = 0;
     if (h->last_used_queue && h->last_flag) {
         hipStream_t s = h->last_stream ? h->last_stream : h->stream;

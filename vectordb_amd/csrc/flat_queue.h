@@ -13,6 +13,10 @@ struct QueueParams {
     const float* q_sq; const float* q_nrm;
     const uint32_t* mask;
     const float* thr;                              // per query: an upper bound of its k-th best distance
+    // Optional, per query: how far a dot product of this launch may lie from the one the bound was derived for
+    // (bf16 copies of fp32 rows and queries as a filter in front of an exact fp32 selection).  The filter is
+    // loosened by that much, so no row that the exact dot product would pass is dropped.
+    const float* slack;
     int n_tiles, n_slabs, tiles_per_slab, n_qtiles;
     int cap;                                       // queue slots per (query, slab)
     float2* queue;                                 // [nq][n_slabs][cap]  (dot product, row number bits)
@@ -22,6 +26,14 @@ struct QueueParams {
     int tile_stride;
     float* min_out;
 };
+
+// filter_bound<>() for dot products that are only known to within `slack`
+template <int METRIC>
+__device__ __forceinline__ float loosen_bound(float bound, float slack) {
+    if (!(fabsf(bound) < INFINITY)) return bound;                           // passes all or nothing already
+    if (METRIC == VDB_DOT || METRIC == VDB_COSINE) return bound - slack;    // pass: dot >= bound (* |c|)
+    return (bound + 2.0f * slack) * 1.000001f;                              // pass: (|q|^2+|c|^2) - 2 dot <= bound
+}
 
 // Smallest "key" of the 16 values of one accumulator, for the bound pass.  Keys order like the
 // distances of one query: -dot (dot), (|q|^2+|c|^2) - 2 dot (both Euclidean forms, the exact

@@ -63,6 +63,7 @@ __global__ __launch_bounds__(NT, 2) void flat_queue_kernel(QueueParams p) {
     }
     // lanes past the last query must never pass the filter
     float bound = filter_bound<METRIC>(p.thr[my_q_ld], q_term);
+    if (p.slack) bound = loosen_bound<METRIC>(bound, p.slack[my_q_ld]);
     if (!q_ok) bound = (METRIC == VDB_DOT || METRIC == VDB_COSINE) ? INFINITY : -INFINITY;
     float2* my_queue = p.queue + ((int64_t)my_q_ld * p.n_slabs + slab) * p.cap;
     if (tid < TQ) Cnt[tid] = 0;
@@ -282,6 +283,7 @@ __global__ __launch_bounds__(NT, 2) void flat_queue_fast_kernel(QueueParams p) {
     float best = INFINITY;                              // bound pass: this lane's smallest key
     if (!MINPASS) {
         bound = filter_bound<METRIC>(p.thr[my_q_ld], q_term);
+        if (p.slack) bound = loosen_bound<METRIC>(bound, p.slack[my_q_ld]);
         if (!q_ok) bound = (METRIC == VDB_DOT || METRIC == VDB_COSINE) ? INFINITY : -INFINITY;
         my_queue = p.queue + ((int64_t)my_q_ld * p.n_slabs + slab) * p.cap;
     }
@@ -528,6 +530,221 @@ __global__ __launch_bounds__(256) void queue_select_kernel(QueueSelectParams p) 
 }
 
 // --------------------------------------------------------------------------
+// Selection behind a bf16 filter pass.  The queue of a query holds (dot product of the bf16 copies, row) for every
+// row whose copy passed the loosened bound; the dot product of the fp32 values lies within `slack` of it.  In a
+// key that is linear in the dot product and ordered like the distance (-dot; -dot / (|q||c|); (|q|^2+|c|^2) - 2 dot)
+// the two differ by at most E.  With K the k-th smallest approximate key of the queue, k rows have an exact key of
+// at most K + E, so every row of the exact k best (ties at the k-th distance included, and everything at or below the
+// value where the distance is clamped) has an approximate key of at most max(K, clamp) + 2E.  Those few rows get
+// their fp32 dot product recomputed: 32 rows at a time as the A operand of the same v_mfma_f32_32x32x2_f32 chain,
+// in the same order over the columns, as flat_queue_kernel / flat_gemm_kernel run it, the query in every column of
+// B.  Distances and their (distance, row) order are therefore bit for bit those of the fp32 search.
+struct PrefilterSelectParams {
+    float2* queue; const int* counts; int n_slabs, cap;
+    const float* rows; int ld;
+    const float* q; int ldq;
+    const float* row_sq; const float* row_nrm; const float* q_sq; const float* q_nrm;
+    const float* slack;
+    int nq, k;
+    float* out_d; int64_t* out_i; int* out_i32;
+    int* overflow;
+};
+
+template <int METRIC>
+__global__ __launch_bounds__(256) void prefilter_select_kernel(PrefilterSelectParams p) {
+    __shared__ int CandRows[4][96];
+    const int lane = threadIdx.x & 63;
+    const int wave = threadIdx.x >> 6;
+    const int q = blockIdx.x * 4 + wave;
+    if (q >= p.nq) return;                      // no block-wide barrier below: every wave works alone
+    volatile int* cand = CandRows[wave];
+    float q_term = 0.0f;
+    if (METRIC == VDB_COSINE) {
+        q_term = p.q_nrm[q];
+        if (q_term < 1e-8f) q_term = INFINITY;
+    } else if (METRIC != VDB_DOT) {
+        q_term = p.q_sq[q];
+    }
+    const float slack = p.slack[q];
+    bool over = false;
+
+    // ---- pass 1: approximate keys (written back over the dot products), the k-th smallest of them
+    WaveTopK approx;
+    approx.init(p.k);
+    for (int s0 = 0; s0 < p.n_slabs; s0 += 64) {
+        const int s = s0 + lane;
+        int c = 0;
+        if (s < p.n_slabs) {
+            c = p.counts[(int64_t)q * p.n_slabs + s];
+            if (c > p.cap) { over = true; c = p.cap; }
+        }
+        int cmax = c;
+#pragma unroll
+        for (int off = 32; off >= 1; off >>= 1) cmax = max(cmax, __shfl_xor(cmax, off));
+        float2* e = p.queue + ((int64_t)q * p.n_slabs + min(s, p.n_slabs - 1)) * p.cap;
+        for (int j0 = 0; j0 < cmax; j0 += 4) {
+            float2 v[4];
+            float rt[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) v[u] = (j0 + u < c) ? e[j0 + u] : make_float2(0.0f, __int_as_float(EMPTY_IDX));
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                rt[u] = 1.0f;
+                if (METRIC != VDB_DOT && j0 + u < c) {
+                    const int row = __float_as_int(v[u].y);
+                    rt[u] = (METRIC == VDB_COSINE) ? p.row_nrm[row] : p.row_sq[row];
+                    if (METRIC == VDB_COSINE && rt[u] < 1e-8f) rt[u] = 1.0f;
+                }
+            }
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const bool have = j0 + u < c;
+                float key = (METRIC == VDB_DOT) ? -v[u].x
+                          : (METRIC == VDB_COSINE) ? -(v[u].x / (q_term * rt[u]))
+                                                   : __fmaf_rn(-2.0f, v[u].x, q_term + rt[u]);
+                if (have) e[j0 + u].x = key;
+                approx.offer(have, have ? key : INFINITY, __float_as_int(v[u].y), lane);
+            }
+        }
+    }
+    // the largest approximate key a row of the exact k best can have
+    float limit = approx.thr;
+    if (METRIC == VDB_DOT) {
+        limit = limit + 2.0f * slack;
+    } else if (METRIC == VDB_COSINE) {
+        // E = slack / |q| plus the roundings of the quotient; distances are clamped to [0, 2]: keys <= -1 tie at 0
+        const float E = slack / q_term + 1e-6f;
+        limit = fmaxf(limit, -1.0f) + 2.0f * E;
+        if (limit >= 1.0f - 1e-6f && limit < INFINITY) over = true;     // ties at distance 2: every row would be needed
+    } else {
+        // E = 2 slack; squared distances are clamped at 0
+        limit = fmaxf(limit, 0.0f) + 4.0f * slack;
+        limit = limit + fabsf(limit) * 2e-6f;
+    }
+
+    // ---- pass 2: rows within the limit, 32 at a time through the fp32 matrix instruction chain
+    WaveTopK top;
+    top.init(p.k);
+    const int col = lane & 31, half = lane >> 5;
+    const float* qrow = p.q + (int64_t)q * p.ldq + half * 4;
+    const int ksteps = (p.ld * 4 + TKB - 1) / TKB;
+    auto refine = [&](int cnt) {
+        const int my_row = cand[col < cnt ? col : 0];
+        const float* a = p.rows + (int64_t)my_row * p.ld + half * 4;
+        f32x16 acc;
+#pragma unroll
+        for (int i = 0; i < 16; ++i) acc[i] = 0.0f;
+        for (int ks = 0; ks < ksteps; ++ks) {
+#pragma unroll
+            for (int c2 = 0; c2 < 4; ++c2) {
+                const int off = ks * (TKB / 4) + c2 * 8;
+                const bool in = off + half * 4 < p.ld;          // the pitch is a multiple of 4 floats: all or nothing
+                const float4 av = in ? *reinterpret_cast<const float4*>(a + off) : make_float4(0, 0, 0, 0);
+                const float4 bv = in ? *reinterpret_cast<const float4*>(qrow + off) : make_float4(0, 0, 0, 0);
+                acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av.x, bv.x, acc, 0, 0, 0);
+                acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av.y, bv.y, acc, 0, 0, 0);
+                acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av.z, bv.z, acc, 0, 0, 0);
+                acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av.w, bv.w, acc, 0, 0, 0);
+            }
+        }
+        // row i of the tile sits in value 4 (i / 8) + i % 4 of the lanes whose half is (i / 4) % 2; every column
+        // holds the same query, so lane (column i, that half) takes row i
+        const bool own = half == ((col >> 2) & 1) && col < cnt;
+        const float dot = pick16(acc, 4 * (col >> 3) + (col & 3));
+        float rt = 1.0f;
+        if (METRIC != VDB_DOT) {
+            rt = (METRIC == VDB_COSINE) ? p.row_nrm[my_row] : p.row_sq[my_row];
+            if (METRIC == VDB_COSINE && rt < 1e-8f) rt = 1.0f;
+        }
+        top.offer(own, finish<METRIC>(dot, rt, q_term), my_row, lane);
+    };
+    int nc = 0;
+    for (int s0 = 0; s0 < p.n_slabs; s0 += 64) {
+        const int s = s0 + lane;
+        int c = 0;
+        if (s < p.n_slabs) c = min(p.counts[(int64_t)q * p.n_slabs + s], p.cap);
+        int cmax = c;
+#pragma unroll
+        for (int off = 32; off >= 1; off >>= 1) cmax = max(cmax, __shfl_xor(cmax, off));
+        const float2* e = p.queue + ((int64_t)q * p.n_slabs + min(s, p.n_slabs - 1)) * p.cap;
+        for (int j0 = 0; j0 < cmax; j0 += 4) {
+            float2 v[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) v[u] = (j0 + u < c) ? e[j0 + u] : make_float2(INFINITY, 0.0f);
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const bool want = j0 + u < c && v[u].x <= limit;
+                const unsigned long long m = __ballot(want);
+                if (m == 0) continue;
+                if (want) cand[nc + __popcll(m & ((1ull << lane) - 1ull))] = __float_as_int(v[u].y);
+                nc += __popcll(m);
+                while (nc >= 32) {
+                    refine(32);
+                    const int moved = (lane < nc - 32) ? cand[32 + lane] : 0;
+                    if (lane < nc - 32) cand[lane] = moved;
+                    nc -= 32;
+                }
+            }
+        }
+    }
+    if (nc > 0) refine(nc);
+
+    if (over) *p.overflow = 1;
+    if (lane < p.k) {
+        const bool empty = top.eid == EMPTY_IDX;
+        const int64_t at = (int64_t)q * p.k + lane;
+        const int64_t row = empty ? -1 : (int64_t)top.eid;
+        if (p.out_d) p.out_d[at] = empty ? INFINITY : top.e;
+        if (p.out_i) p.out_i[at] = row;
+        if (p.out_i32) p.out_i32[at] = (int)row;
+    }
+}
+
+// slack[q]: the largest |dot(bf16(q), bf16(c)) - dot(q, c)| over the rows c, both sums as the matrix cores form them.
+// Rounding an element to bf16 moves it by at most 2^-9 of itself (or 2^-126 where the format runs out of exponent),
+// so the sum of products moves by at most (2^-8 + 2^-18) sum|q_i c_i| <= 0.0039101 |q||c|; the two accumulations
+// in fp32 add at most dim 2^-22 |q||c| between them.  Cosine compares dot >= bound |c|, the others use the largest
+// row norm.  Products that could overflow, or norms that are not numbers, send the search to the fp32 kernel.
+__global__ void prefilter_slack_kernel(int metric, const float* __restrict__ q_nrm, const float* __restrict__ max_row_nrm,
+                                       int nq, int dim, float* __restrict__ slack, int* __restrict__ overflow) {
+    const int q = blockIdx.x * blockDim.x + threadIdx.x;
+    if (q >= nq) return;
+    const float qn = q_nrm[q];
+    const float big = *max_row_nrm;
+    const float rel = (0.0039101f + (float)dim * 2.4e-7f) * 1.0001f;
+    const float prod = qn * big;
+    if (!(prod < 1e37f)) *overflow = 1;
+    const float tiny = sqrtf((float)dim) * 1.2e-38f * (qn + big) + 1e-30f;
+    slack[q] = (metric == VDB_COSINE) ? rel * qn : rel * prod + tiny;
+}
+
+__global__ void max_norm_kernel(const float* __restrict__ nrm, int64_t n0, int64_t n1, float* __restrict__ out) {
+    // non-negative floats (and NaNs above them) order like their bit patterns
+    int m = 0;
+    for (int64_t i = n0 + (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n1; i += (int64_t)gridDim.x * blockDim.x)
+        m = max(m, __float_as_int(nrm[i]) & 0x7fffffff);
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) m = max(m, __shfl_xor(m, off));
+    if ((threadIdx.x & 63) == 0 && m > 0) atomicMax(reinterpret_cast<int*>(out), m);
+}
+
+int launch_prefilter_slack(int metric, const float* q_nrm, const float* max_row_nrm, int nq, int dim, float* slack,
+                           int* overflow, hipStream_t s) {
+    hipLaunchKernelGGL(prefilter_slack_kernel, dim3((nq + 255) / 256), dim3(256), 0, s, metric, q_nrm, max_row_nrm, nq, dim,
+                       slack, overflow);
+    VDB_HIP(hipGetLastError());
+    return VDB_OK;
+}
+
+int launch_max_norm(const float* row_nrm, int64_t n0, int64_t n1, float* max_nrm, hipStream_t s) {
+    if (n1 <= n0) return VDB_OK;
+    const int blocks = (int)std::min<int64_t>((n1 - n0 + 255) / 256, 1024);
+    hipLaunchKernelGGL(max_norm_kernel, dim3(blocks), dim3(256), 0, s, row_nrm, n0, n1, max_nrm);
+    VDB_HIP(hipGetLastError());
+    return VDB_OK;
+}
+
+// --------------------------------------------------------------------------
 // Bound pass: per query, the k-th smallest of its per-lane minima over the sampled tiles.  Every
 // minimum is the distance of a real row, and minima of different lanes belong to different rows, so
 // the k-th smallest of them is at least the k-th best distance of the whole row set.
@@ -645,13 +862,14 @@ static int launch_queue(int metric, QueueParams& p, bool fast, hipStream_t s) {
 
 int launch_flat_queue(const Rows& r, int metric, const void* q, const float* q_sq, const float* q_nrm, int nq, int k,
                       const uint32_t* mask, const float* thr, int n_slabs, int cap, void* queue, int* counts,
-                      int* overflow, float* out_d, int64_t* out_i, int* out_i32, hipStream_t s) {
+                      int* overflow, float* out_d, int64_t* out_i, int* out_i32, hipStream_t s, const PrefilterArgs* pf) {
     VDB_REQUIRE(k >= 1 && k <= 64, "queue selection supports 1 <= k <= 64, got %d", k);
     VDB_REQUIRE(r.n >= 1 && r.n < (1LL << 31) && nq >= 1 && thr != nullptr, "bad queue search arguments");
     QueueParams p{};
     p.rows = r.bf16 ? (const void*)r.data16 : (const void*)r.data; p.n = r.n;
     p.ld_bytes = r.bf16 ? r.ld16 * 2 : r.ld * 4; p.row_sq = r.sq; p.row_nrm = r.nrm;
     p.q = q; p.nq = nq; p.q_sq = q_sq; p.q_nrm = q_nrm; p.mask = mask; p.thr = thr;
+    p.slack = pf ? pf->slack : nullptr;
     const bool wide = queue_use_wide(r);
     if (wide) {
         p.n_tiles = (int)((r.n + WM - 1) / WM);
@@ -667,6 +885,22 @@ int launch_flat_queue(const Rows& r, int metric, const void* q, const float* q_s
     if (wide) VDB_TRY(launch_queue_wide(metric, p, s));
     else VDB_TRY(r.bf16 ? launch_queue<true>(metric, p, fast, s) : launch_queue<false>(metric, p, fast, s));
 
+    if (pf) {
+        PrefilterSelectParams fp{};
+        fp.queue = p.queue; fp.counts = counts; fp.n_slabs = n_slabs; fp.cap = cap;
+        fp.rows = pf->rows32; fp.ld = pf->ld32; fp.q = pf->q32; fp.ldq = pf->ldq32;
+        fp.row_sq = r.sq; fp.row_nrm = r.nrm; fp.q_sq = q_sq; fp.q_nrm = q_nrm; fp.slack = pf->slack;
+        fp.nq = nq; fp.k = k; fp.out_d = out_d; fp.out_i = out_i; fp.out_i32 = out_i32; fp.overflow = overflow;
+        const dim3 fgrid((nq + 3) / 4);
+        switch (metric) {
+            case VDB_EUCLIDEAN: hipLaunchKernelGGL(prefilter_select_kernel<VDB_EUCLIDEAN>, fgrid, dim3(256), 0, s, fp); break;
+            case VDB_EUCLIDEAN_SQ: hipLaunchKernelGGL(prefilter_select_kernel<VDB_EUCLIDEAN_SQ>, fgrid, dim3(256), 0, s, fp); break;
+            case VDB_COSINE: hipLaunchKernelGGL(prefilter_select_kernel<VDB_COSINE>, fgrid, dim3(256), 0, s, fp); break;
+            default: hipLaunchKernelGGL(prefilter_select_kernel<VDB_DOT>, fgrid, dim3(256), 0, s, fp); break;
+        }
+        VDB_HIP(hipGetLastError());
+        return VDB_OK;
+    }
     QueueSelectParams sp{};
     sp.queue = p.queue; sp.counts = counts; sp.n_slabs = n_slabs; sp.cap = cap;
     sp.row_sq = r.sq; sp.row_nrm = r.nrm; sp.q_sq = q_sq; sp.q_nrm = q_nrm; sp.nq = nq; sp.k = k;

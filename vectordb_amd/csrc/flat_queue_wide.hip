@@ -73,6 +73,7 @@ __global__ __launch_bounds__(WNT, 1) void flat_queue_wide_kernel(QueueParams p) 
             q_term[qd] = p.q_sq[my_q_ld];
         }
         bound[qd] = filter_bound<METRIC>(p.thr[my_q_ld], q_term[qd]);
+        if (p.slack) bound[qd] = loosen_bound<METRIC>(bound[qd], p.slack[my_q_ld]);
         if (my_q >= p.nq) bound[qd] = (METRIC == VDB_DOT || METRIC == VDB_COSINE) ? INFINITY : -INFINITY;
         my_queue[qd] = p.queue + ((int64_t)my_q_ld * p.n_slabs + slab) * p.cap;
         my_cnt[qd] = &Cnt[ql];
@@ -325,6 +326,7 @@ __global__ __launch_bounds__(WNT, 1) void flat_queue_wide_dma_kernel(QueueParams
             q_term[qd] = p.q_sq[my_q_ld];
         }
         bound[qd] = filter_bound<METRIC>(p.thr[my_q_ld], q_term[qd]);
+        if (p.slack) bound[qd] = loosen_bound<METRIC>(bound[qd], p.slack[my_q_ld]);
         if (my_q >= p.nq) bound[qd] = (METRIC == VDB_DOT || METRIC == VDB_COSINE) ? INFINITY : -INFINITY;
         my_queue[qd] = p.queue + ((int64_t)my_q_ld * p.n_slabs + slab) * p.cap;
         my_cnt[qd] = &Cnt[ql];

@@ -167,9 +167,28 @@ int launch_flat_min_sample(const Rows& r, int metric, const void* q, const float
                            const uint32_t* mask, int sample_tiles, int tile_stride, float* mins, float* thr,
                            int* clear_flag, hipStream_t s);
 int flat_queue_plan(const Rows& r, int nq, int k, int sample_stride, int* n_slabs, int* cap);
+// bf16 rows with whole 128-byte column steps and whole readable 256-row tiles take the 256 x 256 kernel
+bool queue_use_wide(const Rows& r);
+// Exact search behind a bf16 filter: `r` and `q` of launch_flat_queue are then bf16 copies (rounded to nearest) of
+// the fp32 rows and queries below, with the norm terms of the fp32 values.  The queue pass runs on the copies with
+// its bound loosened by the largest difference rounding can make (slack[query], in dot-product units), and the
+// selection recomputes the fp32 dot product of every queued row that can still be among the k best, with the same
+// instruction sequence as the fp32 kernels, so distances and order are those of the fp32 search.
+struct PrefilterArgs {
+    const float* rows32; int ld32;      // fp32 rows, pitch in floats
+    const float* q32; int ldq32;        // fp32 queries of this launch, padded like the rows
+    const float* slack;                 // [nq]
+};
+// slack[q] from the query norms and the largest row norm; sets *overflow (the flag of the queue pass, which makes the
+// fp32 list kernel repeat the search) when a dot product could overflow or is not a number
+int launch_prefilter_slack(int metric, const float* q_nrm, const float* max_row_nrm, int nq, int dim, float* slack,
+                           int* overflow, hipStream_t s);
+// max over row_nrm[n0, n1) folded into *max_nrm (a device float that starts at 0; a NaN norm wins)
+int launch_max_norm(const float* row_nrm, int64_t n0, int64_t n1, float* max_nrm, hipStream_t s);
 int launch_flat_queue(const Rows& r, int metric, const void* q, const float* q_sq, const float* q_nrm, int nq, int k,
                       const uint32_t* mask, const float* thr, int n_slabs, int cap, void* queue, int* counts,
-                      int* overflow, float* out_d, int64_t* out_i, int* out_i32, hipStream_t s);
+                      int* overflow, float* out_d, int64_t* out_i, int* out_i32, hipStream_t s,
+                      const PrefilterArgs* pf = nullptr);
 // MFMA path, full distance matrix out[nq][n]
 int launch_flat_gemm_dist(const Rows& r, int metric, const void* q, const float* q_sq, const float* q_nrm,
                           int nq, float* out, hipStream_t s);
