@@ -27,10 +27,15 @@ arithmetic) on a sample of the same queries and rows on the host cores; a
 sample of the queries is checked against that oracle at every N.
 
 `extra` holds side measurements that do not enter `value`:
+  prefilter the headline's steps on the same store behind the bf16 filter pass
+            (vdb_rows_set_prefilter): queries/s, the bf16 kernel's time and
+            fraction of the bf16 MFMA peak, and whether distances and rows are
+            bit for bit the headline's;
   c3        BASELINE.json configs[2]: Flat dot 10M x 768, rows / N per GPU,
-            fp32 and bf16 storage, batch 1024 (queries/s, kernel ms, fraction
-            of the MFMA peak of the storage type), with a spot check of the
-            returned distances against the oracle;
+            fp32 storage, fp32 storage behind the bf16 filter pass (compared
+            bit for bit with the former) and bf16 storage, batch 1024
+            (queries/s, kernel ms, fraction of the MFMA peak of the kernel's
+            type), with a spot check of the returned distances against the oracle;
   c1        configs[0]: 10k x 128 euclidean, 100 single queries, through the
             Collection.search-shaped path and as bare distances + top-k, on the
             GPU and on the host oracle (N = 1 only);
@@ -235,13 +240,33 @@ def main() -> None:
                                       f"(NumPy restatement of query_distances + stable top-{k})"}
         del rows_host
 
+    # ---- the same steps behind the bf16 filter pass (vdb_rows_set_prefilter): bit-equal results, not part of `value`
+    prefilter = None
+    if not args.no_extra:
+        try:
+            backend.store.set_prefilter("bf16")
+            p_elapsed, p_kernel_ms, p_launches, (p_d, p_r) = timed_steps(index, queries, k, args.steps, args.warmup, barrier, _native)
+            p_elapsed = max_over_ranks(p_elapsed)
+            p_kern = p_kernel_ms / max(p_launches, 1)
+            p_tflops = flop_per_launch / (p_kern * 1e-3) / 1e12 if p_launches else 0.0
+            prefilter = {"what": "same workload and steps; the pass over all rows on bf16 copies with a loosened bound, the fp32 "
+                                 "dot products of the remaining rows recomputed (results bit-equal to the headline's)",
+                         "queries_per_s": round(nq * args.steps / p_elapsed, 1), "ms_per_step": round(p_elapsed / args.steps * 1e3, 4),
+                         "kernel": "flat_queue_wide_kernel<cosine> (bf16 MFMA)", "kernel_ms": round(p_kern, 4),
+                         "tflops": round(p_tflops, 1), "peak_tflops": MFMA_BF16_PEAK_TFLOPS,
+                         "frac": round(p_tflops / MFMA_BF16_PEAK_TFLOPS, 4), "used_filter": backend.store.used_prefilter(),
+                         "identical_to_fp32_search": bool(torch.equal(p_d.view(torch.int32), out_d.view(torch.int32))
+                                                          and torch.equal(p_r, out_r))}
+        except Exception as e:
+            prefilter = {"error": f"{type(e).__name__}: {e}"}
+
     backend.store.close()
     del index, backend
     torch.cuda.empty_cache()
 
     extra = None
     if not args.no_extra:
-        extra = {}
+        extra = {"prefilter": prefilter}
         try:
             extra["c3"] = bench_c3(world, rank, dev, gen, barrier, max_over_ranks, _native)
         except Exception as e:          # a side measurement must not take the headline line with it
@@ -279,8 +304,10 @@ def bench_c3(world, rank, dev, gen, barrier, max_over_ranks, native, steps=5, wa
     queries = torch.randn((nq, d), device=dev, dtype=torch.float32, generator=gen)
     out = {"workload": f"Flat dot 10M x 768, batch {nq}, k={k}, rows/{world} per GPU (BASELINE configs[2])",
            "rows_per_gpu": hi - lo, "steps": steps, "warmup": warmup}
-    for storage, peak in (("f32", MFMA_F32_PEAK_TFLOPS), ("bf16", MFMA_BF16_PEAK_TFLOPS)):
-        backend = HipFlatBackend(d, native.DOT, storage=storage)
+    f32_result = None
+    for name, storage, peak in (("f32", "f32", MFMA_F32_PEAK_TFLOPS), ("f32_bf16_filter", "f32", MFMA_BF16_PEAK_TFLOPS),
+                                ("bf16", "bf16", MFMA_BF16_PEAK_TFLOPS)):
+        backend = HipFlatBackend(d, native.DOT, storage=storage, prefilter="bf16" if name == "f32_bf16_filter" else None)
         fill_store(backend, lo, hi, d, 4242, dev, gen)
         index = ShardedFlat(backend, n_total, rank, world)
         elapsed, kernel_ms, launches, (od, orow) = timed_steps(index, queries, k, steps, warmup, barrier, native)
@@ -303,9 +330,15 @@ def bench_c3(world, rank, dev, gen, barrier, max_over_ranks, native, steps=5, wa
                 ref = R.query_distances(qv, rows, "dot")
                 atol = 1e-5 * float(np.max(np.abs(rows).sum(axis=1)) * np.max(np.abs(qv)))
                 ok &= bool(np.allclose(od_h[qi], ref, rtol=1e-4, atol=atol)) and bool(np.all(np.diff(od_h[qi]) >= 0))
-        out[storage] = {"queries_per_s": round(nq * steps / elapsed, 1), "ms_per_step": round(elapsed / steps * 1e3, 4),
-                        "kernel_ms": round(kern, 4), "tflops": round(tflops, 1), "peak_tflops": peak,
-                        "frac": round(tflops / peak, 4), "returned_distances_ok": ok}
+        out[name] = {"queries_per_s": round(nq * steps / elapsed, 1), "ms_per_step": round(elapsed / steps * 1e3, 4),
+                     "kernel_ms": round(kern, 4), "tflops": round(tflops, 1), "peak_tflops": peak,
+                     "frac": round(tflops / peak, 4), "returned_distances_ok": ok}
+        if name == "f32":
+            f32_result = (od.clone(), orow.clone())
+        elif name == "f32_bf16_filter":
+            out[name]["identical_to_f32"] = bool(torch.equal(od.view(torch.int32), f32_result[0].view(torch.int32))
+                                                 and torch.equal(orow, f32_result[1]))
+            f32_result = None
         backend.store.close()
         del index, backend
         torch.cuda.empty_cache()

@@ -639,23 +639,46 @@ static int flat_search_impl(vdb_rows* h, int metric, const float* d_q, int nq, i
     const bool will_queue = sample_tiles > 0 && !multi && !no_queue;
     bool flag_cleared = false;
     if (will_queue) VDB_TRY(ws.flag.reserve(sizeof(int)));
+    // Filter pass on bf16 copies, exact selection in fp32 (vdb_rows_set_prefilter): only where the 256 x 256 bf16
+    // kernel can read the copy, and never from the entry point that must not allocate (the copy is allocated here)
+    Rows rf = r;
+    rf.bf16 = true;
+    const bool prefilter = will_queue && h->prefilter == VDB_PREFILTER_BF16 && !r.bf16 && ws_in == nullptr && queue_use_wide(rf);
+    bool thr_from_copies = false;
+    if (prefilter) {
+        VDB_TRY(shadow_sync(h, s));
+        rf.data16 = h->shadow16.as<uint16_t>();
+        VDB_TRY(ws.q16.reserve((size_t)nq * r.ld16 * 2));
+        hipLaunchKernelGGL(round_bf16_kernel, dim3(grid_for((int64_t)nq * r.ld16)), dim3(256), 0, s,
+                           reinterpret_cast<const float*>(q), (int64_t)r.ld, r.dim, (int64_t)nq, ws.q16.as<uint16_t>(), r.ld16,
+                           (float*)nullptr, 0);
+        VDB_HIP(hipGetLastError());
+        VDB_TRY(h->slack.reserve((size_t)nq * sizeof(float)));
+    }
+    h->last_used_prefilter = prefilter;
     if (sample_tiles > 0) {
         // k-th best distance over a strided sample of the rows: an upper bound of the
         // k-th best over all rows, used as the initial filter threshold of the full pass
         VDB_TRY(ws.thr_d.reserve((size_t)nq * sizeof(float)));
         VDB_TRY(ws.thr_k.reserve((size_t)nq * sizeof(int64_t)));
         static const bool no_min = getenv("VDB_NO_MINPASS") != nullptr;
-        if (flat_queue_fast_ok(r) && !no_min) {
+        // behind the bf16 filter the bound pass reads the copies too; the bound it finds is widened below by what
+        // rounding can have moved the k distances it stands for
+        static const bool f32_bound = getenv("VDB_PREFILTER_F32_BOUND") != nullptr;
+        const bool bound_on_copies = prefilter && !f32_bound && flat_queue_fast_ok(rf);
+        const Rows& rb = bound_on_copies ? rf : r;
+        if (flat_queue_fast_ok(rb) && !no_min) {
             // per-lane minima over the sample, then the k-th smallest of them (blocks of queries keep
             // the number of lanes per query well above k)
-            const char* qb = reinterpret_cast<const char*>(q);
-            const size_t q_pitch = r.bf16 ? (size_t)r.ld16 * 2 : (size_t)r.ld * 4;
+            const char* qb = bound_on_copies ? ws.q16.as<char>() : reinterpret_cast<const char*>(q);
+            const size_t q_pitch = rb.bf16 ? (size_t)r.ld16 * 2 : (size_t)r.ld * 4;
+            thr_from_copies = bound_on_copies;
             for (int q0 = 0; q0 < nq; q0 += QUEUE_Q_BLOCK) {
                 const int nb = std::min(QUEUE_Q_BLOCK, nq - q0);
                 int ns = 0;
                 const int n_lists = flat_min_sample_lists(sample_tiles, nb, kmax, &ns);
                 VDB_TRY(ws.mins.reserve((size_t)nb * n_lists * sizeof(float)));
-                VDB_TRY(launch_flat_min_sample(r, metric, qb + (size_t)q0 * q_pitch, ws.q_sq.as<float>() + q0,
+                VDB_TRY(launch_flat_min_sample(rb, metric, qb + (size_t)q0 * q_pitch, ws.q_sq.as<float>() + q0,
                                                ws.q_nrm.as<float>() + q0, nb, kmax, d_mask, sample_tiles, sample_stride,
                                                ws.mins.as<float>(), ws.thr_d.as<float>() + q0,
                                                will_queue ? ws.flag.as<int>() : nullptr, s));
@@ -679,31 +702,16 @@ static int flat_search_impl(vdb_rows* h, int metric, const float* d_q, int nq, i
         h->last_used_queue = true;
         h->last_flag = ws.flag.as<int>();
         if (!flag_cleared) VDB_HIP(hipMemsetAsync(ws.flag.p, 0, sizeof(int), s));
-        // Filter pass on bf16 copies, exact selection in fp32 (vdb_rows_set_prefilter): only where the 256 x 256 bf16
-        // kernel can read the copy, and never from the entry point that must not allocate (the copy is allocated here)
-        Rows rf = r;
-        rf.bf16 = true;
-        bool prefilter = h->prefilter == VDB_PREFILTER_BF16 && !r.bf16 && ws_in == nullptr && queue_use_wide(rf);
-        if (prefilter) {
-            VDB_TRY(shadow_sync(h, s));
-            rf.data16 = h->shadow16.as<uint16_t>();
-            VDB_TRY(ws.q16.reserve((size_t)nq * r.ld16 * 2));
-            hipLaunchKernelGGL(round_bf16_kernel, dim3(grid_for((int64_t)nq * r.ld16)), dim3(256), 0, s,
-                               reinterpret_cast<const float*>(q), (int64_t)r.ld, r.dim, (int64_t)nq, ws.q16.as<uint16_t>(), r.ld16,
-                               (float*)nullptr, 0);
-            VDB_HIP(hipGetLastError());
-            VDB_TRY(h->slack.reserve((size_t)nq * sizeof(float)));
+        if (prefilter)
             VDB_TRY(launch_prefilter_slack(metric, ws.q_nrm.as<float>(), h->max_nrm.as<float>(), nq, r.dim, h->slack.as<float>(),
-                                           ws.flag.as<int>(), s));
-        }
-        h->last_used_prefilter = prefilter;
+                                           thr_from_copies ? ws.thr_d.as<float>() : nullptr, ws.flag.as<int>(), s));
         const Rows& rq = prefilter ? rf : r;
         const char* qb = prefilter ? ws.q16.as<char>() : reinterpret_cast<const char*>(q);
         const size_t q_pitch = rq.bf16 ? (size_t)r.ld16 * 2 : (size_t)r.ld * 4;
         for (int q0 = 0; q0 < nq; q0 += QUEUE_Q_BLOCK) {
             const int nb = std::min(QUEUE_Q_BLOCK, nq - q0);
             int n_slabs = 0, cap = 0;
-            VDB_TRY(flat_queue_plan(rq, nb, kmax, sample_stride, &n_slabs, &cap));
+            VDB_TRY(flat_queue_plan(rq, nb, kmax, sample_stride, &n_slabs, &cap, prefilter));
             VDB_TRY(ws.queue.reserve((size_t)nb * n_slabs * cap * 8));
             VDB_TRY(ws.queue_cnt.reserve((size_t)nb * n_slabs * sizeof(int)));
             PrefilterArgs pf{r.data, r.ld, reinterpret_cast<const float*>(q) + (size_t)q0 * r.ld, r.ld, h->slack.as<float>() + q0};

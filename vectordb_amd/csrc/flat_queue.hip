@@ -706,7 +706,8 @@ __global__ __launch_bounds__(256) void prefilter_select_kernel(PrefilterSelectPa
 // in fp32 add at most dim 2^-22 |q||c| between them.  Cosine compares dot >= bound |c|, the others use the largest
 // row norm.  Products that could overflow, or norms that are not numbers, send the search to the fp32 kernel.
 __global__ void prefilter_slack_kernel(int metric, const float* __restrict__ q_nrm, const float* __restrict__ max_row_nrm,
-                                       int nq, int dim, float* __restrict__ slack, int* __restrict__ overflow) {
+                                       int nq, int dim, float* __restrict__ slack, float* __restrict__ widen_thr,
+                                       int* __restrict__ overflow) {
     const int q = blockIdx.x * blockDim.x + threadIdx.x;
     if (q >= nq) return;
     const float qn = q_nrm[q];
@@ -715,7 +716,19 @@ __global__ void prefilter_slack_kernel(int metric, const float* __restrict__ q_n
     const float prod = qn * big;
     if (!(prod < 1e37f)) *overflow = 1;
     const float tiny = sqrtf((float)dim) * 1.2e-38f * (qn + big) + 1e-30f;
-    slack[q] = (metric == VDB_COSINE) ? rel * qn : rel * prod + tiny;
+    const float sl = (metric == VDB_COSINE) ? rel * qn : rel * prod + tiny;
+    slack[q] = sl;
+    if (widen_thr) {
+        // a distance formed from a dot product that is off by at most `sl`: the exact one is at most ...
+        float t = widen_thr[q];
+        if (t < INFINITY) {
+            if (metric == VDB_DOT) t = t + sl + fabsf(t) * 1e-6f;                          // -dot
+            else if (metric == VDB_COSINE) t = t + (qn >= 1e-8f ? rel : 0.0f) + 2e-6f;     // 1 - dot / (|q||c|), clamped
+            else if (metric == VDB_EUCLIDEAN_SQ) t = (t + 2.0f * sl) * 1.000001f;          // max(s - 2 dot, 0)
+            else t = sqrtf(t * t * 1.000001f + 2.0f * sl) * 1.000001f;                     // its square root
+            widen_thr[q] = t;
+        }
+    }
 }
 
 __global__ void max_norm_kernel(const float* __restrict__ nrm, int64_t n0, int64_t n1, float* __restrict__ out) {
@@ -729,9 +742,9 @@ __global__ void max_norm_kernel(const float* __restrict__ nrm, int64_t n0, int64
 }
 
 int launch_prefilter_slack(int metric, const float* q_nrm, const float* max_row_nrm, int nq, int dim, float* slack,
-                           int* overflow, hipStream_t s) {
+                           float* widen_thr, int* overflow, hipStream_t s) {
     hipLaunchKernelGGL(prefilter_slack_kernel, dim3((nq + 255) / 256), dim3(256), 0, s, metric, q_nrm, max_row_nrm, nq, dim,
-                       slack, overflow);
+                       slack, widen_thr, overflow);
     VDB_HIP(hipGetLastError());
     return VDB_OK;
 }
@@ -819,13 +832,16 @@ int launch_flat_min_sample(const Rows& r, int metric, const void* q, const float
     return VDB_OK;
 }
 
-int flat_queue_plan(const Rows& r, int nq, int k, int sample_stride, int* n_slabs, int* cap) {
+int flat_queue_plan(const Rows& r, int nq, int k, int sample_stride, int* n_slabs, int* cap, bool loosened) {
     int nqt, tps;
     if (queue_use_wide(r)) plan_grid_wide((int)((r.n + WM - 1) / WM), nq, ctx().num_cus, &nqt, n_slabs, &tps);
     else plan_grid((int)((r.n + TM - 1) / TM), nq, ctx().num_cus, &nqt, n_slabs, &tps);
     // survivors per query: about sample_stride * k in expectation (the bound is the k-th best of
     // one row in sample_stride); four times that plus a constant, spread over the slabs
-    const int64_t total = 4LL * sample_stride * k + 1024;
+    // Behind a bf16 filter both the bound and the test are loosened by the rounding slack: two to three times as
+    // many survivors on Gaussian rows, and a query whose sampled bound is loose on top of that must still fit the
+    // slots of every slab (a full queue costs the whole batch a second search).
+    const int64_t total = loosened ? 16LL * sample_stride * k + 2048 : 4LL * sample_stride * k + 1024;
     int c = (int)((total + *n_slabs - 1) / *n_slabs);
     c = std::max(32, (c + 7) / 8 * 8);
     *cap = c;

@@ -166,7 +166,7 @@ int flat_min_sample_lists(int sample_tiles, int nq, int k, int* n_slabs);
 int launch_flat_min_sample(const Rows& r, int metric, const void* q, const float* q_sq, const float* q_nrm, int nq, int k,
                            const uint32_t* mask, int sample_tiles, int tile_stride, float* mins, float* thr,
                            int* clear_flag, hipStream_t s);
-int flat_queue_plan(const Rows& r, int nq, int k, int sample_stride, int* n_slabs, int* cap);
+int flat_queue_plan(const Rows& r, int nq, int k, int sample_stride, int* n_slabs, int* cap, bool loosened = false);
 // bf16 rows with whole 128-byte column steps and whole readable 256-row tiles take the 256 x 256 kernel
 bool queue_use_wide(const Rows& r);
 // Exact search behind a bf16 filter: `r` and `q` of launch_flat_queue are then bf16 copies (rounded to nearest) of
@@ -180,9 +180,11 @@ struct PrefilterArgs {
     const float* slack;                 // [nq]
 };
 // slack[q] from the query norms and the largest row norm; sets *overflow (the flag of the queue pass, which makes the
-// fp32 list kernel repeat the search) when a dot product could overflow or is not a number
+// fp32 list kernel repeat the search) when a dot product could overflow or is not a number.  With `widen_thr`
+// (per-query bounds of the k-th best distance found on the bf16 copies) every bound is raised to what the exact
+// distances of the same k rows cannot exceed.
 int launch_prefilter_slack(int metric, const float* q_nrm, const float* max_row_nrm, int nq, int dim, float* slack,
-                           int* overflow, hipStream_t s);
+                           float* widen_thr, int* overflow, hipStream_t s);
 // max over row_nrm[n0, n1) folded into *max_nrm (a device float that starts at 0; a NaN norm wins)
 int launch_max_norm(const float* row_nrm, int64_t n0, int64_t n1, float* max_nrm, hipStream_t s);
 int launch_flat_queue(const Rows& r, int metric, const void* q, const float* q_sq, const float* q_nrm, int nq, int k,

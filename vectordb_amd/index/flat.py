@@ -35,14 +35,20 @@ class FlatIndex(BaseIndex):
     """Exact k-NN over every stored row (index/flat.py:69-956)."""
 
     def __init__(self, dimension: int, metric: str = "euclidean", normalize: bool = False, use_matrix: bool = True,
-                 initial_capacity: int = 1000, storage: str = "f32", **kwargs):
+                 initial_capacity: int = 1000, storage: str = "f32", prefilter: Optional[str] = None, **kwargs):
         """`storage` is not a reference argument: "bf16" keeps the device copy of the rows in
         bfloat16 (euclidean, euclidean_squared, cosine, dot only; distances are those of inputs
-        rounded to bf16).  The host copy returned by get()/include_vectors stays fp32."""
+        rounded to bf16).  The host copy returned by get()/include_vectors stays fp32.
+        `prefilter="bf16"` (fp32 storage only, not a reference argument either) runs the pass of a batched
+        search over all rows on a bf16 copy of them and recomputes the few remaining rows in fp32: results
+        are bit for bit those without it, the device holds half as many bytes again."""
         super().__init__(dimension, metric, **kwargs)
         if storage not in N.STORAGE:
             raise ValueError(f"storage must be one of {sorted(N.STORAGE)}, got {storage!r}")
+        if prefilter not in (None, "bf16") or (prefilter and storage != "f32"):
+            raise ValueError(f"prefilter must be None or 'bf16' (with fp32 storage), got {prefilter!r}")
         self._storage = storage
+        self._prefilter = prefilter
         self.config = FlatIndexConfig(dimension=dimension, metric=metric, normalize=normalize, use_matrix=use_matrix,
                                       initial_capacity=initial_capacity)
         self._ids: List[str] = []
@@ -71,6 +77,8 @@ class FlatIndex(BaseIndex):
         threads that both saw the same pending tail would append it twice."""
         if self._store is None:
             self._store = N.RowStore(self._dimension, storage=self._storage)
+            if self._prefilter:
+                self._store.set_prefilter(self._prefilter)
             self._synced = 0
         if self._synced < self._size:
             self._store.append(self._vectors[self._synced:self._size])
@@ -295,7 +303,8 @@ class FlatIndex(BaseIndex):
     def to_dict(self) -> Dict[str, Any]:
         return {"index_type": self.index_type.value, "dimension": self._dimension, "metric": self._metric,
                 "config": {"normalize": self.config.normalize, "use_matrix": self.config.use_matrix,
-                           "initial_capacity": self.config.initial_capacity, "storage": self._storage},
+                           "initial_capacity": self.config.initial_capacity, "storage": self._storage,
+                           "prefilter": self._prefilter},
                 "ids": self._ids.copy(), "vectors": self._vectors[:self._size].tolist(),
                 "metadata": {id: meta.copy() for id, meta in self._metadata.items()}}
 
@@ -306,7 +315,7 @@ class FlatIndex(BaseIndex):
         index = cls(dimension=data["dimension"], metric=data["metric"], normalize=cfg.get("normalize", False),
                     use_matrix=cfg.get("use_matrix", True),
                     initial_capacity=max(cfg.get("initial_capacity", 1000), len(ids)),
-                    storage=cfg.get("storage", "f32"))
+                    storage=cfg.get("storage", "f32"), prefilter=cfg.get("prefilter"))
         if len(ids) > 0:
             meta = data.get("metadata", {})
             index.add_batch(ids, np.array(data.get("vectors", []), dtype=np.float32), [meta.get(i, {}) for i in ids])

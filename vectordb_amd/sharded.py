@@ -34,10 +34,12 @@ def shard_range(n_total: int, world: int, rank: int) -> Tuple[int, int]:
 class HipFlatBackend:
     """Local search and merge on the GPU through the C ABI."""
 
-    def __init__(self, dim: int, metric: int, storage: str = "f32"):
+    def __init__(self, dim: int, metric: int, storage: str = "f32", prefilter: Optional[str] = None):
         from . import _native
         self._n = _native
         self.store = _native.RowStore(dim, storage=storage)
+        if prefilter is not None:
+            self.store.set_prefilter(prefilter)     # same results, the pass over all rows on the bf16 matrix cores
         self.metric = metric
 
     def add_device(self, rows: torch.Tensor) -> None:
