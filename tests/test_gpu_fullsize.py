@@ -295,20 +295,31 @@ def _dot_atol(rows_h, q_h):
     return 1e-5 * float(np.max(np.abs(rows_h).sum(axis=1)) * np.max(np.abs(q_h)))
 
 
-@pytest.mark.parametrize("storage", ["f32", "bf16"])
+@pytest.mark.parametrize("storage", ["f32", "f32+filter", "bf16"])
 def test_flat_dot_c3_one_shard(nat, storage):
     """One GPU's shard of configs[2]: 1.25M x 768 rows, dot product, batch 1024, k = 10, fp32 and bf16 storage.
+    "f32+filter": fp32 storage behind the bf16 filter pass, held to the fp32 bars and to bit equality with the
+    search without the filter.
     bf16 storage is checked against the oracle on bf16-rounded rows and queries (products of bf16 values are
     exact in fp32, the sums are fp32): the fp32 bar, 1e-4 relative plus the rounding floor of a 768-term dot
     product.  Recall@10 of the bf16 results against the unrounded fp32 oracle is reported."""
     n, d, nq, k = 1_250_000, 768, 1024, 10
     x = randn(n, d, 4242)
     q = randn(nq, d, 321)
+    filtered = storage == "f32+filter"
+    if filtered:
+        storage = "f32"
     store = nat.RowStore(d, storage=storage)
     store.append_device(x.data_ptr(), n, d, 0)
     fn = lambda qp, m, kk, dp, rp: store.search_device(qp, m, kk, nat.DOT, dp, rp)
+    if filtered:
+        plain = search_dev(fn, q, k)
+        store.set_prefilter("bf16")
     dist, rows = search_dev(fn, q, k)
     assert store.search_stats() == (True, False), "the batch must take the candidate-queue kernel without overflow"
+    if filtered:
+        assert store.used_prefilter()
+        assert np.array_equal(plain[1], rows) and np.array_equal(plain[0].view(np.uint32), dist.view(np.uint32))
     dist2, rows2 = search_dev(fn, q, k)
     assert np.array_equal(rows, rows2) and np.array_equal(dist, dist2), "same call, same bits"
     check_shape_properties(dist, rows, n)
