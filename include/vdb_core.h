@@ -130,9 +130,10 @@ int vdb_rows_set_cosine_eps(vdb_rows* h, float eps);
  * converted on the first search and after every write), the pass over all rows runs on the bf16 matrix cores with
  * its bound loosened by the largest error rounding to bf16 can cause, and the fp32 dot product of every row that
  * can still be among the k best is recomputed with the instruction sequence of the fp32 kernel.  Distances, rows
- * and their order are bit for bit those of VDB_PREFILTER_NONE (tests/test_gpu_prefilter.py).  Applies where the
- * dimension rounded up to 8 is a multiple of 64 and k <= 32; other shapes, vdb_flat_search_static_dev and values
- * whose products could overflow take the fp32 kernels.  The environment variable VDB_PREFILTER=1 makes it the
+ * and their order are bit for bit those of VDB_PREFILTER_NONE (tests/test_gpu_prefilter.py).  Applies to batches
+ * of at least 4 queries over at least 65536 rows with k <= 32, any dimension (the copy's rows are padded to whole
+ * 128-byte steps); other calls, vdb_flat_search_static_dev and values whose products could overflow take the fp32
+ * kernels.  The environment variable VDB_PREFILTER=1 makes it the
  * default of new fp32 handles. */
 enum vdb_prefilter { VDB_PREFILTER_NONE = 0, VDB_PREFILTER_BF16 = 1 };
 int vdb_rows_set_prefilter(vdb_rows* h, int mode);

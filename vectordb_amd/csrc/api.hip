@@ -566,8 +566,11 @@ static int stream_flat_search(vdb_rows* h, Workspace& ws, int metric, const floa
 }
 
 // bf16 copy of the fp32 rows for the filter pass: rows [shadow_n, n) are converted now
+static int shadow_pitch(const Rows& r) { return round_up(r.dim, 64); }     // whole 128-byte column steps for any dimension
+
 static int shadow_sync(vdb_rows* h, hipStream_t s) {
     Rows& r = h->r;
+    const int ld16 = shadow_pitch(r);
     h->shadow_n = std::min(h->shadow_n, r.n);
     if (!h->max_nrm.p) {
         VDB_TRY(h->max_nrm.reserve(sizeof(float)));
@@ -575,13 +578,13 @@ static int shadow_sync(vdb_rows* h, hipStream_t s) {
         h->shadow_n = 0;
     }
     if (h->shadow_cap < r.cap) {
-        VDB_TRY(h->shadow16.reserve_keep((size_t)r.cap * r.ld16 * 2, (size_t)h->shadow_n * r.ld16 * 2, s));
+        VDB_TRY(h->shadow16.reserve_keep((size_t)r.cap * ld16 * 2, (size_t)h->shadow_n * ld16 * 2, s));
         h->shadow_cap = r.cap;
     }
     if (h->shadow_n < r.n) {
         const int64_t c = r.n - h->shadow_n;
-        hipLaunchKernelGGL(round_bf16_kernel, dim3(grid_for(c * r.ld16)), dim3(256), 0, s, r.data + h->shadow_n * r.ld, (int64_t)r.ld,
-                           r.dim, c, h->shadow16.as<uint16_t>() + h->shadow_n * r.ld16, r.ld16, (float*)nullptr, 0);
+        hipLaunchKernelGGL(round_bf16_kernel, dim3(grid_for(c * ld16)), dim3(256), 0, s, r.data + h->shadow_n * r.ld, (int64_t)r.ld,
+                           r.dim, c, h->shadow16.as<uint16_t>() + h->shadow_n * ld16, ld16, (float*)nullptr, 0);
         VDB_HIP(hipGetLastError());
         VDB_TRY(launch_max_norm(r.nrm, h->shadow_n, r.n, h->max_nrm.as<float>(), s));
         h->shadow_n = r.n;
@@ -643,14 +646,15 @@ static int flat_search_impl(vdb_rows* h, int metric, const float* d_q, int nq, i
     // kernel can read the copy, and never from the entry point that must not allocate (the copy is allocated here)
     Rows rf = r;
     rf.bf16 = true;
+    rf.ld16 = shadow_pitch(r);
     const bool prefilter = will_queue && h->prefilter == VDB_PREFILTER_BF16 && !r.bf16 && ws_in == nullptr && queue_use_wide(rf);
     bool thr_from_copies = false;
     if (prefilter) {
         VDB_TRY(shadow_sync(h, s));
         rf.data16 = h->shadow16.as<uint16_t>();
-        VDB_TRY(ws.q16.reserve((size_t)nq * r.ld16 * 2));
-        hipLaunchKernelGGL(round_bf16_kernel, dim3(grid_for((int64_t)nq * r.ld16)), dim3(256), 0, s,
-                           reinterpret_cast<const float*>(q), (int64_t)r.ld, r.dim, (int64_t)nq, ws.q16.as<uint16_t>(), r.ld16,
+        VDB_TRY(ws.q16.reserve((size_t)nq * rf.ld16 * 2));
+        hipLaunchKernelGGL(round_bf16_kernel, dim3(grid_for((int64_t)nq * rf.ld16)), dim3(256), 0, s,
+                           reinterpret_cast<const float*>(q), (int64_t)r.ld, r.dim, (int64_t)nq, ws.q16.as<uint16_t>(), rf.ld16,
                            (float*)nullptr, 0);
         VDB_HIP(hipGetLastError());
         VDB_TRY(h->slack.reserve((size_t)nq * sizeof(float)));
@@ -671,7 +675,7 @@ static int flat_search_impl(vdb_rows* h, int metric, const float* d_q, int nq, i
             // per-lane minima over the sample, then the k-th smallest of them (blocks of queries keep
             // the number of lanes per query well above k)
             const char* qb = bound_on_copies ? ws.q16.as<char>() : reinterpret_cast<const char*>(q);
-            const size_t q_pitch = rb.bf16 ? (size_t)r.ld16 * 2 : (size_t)r.ld * 4;
+            const size_t q_pitch = rb.bf16 ? (size_t)rb.ld16 * 2 : (size_t)r.ld * 4;
             thr_from_copies = bound_on_copies;
             for (int q0 = 0; q0 < nq; q0 += QUEUE_Q_BLOCK) {
                 const int nb = std::min(QUEUE_Q_BLOCK, nq - q0);
@@ -707,7 +711,7 @@ static int flat_search_impl(vdb_rows* h, int metric, const float* d_q, int nq, i
                                            thr_from_copies ? ws.thr_d.as<float>() : nullptr, ws.flag.as<int>(), s));
         const Rows& rq = prefilter ? rf : r;
         const char* qb = prefilter ? ws.q16.as<char>() : reinterpret_cast<const char*>(q);
-        const size_t q_pitch = rq.bf16 ? (size_t)r.ld16 * 2 : (size_t)r.ld * 4;
+        const size_t q_pitch = rq.bf16 ? (size_t)rq.ld16 * 2 : (size_t)r.ld * 4;
         for (int q0 = 0; q0 < nq; q0 += QUEUE_Q_BLOCK) {
             const int nb = std::min(QUEUE_Q_BLOCK, nq - q0);
             int n_slabs = 0, cap = 0;
