@@ -150,6 +150,16 @@ def main():
                  ms_per_batch=round(wall * 1e3, 4), kernel_ms=round(kern * 1e3, 4), recall_at_10_vs_fp32=round(recall, 4),
                  roofline={"bound": "mfma", "achieved": round(flop / kern / 1e12, 2), "peak": MFMA_BF16_PEAK, "unit": "TFLOP/s",
                            "frac": round(flop / kern / 1e12 / MFMA_BF16_PEAK, 4), "flop_per_launch": flop})
+            # the fp32 store behind the bf16 filter pass: the same 256 x 256 kernel, fp32 results bit for bit
+            ref.set_prefilter("bf16")
+            fd, frow = outputs(nq, 10)
+            wall, kern, launches = timed(lambda: ref.search_device(q.data_ptr(), nq, 10, metric, fd.data_ptr(), frow.data_ptr()), 10)
+            same = bool(torch.equal(fd.view(torch.int32), rd.view(torch.int32)) and torch.equal(frow, rrow))
+            emit("prefilter", workload=f"Flat {mname} {n}x{d} fp32 storage behind the bf16 filter pass, batch {nq}, k=10",
+                 qps=round(nq / wall, 1), ms_per_batch=round(wall * 1e3, 4), kernel_ms=round(kern * 1e3, 4),
+                 identical_to_fp32_search=same, used_filter=ref.used_prefilter(),
+                 roofline={"bound": "mfma", "achieved": round(flop / kern / 1e12, 2), "peak": MFMA_BF16_PEAK, "unit": "TFLOP/s",
+                           "frac": round(flop / kern / 1e12 / MFMA_BF16_PEAK, 4), "flop_per_launch": flop})
             store.close(); ref.close()
             torch.cuda.empty_cache()
 
