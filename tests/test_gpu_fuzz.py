@@ -47,3 +47,10 @@ def test_ivf_pq_soak_pq_bound_pass_on_small_sets(native):
 
 def test_bf16_soak(native):
     run_soak("fuzz_bf16.py", 10, 104)
+
+
+def test_prefilter_soak(native):
+    # VDB_SAMPLE_MIN_TILES=32: batches take the candidate-queue kernels (and with them the bf16 filter pass) from
+    # 4096 rows on, so a short run covers many shapes; every case is compared bit for bit with the filter off
+    run_soak("fuzz_prefilter.py", 12, 106, env={"VDB_SAMPLE_MIN_TILES": "32"})
+

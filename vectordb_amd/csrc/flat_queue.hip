@@ -712,9 +712,9 @@ __global__ __launch_bounds__(256) void prefilter_select_kernel(PrefilterSelectPa
 }
 
 // slack[q]: the largest |dot(bf16(q), bf16(c)) - dot(q, c)| over the rows c, both sums as the matrix cores form them.
-// Rounding an element to bf16 moves it by at most 2^-9 of itself (or 2^-126 where the format runs out of exponent),
-// so the sum of products moves by at most (2^-8 + 2^-18) sum|q_i c_i| <= 0.0039101 |q||c|; the two accumulations
-// in fp32 add at most dim 2^-22 |q||c| between them.  Cosine compares dot >= bound |c|, the others use the largest
+// bf16 keeps eight significant bits: rounding to nearest moves an element by at most 2^-8 of itself (or 2^-126 where
+// the format runs out of exponent), so the sum of products moves by at most (2^-7 + 2^-16) sum|q_i c_i| <=
+// 0.0078278 |q||c|; the two accumulations in fp32 add at most dim 2^-22 |q||c| between them.  Cosine compares dot >= bound |c|, the others use the largest
 // row norm.  Products that could overflow, or norms that are not numbers, send the search to the fp32 kernel.
 __global__ void prefilter_slack_kernel(int metric, const float* __restrict__ q_nrm, const float* __restrict__ max_row_nrm,
                                        int nq, int dim, float* __restrict__ slack, float* __restrict__ widen_thr,
@@ -723,7 +723,7 @@ __global__ void prefilter_slack_kernel(int metric, const float* __restrict__ q_n
     if (q >= nq) return;
     const float qn = q_nrm[q];
     const float big = *max_row_nrm;
-    const float rel = (0.0039101f + (float)dim * 2.4e-7f) * 1.0001f;
+    const float rel = (0.0078278f + (float)dim * 2.4e-7f) * 1.0001f;
     const float prod = qn * big;
     if (!(prod < 1e37f)) *overflow = 1;
     const float tiny = sqrtf((float)dim) * 1.2e-38f * (qn + big) + 1e-30f;
