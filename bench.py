@@ -287,7 +287,12 @@ def main() -> None:
             "config": {"workload": "Flat cosine 1M x 384 fp32, batch 1024 queries, k=10 (BASELINE configs[1])",
                        "rows": n_total, "dim": d, "queries_per_step": nq, "k": k,
                        "sharding": f"rows/{world}" + (" + all-gather top-k merge" if world > 1 else "")},
-            "roofline": roofline, "cpu_baseline": cpu_baseline, "parity_sample_ok": parity, "extra": extra,
+            "roofline": roofline, "cpu_baseline": cpu_baseline, "parity_sample_ok": parity,
+            # the same steps with the pass over all rows on bf16 copies and the candidates recomputed in fp32
+            # (bit-equal results; details in extra.prefilter); not the headline, whose kernel is the fp32 one
+            "value_behind_bf16_filter": (prefilter or {}).get("queries_per_s"),
+            "identical_behind_bf16_filter": (prefilter or {}).get("identical_to_fp32_search"),
+            "extra": extra,
         }))
     if world > 1:
         dist.destroy_process_group()
