@@ -627,6 +627,19 @@ static int flat_search_impl(vdb_rows* h, int metric, const float* d_q, int nq, i
     int n_cand = 0, sample_tiles = 0, sample_stride = 1, n_cand_sample = 0;
     VDB_TRY(flat_gemm_num_cand(r.n, nq, k, &n_cand));
     VDB_TRY(flat_gemm_sample_plan(r.n, &sample_tiles, &sample_stride));
+    if (h->prefilter == VDB_PREFILTER_BF16 && !r.bf16 && ws_in == nullptr && sample_tiles > 0) {
+        // Behind the bf16 filter every survivor of the bound costs more (a looser test, an fp32 recomputation for some)
+        // and the bound pass a quarter of the fp32 one: a denser sample pays while rows are short.  Cosine 1M x 384,
+        // batch 1024: 1.01 ms at 1/64 of the tiles, 0.96 at 1/32, 0.93 at 1/16, 0.96 at 1/8; euclidean 1M x 128: 0.71,
+        // 0.64, 0.61, 0.59; dot 1.25M x 768: 2.10 at all of 1/64 ... 1/16, and 10M x 768 14.2 ms at 1/64 against 14.8.
+        static const int forced = getenv("VDB_PREFILTER_SAMPLE") ? std::max(1, atoi(getenv("VDB_PREFILTER_SAMPLE"))) : 0;
+        const int pitch = shadow_pitch(r);
+        const int dens = forced ? forced : (pitch <= 384 ? 4 : (pitch <= 512 ? 2 : 1));
+        const int stride = std::max(1, sample_stride / dens);
+        const int n_tiles128 = (int)((r.n + 127) / 128);
+        sample_tiles = std::max(sample_tiles, n_tiles128 / stride);
+        sample_stride = std::max(1, n_tiles128 / sample_tiles);
+    }
     if (sample_tiles > 0) VDB_TRY(flat_gemm_num_cand_tiles(sample_tiles, nq, &n_cand_sample));
     const int kmax = (int)std::min<int64_t>(KMAX_FUSED, k_eff);
     const int cand_max = std::max(n_cand, n_cand_sample);
