@@ -660,10 +660,20 @@ static int flat_search_impl(vdb_rows* h, int metric, const float* d_q, int nq, i
     Rows rf = r;
     rf.bf16 = true;
     rf.ld16 = shadow_pitch(r);
-    const bool prefilter = will_queue && h->prefilter == VDB_PREFILTER_BF16 && !r.bf16 && ws_in == nullptr && queue_use_wide(rf);
+    bool prefilter = will_queue && h->prefilter == VDB_PREFILTER_BF16 && !r.bf16 && ws_in == nullptr && queue_use_wide(rf);
     bool thr_from_copies = false;
     if (prefilter) {
-        VDB_TRY(shadow_sync(h, s));
+        // no room for the copy: the search runs on the fp32 kernels alone, as it would without the filter
+        const int st = shadow_sync(h, s);
+        if (st == VDB_ERR_NOMEM) {
+            (void)hipGetLastError();
+            h->shadow16.release(); h->shadow_n = 0; h->shadow_cap = 0;
+            prefilter = false;
+        } else {
+            VDB_TRY(st);
+        }
+    }
+    if (prefilter) {
         rf.data16 = h->shadow16.as<uint16_t>();
         VDB_TRY(ws.q16.reserve((size_t)nq * rf.ld16 * 2));
         hipLaunchKernelGGL(round_bf16_kernel, dim3(grid_for((int64_t)nq * rf.ld16)), dim3(256), 0, s,

@@ -634,29 +634,35 @@ __global__ __launch_bounds__(256) void prefilter_select_kernel(PrefilterSelectPa
         f32x16 acc;
 #pragma unroll
         for (int i = 0; i < 16; ++i) acc[i] = 0.0f;
-        // the operands of column step ks + 1 are fetched while step ks is multiplied
-        float4 av[4], bv[4], an[4], bn[4];
-        auto fetch = [&](int ks, float4 (&fa)[4], float4 (&fb)[4]) {
+        // The rows are gathered from all over the store: every column step's loads take a trip to HBM.  Four steps
+        // are kept in flight (a ring of four operand sets, the loop unrolled by four so that the set in use is a
+        // literal); a step past the last one loads nothing and multiplies nothing.
+        float4 fa[4][4], fb[4][4];
+        auto fetch = [&](int ks, float4 (&xa)[4], float4 (&xb)[4]) {
 #pragma unroll
             for (int c2 = 0; c2 < 4; ++c2) {
                 const int off = ks * (TKB / 4) + c2 * 8;
-                const bool in = off + half * 4 < p.ld;          // the pitch is a multiple of 4 floats: all or nothing
-                fa[c2] = in ? *reinterpret_cast<const float4*>(a + off) : make_float4(0, 0, 0, 0);
-                fb[c2] = in ? *reinterpret_cast<const float4*>(qrow + off) : make_float4(0, 0, 0, 0);
+                const bool in = ks < ksteps && off + half * 4 < p.ld;   // the pitch is a multiple of 4 floats: all or nothing
+                xa[c2] = in ? *reinterpret_cast<const float4*>(a + off) : make_float4(0, 0, 0, 0);
+                xb[c2] = in ? *reinterpret_cast<const float4*>(qrow + off) : make_float4(0, 0, 0, 0);
             }
         };
-        fetch(0, av, bv);
-        for (int ks = 0; ks < ksteps; ++ks) {
-            if (ks + 1 < ksteps) fetch(ks + 1, an, bn);
 #pragma unroll
-            for (int c2 = 0; c2 < 4; ++c2) {
-                acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av[c2].x, bv[c2].x, acc, 0, 0, 0);
-                acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av[c2].y, bv[c2].y, acc, 0, 0, 0);
-                acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av[c2].z, bv[c2].z, acc, 0, 0, 0);
-                acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av[c2].w, bv[c2].w, acc, 0, 0, 0);
+        for (int u = 0; u < 4; ++u) fetch(u, fa[u], fb[u]);
+        for (int ks0 = 0; ks0 < ksteps; ks0 += 4) {
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                if (ks0 + u < ksteps) {
+#pragma unroll
+                    for (int c2 = 0; c2 < 4; ++c2) {
+                        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[u][c2].x, fb[u][c2].x, acc, 0, 0, 0);
+                        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[u][c2].y, fb[u][c2].y, acc, 0, 0, 0);
+                        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[u][c2].z, fb[u][c2].z, acc, 0, 0, 0);
+                        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[u][c2].w, fb[u][c2].w, acc, 0, 0, 0);
+                    }
+                }
+                fetch(ks0 + u + 4, fa[u], fb[u]);
             }
-#pragma unroll
-            for (int c2 = 0; c2 < 4; ++c2) { av[c2] = an[c2]; bv[c2] = bn[c2]; }
         }
         // row i of the tile sits in value 4 (i / 8) + i % 4 of the lanes whose half is (i / 4) % 2; every column
         // holds the same query, so lane (column i, that half) takes row i
