@@ -73,3 +73,20 @@ def test_bulk_loaders_keep_list_order():
     h = HybridIndex.from_dict(hd)
     assert h.size == 3 and h._row_ids == ["x", "y", "z"] and h._list_of_row[:3].tolist() == [1, 1, 0]
     np.testing.assert_array_equal(h._codes_arr[:3], np.array([[1, 2], [3, 0], [0, 0]], dtype=np.uint8))
+
+
+def test_flat_index_prefilter_argument():
+    """`prefilter` (no counterpart in the reference): validated at construction, kept by to_dict / from_dict;
+    nothing here touches the device."""
+    from vectordb_amd.index.flat import FlatIndex
+    ix = FlatIndex(8, metric="cosine", prefilter="bf16")
+    ix.add("a", np.arange(8, dtype=np.float32))
+    d = ix.to_dict()
+    assert d["config"]["prefilter"] == "bf16" and d["config"]["storage"] == "f32"
+    back = FlatIndex.from_dict(d)
+    assert back._prefilter == "bf16" and back.size == 1
+    assert FlatIndex.from_dict(FlatIndex(8).to_dict())._prefilter is None
+    with pytest.raises(ValueError):
+        FlatIndex(8, prefilter="fp8")
+    with pytest.raises(ValueError):
+        FlatIndex(8, storage="bf16", prefilter="bf16")
