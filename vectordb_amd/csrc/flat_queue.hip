@@ -568,9 +568,15 @@ __global__ __launch_bounds__(256) void prefilter_select_kernel(PrefilterSelectPa
     const float slack = p.slack[q];
     bool over = false;
 
-    // ---- pass 1: approximate keys (written back over the dot products), the k-th smallest of them
+    // ---- pass 1: approximate keys (written back over the dot products) and a value K that at least k rows of the
+    // queue do not exceed.  With enough lanes at work K is the k-th smallest of the lanes' own minima (different rows,
+    // so k rows lie at or below it; at most a row or two looser than the k-th smallest key, and one sort of 64 values
+    // instead of one merge per batch of entries); otherwise the k-th smallest key itself.
     WaveTopK approx;
     approx.init(p.k);
+    const bool by_lane_minima = min(p.n_slabs, 64) >= 2 * p.k;
+    float lane_min = INFINITY;
+    int lane_row = EMPTY_IDX;
     for (int s0 = 0; s0 < p.n_slabs; s0 += 64) {
         const int s = s0 + lane;
         int c = 0;
@@ -603,10 +609,15 @@ __global__ __launch_bounds__(256) void prefilter_select_kernel(PrefilterSelectPa
                           : (METRIC == VDB_COSINE) ? -(v[u].x / (q_term * rt[u]))
                                                    : __fmaf_rn(-2.0f, v[u].x, q_term + rt[u]);
                 if (have) e[j0 + u].x = key;
-                approx.offer(have, have ? key : INFINITY, __float_as_int(v[u].y), lane);
+                if (by_lane_minima) {
+                    if (have && key < lane_min) { lane_min = key; lane_row = __float_as_int(v[u].y); }
+                } else {
+                    approx.offer(have, have ? key : INFINITY, __float_as_int(v[u].y), lane);
+                }
             }
         }
     }
+    if (by_lane_minima) approx.offer(lane_min < INFINITY, lane_min, lane_row, lane);
     // the largest approximate key a row of the exact k best can have
     float limit = approx.thr;
     if (METRIC == VDB_DOT) {
