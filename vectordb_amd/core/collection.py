@@ -163,6 +163,11 @@ class Collection:
                  max_vectors: Optional[int] = None, enable_metadata_index: bool = True,
                  index_type: Optional[str] = None, index_params: Optional[Dict[str, Any]] = None, **index_kwargs):
         self.index_type = index_type.lower() if index_type else None
+        # `prefilter="bf16"` without an index type: the exact scan's batches (search_batch) run behind the bf16 filter
+        # pass of the row store, with the same results (not a reference argument)
+        self._prefilter = index_kwargs.pop("prefilter", None) if self.index_type is None else None
+        if self._prefilter not in (None, "bf16"):
+            raise ValueError(f"prefilter must be None or 'bf16', got {self._prefilter!r}")
         if self.index_type is None and (index_params or index_kwargs):
             raise TypeError("index parameters given without index_type")
         self._index_params = {**(index_params or {}), **index_kwargs}
@@ -318,6 +323,8 @@ class Collection:
         since the last search."""
         if self._store is None:
             self._store = N.RowStore(self.dimension)
+            if self._prefilter:
+                self._store.set_prefilter(self._prefilter)
             self._matrix_dirty = True
         if self._matrix_dirty:
             self._store.truncate(0)
