@@ -439,7 +439,8 @@ class Collection:
         out = {"name": self.name,
                "config": {"dimension": self.dimension, "metric": self.metric, "index_type": self.index_type or "flat",
                           "normalize_vectors": self.normalize, "max_vectors": self.max_vectors,
-                          "enable_metadata_index": self.enable_metadata_index, "index_params": dict(self._index_params)},
+                          "enable_metadata_index": self.enable_metadata_index, "index_params": dict(self._index_params),
+                          "prefilter": self._prefilter},
                "created_at": self._created_at, "updated_at": self._updated_at}
         if arrays:
             out["matrix"] = (np.stack([self._vectors[i] for i in ids]).astype(np.float32) if ids
@@ -462,6 +463,8 @@ class Collection:
                   enable_metadata_index=config.get("enable_metadata_index", True),
                   index_type=index_type if (index_type and index_type != "flat") else None,
                   index_params=params if (index_type and index_type != "flat") else None)
+        if col.index_type is None and config.get("prefilter"):
+            col._prefilter = config["prefilter"]
         records = data.get("vectors", [])
         if "matrix" in data:
             matrix = np.ascontiguousarray(data["matrix"], dtype=np.float32).reshape(len(records), config["dimension"])
