@@ -246,3 +246,16 @@ def test_prefilter_through_the_index_and_collection_classes(nat):
     assert [[(r.id, r.distance) for r in rs] for rs in a] == [[(r.id, r.distance) for r in rs] for rs in b]
     with pytest.raises(ValueError):
         Collection("c2", d, prefilter="fp8")
+
+
+def test_prefilter_more_than_one_block_of_queries(nat):
+    """1100 queries: the queue pass runs in blocks of 1024 queries, each with its own bounds, slack and fp32 queries."""
+    rng = np.random.default_rng(43)
+    n, d = N_MIN + 17, 32
+    x = rng.standard_normal((n, d), dtype=np.float32)
+    q = rng.standard_normal((1100, d), dtype=np.float32)
+    store = nat.RowStore(d)
+    store.append(x)
+    for metric in ("cosine", "euclidean"):
+        both_ways(nat, store, q, 10, metric)
+    store.close()
