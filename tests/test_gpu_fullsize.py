@@ -365,7 +365,7 @@ def test_flat_dot_c3_one_shard(nat, storage):
     store.close()
 
 
-@pytest.mark.parametrize("storage", ["f32", "bf16"])
+@pytest.mark.parametrize("storage", ["f32", "f32+filter", "bf16"])
 def test_flat_dot_c3_10m_eight_logical_shards(nat, storage):
     """All of configs[2] on one GPU: 10M x 768 rows held once as a single store and once as 8 row shards.  Every
     shard is searched as rank r of an 8-rank group would search it, its packed block goes where the all-gather
@@ -376,8 +376,12 @@ def test_flat_dot_c3_10m_eight_logical_shards(nat, storage):
     n, d, nq, k, shards = 10_000_000, 768, 1024, 10, 8
     dev = torch.device("cuda", 0)
     q = randn(nq, d, 321)
+    # "f32+filter": every store searches behind the bf16 filter pass; held to the fp32 checks below
+    prefilter = "bf16" if storage == "f32+filter" else None
+    if prefilter:
+        storage = "f32"
     qh = (_bf16_round_t(q) if storage == "bf16" else q).cpu().numpy()
-    single = HipFlatBackend(d, nat.DOT, storage=storage)
+    single = HipFlatBackend(d, nat.DOT, storage=storage, prefilter=prefilter)
     parts, backends, blocks = [], [], []
     full_scan_q = (0, 500, 1023)
     ref_scan = {qi: [] for qi in full_scan_q}
@@ -385,7 +389,7 @@ def test_flat_dot_c3_10m_eight_logical_shards(nat, storage):
         lo, hi = shard_range(n, shards, r)
         part = randn(hi - lo, d, 9000 + r)
         single.add_device(part)
-        be = HipFlatBackend(d, nat.DOT, storage=storage)
+        be = HipFlatBackend(d, nat.DOT, storage=storage, prefilter=prefilter)
         be.add_device(part)
         torch.cuda.synchronize()
         backends.append(be)
@@ -402,6 +406,7 @@ def test_flat_dot_c3_10m_eight_logical_shards(nat, storage):
     sd, sr = one.search(q, k)
     torch.cuda.synchronize()
     assert single.store.search_stats() == (True, False)
+    assert single.store.used_prefilter() == (prefilter is not None)
     sd_h, sr_h = sd.cpu().numpy(), sr.cpu().numpy()
     check_shape_properties(sd_h, sr_h, n)
 
