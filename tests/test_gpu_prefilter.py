@@ -259,3 +259,20 @@ def test_prefilter_more_than_one_block_of_queries(nat):
     for metric in ("cosine", "euclidean"):
         both_ways(nat, store, q, 10, metric)
     store.close()
+
+
+def test_prefilter_recovers_from_an_overwritten_outlier(nat):
+    """One row with a norm a million times the others makes the slack of dot searches useless (every row passes the
+    loosened bound, the queues fill up, the fp32 kernel repeats the batch); once it is overwritten the largest norm
+    is taken afresh and the filter pass works again.  Results equal the fp32 search either way."""
+    rng = np.random.default_rng(47)
+    n, d = N_MIN, 64
+    x = rng.standard_normal((n, d), dtype=np.float32)
+    x[123] *= 1e6
+    q = rng.standard_normal((16, d), dtype=np.float32)
+    store = nat.RowStore(d)
+    store.append(x)
+    both_ways(nat, store, q, 10, "dot", expect_overflow=True)
+    store.set_row(123, rng.standard_normal(d).astype(np.float32))
+    both_ways(nat, store, q, 10, "dot", expect_overflow=False)
+    store.close()

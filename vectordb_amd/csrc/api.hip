@@ -586,7 +586,9 @@ static int shadow_sync(vdb_rows* h, hipStream_t s) {
         hipLaunchKernelGGL(round_bf16_kernel, dim3(grid_for(c * ld16)), dim3(256), 0, s, r.data + h->shadow_n * r.ld, (int64_t)r.ld,
                            r.dim, c, h->shadow16.as<uint16_t>() + h->shadow_n * ld16, ld16, (float*)nullptr, 0);
         VDB_HIP(hipGetLastError());
-        VDB_TRY(launch_max_norm(r.nrm, h->shadow_n, r.n, h->max_nrm.as<float>(), s));
+        // the largest norm over all rows, taken afresh (4 bytes per row): an overwritten outlier stops loosening the slack
+        VDB_HIP(hipMemsetAsync(h->max_nrm.p, 0, sizeof(float), s));
+        VDB_TRY(launch_max_norm(r.nrm, 0, r.n, h->max_nrm.as<float>(), s));
         h->shadow_n = r.n;
     }
     return VDB_OK;
