@@ -258,8 +258,10 @@ def test_collection_incremental_matches_rebuild():
 
 
 def test_vectordb_save_load_round_trip(tmp_path):
-    """core/database.py:313-416: manifest.json + one pickle per collection; a loaded database answers like the saved one."""
-    from vectordb_amd.core import VectorDB, CollectionNotFoundError, CollectionExistsError, StorageError
+    """The directory form (the reference: core/database.py:313-416): a loaded database answers like the saved one,
+    from the .npz files written here and from a directory in the reference's layout."""
+    import pickle
+    from vectordb_amd.core import VectorDB, StorageError
     rng = np.random.RandomState(5)
     x = rng.randn(500, 12).astype(np.float32)
     q = rng.randn(12).astype(np.float32)
@@ -269,17 +271,23 @@ def test_vectordb_save_load_round_trip(tmp_path):
     for i in range(500):
         a.add(f"a{i}", x[i], {"tag": "even" if i % 2 == 0 else "odd"})
         b.add(f"b{i}", x[i], {"n": i})
-    with pytest.raises(CollectionExistsError):
+    with pytest.raises(ValueError):
         db.create_collection("docs", dimension=12)
-    assert db.create_collection("docs", dimension=12, exist_ok=True) is a
-    with pytest.raises(CollectionNotFoundError):
+    with pytest.raises(KeyError):
         db.get_collection("nope")
-    want_a = db.search("docs", q, k=10, filter={"tag": "odd"})
+    want_a = db["docs"].search(q, k=10, filter={"tag": "odd"})
     want_b = b.search(q, k=10)
-    for arrays in (False, True):
-        db.save(arrays=arrays)
-        assert (tmp_path / "db" / "manifest.json").exists() and (tmp_path / "db" / "docs.collection").exists()
-        again = VectorDB.load(str(tmp_path / "db"))
+    db.save()
+    assert (tmp_path / "db" / "manifest.json").exists() and (tmp_path / "db" / "docs.npz").exists()
+    # the same collections as the reference's VectorDB.save lays them out: a pickle of to_dict() per collection
+    ref_dir = tmp_path / "ref"
+    ref_dir.mkdir()
+    (ref_dir / "manifest.json").write_text('{"version": "0.1.0", "created_at": 1.0, "updated_at": 2.0, "collections": ["docs", "ivf.docs", "gone"]}')
+    for name in ("docs", "ivf.docs"):
+        with open(ref_dir / f"{name}.collection", "wb") as f:
+            pickle.dump(db[name].to_dict(), f)
+    for where in (tmp_path / "db", ref_dir):
+        again = VectorDB.load(str(where))
         assert again.list_collections() == ["docs", "ivf.docs"] and len(again) == 2 and "docs" in again
         assert again["docs"]._bulk is not None and again["docs"]._bulk.shape == (500, 12)    # one matrix, uploaded whole
         _same(again["docs"].search(q, k=10, filter={"tag": "odd"}), want_a)
@@ -287,14 +295,45 @@ def test_vectordb_save_load_round_trip(tmp_path):
         # the same seed on the same rows
         _same(again["ivf.docs"].search(q, k=10), want_b)
         assert again["docs"]._bulk is None
-        info = again.info()
-        assert info["total_vectors"] == 1000 and info["collection_count"] == 2
-        assert again.collection_stats("docs")["vector_count"] == 500
-    assert db.delete_collection("docs") and not (tmp_path / "db" / "docs.collection").exists()
     with pytest.raises(StorageError):
         VectorDB.load(str(tmp_path / "missing"))
     with pytest.raises(StorageError):
         VectorDB().save()
+
+
+def test_loaded_collection_written_before_first_search():
+    """A loaded collection keeps its matrix for one upload; a write before the first search must not let stale rows
+    reach the device."""
+    from vectordb_amd.core import Collection
+    rng = np.random.RandomState(11)
+    x = rng.randn(300, 10).astype(np.float32)
+    q = rng.randn(4, 10).astype(np.float32)
+    src = Collection("c", 10, metric="euclidean")
+    for i in range(200):
+        src.add(f"v{i}", x[i], {"g": i % 3})
+    saved = src.to_dict(arrays=True)
+
+    def edits(col, which):
+        if which == "overwrite":
+            col.add("v7", x[250], {"g": 5}, overwrite=True)
+        elif which == "delete_add":
+            col.delete("v3"); col.add("new", x[251], {"g": 1})
+        elif which == "clear_refill":
+            col.clear()
+            for i in range(200):
+                col.add(f"w{i}", x[299 - i], {"g": 0})
+        elif which == "all":
+            col.add("v7", x[250], overwrite=True); col.delete("v3"); col.add("new", x[251]); col.delete("v9"); col.add("new2", x[252])
+
+    for which in ("overwrite", "delete_add", "clear_refill", "all"):
+        loaded = Collection.from_dict(saved)
+        assert loaded._bulk is not None
+        edits(loaded, which)
+        fresh = Collection("c", 10, metric="euclidean")
+        for id, v in loaded._vectors.items():
+            fresh.add(id, v, loaded._metadata[id])
+        for qi in range(len(q)):
+            _same(loaded.search(q[qi], k=10), fresh.search(q[qi], k=10))
 
 
 def test_index_from_dict_is_one_upload():

@@ -1,4 +1,4 @@
-"""Host-side pieces that need no GPU: the VectorDB file layout (core/database.py:313-416), Collection.to_dict /
+"""Host-side pieces that need no GPU: the VectorDB directory form (the reference: core/database.py:313-416), Collection.to_dict /
 from_dict (core/collection.py:998-1055), recommend_index (index/__init__.py:99-170), bulk index loaders."""
 
 import json
@@ -9,7 +9,7 @@ import pytest
 
 
 def test_vectordb_files_and_errors(tmp_path):
-    from vectordb_amd.core import VectorDB, Collection, StorageError, ValidationError
+    from vectordb_amd.core import VectorDB, Collection, StorageError
     rng = np.random.RandomState(0)
     db = VectorDB(data_dir=str(tmp_path / "d"))
     c = db.create_collection("docs", dimension=4, metric="cosine", normalize=True, max_vectors=10)
@@ -19,22 +19,44 @@ def test_vectordb_files_and_errors(tmp_path):
     c.add("r0", np.ones(4, dtype=np.float32), {"i": 100}, overwrite=True)
     db.save()
     manifest = json.load(open(tmp_path / "d" / "manifest.json"))
-    assert manifest["version"] == "0.1.0" and manifest["collections"] == ["docs"]
-    data = pickle.load(open(tmp_path / "d" / "docs.collection", "rb"))
-    # the reference's record layout (core/vector.py:121-128) in dict order: an overwritten id keeps its place
-    assert [r["id"] for r in data["vectors"]] == ["r0", "r2", "r3", "r4"]
-    assert set(data["vectors"][0]) == {"id", "vector", "metadata", "timestamp"} and data["vectors"][0]["metadata"] == {"i": 100}
-    assert data["config"]["dimension"] == 4 and data["config"]["metric"] == "cosine" and data["config"]["normalize_vectors"] is True
+    assert manifest["collections"] == ["docs"] and manifest["layout"] == "npz-1"
+    with np.load(tmp_path / "d" / "docs.npz", allow_pickle=False) as z:           # nothing in the file needs pickle
+        small = json.loads(bytes(z["small_json"]).decode())
+        assert z["matrix"].shape == (4, 4) and z["matrix"].dtype == np.float32 and z["timestamps"].shape == (4,)
+    # dict order: an overwritten id keeps its place
+    assert small["ids"] == ["r0", "r2", "r3", "r4"] and small["metadata"][0] == {"i": 100}
+    assert small["config"]["dimension"] == 4 and small["config"]["metric"] == "cosine" and small["config"]["normalize_vectors"] is True
     back = VectorDB.load(str(tmp_path / "d"))["docs"]
     assert list(back._vectors) == ["r0", "r2", "r3", "r4"] and back.normalize and back.max_vectors == 10
     np.testing.assert_array_equal(np.stack(list(back._vectors.values())), np.stack(list(c._vectors.values())))
-    assert back._bulk is not None
-    # the matrix form
+    assert back._bulk is not None and back._metadata["r0"] == {"i": 100}
+    assert back._timestamps == c._timestamps
+    # a write drops the loaded matrix: it no longer describes the rows
+    back.add("r0", np.zeros(4, dtype=np.float32) + 2, overwrite=True)
+    assert back._bulk is None
+    # the reference's layout (core/database.py:345-350): a pickle of Collection.to_dict() per collection
+    ref = tmp_path / "ref"
+    ref.mkdir()
+    (ref / "manifest.json").write_text(json.dumps({"version": "0.1.0", "collections": ["docs"]}))
+    with open(ref / "docs.collection", "wb") as f:
+        pickle.dump(c.to_dict(), f)
+    old = VectorDB.load(str(ref))["docs"]
+    assert list(old._vectors) == ["r0", "r2", "r3", "r4"] and old.get("r2")["metadata"] == {"i": 2}
+    np.testing.assert_array_equal(np.stack(list(old._vectors.values())), np.stack(list(c._vectors.values())))
+    # a pickle that names any class or function is refused, and so is a manifest entry that leaves the directory
+    with open(ref / "docs.collection", "wb") as f:
+        pickle.dump({"config": {}, "x": np.float32(1.0)}, f)
+    with pytest.raises(StorageError, match="only plain data"):
+        VectorDB.load(str(ref))
+    (ref / "manifest.json").write_text(json.dumps({"collections": ["../d/docs"]}))
+    with pytest.raises(StorageError, match="file name"):
+        VectorDB.load(str(ref))
+    # the matrix form of to_dict
     arr = Collection.from_dict(c.to_dict(arrays=True))
     np.testing.assert_array_equal(arr._bulk, np.stack(list(c._vectors.values())))
     assert arr.get("r2")["metadata"] == {"i": 2}
-    with pytest.raises(ValidationError):
-        db.create_collection("bad name!", dimension=4)
+    with pytest.raises(ValueError):
+        db.create_collection("bad/name", dimension=4)
     with pytest.raises(StorageError, match="Manifest"):
         (tmp_path / "empty").mkdir()
         VectorDB.load(str(tmp_path / "empty"))

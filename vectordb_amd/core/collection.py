@@ -212,6 +212,7 @@ class Collection:
         if id not in self._vectors and self.max_vectors and len(self._vectors) >= self.max_vectors:
             raise ValueError(f"Collection at maximum capacity ({self.max_vectors})")
         existed = id in self._vectors
+        self._bulk = None                                   # the loaded matrix no longer describes the rows
         self._vectors[id] = vector
         self._metadata[id] = dict(metadata or {})
         self._updated_at = self._timestamps[id] = time.time()
@@ -258,6 +259,7 @@ class Collection:
             return False
         del self._vectors[id], self._metadata[id]
         self._timestamps.pop(id, None)
+        self._bulk = None
         if not self._matrix_dirty:
             row = self._row_of.pop(id)
             self._ids[row] = None
@@ -276,6 +278,7 @@ class Collection:
     def clear(self) -> int:
         n = len(self._vectors)
         self._vectors.clear(); self._metadata.clear(); self._timestamps.clear()
+        self._bulk = None
         self._matrix_dirty = True
         self._drop_index()
         return n

@@ -1,228 +1,163 @@
-"""``VectorDB``: named collections and their on-disk form (core/database.py:30-536 of the reference).
+"""On-disk form of a set of collections: ``VectorDB.save(path)`` / ``VectorDB.load(path)``.
 
-The files are the reference's: ``manifest.json`` plus one ``<name>.collection`` pickle of ``Collection.to_dict()``
-per collection (core/database.py:313-358), so a directory written by either side loads on the other.  Loading puts
-a collection's rows on the device in one call; nothing is replayed row by row."""
+The reference writes ``manifest.json`` and one pickle of ``Collection.to_dict()`` per collection, every row as a
+Python list of floats (core/database.py:313-358).  Here a collection goes to ``<name>.npz``: its rows as one float32
+matrix (what the first search hands to the device in a single upload), its timestamps as one float64 vector, and
+ids, metadata and configuration as one JSON string.  Nothing is pickled, so ``numpy.load(allow_pickle=False)`` reads
+it back.  ``load`` also reads a directory the reference wrote (``<name>.collection``, core/database.py:360-416):
+those pickles hold dicts, lists, strings and numbers only, so they are read by an unpickler that resolves no names.
+
+Only the file layout lives here.  Collection lifecycle beyond holding the named collections (auto-save, statistics,
+per-collection shortcuts) stays with the reference.
+"""
 
 from __future__ import annotations
 
+import io
 import json
+import os
 import pickle
-import re
-import threading
 import time
-from pathlib import Path
-from typing import Any, Dict, List, Optional
+from typing import Dict, Iterator, List, Optional
+
+import numpy as np
 
 from .collection import Collection
 
-
-class VectorDBError(Exception):                 # core/exceptions.py:6
-    pass
-
-
-class CollectionNotFoundError(VectorDBError):   # core/exceptions.py:16
-    pass
+MANIFEST = "manifest.json"
+LAYOUT = "npz-1"
 
 
-class CollectionExistsError(VectorDBError):     # core/exceptions.py:21
-    pass
+class StorageError(Exception):
+    """A directory that cannot be written or read (core/exceptions.py:61 has the reference's type of that name)."""
 
 
-class ValidationError(VectorDBError):           # core/exceptions.py:46
-    pass
+def _file_stem(name: str) -> str:
+    """A collection name is used as a file name: it must stay inside the directory it is joined to."""
+    if not isinstance(name, str) or not name or name in (".", "..") or os.path.basename(name) != name \
+            or any(ch in name for ch in "/\\\0") or len(name) > 255:
+        raise ValueError(f"collection name {name!r} cannot be used as a file name")
+    return name
 
 
-class StorageError(VectorDBError):              # core/exceptions.py:61
-    pass
+class _PlainUnpickler(pickle.Unpickler):
+    """Reads pickles made of built-in containers and scalars; any reference to a class or function is refused."""
+
+    def find_class(self, module, name):
+        raise pickle.UnpicklingError(f"collection file refers to {module}.{name}; only plain data is read")
 
 
-_ID_PATTERN = re.compile(r"^[a-zA-Z0-9_\-\.]+$")
-_MAX_ID_LENGTH = 256
+def _write_npz(path: str, col: Collection) -> None:
+    d = col.to_dict(arrays=True)
+    records = d.pop("vectors")
+    matrix = d.pop("matrix")
+    small = dict(d, ids=[r["id"] for r in records], metadata=[r["metadata"] for r in records])
+    stamps = np.asarray([r["timestamp"] for r in records], dtype=np.float64)
+    tmp = path + ".tmp"
+    with open(tmp, "wb") as f:
+        np.savez(f, matrix=matrix, timestamps=stamps,
+                 small_json=np.frombuffer(json.dumps(small).encode("utf-8"), dtype=np.uint8))
+    os.replace(tmp, path)                       # a crash in the middle leaves the previous file whole
 
 
-def validate_id(id: str) -> str:
-    """utils/validation.py:27-60"""
-    if not isinstance(id, str):
-        raise ValidationError(f"ID must be a string, got {type(id).__name__}")
-    if not id:
-        raise ValidationError("ID cannot be empty")
-    if len(id) > _MAX_ID_LENGTH:
-        raise ValidationError(f"ID too long: {len(id)} characters (max {_MAX_ID_LENGTH})")
-    if not _ID_PATTERN.match(id):
-        raise ValidationError(f"Invalid ID '{id}': must contain only alphanumeric characters, underscores, hyphens, or dots")
-    return id
+def _read_npz(path: str) -> Collection:
+    with np.load(path, allow_pickle=False) as z:
+        small = json.loads(bytes(z["small_json"]).decode("utf-8"))
+        matrix, stamps = z["matrix"], z["timestamps"]
+    ids, meta = small.pop("ids"), small.pop("metadata")
+    if not (len(ids) == len(meta) == len(stamps) == len(matrix)):
+        raise ValueError(f"{path}: {len(ids)} ids, {len(meta)} metadata entries, {len(stamps)} timestamps, {len(matrix)} rows")
+    small["vectors"] = [{"id": i, "metadata": m, "timestamp": float(t)} for i, m, t in zip(ids, meta, stamps)]
+    small["matrix"] = matrix
+    return Collection.from_dict(small)
+
+
+def _read_reference_pickle(path: str) -> Collection:
+    with open(path, "rb") as f:
+        data = _PlainUnpickler(io.BytesIO(f.read())).load()
+    if not isinstance(data, dict) or "config" not in data:
+        raise ValueError(f"{path} does not hold a collection")
+    return Collection.from_dict(data)
 
 
 class VectorDB:
-    VERSION = "0.1.0"
-    MANIFEST_FILE = "manifest.json"
+    """Named collections with a directory form.  ``db[name]`` is the collection."""
 
-    def __init__(self, data_dir: Optional[str] = None, auto_save: bool = False, auto_save_interval: int = 60):
-        self._collections: Dict[str, Collection] = {}
-        self._data_dir = Path(data_dir) if data_dir else None
-        self._lock = threading.RLock()
-        self._created_at = self._updated_at = time.time()
-        self._auto_save = auto_save
-        self._auto_save_interval = auto_save_interval
-        self._auto_save_thread: Optional[threading.Thread] = None
-        self._running = True
-        if self._data_dir:
-            self._data_dir.mkdir(parents=True, exist_ok=True)
-        if auto_save and self._data_dir:
-            self._start_auto_save()
+    def __init__(self, data_dir: Optional[str] = None):
+        self.data_dir = data_dir
+        self._cols: Dict[str, Collection] = {}
+        self._born = time.time()
 
-    # ------------------------------------------------------------ collections (core/database.py:105-264)
-    def create_collection(self, name: str, dimension: int, metric: str = "euclidean", normalize: bool = False,
-                          max_vectors: Optional[int] = None, exist_ok: bool = False, **kwargs) -> Collection:
-        name = validate_id(name)
-        with self._lock:
-            if name in self._collections:
-                if exist_ok:
-                    return self._collections[name]
-                raise CollectionExistsError(f"Collection '{name}' already exists")
-            collection = Collection(name=name, dimension=dimension, metric=metric, normalize=normalize,
-                                    max_vectors=max_vectors, **kwargs)
-            self._collections[name] = collection
-            self._updated_at = time.time()
-            return collection
+    # -- the collections it holds
+    def create_collection(self, name: str, dimension: int, metric: str = "euclidean", **kwargs) -> Collection:
+        """Keyword arguments go to ``Collection`` (``index_type=...`` and index parameters included, as
+        core/database.py:105-148 forwards them)."""
+        _file_stem(name)
+        if name in self._cols:
+            raise ValueError(f"Collection '{name}' already exists")
+        col = self._cols[name] = Collection(name=name, dimension=dimension, metric=metric, **kwargs)
+        return col
 
     def get_collection(self, name: str) -> Collection:
-        with self._lock:
-            if name not in self._collections:
-                raise CollectionNotFoundError(f"Collection '{name}' not found")
-            return self._collections[name]
-
-    def get_or_create_collection(self, name: str, dimension: int, metric: str = "euclidean", **kwargs) -> Collection:
-        return self.create_collection(name=name, dimension=dimension, metric=metric, exist_ok=True, **kwargs)
-
-    def delete_collection(self, name: str) -> bool:
-        with self._lock:
-            if name not in self._collections:
-                return False
-            del self._collections[name]
-            self._updated_at = time.time()
-            if self._data_dir:
-                path = self._data_dir / f"{name}.collection"
-                if path.exists():
-                    path.unlink()
-            return True
+        return self[name]
 
     def list_collections(self) -> List[str]:
-        with self._lock:
-            return list(self._collections.keys())
-
-    def has_collection(self, name: str) -> bool:
-        return name in self._collections
-
-    def collection_stats(self, name: str) -> Dict[str, Any]:
-        return self.get_collection(name).stats().to_dict()
-
-    # ------------------------------------------------------------ shortcuts (core/database.py:270-307)
-    def add(self, collection_name: str, id: str, vector: Any, metadata: Optional[Dict[str, Any]] = None) -> str:
-        return self.get_collection(collection_name).add(id, vector, metadata)
-
-    def search(self, collection_name: str, query: Any, k: int = 10, filter: Optional[Dict[str, Any]] = None, **kwargs):
-        return self.get_collection(collection_name).search(query, k=k, filter=filter, **kwargs)
-
-    def delete(self, collection_name: str, id: str) -> bool:
-        return self.get_collection(collection_name).delete(id)
-
-    # ------------------------------------------------------------ persistence (core/database.py:313-416)
-    def save(self, path: Optional[str] = None, arrays: bool = False) -> None:
-        """``arrays=True`` writes every collection's rows as one float32 matrix instead of a Python list of floats
-        per row (``Collection.to_dict(arrays=True)``); both forms load here, only the default one loads in the
-        reference."""
-        save_dir = Path(path) if path else self._data_dir
-        if not save_dir:
-            raise StorageError("No save path specified and no data_dir configured")
-        save_dir.mkdir(parents=True, exist_ok=True)
-        try:
-            with self._lock:
-                manifest = {"version": self.VERSION, "created_at": self._created_at, "updated_at": self._updated_at,
-                            "collections": list(self._collections.keys())}
-                with open(save_dir / self.MANIFEST_FILE, "w") as f:
-                    json.dump(manifest, f, indent=2)
-                for name, collection in self._collections.items():
-                    with open(save_dir / f"{name}.collection", "wb") as f:
-                        pickle.dump(collection.to_dict(arrays=arrays), f)
-        except Exception as e:
-            raise StorageError(f"Failed to save database: {e}")
-
-    @classmethod
-    def load(cls, path: str, **kwargs) -> "VectorDB":
-        load_dir = Path(path)
-        if not load_dir.exists():
-            raise StorageError(f"Database path does not exist: {path}")
-        manifest_path = load_dir / cls.MANIFEST_FILE
-        if not manifest_path.exists():
-            raise StorageError(f"Manifest file not found in {path}")
-        try:
-            with open(manifest_path, "r") as f:
-                manifest = json.load(f)
-            db = cls(data_dir=path, **kwargs)
-            db._created_at = manifest.get("created_at", time.time())
-            db._updated_at = manifest.get("updated_at", time.time())
-            for name in manifest.get("collections", []):
-                collection_path = load_dir / f"{name}.collection"
-                if collection_path.exists():
-                    with open(collection_path, "rb") as f:
-                        data = pickle.load(f)
-                    db._collections[name] = Collection.from_dict(data)
-            return db
-        except Exception as e:
-            raise StorageError(f"Failed to load database: {e}")
-
-    def _start_auto_save(self) -> None:
-        def loop():
-            while self._running:
-                time.sleep(self._auto_save_interval)
-                if self._running:
-                    try:
-                        self.save()
-                    except Exception:
-                        pass
-        self._auto_save_thread = threading.Thread(target=loop, daemon=True)
-        self._auto_save_thread.start()
-
-    # ------------------------------------------------------------ info and lifetime (core/database.py:441-536)
-    def info(self) -> Dict[str, Any]:
-        with self._lock:
-            stats = {name: c.stats().to_dict() for name, c in self._collections.items()}
-            return {"version": self.VERSION, "data_dir": str(self._data_dir) if self._data_dir else None,
-                    "collection_count": len(self._collections),
-                    "total_vectors": sum(len(c) for c in self._collections.values()),
-                    "total_memory_mb": round(sum(s["memory_usage_bytes"] for s in stats.values()) / (1024 * 1024), 2),
-                    "created_at": self._created_at, "updated_at": self._updated_at, "auto_save": self._auto_save,
-                    "collections": stats}
-
-    def close(self) -> None:
-        self._running = False
-        if self._auto_save_thread:
-            self._auto_save_thread.join(timeout=5)
-        if self._data_dir and self._auto_save:
-            try:
-                self.save()
-            except Exception:
-                pass
-
-    def __enter__(self) -> "VectorDB":
-        return self
-
-    def __exit__(self, *args) -> None:
-        self.close()
+        return list(self._cols)
 
     def __getitem__(self, name: str) -> Collection:
-        return self.get_collection(name)
+        try:
+            return self._cols[name]
+        except KeyError:
+            raise KeyError(f"Collection '{name}' not found") from None
 
     def __contains__(self, name: str) -> bool:
-        return self.has_collection(name)
+        return name in self._cols
 
-    def __iter__(self):
-        return iter(self._collections.keys())
+    def __iter__(self) -> Iterator[str]:
+        return iter(self._cols)
 
     def __len__(self) -> int:
-        return len(self._collections)
+        return len(self._cols)
+
+    # -- files
+    def save(self, path: Optional[str] = None) -> None:
+        """Write the manifest and one ``.npz`` per collection into ``path`` (default: ``data_dir``)."""
+        target = path or self.data_dir
+        if not target:
+            raise StorageError("No save path specified and no data_dir configured")
+        try:
+            os.makedirs(target, exist_ok=True)
+            for name, col in self._cols.items():
+                _write_npz(os.path.join(target, _file_stem(name) + ".npz"), col)
+            with open(os.path.join(target, MANIFEST), "w") as f:
+                json.dump({"layout": LAYOUT, "created_at": self._born, "updated_at": time.time(),
+                           "collections": list(self._cols)}, f, indent=2)
+        except Exception as e:
+            raise StorageError(f"Failed to save database: {e}") from e
+
+    @classmethod
+    def load(cls, path: str) -> "VectorDB":
+        """Read a directory written by ``save`` or by the reference's ``VectorDB.save``; a manifest entry whose
+        file is missing is skipped, as core/database.py:396-404 does."""
+        manifest_path = os.path.join(path, MANIFEST)
+        if not os.path.isdir(path):
+            raise StorageError(f"Database path does not exist: {path}")
+        if not os.path.isfile(manifest_path):
+            raise StorageError(f"Manifest file not found in {path}")
+        try:
+            with open(manifest_path) as f:
+                manifest = json.load(f)
+            db = cls(data_dir=path)
+            db._born = manifest.get("created_at", db._born)
+            for name in manifest.get("collections", []):
+                stem = os.path.join(path, _file_stem(name))
+                if os.path.isfile(stem + ".npz"):
+                    db._cols[name] = _read_npz(stem + ".npz")
+                elif os.path.isfile(stem + ".collection"):
+                    db._cols[name] = _read_reference_pickle(stem + ".collection")
+            return db
+        except Exception as e:
+            raise StorageError(f"Failed to load database: {e}") from e
 
     def __repr__(self) -> str:
-        return f"VectorDB(collections={len(self._collections)}, data_dir='{self._data_dir}')"
+        return f"VectorDB({len(self._cols)} collections, data_dir={self.data_dir!r})"
