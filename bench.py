@@ -186,7 +186,7 @@ def main() -> None:
     gen.manual_seed(123)
     queries = torch.randn((nq, d), device=dev, dtype=torch.float32, generator=gen)
 
-    backend = HipFlatBackend(d, _native.COSINE)
+    backend = HipFlatBackend(d, _native.COSINE, prefilter=None)      # the fp32 kernels alone: the headline
     fill_store(backend, lo, hi, d, 42, dev, gen)
     index = ShardedFlat(backend, n_total, rank, world)
 

@@ -98,6 +98,20 @@ int vdb_measure_ceilings(float* copy_gbs, float* mfma_f32_tflops, float* mfma_bf
 int vdb_profile_enable(int on);
 int vdb_profile_read(float* kernel_ms, int* launches);
 
+/* ---- resident filter masks ----------------------------------------------
+ * The reference evaluates filter_fn(id, metadata) for every row inside every filtered search
+ * (index/base.py:125; index/flat.py:396-413, index/ivf.py:622, index/pq.py:287-297) and rebuilds the id
+ * set of a metadata filter per call (core/collection.py:724).  Here a filter is evaluated once per write
+ * version of an index, packed (bit i = row i passes) and kept in HBM as a vdb_mask; the *_search_masked
+ * entry points name it instead of uploading the words again.  `words` holds (n_bits + 31) / 32 little-endian
+ * words; vdb_mask_create returns when the copy is on the device.  A mask may be shorter-lived than the
+ * index but must cover at least the index's rows when a search names it (VDB_ERR_INVALID otherwise).
+ * vdb_mask_info returns the bit count and the device address of the words, for the *_dev entry points. */
+typedef struct vdb_mask vdb_mask;
+int vdb_mask_create(vdb_mask** out, const uint32_t* words, int64_t n_bits);
+int vdb_mask_destroy(vdb_mask* m);
+int vdb_mask_info(const vdb_mask* m, int64_t* n_bits, const uint32_t** d_words);
+
 /* ---- resident fp32 row matrix (FlatIndex storage, Collection matrix) ---
  * index/flat.py:136-141,261,276-282 (growable fp32 matrix) and
  * core/collection.py:809-828 (_ensure_matrix).  Appending also computes and
@@ -133,9 +147,11 @@ int vdb_rows_set_cosine_eps(vdb_rows* h, float eps);
  * and their order are bit for bit those of VDB_PREFILTER_NONE (tests/test_gpu_prefilter.py).  Applies to batches
  * of at least 4 queries over at least 65536 rows with k <= 32, any dimension (the copy's rows are padded to whole
  * 128-byte steps); other calls, vdb_flat_search_static_dev and values whose products could overflow take the fp32
- * kernels.  The environment variable VDB_PREFILTER=1 makes it the
- * default of new fp32 handles. */
-enum vdb_prefilter { VDB_PREFILTER_NONE = 0, VDB_PREFILTER_BF16 = 1 };
+ * kernels.  VDB_PREFILTER_AUTO is the same with a condition: the copy is
+ * taken (and grown) only while that leaves a tenth of the device memory, at least 2 GiB, free; a search that finds no
+ * room runs on the fp32 kernels alone, with the same results.  The environment variable VDB_PREFILTER=1 makes
+ * VDB_PREFILTER_BF16 the default of new fp32 handles. */
+enum vdb_prefilter { VDB_PREFILTER_NONE = 0, VDB_PREFILTER_BF16 = 1, VDB_PREFILTER_AUTO = 2 };
 int vdb_rows_set_prefilter(vdb_rows* h, int mode);
 
 /* FlatIndex.search / search_batch (index/flat.py:288-460), the search part of
@@ -146,6 +162,9 @@ int vdb_flat_search(vdb_rows* h, int metric, const float* queries, int nq, int k
                     const uint32_t* mask, float* out_dist, int64_t* out_row);
 int vdb_flat_search_dev(vdb_rows* h, int metric, const float* d_queries, int nq, int k,
                         const uint32_t* d_mask, float* d_out_dist, int64_t* d_out_row, void* stream);
+/* vdb_flat_search with a resident mask (index/flat.py:386-431 _search_with_filter) */
+int vdb_flat_search_masked(vdb_rows* h, int metric, const float* queries, int nq, int k,
+                           const vdb_mask* mask, float* out_dist, int64_t* out_row);
 
 /* vdb_flat_search_dev for callers that cannot allocate: code under HIP graph capture, tight serving
  * loops, harnesses that forbid hipMalloc.  No counterpart in the reference.  Same arguments, same
@@ -271,6 +290,9 @@ int vdb_ivf_search(vdb_ivf* h, const float* queries, int nq, int k, int n_probe,
                    const uint32_t* mask, float* out_dist, int64_t* out_row);
 int vdb_ivf_search_dev(vdb_ivf* h, const float* d_queries, int nq, int k, int n_probe,
                        const uint32_t* d_mask, float* d_out_dist, int64_t* d_out_row, void* stream);
+/* vdb_ivf_search with a resident mask (index/ivf.py:619-628, the filter_fn test inside the list scan) */
+int vdb_ivf_search_masked(vdb_ivf* h, const float* queries, int nq, int k, int n_probe,
+                          const vdb_mask* mask, float* out_dist, int64_t* out_row);
 /* The same search, plus for every result its place in the reference's visiting
  * order (ivf.py:619-628): order = probe rank << 32 | position in the list, -1 for
  * an unfilled slot.  Equal distances are ordered by it; a shard that holds only
@@ -305,6 +327,9 @@ int vdb_pq_search(vdb_pq* h, const float* queries, int nq, int k,
                   const uint32_t* mask, float* out_dist, int64_t* out_row);
 int vdb_pq_search_dev(vdb_pq* h, const float* d_queries, int nq, int k,
                       const uint32_t* d_mask, float* d_out_dist, int64_t* d_out_row, void* stream);
+/* vdb_pq_search with a resident mask (index/pq.py:287-297, the filter_fn test inside the ADC scan) */
+int vdb_pq_search_masked(vdb_pq* h, const float* queries, int nq, int k,
+                         const vdb_mask* mask, float* out_dist, int64_t* out_row);
 
 /* ---- IVF-PQ (HybridIndex, index/hybrid.py:41-536) ----------------------------
  * Coarse k-means centroids + a PQ codebook trained on residuals.  Rows live as
@@ -333,6 +358,9 @@ int vdb_ivfpq_search(vdb_ivfpq* h, const float* queries, int nq, int k, int n_pr
                      const uint32_t* mask, float* out_dist, int64_t* out_row);
 int vdb_ivfpq_search_dev(vdb_ivfpq* h, const float* d_queries, int nq, int k, int n_probe,
                          const uint32_t* d_mask, float* d_out_dist, int64_t* d_out_row, void* stream);
+/* vdb_ivfpq_search with a resident mask (index/hybrid.py:303-329, the filter_fn test inside the scan) */
+int vdb_ivfpq_search_masked(vdb_ivfpq* h, const float* queries, int nq, int k, int n_probe,
+                            const vdb_mask* mask, float* out_dist, int64_t* out_row);
 
 /* ---- cross-shard merge ------------------------------------------------------
  * No counterpart in the reference (it is single-process).  After an
@@ -354,6 +382,12 @@ int vdb_topk_merge_strided_dev(const float* d_dist, const int64_t* d_row, int64_
  * IVF shards, key = the visiting order of vdb_ivf_search_ordered_dev. */
 int vdb_topk_merge_keyed_dev(const float* d_dist, const int64_t* d_key, const int64_t* d_row, int n_lists, int nq, int k,
                              float* d_out_dist, int64_t* d_out_row, void* stream);
+/* The same over lists that lie list_stride_dist floats / list_stride_key_row int64 apart (keys and rows share
+ * one stride): the blocks of ONE packed all-gather, [nq*k distances | pad to 8 bytes | nq*k keys | nq*k rows] per
+ * rank, are merged where they arrived.  No counterpart in the reference (nothing there shards). */
+int vdb_topk_merge_keyed_strided_dev(const float* d_dist, const int64_t* d_key, const int64_t* d_row,
+                                     int64_t list_stride_dist, int64_t list_stride_key_row, int n_lists, int nq, int k,
+                                     float* d_out_dist, int64_t* d_out_row, void* stream);
 
 #ifdef __cplusplus
 }

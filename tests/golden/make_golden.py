@@ -443,3 +443,4 @@ if __name__ == "__main__":
     gen_ivf()
     gen_pq()
     gen_hybrid()
+    gen_round2()

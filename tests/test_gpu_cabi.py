@@ -582,6 +582,18 @@ def test_sharded_ivf_lists_equal_single_index(nat, shards):
     members = [np.flatnonzero(assign == l).astype(np.int64) for l in range(len(cent))]
     ref_r, ref_d = R.ivf_search(q[0], x, cent, members, k, n_probe, "euclidean")
     np.testing.assert_array_equal(sr[0], ref_r)
+    # the packed form of one all-gather: every shard's (distances | visiting orders | rows) block side by side,
+    # merged where the blocks lie
+    sh = ShardedIVF(backends[0], 0, shards)
+    _local, gathered, _ld, _lo, _lr, pd, po, pr, pod, porow = sh._buffers(len(q), k, dev)
+    gathered.fill_(0xEE)
+    for r, be in enumerate(backends):
+        be.local_search(tq, k, n_probe, pd[r], pr[r], po[r])
+    backends[0].merge(pd, po, pr, k, pod, porow)
+    torch.cuda.synchronize()
+    np.testing.assert_array_equal(porow.cpu().numpy(), sr)
+    np.testing.assert_array_equal(pod.cpu().numpy(), sd)
+    assert sh._buffers(len(q), k, dev)[1] is gathered                     # made once, reused
     # ShardedIVF with one shard is the plain index
     d1, r1 = ShardedIVF(backends[0], 0, 1).search(tq, k, n_probe)
     assert d1.shape == (len(q), k)

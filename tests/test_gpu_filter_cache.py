@@ -1,0 +1,173 @@
+"""A filter is evaluated once per write version of an index and stays on the device as a packed mask.
+
+The reference calls ``filter_fn(id, metadata)`` for every row inside every filtered search (index/flat.py:396-413,
+index/ivf.py:622, index/pq.py:287-297, index/hybrid.py:303-329) and ``MetadataIndex.query`` per ``Collection.search``
+(core/collection.py:724).  Here the second search with the same filter must call ``filter_fn`` zero times and upload
+nothing, any write must invalidate, and results must equal those of a freshly evaluated filter and of the oracle."""
+
+import numpy as np
+import pytest
+
+from oracle import ref_numpy as R
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def nat(native):
+    from vectordb_amd import _native
+    return _native
+
+
+class CountingFilter:
+    def __init__(self, fn):
+        self.fn, self.calls = fn, 0
+
+    def __call__(self, id, metadata):
+        self.calls += 1
+        return self.fn(id, metadata)
+
+
+def _same(a, b):
+    assert [r.id for r in a] == [r.id for r in b]
+    np.testing.assert_array_equal(np.array([r.distance for r in a], dtype=np.float64),
+                                  np.array([r.distance for r in b], dtype=np.float64))
+
+
+def _make(kind, x, meta):
+    from vectordb_amd.index import FlatIndex, IVFIndex
+    from vectordb_amd.index.pq import PQIndex
+    from vectordb_amd.index.hybrid import HybridIndex
+    d = x.shape[1]
+    ids = [f"v{i}" for i in range(len(x))]
+    if kind == "flat":
+        ix = FlatIndex(d, metric="euclidean")
+    elif kind == "ivf":
+        ix = IVFIndex(d, metric="euclidean", n_clusters=16, n_probe=16, seed=3)
+        ix.train(x)
+    elif kind == "pq":
+        ix = PQIndex(d, n_subvectors=4, n_bits=6, seed=3)
+        ix.train(x)
+    else:
+        ix = HybridIndex(d, n_clusters=8, n_probe=8, n_subvectors=4, n_bits=6, seed=3)
+        ix.train(x)
+    ix.add_batch(ids, x, meta)
+    return ix
+
+
+@pytest.mark.parametrize("kind", ["flat", "ivf", "pq", "hybrid"])
+def test_second_search_evaluates_and_uploads_nothing(nat, kind):
+    rng = np.random.RandomState(7)
+    x = rng.randn(3000, 16).astype(np.float32)
+    q = rng.randn(5, 16).astype(np.float32)
+    meta = [{"g": i % 5, "tag": "a" if i % 3 else "b"} for i in range(len(x))]
+    ix = _make(kind, x, meta)
+    flt = CountingFilter(lambda id, m: m["g"] in (1, 3))
+    first = ix.search(q[0], k=10, filter_fn=flt)
+    assert flt.calls == len(x) and all(r.metadata["g"] in (1, 3) for r in first) and len(first) == 10
+    uploads = nat.DeviceMask.uploads
+    again = ix.search(q[0], k=10, filter_fn=flt)
+    batch = ix.search_batch(q, k=10, filter_fn=flt)
+    assert flt.calls == len(x), "the cached filter was evaluated again"
+    assert nat.DeviceMask.uploads == uploads, "the cached mask was uploaded again"
+    _same(first, again)
+    _same(first, batch[0])
+    # an equal but distinct callable is another filter; the unfiltered search is untouched
+    other = CountingFilter(lambda id, m: m["g"] in (1, 3))
+    _same(ix.search(q[0], k=10, filter_fn=other), first)
+    assert other.calls == len(x)
+    assert len(ix.search(q[0], k=10)) == 10
+    # every kind of write invalidates: the filter sees the new row, and no removed row comes back
+    ix.add("fresh", q[0].copy(), {"g": 1, "tag": "a"})
+    got = ix.search(q[0], k=10, filter_fn=flt)
+    assert flt.calls == 2 * len(x) + 1
+    if kind in ("flat", "ivf"):
+        assert got[0].id == "fresh" and got[0].distance == 0.0
+    gone = got[1].id if got[0].id == "fresh" else got[0].id
+    assert ix.remove(gone)
+    after = ix.search(q[0], k=10, filter_fn=flt)
+    assert gone not in [r.id for r in after] and flt.calls == 3 * len(x) + 1
+    # against a filter evaluated afresh on an index built from scratch over the same state
+    keep = [i for i in range(len(x)) if f"v{i}" != gone]
+    ref_ix = _make(kind, x, meta) if kind != "flat" else None
+    if ref_ix is not None:
+        ref_ix.add("fresh", q[0].copy(), {"g": 1, "tag": "a"})
+        ref_ix.remove(gone)
+        _same(after, ref_ix.search(q[0], k=10, filter_fn=lambda id, m: m["g"] in (1, 3)))
+    else:
+        rows = np.concatenate([x[keep], q[:1]])
+        passing = np.array([meta[i]["g"] in (1, 3) for i in keep] + [True])
+        ref_rows, ref_dist = R.flat_search(q[0], rows[passing], 10, "euclidean")
+        np.testing.assert_allclose([r.distance for r in after], ref_dist, rtol=1e-4, atol=2e-6)
+    # caching switched off: evaluated on every search
+    ix.filter_cache_slots = 0
+    calls = flt.calls
+    ix.search(q[0], k=5, filter_fn=flt); ix.search(q[0], k=5, filter_fn=flt)
+    assert flt.calls == calls + 2 * ix.size
+
+
+def test_cache_keeps_a_few_filters_and_metadata_updates_invalidate(nat):
+    from vectordb_amd.index import FlatIndex
+    rng = np.random.RandomState(8)
+    x = rng.randn(500, 8).astype(np.float32)
+    ix = FlatIndex(8)
+    ix.add_batch([f"v{i}" for i in range(500)], x, [{"g": i % 7} for i in range(500)])
+    fs = [CountingFilter(lambda id, m, g=g: m["g"] == g) for g in range(6)]
+    for f in fs:
+        ix.search(x[0], k=3, filter_fn=f)
+    for f in fs[2:]:                                 # the four most recent are still there
+        ix.search(x[0], k=3, filter_fn=f)
+        assert f.calls == 500
+    ix.search(x[0], k=3, filter_fn=fs[0])            # the oldest was dropped
+    assert fs[0].calls == 1000
+    ix.update("v3", metadata={"g": 5})               # a metadata update is a write
+    got = ix.search(x[3], k=1, filter_fn=fs[5])
+    assert fs[5].calls == 1000 and got[0].id == "v3"
+    # range_search shares the evaluated filter (host words)
+    calls = fs[5].calls
+    near = ix.range_search(x[3], 1e-3, filter_fn=fs[5])
+    assert [r.id for r in near] == ["v3"] and fs[5].calls == calls
+
+
+def test_collection_filter_masks_are_cached_and_match_the_predicate(nat):
+    from vectordb_amd.core import Collection, MetadataFilter
+    from vectordb_amd.core import collection as C
+    rng = np.random.RandomState(9)
+    x = rng.randn(4000, 12).astype(np.float32)
+    col = Collection("c", 12, metric="euclidean")
+    for i in range(4000):
+        col.add(f"v{i}", x[i], {"g": i % 9, "tags": ["x", "y"] if i % 4 == 0 else ["y"], "w": float(i) / 10})
+    for i in range(0, 4000, 11):
+        col.delete(f"v{i}")
+    filters = [{"g": 3}, {"g": [1, 2]}, {"g": {"$in": [4, 5]}, "tags": "x"}, {"w": {"$gt": 100.0, "$lt": 300.0}},
+               {"g": {"$nin": [0, 1, 2]}}, {"tags": {"$exists": True}, "g": {"$ne": 3}}, {"nope": 1}, {"g": {"$gte": 7}}]
+    builds = []
+    inner = C._FieldTable.__init__
+
+    def counting(self, name, ids, metadata):
+        builds.append(name)
+        inner(self, name, ids, metadata)
+    C._FieldTable.__init__ = counting
+    try:
+        for flt in filters:
+            pred = MetadataFilter(flt)
+            got = col.search(x[5], k=25, filter=flt)
+            want_ids = [i for i in col._vectors if pred(col._metadata[i])]
+            if not want_ids:
+                assert got == []
+                continue
+            ref_rows, ref_dist = R.flat_search(x[5], np.stack([col._vectors[i] for i in want_ids]), min(25, len(want_ids)), "euclidean")
+            assert all(pred(r.metadata) for r in got) and len(got) == len(ref_rows)
+            np.testing.assert_allclose([r.distance for r in got], ref_dist, rtol=1e-4, atol=2e-6)
+        # one table per field and write version, however many filters name the field
+        assert sorted(builds) == ["g", "nope", "tags", "w"]
+        evaluations, uploads = col._filters.evaluations, nat.DeviceMask.uploads
+        for flt in filters[-4:]:
+            col.search(x[5], k=25, filter=flt)
+            col.search_batch(x[:3], k=5, filter=dict(flt))           # an equal dict is the same filter
+        assert col._filters.evaluations == evaluations and nat.DeviceMask.uploads == uploads and len(builds) == 4
+        col.add("late", x[5], {"g": 7})
+        assert col.search(x[5], k=1, filter={"g": {"$gte": 7}})[0].id == "late"
+        assert col._filters.evaluations == evaluations + 1
+    finally:
+        C._FieldTable.__init__ = inner

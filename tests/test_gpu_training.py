@@ -111,8 +111,14 @@ def test_subquantizer_steps_match_reference(nat, which):
         else:
             np.testing.assert_allclose(got, want, rtol=1e-5, atol=1e-6)
         if which == "pq":
-            np.testing.assert_array_equal(np.argmin(R.pairwise_euclidean_squared(sub, want.astype(np.float32)), axis=1).shape,
-                                          g[f"pq_assign_from_{steps}"].shape)
+            # the assignment the next step would start from (a step without commit leaves the centroids as they are)
+            tr.step(nat.KMEANS_PQ)
+            assign = tr.assignments().astype(np.int64)
+            ref_assign = g[f"pq_assign_from_{steps}"].astype(np.int64)
+            if steps <= 3:
+                np.testing.assert_array_equal(assign, ref_assign)
+            else:
+                assert (assign != ref_assign).mean() <= 0.005
     np.testing.assert_array_equal(tr.centroids(), tr.centroids(float64=True).astype(np.float32))
     tr.close(); store.close()
 

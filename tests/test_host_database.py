@@ -107,8 +107,46 @@ def test_flat_index_prefilter_argument():
     assert d["config"]["prefilter"] == "bf16" and d["config"]["storage"] == "f32"
     back = FlatIndex.from_dict(d)
     assert back._prefilter == "bf16" and back.size == 1
-    assert FlatIndex.from_dict(FlatIndex(8).to_dict())._prefilter is None
+    assert FlatIndex.from_dict(FlatIndex(8).to_dict())._prefilter == "auto"            # the default: on while it fits
+    assert FlatIndex.from_dict(FlatIndex(8, prefilter=None).to_dict())._prefilter is None
+    assert FlatIndex(8, storage="bf16")._prefilter is None
     with pytest.raises(ValueError):
         FlatIndex(8, prefilter="fp8")
     with pytest.raises(ValueError):
         FlatIndex(8, storage="bf16", prefilter="bf16")
+
+
+def test_metadata_row_masks_equal_the_row_predicate():
+    """The NumPy row masks of a metadata filter against the per-row predicate (MetadataIndex.query semantics,
+    core/collection.py:183-282) on random metadata: scalars, lists, empty lists, dicts, missing fields, every operator."""
+    import random
+    from vectordb_amd.core.collection import MetadataFilter, metadata_row_mask, _FieldTable
+    random.seed(1)
+    vals = [1, 2, 3, 2.5, "a", "b", True, None, [1, 2], ["a"], [], {"x": 1}]
+    for _ in range(400):
+        n = random.randint(1, 60)
+        ids = [f"v{i}" if random.random() > 0.1 else None for i in range(n)]
+        md = {i: {f: random.choice(vals) for f in ("p", "q", "r") if random.random() < 0.7} for i in ids if i is not None}
+
+        def cond():
+            t = random.random()
+            if t < 0.3:
+                return random.choice(vals[:9])
+            if t < 0.4:
+                return [random.choice(vals[:8]) for _ in range(random.randint(0, 3))]
+            ops = {}
+            for _ in range(random.randint(1, 3)):
+                op = random.choice(["$in", "$nin", "$exists", "$gt", "$gte", "$lt", "$lte", "$ne", "$bogus"])
+                if op in ("$in", "$nin"):
+                    ops[op] = [random.choice(vals[:8]) for _ in range(random.randint(0, 3))]
+                elif op == "$exists":
+                    ops[op] = random.choice([True, False])
+                else:
+                    ops[op] = random.choice([1, 2, 2.5, "a", None])
+            return ops
+        flt = {f: cond() for f in random.sample(["p", "q", "r", "zz"], random.randint(1, 2))}
+        pred = MetadataFilter(flt)
+        want = np.array([i is not None and pred(md[i]) for i in ids], dtype=bool)
+        tables = {}
+        got = metadata_row_mask(flt, lambda name: tables.setdefault(name, _FieldTable(name, ids, md)))
+        np.testing.assert_array_equal(got, want, err_msg=repr(flt))

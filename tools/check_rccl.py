@@ -22,7 +22,7 @@ n, d, nq, k = 70000, 32, 33, 10
 g = torch.Generator(device=dev); g.manual_seed(1)
 rows = torch.randn((n, d), device=dev, generator=g)
 q = torch.randn((nq, d), device=dev, generator=g)
-be = HipFlatBackend(d, _native.COSINE)
+be = HipFlatBackend(d, _native.COSINE, prefilter=None)
 be.add_device(rows)
 single = ShardedFlat(be, n, 0, 1)
 sd, sr = single.search(q, k)

@@ -51,6 +51,13 @@ SIGNATURES = {
     "vdb_measure_ceilings": (C.c_int, [c_float_p, c_float_p, c_float_p, c_float_p]),
     "vdb_profile_enable": (C.c_int, [C.c_int]),
     "vdb_profile_read": (C.c_int, [c_float_p, C.POINTER(C.c_int)]),
+    "vdb_mask_create": (C.c_int, [C.POINTER(C.c_void_p), c_u32_p, C.c_int64]),
+    "vdb_mask_destroy": (C.c_int, [C.c_void_p]),
+    "vdb_mask_info": (C.c_int, [C.c_void_p, c_i64_p, C.POINTER(C.c_void_p)]),
+    "vdb_flat_search_masked": (C.c_int, [C.c_void_p, C.c_int, c_float_p, C.c_int, C.c_int, C.c_void_p, c_float_p, c_i64_p]),
+    "vdb_ivf_search_masked": (C.c_int, [C.c_void_p, c_float_p, C.c_int, C.c_int, C.c_int, C.c_void_p, c_float_p, c_i64_p]),
+    "vdb_pq_search_masked": (C.c_int, [C.c_void_p, c_float_p, C.c_int, C.c_int, C.c_void_p, c_float_p, c_i64_p]),
+    "vdb_ivfpq_search_masked": (C.c_int, [C.c_void_p, c_float_p, C.c_int, C.c_int, C.c_int, C.c_void_p, c_float_p, c_i64_p]),
     "vdb_rows_create": (C.c_int, [C.POINTER(C.c_void_p), C.c_int]),
     "vdb_rows_create_typed": (C.c_int, [C.POINTER(C.c_void_p), C.c_int, C.c_int]),
     "vdb_rows_destroy": (C.c_int, [C.c_void_p]),
@@ -132,6 +139,8 @@ SIGNATURES = {
                                              C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]),
     "vdb_topk_merge_keyed_dev": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p,
                                            C.c_void_p, C.c_void_p]),
+    "vdb_topk_merge_keyed_strided_dev": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_int64, C.c_int, C.c_int,
+                                                   C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]),
 }
 
 _lib: Optional[C.CDLL] = None
@@ -267,7 +276,47 @@ def u32ptr(a: Optional[np.ndarray]):
     return None if a is None else a.ctypes.data_as(c_u32_p)
 
 
+class DeviceMask:
+    """Owner of a vdb_mask handle: a packed row filter that stays in HBM.  Every ``search`` of the handle classes
+    below takes either packed host words (uploaded by that call) or one of these (nothing is uploaded)."""
+
+    uploads = 0          # masks sent to the device by this process (what the filter-cache tests count)
+
+    def __init__(self, mask_or_words, n_bits: Optional[int] = None):
+        init()
+        self.lib = load()
+        a = np.asarray(mask_or_words)
+        if a.dtype == bool:
+            n_bits = len(a) if n_bits is None else n_bits
+            a = pack_mask(a)
+        words = np.ascontiguousarray(a, dtype=np.uint32)
+        self.n_bits = int(len(words) * 32 if n_bits is None else n_bits)
+        if (self.n_bits + 31) // 32 > len(words):
+            raise ValueError(f"{len(words)} words do not hold {self.n_bits} bits")
+        self.h = C.c_void_p()
+        check(self.lib.vdb_mask_create(C.byref(self.h), u32ptr(words), self.n_bits))
+        DeviceMask.uploads += 1
+
+    @property
+    def device_ptr(self) -> int:
+        p = C.c_void_p()
+        check(self.lib.vdb_mask_info(self.h, None, C.byref(p)))
+        return p.value or 0
+
+    def close(self):
+        if getattr(self, "h", None) is not None and self.h:
+            self.lib.vdb_mask_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
 STORAGE = {"f32": 0, "bf16": 1}
+PREFILTER = {None: 0, "bf16": 1, "auto": 2}
 
 
 class RowStore:
@@ -320,10 +369,11 @@ class RowStore:
         check(self.lib.vdb_rows_set_cosine_eps(self.h, float(eps)))
 
     def set_prefilter(self, mode: Optional[str]) -> None:
-        """Batched searches behind a bf16 filter pass ("bf16") or on the fp32 kernels alone (None): same results."""
-        if mode not in (None, "bf16"):
-            raise ValueError(f"prefilter must be None or 'bf16', got {mode!r}")
-        check(self.lib.vdb_rows_set_prefilter(self.h, 1 if mode == "bf16" else 0))
+        """Batched searches behind a bf16 filter pass ("bf16"; "auto": while the bf16 copy of the rows leaves a tenth
+        of the device memory free) or on the fp32 kernels alone (None): same results."""
+        if mode not in PREFILTER:
+            raise ValueError(f"prefilter must be None, 'bf16' or 'auto', got {mode!r}")
+        check(self.lib.vdb_rows_set_prefilter(self.h, PREFILTER[mode]))
 
     def used_prefilter(self) -> bool:
         """True when the last search on this store ran the bf16 filter pass."""
@@ -344,8 +394,12 @@ class RowStore:
         nq = q.shape[0]
         dist = np.empty((nq, k), np.float32)
         rows = np.empty((nq, k), np.int64)
-        check(self.lib.vdb_flat_search(self.h, metric, fptr(q), nq, k, u32ptr(mask_words), fptr(dist),
-                                       rows.ctypes.data_as(c_i64_p)))
+        if isinstance(mask_words, DeviceMask):
+            check(self.lib.vdb_flat_search_masked(self.h, metric, fptr(q), nq, k, mask_words.h, fptr(dist),
+                                                  rows.ctypes.data_as(c_i64_p)))
+        else:
+            check(self.lib.vdb_flat_search(self.h, metric, fptr(q), nq, k, u32ptr(mask_words), fptr(dist),
+                                           rows.ctypes.data_as(c_i64_p)))
         return dist, rows
 
     def search_stats(self):
@@ -566,8 +620,12 @@ class IvfLists:
         nq = q.shape[0]
         dist = np.empty((nq, k), np.float32)
         rows = np.empty((nq, k), np.int64)
-        check(self.lib.vdb_ivf_search(self.h, fptr(q), nq, k, n_probe, u32ptr(mask_words), fptr(dist),
-                                      rows.ctypes.data_as(c_i64_p)))
+        if isinstance(mask_words, DeviceMask):
+            check(self.lib.vdb_ivf_search_masked(self.h, fptr(q), nq, k, n_probe, mask_words.h, fptr(dist),
+                                                 rows.ctypes.data_as(c_i64_p)))
+        else:
+            check(self.lib.vdb_ivf_search(self.h, fptr(q), nq, k, n_probe, u32ptr(mask_words), fptr(dist),
+                                          rows.ctypes.data_as(c_i64_p)))
         return dist, rows
 
     def search_device(self, q_ptr: int, nq: int, k: int, n_probe: int, out_dist_ptr: int, out_row_ptr: int,
@@ -660,8 +718,12 @@ class PqCodes:
         nq = q.shape[0]
         dist = np.empty((nq, k), np.float32)
         rows = np.empty((nq, k), np.int64)
-        check(self.lib.vdb_pq_search(self.h, fptr(q), nq, k, u32ptr(mask_words), fptr(dist),
-                                     rows.ctypes.data_as(c_i64_p)))
+        if isinstance(mask_words, DeviceMask):
+            check(self.lib.vdb_pq_search_masked(self.h, fptr(q), nq, k, mask_words.h, fptr(dist),
+                                                rows.ctypes.data_as(c_i64_p)))
+        else:
+            check(self.lib.vdb_pq_search(self.h, fptr(q), nq, k, u32ptr(mask_words), fptr(dist),
+                                         rows.ctypes.data_as(c_i64_p)))
         return dist, rows
 
     def search_device(self, q_ptr: int, nq: int, k: int, out_dist_ptr: int, out_row_ptr: int,
@@ -745,8 +807,12 @@ class IvfPqLists:
         nq = q.shape[0]
         dist = np.empty((nq, k), np.float32)
         rows = np.empty((nq, k), np.int64)
-        check(self.lib.vdb_ivfpq_search(self.h, fptr(q), nq, k, n_probe, u32ptr(mask_words), fptr(dist),
-                                        rows.ctypes.data_as(c_i64_p)))
+        if isinstance(mask_words, DeviceMask):
+            check(self.lib.vdb_ivfpq_search_masked(self.h, fptr(q), nq, k, n_probe, mask_words.h, fptr(dist),
+                                                   rows.ctypes.data_as(c_i64_p)))
+        else:
+            check(self.lib.vdb_ivfpq_search(self.h, fptr(q), nq, k, n_probe, u32ptr(mask_words), fptr(dist),
+                                            rows.ctypes.data_as(c_i64_p)))
         return dist, rows
 
     def search_device(self, q_ptr: int, nq: int, k: int, n_probe: int, out_dist_ptr: int, out_row_ptr: int,
@@ -777,3 +843,12 @@ def topk_merge_keyed_device(dist_ptr: int, key_ptr: int, row_ptr: int, n_lists: 
     init()
     check(load().vdb_topk_merge_keyed_dev(C.c_void_p(dist_ptr), C.c_void_p(key_ptr), C.c_void_p(row_ptr), n_lists, nq, k,
                                           C.c_void_p(out_dist_ptr), C.c_void_p(out_row_ptr), C.c_void_p(stream or None)))
+
+
+def topk_merge_keyed_strided_device(dist_ptr: int, key_ptr: int, row_ptr: int, list_stride_dist: int, list_stride_key_row: int,
+                                    n_lists: int, nq: int, k: int, out_dist_ptr: int, out_row_ptr: int, stream: int = 0) -> None:
+    """topk_merge_keyed_device over lists `list_stride_*` elements apart (blocks of one packed all-gather)."""
+    init()
+    check(load().vdb_topk_merge_keyed_strided_dev(C.c_void_p(dist_ptr), C.c_void_p(key_ptr), C.c_void_p(row_ptr),
+                                                  list_stride_dist, list_stride_key_row, n_lists, nq, k,
+                                                  C.c_void_p(out_dist_ptr), C.c_void_p(out_row_ptr), C.c_void_p(stream or None)))

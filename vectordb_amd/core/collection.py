@@ -130,6 +130,92 @@ class MetadataFilter:
         return True
 
 
+def _value_key(v):
+    """What a metadata value is compared by: lists and dicts in a hashable form (core/collection.py:284-290)."""
+    if isinstance(v, list):
+        v = tuple(v)
+    elif isinstance(v, dict):
+        v = tuple(sorted(v.items()))
+    try:
+        hash(v)
+    except TypeError:
+        v = repr(v)
+    return v
+
+
+class _FieldTable:
+    """One metadata field over the rows of the device mirror: the distinct values, and for every row the values it
+    holds (a list-valued field holds several, an absent field or an empty list none)."""
+
+    def __init__(self, field_name: str, ids, metadata):
+        code_of: Dict[Any, int] = {}
+        rows: List[int] = []
+        codes: List[int] = []
+        for r, id in enumerate(ids):
+            if id is None:
+                continue
+            have = metadata[id].get(field_name, _FieldTable)          # the class itself: "absent"
+            if have is _FieldTable:
+                continue
+            for v in (have if isinstance(have, list) else (have,)):
+                k = _value_key(v)
+                c = code_of.get(k)
+                if c is None:
+                    c = code_of[k] = len(code_of)
+                rows.append(r)
+                codes.append(c)
+        self.n_rows = len(ids)
+        self.keys = list(code_of)
+        self.code_of = code_of
+        self.entry_row = np.asarray(rows, dtype=np.int64)
+        self.entry_code = np.asarray(codes, dtype=np.int64)
+        self.has_field = np.zeros(self.n_rows, dtype=bool)
+        self.has_field[self.entry_row] = True
+
+    def rows_with(self, key_ok: np.ndarray) -> np.ndarray:
+        """Rows holding at least one value whose entry of ``key_ok`` (one flag per distinct value) is set."""
+        out = np.zeros(self.n_rows, dtype=bool)
+        if len(self.entry_row):
+            out[self.entry_row[key_ok[self.entry_code]]] = True
+        return out
+
+    def keys_in(self, wanted) -> np.ndarray:
+        ok = np.zeros(len(self.keys), dtype=bool)
+        for w in wanted:
+            c = self.code_of.get(_value_key(w))
+            if c is not None:
+                ok[c] = True
+        return ok
+
+    def keys_where(self, op: str, arg) -> np.ndarray:
+        return np.fromiter((MetadataFilter._cmp(k, op, arg) for k in self.keys), dtype=bool, count=len(self.keys))
+
+
+def metadata_row_mask(filters: Dict[str, Any], table_of) -> np.ndarray:
+    """The rows a metadata filter passes, with the semantics of ``MetadataFilter`` (MetadataIndex.query,
+    core/collection.py:183-282), computed from per-field tables: Python work is per DISTINCT value of a field,
+    the per-row part is NumPy.  ``table_of(field)`` returns the field's ``_FieldTable``."""
+    mask = None
+    for name, cond in filters.items():
+        t = table_of(name)
+        if not isinstance(cond, dict):
+            hit = t.rows_with(t.keys_in(cond if isinstance(cond, list) else [cond]))
+        else:
+            hit = np.zeros(t.n_rows, dtype=bool)
+            for op, arg in cond.items():                       # in order: a later operator builds on or replaces the set
+                if op == "$in":
+                    hit |= t.rows_with(t.keys_in(list(arg)))
+                elif op == "$nin":
+                    hit = t.has_field & ~t.rows_with(t.keys_in(list(arg)))
+                elif op == "$exists":
+                    if arg:
+                        hit |= t.has_field
+                elif op in ("$gt", "$gte", "$lt", "$lte", "$ne"):
+                    hit |= t.rows_with(t.keys_where(op, arg))
+        mask = hit if mask is None else (mask & hit)
+    return mask
+
+
 @dataclass
 class CollectionStats:                                     # core/collection.py:75-100
     name: str
@@ -163,11 +249,12 @@ class Collection:
                  max_vectors: Optional[int] = None, enable_metadata_index: bool = True,
                  index_type: Optional[str] = None, index_params: Optional[Dict[str, Any]] = None, **index_kwargs):
         self.index_type = index_type.lower() if index_type else None
-        # `prefilter="bf16"` without an index type: the exact scan's batches (search_batch) run behind the bf16 filter
-        # pass of the row store, with the same results (not a reference argument)
-        self._prefilter = index_kwargs.pop("prefilter", None) if self.index_type is None else None
-        if self._prefilter not in (None, "bf16"):
-            raise ValueError(f"prefilter must be None or 'bf16', got {self._prefilter!r}")
+        # `prefilter` without an index type ("auto" by default, "bf16", or None): the exact scan's batches
+        # (search_batch) run behind the bf16 filter pass of the row store, with the same results (not a reference
+        # argument)
+        self._prefilter = index_kwargs.pop("prefilter", "auto") if self.index_type is None else None
+        if self._prefilter not in N.PREFILTER:
+            raise ValueError(f"prefilter must be None, 'bf16' or 'auto', got {self._prefilter!r}")
         if self.index_type is None and (index_params or index_kwargs):
             raise TypeError("index parameters given without index_type")
         self._index_params = {**(index_params or {}), **index_kwargs}
@@ -192,6 +279,12 @@ class Collection:
         self._alive = np.zeros(0, dtype=bool)
         self._store: Optional[N.RowStore] = None
         self._bulk: Optional[np.ndarray] = None             # rows of a loaded collection, in dict order, not yet uploaded
+        # evaluated filters (key: the filter dict as JSON text) stay on the device until the next write; the per-field
+        # tables they are computed from are rebuilt lazily after a write
+        from ..index.base import FilterCache
+        self._filters = FilterCache(4)
+        self._field_tables: Dict[str, _FieldTable] = {}
+        self._field_tables_version = -1
         self._timestamps: Dict[str, float] = {}
         self._created_at = self._updated_at = time.time()
 
@@ -213,6 +306,7 @@ class Collection:
             raise ValueError(f"Collection at maximum capacity ({self.max_vectors})")
         existed = id in self._vectors
         self._bulk = None                                   # the loaded matrix no longer describes the rows
+        self._filters.touch()
         self._vectors[id] = vector
         self._metadata[id] = dict(metadata or {})
         self._updated_at = self._timestamps[id] = time.time()
@@ -260,6 +354,7 @@ class Collection:
         del self._vectors[id], self._metadata[id]
         self._timestamps.pop(id, None)
         self._bulk = None
+        self._filters.touch()
         if not self._matrix_dirty:
             row = self._row_of.pop(id)
             self._ids[row] = None
@@ -279,6 +374,7 @@ class Collection:
         n = len(self._vectors)
         self._vectors.clear(); self._metadata.clear(); self._timestamps.clear()
         self._bulk = None
+        self._filters.touch()
         self._matrix_dirty = True
         self._drop_index()
         return n
@@ -360,19 +456,37 @@ class Collection:
         if self.metric not in _QUERY_METRICS:
             raise ValueError(f"Unknown metric: {self.metric}")
         self._ensure_matrix()
-        mask = None
-        if filter and self.enable_metadata_index:
-            pred = MetadataFilter(filter)
-            mask = np.fromiter((i is not None and pred(self._metadata[i]) for i in self._ids), dtype=bool, count=len(self._ids))
-        elif self._n_dead:
-            mask = self._alive
         words = None
-        if mask is not None:
-            if not mask.any():
+        if filter and self.enable_metadata_index:
+            _host, words, any_row = self._filters.lookup(self._filter_key(filter), lambda: self._filter_rows(filter))
+            if words is None:
+                words = _host
+            if not any_row:
                 return None
-            words = N.pack_mask(mask)
+        elif self._n_dead:
+            if not self._alive.any():
+                return None
+            words = N.pack_mask(self._alive)
         k = min(k, len(self._vectors))
         return self._store.search(queries, k, _QUERY_METRICS[self.metric], words)
+
+    @staticmethod
+    def _filter_key(filter: Dict[str, Any]) -> str:
+        import json
+        return json.dumps(filter, default=repr)             # key order kept: the operators of a field apply in order
+
+    def _field_table(self, name: str) -> _FieldTable:
+        if self._field_tables_version != self._filters.version:
+            self._field_tables = {}
+            self._field_tables_version = self._filters.version
+        t = self._field_tables.get(name)
+        if t is None:
+            t = self._field_tables[name] = _FieldTable(name, self._ids, self._metadata)
+        return t
+
+    def _filter_rows(self, filter: Dict[str, Any]) -> np.ndarray:
+        """Row mask of a metadata filter over the device mirror's rows (dead rows hold no values: never set)."""
+        return metadata_row_mask(filter, self._field_table)
 
     def _results(self, dist_row, rows_row, include_vector: bool, include_metadata: bool) -> List[SearchResult]:
         keep = rows_row >= 0
@@ -466,7 +580,7 @@ class Collection:
                   enable_metadata_index=config.get("enable_metadata_index", True),
                   index_type=index_type if (index_type and index_type != "flat") else None,
                   index_params=params if (index_type and index_type != "flat") else None)
-        if col.index_type is None and config.get("prefilter"):
+        if col.index_type is None and "prefilter" in config:
             col._prefilter = config["prefilter"]
         records = data.get("vectors", [])
         if "matrix" in data:

@@ -578,6 +578,13 @@ static int shadow_sync(vdb_rows* h, hipStream_t s) {
         h->shadow_n = 0;
     }
     if (h->shadow_cap < r.cap) {
+        if (h->prefilter == VDB_PREFILTER_AUTO) {
+            // the copy is taken only while it leaves a tenth of the device (at least 2 GiB) free for everything else
+            size_t free_b = 0, total_b = 0;
+            VDB_HIP(hipMemGetInfo(&free_b, &total_b));
+            const size_t want = (size_t)r.cap * ld16 * 2 + std::max<size_t>(total_b / 10, (size_t)2 << 30);
+            if (free_b + h->shadow16.cap < want) return VDB_ERR_NOMEM;
+        }
         VDB_TRY(h->shadow16.reserve_keep((size_t)r.cap * ld16 * 2, (size_t)h->shadow_n * ld16 * 2, s));
         h->shadow_cap = r.cap;
     }
@@ -629,7 +636,7 @@ static int flat_search_impl(vdb_rows* h, int metric, const float* d_q, int nq, i
     int n_cand = 0, sample_tiles = 0, sample_stride = 1, n_cand_sample = 0;
     VDB_TRY(flat_gemm_num_cand(r.n, nq, k, &n_cand));
     VDB_TRY(flat_gemm_sample_plan(r.n, &sample_tiles, &sample_stride));
-    if (h->prefilter == VDB_PREFILTER_BF16 && !r.bf16 && ws_in == nullptr && sample_tiles > 0) {
+    if (h->prefilter != VDB_PREFILTER_NONE && !r.bf16 && ws_in == nullptr && sample_tiles > 0) {
         // Behind the bf16 filter every survivor of the bound costs more (a looser test, an fp32 recomputation for some)
         // and the bound pass a quarter of the fp32 one: a denser sample pays while rows are short.  Cosine 1M x 384,
         // batch 1024: 1.01 ms at 1/64 of the tiles, 0.96 at 1/32, 0.93 at 1/16, 0.96 at 1/8; euclidean 1M x 128: 0.71,
@@ -662,7 +669,7 @@ static int flat_search_impl(vdb_rows* h, int metric, const float* d_q, int nq, i
     Rows rf = r;
     rf.bf16 = true;
     rf.ld16 = shadow_pitch(r);
-    bool prefilter = will_queue && h->prefilter == VDB_PREFILTER_BF16 && !r.bf16 && ws_in == nullptr && queue_use_wide(rf);
+    bool prefilter = will_queue && h->prefilter != VDB_PREFILTER_NONE && !r.bf16 && ws_in == nullptr && queue_use_wide(rf);
     bool thr_from_copies = false;
     if (prefilter) {
         // no room for the copy: the search runs on the fp32 kernels alone, as it would without the filter
@@ -797,6 +804,24 @@ static int upload_mask(Workspace& ws, const uint32_t* mask, int64_t n, const uin
     return VDB_OK;
 }
 
+// A filter bitmask that stays in HBM: evaluated and uploaded once, named by every search that uses it.
+struct vdb_mask {
+    DevBuf words;
+    int64_t n_bits = 0;
+};
+
+// the mask of a host-pointer search: a resident one as it is, a host one uploaded to the workspace
+static int resolve_mask(Workspace& ws, const uint32_t* host_mask, const vdb_mask* resident, int64_t n_rows,
+                        const uint32_t** d_mask, hipStream_t s) {
+    if (!resident) return upload_mask(ws, host_mask, n_rows, d_mask, s);
+    if (resident->n_bits < n_rows) {
+        set_error("the resident mask covers %lld rows, the index holds %lld", (long long)resident->n_bits, (long long)n_rows);
+        return VDB_ERR_INVALID;
+    }
+    *d_mask = resident->words.as<uint32_t>();
+    return VDB_OK;
+}
+
 // host-pointer wrapper: queries up, results down.  Small transfers (a query or a batch of them, k results
 // each) go through page-locked buffers: one asynchronous copy up, one down (distances and rows lie in one
 // device block), one wait.  Copies straight to pageable memory cost a staging round trip each.
@@ -894,13 +919,30 @@ struct ListLayout {
         for (int i = 0; i < std::min(n_probe, n_lists); ++i) t += len_desc[i];
         return t;
     }
+    // what plan_append changed, so that a caller whose allocations fail afterwards can take the plan back: the lists
+    // then describe exactly the rows that are stored (a moved list's old place is never overwritten by the plan)
+    struct Undo {
+        struct Entry { int list; int64_t beg, len, cap; };
+        std::vector<Entry> lists;
+        int64_t tail = 0, live = 0, dead = 0, row_limit = 0, grown = 0;
+        bool dev_stale = false;
+    };
+    void rollback(const Undo& u) {
+        for (const auto& e : u.lists) { beg[e.list] = e.beg; len[e.list] = e.len; cap[e.list] = e.cap; }
+        tail = u.tail; live = u.live; dead = u.dead; row_limit = u.row_limit; grown_since_sort = u.grown;
+        dev_stale = true;       // the device copy may have been refreshed from the plan
+    }
     // positions for `count` new rows (dst[i] for the row that goes to lists[i]) and the lists that have to move first
-    int plan_append(const int32_t* lists, int64_t count, std::vector<int64_t>& dst, std::vector<ListMove>& moves) {
+    int plan_append(const int32_t* lists, int64_t count, std::vector<int64_t>& dst, std::vector<ListMove>& moves, Undo& undo) {
         std::unordered_map<int, int64_t> need;
         for (int64_t i = 0; i < count; ++i) {
             VDB_REQUIRE(lists[i] >= 0 && lists[i] < n_lists, "list number %d out of range", lists[i]);
             ++need[lists[i]];
         }
+        undo.tail = tail; undo.live = live; undo.dead = dead; undo.row_limit = row_limit; undo.grown = grown_since_sort;
+        undo.dev_stale = dev_stale;
+        undo.lists.clear();
+        for (const auto& kv : need) undo.lists.push_back(Undo::Entry{kv.first, beg[kv.first], len[kv.first], cap[kv.first]});
         for (const auto& kv : need) {
             const int l = kv.first;
             if (len[l] + kv.second <= cap[l]) continue;
@@ -1163,7 +1205,7 @@ int vdb_rows_truncate(vdb_rows* h, int64_t n) {
 }
 
 int vdb_rows_set_prefilter(vdb_rows* h, int mode) {
-    VDB_REQUIRE(h && (mode == VDB_PREFILTER_NONE || mode == VDB_PREFILTER_BF16), "unknown prefilter mode %d", mode);
+    VDB_REQUIRE(h && mode >= VDB_PREFILTER_NONE && mode <= VDB_PREFILTER_AUTO, "unknown prefilter mode %d", mode);
     Entry g(h);
     VDB_REQUIRE(mode == VDB_PREFILTER_NONE || !h->r.bf16, "a bf16 filter pass needs fp32 storage");
     h->prefilter = mode;
@@ -1207,18 +1249,68 @@ int vdb_flat_search_dev(vdb_rows* h, int metric, const float* d_queries, int nq,
     return flat_search_impl(h, metric, d_queries, nq, k, d_mask, d_out_dist, d_out_row, nullptr, pick_stream(stream));
 }
 
-int vdb_flat_search(vdb_rows* h, int metric, const float* queries, int nq, int k, const uint32_t* mask,
-                    float* out_dist, int64_t* out_row) {
+static int flat_search_host(vdb_rows* h, int metric, const float* queries, int nq, int k, const uint32_t* mask,
+                            const vdb_mask* resident, float* out_dist, int64_t* out_row) {
     VDB_REQUIRE(h && (queries || nq == 0), "null argument");
     VDB_REQUIRE(k >= 1, "k must be >= 1, got %d", k);
     Entry g(h);
     hipStream_t s = h->stream;
     const uint32_t* d_mask = nullptr;
-    VDB_TRY(upload_mask(h->ws, mask, h->r.n, &d_mask, s));
+    VDB_TRY(resolve_mask(h->ws, mask, resident, h->r.n, &d_mask, s));
     return with_host_io(h->ws, queries, nq, h->r.dim, k, out_dist, out_row, s,
                         [&](const float* dq, float* dd, int64_t* di) {
                             return flat_search_impl(h, metric, dq, nq, k, d_mask, dd, di, nullptr, s);
                         });
+}
+
+int vdb_flat_search(vdb_rows* h, int metric, const float* queries, int nq, int k, const uint32_t* mask,
+                    float* out_dist, int64_t* out_row) {
+    return flat_search_host(h, metric, queries, nq, k, mask, nullptr, out_dist, out_row);
+}
+
+int vdb_flat_search_masked(vdb_rows* h, int metric, const float* queries, int nq, int k, const vdb_mask* mask,
+                           float* out_dist, int64_t* out_row) {
+    VDB_REQUIRE(mask, "null mask");
+    return flat_search_host(h, metric, queries, nq, k, nullptr, mask, out_dist, out_row);
+}
+
+// ---- resident filter masks
+int vdb_mask_create(vdb_mask** out, const uint32_t* words, int64_t n_bits) {
+    VDB_REQUIRE(out && (words || n_bits == 0) && n_bits >= 0, "bad argument");
+    VDB_TRY(ensure_init());
+    (void)hipSetDevice(ctx().device);
+    auto* m = new (std::nothrow) vdb_mask();
+    if (!m) { set_error("out of host memory"); return VDB_ERR_NOMEM; }
+    const size_t bytes = (size_t)((n_bits + 31) / 32) * sizeof(uint32_t);
+    // 16 bytes of slack: the scans read whole words past the last row
+    int rc = m->words.reserve(bytes + 16);
+    if (rc == VDB_OK && hipMemset(m->words.p, 0, bytes + 16) != hipSuccess) rc = VDB_ERR_HIP;
+    if (rc == VDB_OK && bytes && hipMemcpy(m->words.p, words, bytes, hipMemcpyHostToDevice) != hipSuccess) rc = VDB_ERR_HIP;
+    if (rc != VDB_OK) {
+        if (rc == VDB_ERR_HIP) set_error("uploading a mask of %lld bits failed", (long long)n_bits);
+        m->words.release();
+        delete m;
+        return rc;
+    }
+    m->n_bits = n_bits;
+    *out = m;
+    return VDB_OK;
+}
+
+int vdb_mask_destroy(vdb_mask* m) {
+    if (!m) return VDB_OK;
+    (void)hipSetDevice(ctx().device);
+    (void)hipDeviceSynchronize();          // a search enqueued through a *_dev entry point may still read it
+    m->words.release();
+    delete m;
+    return VDB_OK;
+}
+
+int vdb_mask_info(const vdb_mask* m, int64_t* n_bits, const uint32_t** d_words) {
+    VDB_REQUIRE(m, "null mask");
+    if (n_bits) *n_bits = m->n_bits;
+    if (d_words) *d_words = m->words.as<uint32_t>();
+    return VDB_OK;
 }
 
 int vdb_flat_search_static_dev(vdb_rows* h, int metric, const float* d_queries, int nq, int k, const uint32_t* d_mask,
@@ -1793,13 +1885,26 @@ int vdb_ivf_append(vdb_ivf* h, const float* rows, const int64_t* row_numbers, co
     std::vector<int64_t> dst;
     std::vector<ListMove> moves;
     const int64_t old_tail = lay.tail;
-    VDB_TRY(lay.plan_append(lists, count, dst, moves));
-    VDB_REQUIRE(lay.tail < (int64_t)0x7fffffff, "at most 2^31-1 positions per device");
+    ListLayout::Undo undo;
+    VDB_TRY(lay.plan_append(lists, count, dst, moves, undo));
+    // Everything that can fail comes before the first row is written; if it does, the plan is taken back and the
+    // index is what it was (buffers that have grown meanwhile keep their contents).
+    Workspace& ws = h->ws;
+    r.n = old_tail;         // room for every position handed out so far: the rows behind r.n are kept when buffers grow
+    const int reserved = [&]() -> int {
+        VDB_REQUIRE(lay.tail < (int64_t)0x7fffffff, "at most 2^31-1 positions per device");
+        VDB_TRY(rows_reserve(m, lay.tail + 256, s));     // 256 rows of room behind the last position, as after a build
+        VDB_TRY(h->row_ids.reserve_keep((size_t)r.cap * sizeof(int), (size_t)old_tail * sizeof(int), s));
+        VDB_TRY(ws.stage.reserve((size_t)count * h->dim * sizeof(float)));
+        VDB_TRY(h->app_rows.reserve((size_t)count * r.ld * sizeof(float)));
+        VDB_TRY(h->app_sq.reserve((size_t)count * sizeof(float)));
+        VDB_TRY(h->app_nrm.reserve((size_t)count * sizeof(float)));
+        VDB_TRY(h->app_dst.reserve((size_t)count * sizeof(int64_t)));
+        VDB_TRY(h->app_no.reserve((size_t)count * sizeof(int)));
+        return VDB_OK;
+    }();
+    if (reserved != VDB_OK) { lay.rollback(undo); return reserved; }
     lay.row_limit = row_limit;
-    // room for every position handed out so far (the rows behind r.n are kept when the buffers grow)
-    r.n = old_tail;
-    VDB_TRY(rows_reserve(m, lay.tail + 256, s));     // 256 rows of room behind the last position, as after a build
-    VDB_TRY(h->row_ids.reserve_keep((size_t)r.cap * sizeof(int), (size_t)old_tail * sizeof(int), s));
     r.n = lay.tail;
     for (const ListMove& mv : moves) {
         hipLaunchKernelGGL(ivf_move_rows_kernel, dim3(grid_for(mv.count * r.ld)), dim3(256), 0, s, r.data, r.sq, r.nrm,
@@ -1807,13 +1912,6 @@ int vdb_ivf_append(vdb_ivf* h, const float* rows, const int64_t* row_numbers, co
     }
     VDB_HIP(hipGetLastError());
     // the new rows: padded copy, norms in the order every other row's norms were summed in, then into their places
-    Workspace& ws = h->ws;
-    VDB_TRY(ws.stage.reserve((size_t)count * h->dim * sizeof(float)));
-    VDB_TRY(h->app_rows.reserve((size_t)count * r.ld * sizeof(float)));
-    VDB_TRY(h->app_sq.reserve((size_t)count * sizeof(float)));
-    VDB_TRY(h->app_nrm.reserve((size_t)count * sizeof(float)));
-    VDB_TRY(h->app_dst.reserve((size_t)count * sizeof(int64_t)));
-    VDB_TRY(h->app_no.reserve((size_t)count * sizeof(int)));
     VDB_HIP(hipMemcpyAsync(ws.stage.p, rows, (size_t)count * h->dim * sizeof(float), hipMemcpyHostToDevice, s));
     VDB_HIP(hipMemcpyAsync(h->app_dst.p, dst.data(), (size_t)count * sizeof(int64_t), hipMemcpyHostToDevice, s));
     VDB_HIP(hipMemcpyAsync(h->app_no.p, nums.data(), (size_t)count * sizeof(int), hipMemcpyHostToDevice, s));
@@ -2084,18 +2182,29 @@ int vdb_ivf_search_ordered_dev(vdb_ivf* h, const float* d_queries, int nq, int k
     return ivf_search_impl(h, d_queries, nq, k, n_probe, d_mask, d_out_dist, d_out_row, d_out_order, pick_stream(stream));
 }
 
-int vdb_ivf_search(vdb_ivf* h, const float* queries, int nq, int k, int n_probe, const uint32_t* mask,
-                   float* out_dist, int64_t* out_row) {
+static int ivf_search_host(vdb_ivf* h, const float* queries, int nq, int k, int n_probe, const uint32_t* mask,
+                           const vdb_mask* resident, float* out_dist, int64_t* out_row) {
     VDB_REQUIRE(h && (queries || nq == 0), "null argument");
     VDB_REQUIRE(k >= 1, "k must be >= 1, got %d", k);
     Entry g(h);
     hipStream_t s = h->stream;
     const uint32_t* d_mask = nullptr;
-    VDB_TRY(upload_mask(h->ws, mask, h->lay.row_limit, &d_mask, s));
+    VDB_TRY(resolve_mask(h->ws, mask, resident, h->lay.row_limit, &d_mask, s));
     return with_host_io(h->members->ws, queries, nq, h->dim, k, out_dist, out_row, s,
                         [&](const float* dq, float* dd, int64_t* di) {
                             return ivf_search_impl(h, dq, nq, k, n_probe, d_mask, dd, di, nullptr, s);
                         });
+}
+
+int vdb_ivf_search(vdb_ivf* h, const float* queries, int nq, int k, int n_probe, const uint32_t* mask,
+                   float* out_dist, int64_t* out_row) {
+    return ivf_search_host(h, queries, nq, k, n_probe, mask, nullptr, out_dist, out_row);
+}
+
+int vdb_ivf_search_masked(vdb_ivf* h, const float* queries, int nq, int k, int n_probe, const vdb_mask* mask,
+                          float* out_dist, int64_t* out_row) {
+    VDB_REQUIRE(mask, "null mask");
+    return ivf_search_host(h, queries, nq, k, n_probe, nullptr, mask, out_dist, out_row);
 }
 
 int vdb_ivf_probe(vdb_ivf* h, const float* queries, int nq, int n_probe, int32_t* out_lists, float* out_dist) {
@@ -2375,17 +2484,28 @@ int vdb_pq_search_dev(vdb_pq* h, const float* d_queries, int nq, int k, const ui
     return pq_search_impl(h, d_queries, nq, k, d_mask, d_out_dist, d_out_row, pick_stream(stream));
 }
 
-int vdb_pq_search(vdb_pq* h, const float* queries, int nq, int k, const uint32_t* mask, float* out_dist, int64_t* out_row) {
+static int pq_search_host(vdb_pq* h, const float* queries, int nq, int k, const uint32_t* mask, const vdb_mask* resident,
+                          float* out_dist, int64_t* out_row) {
     VDB_REQUIRE(h && (queries || nq == 0), "null argument");
     VDB_REQUIRE(k >= 1, "k must be >= 1, got %d", k);
     Entry g(h);
     hipStream_t s = h->stream;
     const uint32_t* d_mask = nullptr;
-    VDB_TRY(upload_mask(h->ws, mask, h->n, &d_mask, s));
+    VDB_TRY(resolve_mask(h->ws, mask, resident, h->n, &d_mask, s));
     return with_host_io(h->io, queries, nq, h->dim, k, out_dist, out_row, s,
                         [&](const float* dq, float* dd, int64_t* di) {
                             return pq_search_impl(h, dq, nq, k, d_mask, dd, di, s);
                         });
+}
+
+int vdb_pq_search(vdb_pq* h, const float* queries, int nq, int k, const uint32_t* mask, float* out_dist, int64_t* out_row) {
+    return pq_search_host(h, queries, nq, k, mask, nullptr, out_dist, out_row);
+}
+
+int vdb_pq_search_masked(vdb_pq* h, const float* queries, int nq, int k, const vdb_mask* mask, float* out_dist,
+                         int64_t* out_row) {
+    VDB_REQUIRE(mask, "null mask");
+    return pq_search_host(h, queries, nq, k, nullptr, mask, out_dist, out_row);
 }
 
 // ============================================================== IVF-PQ (index/hybrid.py)
@@ -2568,18 +2688,24 @@ int vdb_ivfpq_append(vdb_ivfpq* h, const uint8_t* codes, const int64_t* row_numb
     std::vector<int64_t> dst;
     std::vector<ListMove> moves;
     const int64_t old_tail = lay.tail;
-    VDB_TRY(lay.plan_append(lists, count, dst, moves));
-    VDB_REQUIRE(lay.tail < (int64_t)0x7fffffff, "at most 2^31-1 positions per device");
+    ListLayout::Undo undo;
+    VDB_TRY(lay.plan_append(lists, count, dst, moves, undo));
+    // every allocation before the first code is written; a failure takes the plan back
+    const int reserved = [&]() -> int {
+        VDB_REQUIRE(lay.tail < (int64_t)0x7fffffff, "at most 2^31-1 positions per device");
+        VDB_TRY(h->codes.reserve_keep((size_t)lay.tail * h->m, (size_t)old_tail * h->m, s));
+        VDB_TRY(h->row_ids.reserve_keep((size_t)lay.tail * sizeof(int), (size_t)old_tail * sizeof(int), s));
+        VDB_TRY(h->app_codes.reserve((size_t)count * h->m));
+        VDB_TRY(h->app_dst.reserve((size_t)count * sizeof(int64_t)));
+        VDB_TRY(h->app_no.reserve((size_t)count * sizeof(int)));
+        return VDB_OK;
+    }();
+    if (reserved != VDB_OK) { lay.rollback(undo); return reserved; }
     lay.row_limit = row_limit;
-    VDB_TRY(h->codes.reserve_keep((size_t)lay.tail * h->m, (size_t)old_tail * h->m, s));
-    VDB_TRY(h->row_ids.reserve_keep((size_t)lay.tail * sizeof(int), (size_t)old_tail * sizeof(int), s));
     for (const ListMove& mv : moves)
         hipLaunchKernelGGL(ivfpq_move_codes_kernel, dim3(grid_for(mv.count * h->m)), dim3(256), 0, s, h->codes.as<uint8_t>(),
                            h->row_ids.as<int>(), h->m, mv.from, mv.to, mv.count);
     VDB_HIP(hipGetLastError());
-    VDB_TRY(h->app_codes.reserve((size_t)count * h->m));
-    VDB_TRY(h->app_dst.reserve((size_t)count * sizeof(int64_t)));
-    VDB_TRY(h->app_no.reserve((size_t)count * sizeof(int)));
     VDB_HIP(hipMemcpyAsync(h->app_codes.p, codes, (size_t)count * h->m, hipMemcpyHostToDevice, s));
     VDB_HIP(hipMemcpyAsync(h->app_dst.p, dst.data(), (size_t)count * sizeof(int64_t), hipMemcpyHostToDevice, s));
     VDB_HIP(hipMemcpyAsync(h->app_no.p, nums.data(), (size_t)count * sizeof(int), hipMemcpyHostToDevice, s));
@@ -2712,18 +2838,29 @@ int vdb_ivfpq_search_dev(vdb_ivfpq* h, const float* d_queries, int nq, int k, in
     return ivfpq_search_impl(h, d_queries, nq, k, n_probe, d_mask, d_out_dist, d_out_row, pick_stream(stream));
 }
 
-int vdb_ivfpq_search(vdb_ivfpq* h, const float* queries, int nq, int k, int n_probe, const uint32_t* mask,
-                     float* out_dist, int64_t* out_row) {
+static int ivfpq_search_host(vdb_ivfpq* h, const float* queries, int nq, int k, int n_probe, const uint32_t* mask,
+                             const vdb_mask* resident, float* out_dist, int64_t* out_row) {
     VDB_REQUIRE(h && (queries || nq == 0), "null argument");
     VDB_REQUIRE(k >= 1, "k must be >= 1, got %d", k);
     Entry g(h);
     hipStream_t s = h->stream;
     const uint32_t* d_mask = nullptr;
-    VDB_TRY(upload_mask(h->ws, mask, h->lay.row_limit, &d_mask, s));
+    VDB_TRY(resolve_mask(h->ws, mask, resident, h->lay.row_limit, &d_mask, s));
     return with_host_io(h->io, queries, nq, h->dim, k, out_dist, out_row, s,
                         [&](const float* dq, float* dd, int64_t* di) {
                             return ivfpq_search_impl(h, dq, nq, k, n_probe, d_mask, dd, di, s);
                         });
+}
+
+int vdb_ivfpq_search(vdb_ivfpq* h, const float* queries, int nq, int k, int n_probe, const uint32_t* mask,
+                     float* out_dist, int64_t* out_row) {
+    return ivfpq_search_host(h, queries, nq, k, n_probe, mask, nullptr, out_dist, out_row);
+}
+
+int vdb_ivfpq_search_masked(vdb_ivfpq* h, const float* queries, int nq, int k, int n_probe, const vdb_mask* mask,
+                            float* out_dist, int64_t* out_row) {
+    VDB_REQUIRE(mask, "null mask");
+    return ivfpq_search_host(h, queries, nq, k, n_probe, nullptr, mask, out_dist, out_row);
 }
 
 // ============================================================== cross-shard merge
@@ -2758,6 +2895,21 @@ int vdb_topk_merge_keyed_dev(const float* d_dist, const int64_t* d_key, const in
     VDB_REQUIRE(d_dist && d_key && d_row && d_out_dist && d_out_row && n_lists >= 1 && nq >= 0 && k >= 1,
                 "bad arguments to vdb_topk_merge_keyed_dev");
     return launch_select_i64(d_dist, d_key, d_row, (int64_t)nq * k, (int64_t)nq * k, nullptr, n_lists, nq, k,
+                             d_out_dist, d_out_row, pick_stream(stream));
+}
+
+// the keyed merge over lists that lie `list_stride_*` elements apart (blocks of one packed all-gather)
+int vdb_topk_merge_keyed_strided_dev(const float* d_dist, const int64_t* d_key, const int64_t* d_row, int64_t list_stride_dist,
+                                     int64_t list_stride_key_row, int n_lists, int nq, int k,
+                                     float* d_out_dist, int64_t* d_out_row, void* stream) {
+    VDB_TRY(ensure_init());
+    (void)hipSetDevice(ctx().device);
+    VDB_REQUIRE(d_dist && d_key && d_row && d_out_dist && d_out_row && n_lists >= 1 && nq >= 0 && k >= 1,
+                "bad arguments to vdb_topk_merge_keyed_strided_dev");
+    VDB_REQUIRE(list_stride_dist >= (int64_t)nq * k && list_stride_key_row >= (int64_t)nq * k,
+                "list strides (%lld, %lld) are shorter than one list of %lld entries", (long long)list_stride_dist,
+                (long long)list_stride_key_row, (long long)nq * k);
+    return launch_select_i64(d_dist, d_key, d_row, list_stride_dist, list_stride_key_row, nullptr, n_lists, nq, k,
                              d_out_dist, d_out_row, pick_stream(stream));
 }
 

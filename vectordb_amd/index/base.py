@@ -80,12 +80,15 @@ class SearchResult:                                              # index/base.py
 class BaseIndex(ABC):
     """index/base.py:128-485"""
 
+    filter_cache_slots = 4          # evaluated filters kept per index (FilterCache); 0 evaluates on every search
+
     def __init__(self, dimension: int, metric: str = "euclidean", **kwargs):
         self._dimension = dimension
         self._metric = metric
         self._is_trained = False
         self._build_time = 0.0
         self._lock = threading.RLock()
+        self._filters = FilterCache(self.filter_cache_slots)
 
     @property
     def dimension(self) -> int:
@@ -183,6 +186,18 @@ class BaseIndex(ABC):
             raise ValueError(f"Vector dimension {vectors.shape[1]} != index dimension {self._dimension}")
         return vectors
 
+    def _filter_for_device(self, filter_fn: Optional[FilterFunction], ids, metadata_of, host_words: bool = False):
+        """What a device search takes as its filter: None, or the resident mask of ``filter_fn`` over ``ids`` (a row
+        whose id is None never passes).  ``host_words=True`` returns the packed words instead."""
+        if filter_fn is None:
+            return None
+        if self._filters.slots != self.filter_cache_slots:
+            self._filters.slots = self.filter_cache_slots
+        words, dev, _ = self._filters.lookup(
+            filter_fn, lambda: np.fromiter((i is not None and bool(filter_fn(i, metadata_of(i))) for i in ids),
+                                           dtype=bool, count=len(ids)))
+        return words if (host_words or dev is None) else dev
+
     def __len__(self) -> int:
         return self.size
 
@@ -206,6 +221,52 @@ def unit_vector(vector: np.ndarray) -> np.ndarray:
     """index/flat.py:186-189,314-317"""
     norm = np.linalg.norm(vector)
     return vector / norm if norm > 1e-8 else vector
+
+
+class FilterCache:
+    """Evaluated filters of one index, kept on the device.
+
+    The reference calls ``filter_fn(id, metadata)`` for every row inside every filtered search
+    (index/flat.py:396-413, index/ivf.py:622, index/pq.py:287-297).  Here a filter is evaluated once per write
+    version of the index: the packed row mask stays in HBM (``_native.DeviceMask``) and later searches with the
+    same filter name it, so they neither call ``filter_fn`` nor upload anything.  "The same filter" is the same
+    callable object (or an equal string key, which is what ``Collection`` derives from a filter dict); a callable
+    whose answers change without a write to the index (it reads outside state) must not be cached: set
+    ``filter_cache_slots = 0`` on the index.  Any add, remove, update or clear drops every entry."""
+
+    def __init__(self, slots: int = 4):
+        self.slots = slots
+        self.version = 0                 # bumped by every write of the owning index
+        self._entries: list = []         # (key, version, packed host words, DeviceMask, any row passes); newest last
+        self.evaluations = 0             # filters evaluated over all rows (a cache hit does not count)
+
+    def touch(self) -> None:
+        self.version += 1
+        if self._entries:
+            self.drop()
+
+    def drop(self) -> None:
+        for e in self._entries:
+            e[3].close()
+        self._entries = []
+
+    def lookup(self, key, build):
+        """(host words, resident mask, any) for ``key``; ``build()`` -> boolean row mask runs on a miss."""
+        for i, e in enumerate(self._entries):
+            if e[1] == self.version and (e[0] is key or (isinstance(key, str) and isinstance(e[0], str) and e[0] == key)):
+                self._entries.append(self._entries.pop(i))
+                return e[2], e[3], e[4]
+        from .. import _native as N
+        mask = np.asarray(build(), dtype=bool)
+        self.evaluations += 1
+        words = N.pack_mask(mask)
+        if self.slots <= 0:
+            return words, None, bool(mask.any())
+        dev = N.DeviceMask(words, n_bits=len(mask))
+        while len(self._entries) >= self.slots:
+            self._entries.pop(0)[3].close()
+        self._entries.append((key, self.version, words, dev, bool(mask.any())))
+        return words, dev, bool(mask.any())
 
 
 def filter_mask(filter_fn: Optional[FilterFunction], ids, metadata_of) -> Optional[np.ndarray]:

@@ -35,18 +35,21 @@ class FlatIndex(BaseIndex):
     """Exact k-NN over every stored row (index/flat.py:69-956)."""
 
     def __init__(self, dimension: int, metric: str = "euclidean", normalize: bool = False, use_matrix: bool = True,
-                 initial_capacity: int = 1000, storage: str = "f32", prefilter: Optional[str] = None, **kwargs):
+                 initial_capacity: int = 1000, storage: str = "f32", prefilter: Optional[str] = "auto", **kwargs):
         """`storage` is not a reference argument: "bf16" keeps the device copy of the rows in
         bfloat16 (euclidean, euclidean_squared, cosine, dot only; distances are those of inputs
         rounded to bf16).  The host copy returned by get()/include_vectors stays fp32.
-        `prefilter="bf16"` (fp32 storage only, not a reference argument either) runs the pass of a batched
+        `prefilter` (fp32 storage only, not a reference argument either): "bf16" runs the pass of a batched
         search over all rows on a bf16 copy of them and recomputes the few remaining rows in fp32: results
-        are bit for bit those without it, the device holds half as many bytes again."""
+        are bit for bit those without it, the device holds half as many bytes again.  "auto" (the default)
+        does so while the copy leaves a tenth of the device memory free; None never does."""
         super().__init__(dimension, metric, **kwargs)
         if storage not in N.STORAGE:
             raise ValueError(f"storage must be one of {sorted(N.STORAGE)}, got {storage!r}")
-        if prefilter not in (None, "bf16") or (prefilter and storage != "f32"):
-            raise ValueError(f"prefilter must be None or 'bf16' (with fp32 storage), got {prefilter!r}")
+        if storage != "f32" and prefilter == "auto":
+            prefilter = None
+        if prefilter not in N.PREFILTER or (prefilter and storage != "f32"):
+            raise ValueError(f"prefilter must be None, 'bf16' or 'auto' (with fp32 storage), got {prefilter!r}")
         self._storage = storage
         self._prefilter = prefilter
         self.config = FlatIndexConfig(dimension=dimension, metric=metric, normalize=normalize, use_matrix=use_matrix,
@@ -112,6 +115,7 @@ class FlatIndex(BaseIndex):
             self._id_to_index[id] = self._size
             self._metadata[id] = metadata or {}
             self._size += 1
+            self._filters.touch()
 
     def add_batch(self, ids: List[str], vectors, metadata: Optional[List[Dict[str, Any]]] = None) -> int:
         vectors = self._validate_vectors(vectors)
@@ -135,6 +139,7 @@ class FlatIndex(BaseIndex):
                 self._id_to_index[id] = self._size + i
                 self._metadata[id] = metadata[i] if metadata else {}
             self._size += n
+            self._filters.touch()
         return n
 
     # ------------------------------------------------------------ search
@@ -151,9 +156,8 @@ class FlatIndex(BaseIndex):
                 metadata=self._metadata.get(id, {}).copy() if include_metadata else None))
         return out
 
-    def _mask_words(self, filter_fn: Optional[FilterFunction]):
-        mask = filter_mask(filter_fn, self._ids, lambda i: self._metadata.get(i, {}))
-        return N.pack_mask(mask)
+    def _mask_words(self, filter_fn: Optional[FilterFunction], host_words: bool = False):
+        return self._filter_for_device(filter_fn, self._ids, lambda i: self._metadata.get(i, {}), host_words)
 
     def search(self, query, k: int = 10, filter_fn: Optional[FilterFunction] = None, include_vectors: bool = False,
                include_metadata: bool = True) -> List[SearchResult]:
@@ -213,7 +217,7 @@ class FlatIndex(BaseIndex):
         with self._lock:
             if self._size == 0:
                 return []
-            dist, rows = self._device().range_search(query, radius, self._metric_code(), self._mask_words(filter_fn),
+            dist, rows = self._device().range_search(query, radius, self._metric_code(), self._mask_words(filter_fn, host_words=True),
                                                      cap=max_results or self._size)
             return self._results(dist, rows, False, True)
 
@@ -243,6 +247,7 @@ class FlatIndex(BaseIndex):
             del self._metadata[id]
             self._ids.pop()
             self._size -= 1
+            self._filters.touch()
             return True
 
     def remove_batch(self, ids: List[str]) -> int:
@@ -262,6 +267,7 @@ class FlatIndex(BaseIndex):
                     self._store.set_row(idx, self._vectors[idx])
             if metadata is not None:
                 self._metadata[id] = metadata
+                self._filters.touch()
             return True
 
     # ------------------------------------------------------------ get / misc
@@ -288,6 +294,7 @@ class FlatIndex(BaseIndex):
             if self._store is not None:
                 self._store.truncate(0)
             self._synced = 0
+            self._filters.touch()
             return count
 
     def stats(self) -> IndexStats:
@@ -315,7 +322,7 @@ class FlatIndex(BaseIndex):
         index = cls(dimension=data["dimension"], metric=data["metric"], normalize=cfg.get("normalize", False),
                     use_matrix=cfg.get("use_matrix", True),
                     initial_capacity=max(cfg.get("initial_capacity", 1000), len(ids)),
-                    storage=cfg.get("storage", "f32"), prefilter=cfg.get("prefilter"))
+                    storage=cfg.get("storage", "f32"), prefilter=cfg.get("prefilter", "auto"))
         if len(ids) > 0:
             meta = data.get("metadata", {})
             index.add_batch(ids, np.array(data.get("vectors", []), dtype=np.float32), [meta.get(i, {}) for i in ids])
@@ -381,3 +388,6 @@ class FlatIndex(BaseIndex):
         store = getattr(self, "_store", None)
         if store is not None:
             store.close()
+        filters = getattr(self, "_filters", None)
+        if filters is not None:
+            filters.drop()

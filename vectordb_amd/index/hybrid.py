@@ -149,6 +149,7 @@ class HybridIndex(BaseIndex):
                 self._ids.append(id)
                 self._metadata[id] = (metadata[i] if metadata else None) or {}
             self._size += n
+            self._filters.touch()
         return n
 
     def remove(self, id: str) -> bool:
@@ -166,6 +167,7 @@ class HybridIndex(BaseIndex):
             self._ids.remove(id)
             self._metadata.pop(id, None)
             self._size -= 1
+            self._filters.touch()
             return True
 
     def remove_batch(self, ids: List[str]) -> int:
@@ -176,6 +178,7 @@ class HybridIndex(BaseIndex):
         self._ids.clear(); self._row_of.clear(); self._row_ids.clear(); self._metadata.clear()
         self._size = 0
         self._dirty = True
+        self._filters.touch()
         return count
 
     # ------------------------------------------------------------ device lists
@@ -194,18 +197,18 @@ class HybridIndex(BaseIndex):
             new = np.arange(self._synced, n_rows, dtype=np.int64)
             new = new[lists[new] >= 0]
             if len(new):
-                self._dev.append(self._codes_arr[new], new, lists[new])
+                try:
+                    self._dev.append(self._codes_arr[new], new, lists[new])
+                except Exception:
+                    self._dirty = True      # the device lists are as they were: the next search builds them afresh
+                    raise
                 live, _positions, dead = self._dev.layout()
                 if dead > live + 4096:      # more abandoned places than rows: pack the lists again at the next search
                     self._dirty = True
         self._synced = n_rows
 
     def _mask_words(self, filter_fn: Optional[FilterFunction]):
-        if filter_fn is None:
-            return None
-        mask = np.fromiter((i is not None and bool(filter_fn(i, self._metadata.get(i, {}))) for i in self._row_ids),
-                           dtype=bool, count=len(self._row_ids))
-        return N.pack_mask(mask)
+        return self._filter_for_device(filter_fn, self._row_ids, lambda i: self._metadata.get(i, {}))
 
     # ------------------------------------------------------------ search
     def _results(self, dist_row, rows_row, include_vectors: bool, include_metadata: bool) -> List[SearchResult]:

@@ -258,6 +258,7 @@ class IVFIndex(BaseIndex):
         self._lists = {i: [] for i in range(self.config.n_clusters)}
         self._is_trained = True
         self._dev_dirty = True
+        self._filters.touch()
         if self._dev is not None:
             self._dev.close()
             self._dev = None
@@ -280,6 +281,7 @@ class IVFIndex(BaseIndex):
         self._id_to_cluster[id] = cluster
         self._id_to_position[id] = len(self._lists[cluster])
         self._lists[cluster].append(slot)
+        self._filters.touch()
         if not self._dev_dirty:
             self._pending.append(slot)
 
@@ -357,7 +359,12 @@ class IVFIndex(BaseIndex):
             return
         slots = np.asarray(self._pending, dtype=np.int64)
         lists = np.fromiter((self._id_to_cluster[self._slot_id[s]] for s in self._pending), dtype=np.int32, count=len(slots))
-        self._dev.append(self._vectors[slots], slots, lists)
+        try:
+            self._dev.append(self._vectors[slots], slots, lists)
+        except Exception:
+            self._dev_dirty = True          # the device lists are as they were: the next search builds them afresh
+            self._pending = []
+            raise
         self._pending = []
         live, _positions, dead = self._dev.layout()
         if dead > live + 4096:              # more abandoned places than rows: pack the lists again at the next search
@@ -365,11 +372,7 @@ class IVFIndex(BaseIndex):
 
     # ------------------------------------------------------------ search
     def _mask_words(self, filter_fn: Optional[FilterFunction]):
-        if filter_fn is None:
-            return None
-        mask = np.fromiter((i is not None and bool(filter_fn(i, self._metadata.get(i, {}))) for i in self._slot_id),
-                           dtype=bool, count=len(self._slot_id))
-        return N.pack_mask(mask)
+        return self._filter_for_device(filter_fn, self._slot_id, lambda i: self._metadata.get(i, {}))
 
     def _results(self, dist_row, rows_row, include_vectors: bool, include_metadata: bool) -> List[SearchResult]:
         out = []
@@ -446,6 +449,7 @@ class IVFIndex(BaseIndex):
             lst.pop()
             self._slot_id[self._slot_of[id]] = None
             del self._slot_of[id], self._metadata[id], self._id_to_cluster[id], self._id_to_position[id]
+            self._filters.touch()
             return True
 
     def remove_batch(self, ids: List[str]) -> int:
@@ -468,6 +472,7 @@ class IVFIndex(BaseIndex):
             self._slot_id = []
             self._n_slots = 0
             self._dev_dirty = True
+            self._filters.touch()
             return count
 
     def reset(self) -> None:
@@ -563,6 +568,7 @@ class IVFIndex(BaseIndex):
                 lst.append(slot)
             self._dev_dirty = True
             self._pending = []
+            self._filters.touch()
 
     def iter_ids(self) -> Iterator[str]:
         return iter(list(self._slot_of))
@@ -608,3 +614,6 @@ class IVFIndex(BaseIndex):
         dev = getattr(self, "_dev", None)
         if dev is not None:
             dev.close()
+        filters = getattr(self, "_filters", None)
+        if filters is not None:
+            filters.drop()

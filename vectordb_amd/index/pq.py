@@ -166,6 +166,7 @@ class PQIndex(BaseIndex):
                 self._ids.append(id)
                 self._metadata[id] = (metadata[i] if metadata else None) or {}
             self._synced = base + n
+            self._filters.touch()
         return n
 
     def _sync(self) -> None:
@@ -179,11 +180,7 @@ class PQIndex(BaseIndex):
 
     # ------------------------------------------------------------ search
     def _mask_words(self, filter_fn: Optional[FilterFunction]):
-        if filter_fn is None:
-            return None
-        mask = np.fromiter((bool(filter_fn(i, self._metadata.get(i, {}))) for i in self._ids), dtype=bool,
-                           count=len(self._ids))
-        return N.pack_mask(mask)
+        return self._filter_for_device(filter_fn, self._ids, lambda i: self._metadata.get(i, {}))
 
     def _results(self, dist_row, rows_row, include_vectors: bool, include_metadata: bool) -> List[SearchResult]:
         out = []
@@ -242,6 +239,7 @@ class PQIndex(BaseIndex):
             for j in range(r, n - 1):
                 self._row_of[self._ids[j]] = j
             self._synced = -1
+            self._filters.touch()
             return True
 
     def remove_batch(self, ids: List[str]) -> int:
@@ -260,6 +258,7 @@ class PQIndex(BaseIndex):
             count = self.size
             self._ids.clear(); self._row_of.clear(); self._metadata.clear()
             self._synced = -1
+            self._filters.touch()
             return count
 
     def stats(self) -> IndexStats:

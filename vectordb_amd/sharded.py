@@ -34,12 +34,13 @@ def shard_range(n_total: int, world: int, rank: int) -> Tuple[int, int]:
 class HipFlatBackend:
     """Local search and merge on the GPU through the C ABI."""
 
-    def __init__(self, dim: int, metric: int, storage: str = "f32", prefilter: Optional[str] = None):
+    def __init__(self, dim: int, metric: int, storage: str = "f32", prefilter: Optional[str] = "auto"):
         from . import _native
         self._n = _native
         self.store = _native.RowStore(dim, storage=storage)
-        if prefilter is not None:
-            self.store.set_prefilter(prefilter)     # same results, the pass over all rows on the bf16 matrix cores
+        if prefilter is not None and storage == "f32":
+            # same results, the pass over all rows on the bf16 matrix cores ("auto": while the bf16 copy leaves room)
+            self.store.set_prefilter(prefilter)
         self.metric = metric
 
     def add_device(self, rows: torch.Tensor) -> None:
@@ -163,53 +164,75 @@ def local_ivf_layout(list_of_row, n_lists: int, owner, rank: int):
 
 
 class HipIvfBackend:
-    """This rank's inverted lists behind the C ABI (all centroids, own lists only)."""
+    """This rank's inverted lists behind the C ABI (all centroids, own lists only).  The rows are stored under
+    their GLOBAL row numbers, so a local search returns global rows and nothing is translated afterwards."""
 
     def __init__(self, dim: int, metric: int, centroids, rows_local, list_rows_local, list_offsets, global_rows):
+        import numpy as np
         from . import _native
         self._n = _native
         self.lists = _native.IvfLists(dim, metric)
         self.lists.set_centroids(centroids)
-        self.lists.build_lists(rows_local, list_rows_local, list_offsets)
-        self.global_rows = torch.as_tensor(global_rows, dtype=torch.int64, device="cuda")
+        order = np.asarray(list_rows_local, dtype=np.int64)            # local rows in list order
+        rows_local = np.ascontiguousarray(rows_local, dtype=np.float32).reshape(-1, dim)
+        self.lists.build_numbered(rows_local[order], np.asarray(global_rows, dtype=np.int64)[order], list_offsets)
 
     def local_search(self, queries, k, n_probe, out_dist, out_rows, out_order) -> None:
         self.lists.search_device(queries.data_ptr(), queries.shape[0], k, n_probe, out_dist.data_ptr(), out_rows.data_ptr(),
                                  stream=torch.cuda.current_stream().cuda_stream, out_order_ptr=out_order.data_ptr())
-        valid = out_rows >= 0
-        out_rows.copy_(torch.where(valid, self.global_rows[out_rows.clamp(min=0)], out_rows))
 
     def merge(self, all_dist, all_order, all_rows, k, out_dist, out_rows) -> None:
+        """all_* : [world][nq][k] views into the gathered blocks (rank stride = one block)."""
         world, nq = all_dist.shape[0], all_dist.shape[1]
-        self._n.topk_merge_keyed_device(all_dist.data_ptr(), all_order.data_ptr(), all_rows.data_ptr(), world, nq, k,
-                                        out_dist.data_ptr(), out_rows.data_ptr(),
-                                        stream=torch.cuda.current_stream().cuda_stream)
+        assert all_dist.stride(1) == k and all_order.stride(1) == k and all_rows.stride(1) == k
+        assert all_order.stride(0) == all_rows.stride(0) or world == 1
+        self._n.topk_merge_keyed_strided_device(all_dist.data_ptr(), all_order.data_ptr(), all_rows.data_ptr(),
+                                                all_dist.stride(0) if world > 1 else nq * k,
+                                                all_order.stride(0) if world > 1 else nq * k, world, nq, k,
+                                                out_dist.data_ptr(), out_rows.data_ptr(),
+                                                stream=torch.cuda.current_stream().cuda_stream)
 
 
 class ShardedIVF:
     """IVF search with the inverted lists spread over the ranks of a process group.
     Every rank ranks all centroids (they are replicated), scans the probed lists it
-    owns, and the per-rank results are merged by (distance, visiting order)."""
+    owns, and the per-rank results are merged by (distance, visiting order).
+
+    A rank's result travels as one packed block, [nq*k fp32 distances | pad to 8 bytes | nq*k int64 visiting
+    orders | nq*k int64 global rows]: one all-gather per search, merged where the blocks arrive.  The buffers
+    are made once per (nq, k, device) and reused."""
 
     def __init__(self, backend, rank: int = 0, world: int = 1, group=None):
         self.backend, self.rank, self.world, self.group = backend, rank, world, group
+        self._buf = {}
+
+    def _buffers(self, nq: int, k: int, device):
+        key = (nq, k, str(device))
+        if key not in self._buf:
+            dist_bytes = (nq * k * 4 + 7) // 8 * 8
+            block = dist_bytes + 2 * nq * k * 8
+            local = torch.empty(block, device=device, dtype=torch.uint8)
+            gathered = torch.empty(self.world * block, device=device, dtype=torch.uint8)
+
+            def views(buf, lead):
+                b2 = buf.view(lead, block)
+                return (b2[:, :nq * k * 4].view(torch.float32).view(lead, nq, k),
+                        b2[:, dist_bytes:dist_bytes + nq * k * 8].view(torch.int64).view(lead, nq, k),
+                        b2[:, dist_bytes + nq * k * 8:].view(torch.int64).view(lead, nq, k))
+            ld, lo, lr = (v[0] for v in views(local, 1))
+            gd, go, gr = views(gathered, self.world)
+            self._buf[key] = (local, gathered, ld, lo, lr, gd, go, gr,
+                              torch.empty((nq, k), device=device, dtype=torch.float32),
+                              torch.empty((nq, k), device=device, dtype=torch.int64))
+        return self._buf[key]
 
     def search(self, queries: torch.Tensor, k: int, n_probe: int):
-        nq, dev = queries.shape[0], queries.device
-        ld = torch.empty((nq, k), device=dev, dtype=torch.float32)
-        lr = torch.empty((nq, k), device=dev, dtype=torch.int64)
-        lo = torch.empty((nq, k), device=dev, dtype=torch.int64)
+        nq = queries.shape[0]
+        local, gathered, ld, lo, lr, gd, go, gr, od, orow = self._buffers(nq, k, queries.device)
         self.backend.local_search(queries, k, n_probe, ld, lr, lo)
         if self.world == 1:
             return ld, lr
-        gd = torch.empty((self.world, nq, k), device=dev, dtype=torch.float32)
-        gr = torch.empty((self.world, nq, k), device=dev, dtype=torch.int64)
-        go = torch.empty((self.world, nq, k), device=dev, dtype=torch.int64)
-        dist.all_gather_into_tensor(gd.view(self.world * nq, k), ld, group=self.group)
-        dist.all_gather_into_tensor(gr.view(self.world * nq, k), lr, group=self.group)
-        dist.all_gather_into_tensor(go.view(self.world * nq, k), lo, group=self.group)
-        od = torch.empty((nq, k), device=dev, dtype=torch.float32)
-        orow = torch.empty((nq, k), device=dev, dtype=torch.int64)
+        dist.all_gather_into_tensor(gathered, local, group=self.group)
         self.backend.merge(gd, go, gr, k, od, orow)
         return od, orow
 
