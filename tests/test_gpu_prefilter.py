@@ -217,8 +217,9 @@ def test_prefilter_config1_full_size(nat):
 
 
 def test_prefilter_through_the_index_and_collection_classes(nat):
-    """FlatIndex(prefilter="bf16") and Collection(prefilter="bf16"): search_batch returns what the same classes
-    return without it (ids, distances, scores), and the device store reports the filter pass."""
+    """FlatIndex / Collection with prefilter="bf16" and with the default ("auto": on while the copy fits): search_batch
+    returns what the same classes return with prefilter=None (ids, distances, scores), and the device store reports
+    the filter pass."""
     from vectordb_amd.index.flat import FlatIndex
     from vectordb_amd.core.collection import Collection
     rng = np.random.default_rng(41)
@@ -226,17 +227,18 @@ def test_prefilter_through_the_index_and_collection_classes(nat):
     x = rng.standard_normal((n, d), dtype=np.float32)
     q = rng.standard_normal((20, d), dtype=np.float32)
     ids = [f"v{i}" for i in range(n)]
-    plain, filt = FlatIndex(d, metric="cosine"), FlatIndex(d, metric="cosine", prefilter="bf16")
-    for ix in (plain, filt):
+    plain, filt, auto = FlatIndex(d, metric="cosine", prefilter=None), FlatIndex(d, metric="cosine", prefilter="bf16"), FlatIndex(d, metric="cosine")
+    for ix in (plain, filt, auto):
         ix.add_batch(ids, x)
-    a, b = plain.search_batch(q, 10), filt.search_batch(q, 10)
-    assert filt._store.used_prefilter() and not plain._store.used_prefilter()
+    a, b, c = plain.search_batch(q, 10), filt.search_batch(q, 10), auto.search_batch(q, 10)
+    assert filt._store.used_prefilter() and auto._store.used_prefilter() and not plain._store.used_prefilter()
     assert [[(r.id, r.distance) for r in rs] for rs in a] == [[(r.id, r.distance) for r in rs] for rs in b]
+    assert [[(r.id, r.distance) for r in rs] for rs in a] == [[(r.id, r.distance) for r in rs] for rs in c]
     odd = lambda id, metadata: int(id[1:]) % 2 == 1
     a, b = plain.search_batch(q, 5, filter_fn=odd), filt.search_batch(q, 5, filter_fn=odd)
     assert [[(r.id, r.distance) for r in rs] for rs in a] == [[(r.id, r.distance) for r in rs] for rs in b]
 
-    cols = [Collection("c0", d, metric="euclidean"), Collection("c1", d, metric="euclidean", prefilter="bf16")]
+    cols = [Collection("c0", d, metric="euclidean", prefilter=None), Collection("c1", d, metric="euclidean", prefilter="bf16")]
     for c in cols:
         c.add_batch([{"id": ids[i], "vector": x[i], "metadata": {"g": i % 3}} for i in range(n)])
     a, b = (c.search_batch(q, 10) for c in cols)

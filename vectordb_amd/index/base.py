@@ -252,6 +252,8 @@ class FilterCache:
 
     def lookup(self, key, build):
         """(host words, resident mask, any) for ``key``; ``build()`` -> boolean row mask runs on a miss."""
+        if self.slots <= 0 and self._entries:
+            self.drop()
         for i, e in enumerate(self._entries):
             if e[1] == self.version and (e[0] is key or (isinstance(key, str) and isinstance(e[0], str) and e[0] == key)):
                 self._entries.append(self._entries.pop(i))
