@@ -302,6 +302,19 @@ int vdb_ivf_search_ordered_dev(vdb_ivf* h, const float* d_queries, int nq, int k
                                int64_t* d_out_order, void* stream);
 /* probe selection alone (ivf.py:611-614): n_probe nearest lists per query, ascending */
 int vdb_ivf_probe(vdb_ivf* h, const float* queries, int nq, int n_probe, int32_t* out_lists, float* out_dist);
+/* Batched Euclidean searches (index/ivf.py:619-632 with the per-pair form of distance/metrics.py:43) behind a
+ * matrix-core scan: the handle keeps a bf16 copy of its member rows (half their size again, brought up to date
+ * lazily after writes), the scan computes |q|^2 + |c|^2 - 2 q.c on the bf16 matrix cores for every (probed row,
+ * query) pair, and only pairs within a proven margin of the query's k-th best are recomputed in the reference's
+ * arithmetic (float32 differences, NumPy's summation order) and ranked.  Rows, their order and the distance bits
+ * are those of the streaming scan (tests/test_gpu_ivf_mfma.py); no counterpart in the reference.  Modes as
+ * vdb_rows_set_prefilter: VDB_PREFILTER_AUTO (the default: the copy is taken while it leaves a tenth of the
+ * device free), VDB_PREFILTER_BF16 (always), VDB_PREFILTER_NONE (never; frees the copy).  Applies to batches of
+ * at least 2 queries with k <= 32. */
+int vdb_ivf_set_prefilter(vdb_ivf* h, int mode);
+/* Diagnostics of the last search on this handle: *used_matrix_scan = 1 when it took the path above, *overflowed = 1
+ * when a candidate queue was too small and the streaming scan repeated the batch.  Waits for the search. */
+int vdb_ivf_search_stats(vdb_ivf* h, int* used_matrix_scan, int* overflowed);
 /* bytes one search of this batch reads from the lists (sum of probed list lengths * dim * 4), for roofline accounting */
 int vdb_ivf_last_scan_rows(vdb_ivf* h, int64_t* rows_scanned);
 

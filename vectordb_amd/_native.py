@@ -107,6 +107,8 @@ SIGNATURES = {
                                              C.c_void_p, C.c_void_p, C.c_void_p]),
     "vdb_ivf_probe": (C.c_int, [C.c_void_p, c_float_p, C.c_int, C.c_int, c_i32_p, c_float_p]),
     "vdb_ivf_last_scan_rows": (C.c_int, [C.c_void_p, c_i64_p]),
+    "vdb_ivf_set_prefilter": (C.c_int, [C.c_void_p, C.c_int]),
+    "vdb_ivf_search_stats": (C.c_int, [C.c_void_p, C.POINTER(C.c_int), C.POINTER(C.c_int)]),
     "vdb_pq_encode": (C.c_int, [c_float_p, C.c_int64, c_float_p, C.c_int, C.c_int, C.c_int, c_u8_p]),
     "vdb_pq_create": (C.c_int, [C.POINTER(C.c_void_p), C.c_int, C.c_int, C.c_int]),
     "vdb_pq_destroy": (C.c_int, [C.c_void_p]),
@@ -651,6 +653,19 @@ class IvfLists:
         n = C.c_int64(0)
         check(self.lib.vdb_ivf_last_scan_rows(self.h, C.byref(n)))
         return n.value
+
+    def set_prefilter(self, mode: Optional[str]) -> None:
+        """Batched Euclidean searches behind the matrix-core scan over a bf16 copy of the member rows: "auto" (the
+        default: while the copy leaves a tenth of the device free), "bf16" (always) or None (never).  Same results."""
+        if mode not in PREFILTER:
+            raise ValueError(f"prefilter must be None, 'bf16' or 'auto', got {mode!r}")
+        check(self.lib.vdb_ivf_set_prefilter(self.h, PREFILTER[mode]))
+
+    def search_stats(self):
+        """(used the matrix-core scan, a queue overflowed and the streaming scan repeated the batch) of the last search."""
+        a, b = C.c_int(0), C.c_int(0)
+        check(self.lib.vdb_ivf_search_stats(self.h, C.byref(a), C.byref(b)))
+        return bool(a.value), bool(b.value)
 
 
 class PqCodes:

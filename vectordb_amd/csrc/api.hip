@@ -241,11 +241,11 @@ struct Workspace {
     // item table of the last flat scan, kept between calls: it depends on (rows, queries, group) only
     DevBuf fp_seg_row_off, fp_seg_q_off, fp_seg_item_off, fp_sq_qid, fp_sq_out, fp_items;
     int64_t fp_n = -1; int fp_nq = -1, fp_group = -1;
-    DevBuf round32, q16, cand, seg_row_off, seg_q_off, seg_item_off, sq_qid, sq_out, cand_off, tile_off, list_cnt, cursor, slots, items;
+    DevBuf round32, q16, cand, seg_row_off, seg_q_off, seg_item_off, sq_qid, sq_out, sq_rank, cand_off, tile_off, list_cnt, cursor, slots, items;
     template <class F> void each(F&& f) {
         DevBuf* all[] = {&q_buf, &q_sq, &q_nrm, &part_d, &part_i, &lb_d, &lb_k, &thr_d, &thr_k, &mask, &out_d, &out_i, &dist,
                          &probes, &probe_d, &lut, &stage, &round32, &q16, &cand, &seg_row_off, &seg_q_off, &seg_item_off, &sq_qid, &sq_out,
-                         &cand_off, &tile_off, &list_cnt, &cursor, &slots, &items,
+                         &cand_off, &tile_off, &list_cnt, &cursor, &slots, &items, &sq_rank,
                          &queue, &queue_cnt, &flag, &mins, &ticket, &mid[0], &mid[1], &mid[2], &mid[3],
                          &fp_seg_row_off, &fp_seg_q_off, &fp_seg_item_off, &fp_sq_qid, &fp_sq_out, &fp_items};
         for (DevBuf* b : all) f(b);
@@ -344,6 +344,10 @@ static int rows_reserve(vdb_rows* h, int64_t n_total, hipStream_t s) {
     if (st == VDB_OK) st = h->nrm.reserve_keep((size_t)cap * sizeof(float), (size_t)r.n * sizeof(float), s);
     r.nrm = h->nrm.as<float>();
     if (st != VDB_OK) return st;
+    // norm terms of positions nobody has written read as zero (inverted lists keep free room between their rows, and
+    // the largest norm over a range of positions must not pick up what the allocator left there)
+    VDB_HIP(hipMemsetAsync(r.sq + r.n, 0, (size_t)(cap - r.n) * sizeof(float), s));
+    VDB_HIP(hipMemsetAsync(r.nrm + r.n, 0, (size_t)(cap - r.n) * sizeof(float), s));
     r.cap = cap;
     return VDB_OK;
 }
@@ -970,6 +974,22 @@ struct vdb_ivf : Handle {
     DevBuf row_ids;                     // int   [positions]  row number of every stored position
     DevBuf app_rows, app_sq, app_nrm, app_dst, app_no;     // staging of appended rows
     int n_lists = 0;
+    // bf16 copy of the member rows for the matrix-core scan of batched Euclidean searches (vdb_ivf_set_prefilter):
+    // same positions as the fp32 rows, brought up to date lazily from the position ranges writes have touched
+    int prefilter = VDB_PREFILTER_AUTO;
+    DevBuf shadow16, max_nrm;
+    int64_t shadow_cap = 0;                                // positions the copy has room for
+    bool shadow_stale = true;                              // everything must be converted (no copy yet, or a rebuild)
+    std::vector<std::pair<int64_t, int64_t>> shadow_dirty; // [from, to) position ranges written since the last search
+    void shadow_note(int64_t from, int64_t to) {
+        if (shadow_stale || to <= from) return;
+        if (shadow_dirty.size() >= 32) {                   // many small writes: one range over all of them
+            for (const auto& r : shadow_dirty) { from = std::min(from, r.first); to = std::max(to, r.second); }
+            shadow_dirty.clear();
+        }
+        shadow_dirty.emplace_back(from, to);
+    }
+    bool last_used_mfma = false;
     int64_t probe_bound(int n_probe) { return lay.probe_bound(n_probe); }
     int64_t last_scan_rows = -1;
     int last_nq = 0, last_nprobe = 0;
@@ -1756,6 +1776,7 @@ int vdb_ivf_destroy(vdb_ivf* h) {
         if (h->last_stream && h->last_stream != h->stream) (void)hipStreamSynchronize(h->last_stream);
         h->lay.dev.release(); h->row_ids.release(); h->ws.release();
         h->app_rows.release(); h->app_sq.release(); h->app_nrm.release(); h->app_dst.release(); h->app_no.release();
+        h->shadow16.release(); h->max_nrm.release();
     }
     vdb_rows_destroy(h->centroids);
     vdb_rows_destroy(h->members);
@@ -1771,6 +1792,8 @@ int vdb_ivf_set_centroids(vdb_ivf* h, const float* centroids, int n_lists) {
     VDB_TRY(vdb_rows_append(h->centroids, centroids, n_lists));
     h->n_lists = n_lists;
     h->lay.reset(n_lists);
+    h->shadow_stale = true;
+    h->shadow_dirty.clear();
     VDB_TRY(vdb_rows_truncate(h->members, 0));
     return VDB_OK;
 }
@@ -1798,6 +1821,8 @@ static int ivf_build_impl(vdb_ivf* h, const float* rows, int64_t n, const int64_
     hipStream_t s = h->stream;
     vdb_rows* m = h->members;
     m->r.n = 0;
+    h->shadow_stale = true;
+    h->shadow_dirty.clear();
     h->lay.set_packed(list_offsets);
     h->lay.row_limit = row_limit;
     VDB_TRY(h->lay.sync(s));
@@ -1906,6 +1931,13 @@ int vdb_ivf_append(vdb_ivf* h, const float* rows, const int64_t* row_numbers, co
     if (reserved != VDB_OK) { lay.rollback(undo); return reserved; }
     lay.row_limit = row_limit;
     r.n = lay.tail;
+    for (const ListMove& mv : moves) h->shadow_note(mv.to, mv.to + mv.count);
+    if (count <= 16) {
+        for (int64_t i = 0; i < count; ++i) h->shadow_note(dst[(size_t)i], dst[(size_t)i] + 1);
+    } else {
+        const auto mm = std::minmax_element(dst.begin(), dst.end());
+        h->shadow_note(*mm.first, *mm.second + 1);
+    }
     for (const ListMove& mv : moves) {
         hipLaunchKernelGGL(ivf_move_rows_kernel, dim3(grid_for(mv.count * r.ld)), dim3(256), 0, s, r.data, r.sq, r.nrm,
                            h->row_ids.as<int>(), r.ld, mv.from, mv.to, mv.count);
@@ -1940,6 +1972,7 @@ int vdb_ivf_remove_at(vdb_ivf* h, int32_t list, int64_t position) {
         hipLaunchKernelGGL(ivf_move_rows_kernel, dim3(1), dim3(256), 0, h->stream, r.data, r.sq, r.nrm, h->row_ids.as<int>(), r.ld,
                            lay.beg[list] + last, lay.beg[list] + position, (int64_t)1);
         VDB_HIP(hipGetLastError());
+        h->shadow_note(lay.beg[list] + position, lay.beg[list] + position + 1);
     }
     --lay.len[list];
     --lay.live;
@@ -2067,6 +2100,57 @@ static int ivf_search_one(vdb_ivf* h, const float* d_q, int k, int n_probe, cons
     return launch_topk_cand(cj, s);
 }
 
+// bf16 copy of the member rows up to date: everything after a build, otherwise the ranges writes have touched.
+// VDB_ERR_NOMEM: no room for the copy (the caller then scans the fp32 rows alone).
+static int ivf_shadow_sync(vdb_ivf* h, hipStream_t s) {
+    Rows& r = h->members->r;
+    const int ld16 = ivf_mfma_pitch(r.dim);
+    if (!h->max_nrm.p) {
+        VDB_TRY(h->max_nrm.reserve(sizeof(float)));
+        h->shadow_stale = true;
+    }
+    if (h->shadow_cap < r.cap || !h->shadow16.p) {
+        const size_t want = (size_t)r.cap * ld16 * 2;
+        if (h->prefilter == VDB_PREFILTER_AUTO) {
+            // the copy is taken only while it leaves a tenth of the device (at least 2 GiB) free for everything else
+            size_t free_b = 0, total_b = 0;
+            VDB_HIP(hipMemGetInfo(&free_b, &total_b));
+            if (free_b + h->shadow16.cap < want + std::max<size_t>(total_b / 10, (size_t)2 << 30)) return VDB_ERR_NOMEM;
+        }
+        // positions past the copy's old end are converted below (they are new, hence noted or stale)
+        VDB_TRY(h->shadow16.reserve_keep(want, h->shadow_stale ? 0 : (size_t)std::min(h->shadow_cap, r.n) * ld16 * 2, s));
+        h->shadow_cap = r.cap;
+    }
+    uint16_t* dst = h->shadow16.as<uint16_t>();
+    if (h->shadow_stale) {
+        VDB_TRY(launch_ivf_round_rows(r.data, r.ld, r.dim, r.n, dst, ld16, s));
+        VDB_HIP(hipMemsetAsync(h->max_nrm.p, 0, sizeof(float), s));
+        VDB_TRY(launch_max_norm(r.nrm, 0, r.n, h->max_nrm.as<float>(), s));
+        h->shadow_stale = false;
+    } else {
+        for (const auto& d : h->shadow_dirty) {
+            const int64_t from = std::max<int64_t>(d.first, 0), to = std::min(d.second, r.n);
+            if (to <= from) continue;
+            VDB_TRY(launch_ivf_round_rows(r.data + from * r.ld, r.ld, r.dim, to - from, dst + from * ld16, ld16, s));
+            // a running maximum: a row that was overwritten may leave it larger than needed, never smaller
+            VDB_TRY(launch_max_norm(r.nrm, from, to, h->max_nrm.as<float>(), s));
+        }
+    }
+    h->shadow_dirty.clear();
+    return VDB_OK;
+}
+
+static constexpr int IVF_MFMA_GROUP = 32;           // queries per item: the columns of one 32 x 32 accumulator
+static constexpr int IVF_MFMA_QUEUE = 8192;         // most (slot, position) entries per query
+static constexpr int64_t IVF_BOUND_ROWS = 1024;     // rows of a query's nearest lists its bound is taken from
+
+static bool ivf_mfma_ok(const vdb_ivf* h, int sm, int nq, int64_t k_eff) {
+    static const bool off = getenv("VDB_IVF_NO_MFMA") != nullptr;
+    const Rows& m = h->members->r;
+    return !off && h->prefilter != VDB_PREFILTER_NONE && (sm == VDB_EUCLIDEAN_DIRECT || sm == VDB_EUCLIDEAN_SQ_DIRECT) && nq >= 2 &&
+           k_eff <= KMAX_FUSED && !m.bf16 && m.dim <= 2048;
+}
+
 static int ivf_search_impl(vdb_ivf* h, const float* d_q, int nq, int k, int n_probe, const uint32_t* d_mask,
                            float* d_out_d, int64_t* d_out_i, int64_t* d_out_order, hipStream_t s) {
     VDB_REQUIRE(h->n_lists >= 1, "index is not trained");
@@ -2093,7 +2177,18 @@ static int ivf_search_impl(vdb_ivf* h, const float* d_q, int nq, int k, int n_pr
     VDB_REQUIRE(cand_stride < (int64_t)0x7fffffff, "n_probe=%d lists can hold more than 2^31 rows", n_probe);
     const int q_block = (int)std::max<int64_t>(1, std::min<int64_t>(nq, CAND_BUDGET / (cand_stride * (int64_t)sizeof(float))));
     // queries per row chunk: 8, or up to 128 with the row-resident kernel (VDB_STREAM_GROUP=8 or 16 for A/B timing)
-    const int group = nq == 1 ? 1 : stream_batch_group(m->r.dim, m->r.ld, m->r.plan, op_of_metric(sm), 8, -1);
+    int group = nq == 1 ? 1 : stream_batch_group(m->r.dim, m->r.ld, m->r.plan, op_of_metric(sm), 8, -1);
+    // Euclidean batches: the scan on the matrix cores over bf16 copies of the rows, the survivors recomputed in the
+    // reference's arithmetic; the streaming scan below then runs only behind the overflow flag
+    bool mfma = ivf_mfma_ok(h, sm, nq, k_eff);
+    if (mfma) {
+        const int st = ivf_shadow_sync(h, s);
+        if (st == VDB_ERR_NOMEM) { (void)hipGetLastError(); mfma = false; }
+        else VDB_TRY(st);
+    }
+    h->last_used_mfma = mfma;
+    const int scan_group = group;                   // what the streaming kernel is configured for
+    if (mfma && group > IVF_MFMA_GROUP) group = IVF_MFMA_GROUP;      // items of at most 32 queries serve both kernels
 
     VDB_TRY(ws.probes.reserve((size_t)nq * n_probe * sizeof(int)));
     VDB_TRY(ws.probe_d.reserve((size_t)nq * n_probe * sizeof(float)));
@@ -2116,20 +2211,54 @@ static int ivf_search_impl(vdb_ivf* h, const float* d_q, int nq, int k, int n_pr
         VDB_TRY(ws.lb_k.reserve((size_t)q_block * sizeof(int64_t)));
     }
     const int64_t avg_tiles = std::max<int64_t>(1, ((int64_t)n_probe * (h->lay.live / std::max(1, h->n_lists)) + 255) / 256);
+    const int ld16 = ivf_mfma_pitch(m->r.dim);
+    const int* run_if = nullptr;
+    // a queue as long as a query's candidates cannot overflow; longer ones are cut at IVF_MFMA_QUEUE entries
+    const int queue_cap = (int)std::min<int64_t>(cand_stride, IVF_MFMA_QUEUE);
+    if (mfma) {
+        VDB_TRY(ws.sq_rank.reserve((size_t)q_block * n_probe * sizeof(int)));
+        VDB_TRY(ws.q16.reserve((size_t)nq * ld16 * 2));
+        VDB_TRY(ws.mins.reserve((size_t)q_block * ivf_mfma_subsets() * sizeof(float)));
+        VDB_TRY(ws.thr_d.reserve((size_t)q_block * sizeof(float)));
+        VDB_TRY(ws.queue.reserve((size_t)q_block * queue_cap * sizeof(int2)));
+        VDB_TRY(ws.queue_cnt.reserve((size_t)q_block * sizeof(int)));
+        VDB_TRY(ws.flag.reserve(sizeof(int)));
+        VDB_TRY(launch_ivf_round_rows(q, m->r.ld, m->r.dim, nq, ws.q16.as<uint16_t>(), ld16, s));
+        run_if = ws.flag.as<int>();
+    }
 
     for (int q0 = 0; q0 < nq; q0 += q_block) {
         const int nb = std::min(q_block, nq - q0);
         const int* probes = ws.probes.as<int>() + (int64_t)q0 * n_probe;
         VDB_TRY(launch_ivf_plan(probes, nb, n_probe, h->lay.d_beg(), h->lay.d_end(), h->n_lists, group, cand_stride,
-                                ws.list_cnt.as<int>(), ws.cursor.as<int>(), ws.cand_off.as<int64_t>(), ws.tile_off.as<int>(), b, s));
+                                ws.list_cnt.as<int>(), ws.cursor.as<int>(), ws.cand_off.as<int64_t>(), ws.tile_off.as<int>(), b, s,
+                                mfma ? ws.sq_rank.as<int>() : nullptr, IVF_BOUND_ROWS));
+        if (mfma) {
+            IvfMfmaJob mj{};
+            mj.rows16 = h->shadow16.as<uint16_t>(); mj.ld16 = ld16; mj.row_sq = m->r.sq;
+            mj.rows = m->r.data; mj.ld = m->r.ld; mj.dim = m->r.dim; mj.sum_plan = m->r.plan;
+            mj.q = q + (int64_t)q0 * m->r.ld; mj.ldq = m->r.ld; mj.q16 = ws.q16.as<uint16_t>() + (int64_t)q0 * ld16;
+            mj.q_sq = ws.q_sq.as<float>() + q0; mj.q_nrm = ws.q_nrm.as<float>() + q0; mj.nq = nb;
+            mj.plan = b; mj.sq_rank = ws.sq_rank.as<int>(); mj.cand_stride = cand_stride;
+            mj.probes = probes; mj.n_probe = n_probe; mj.n_lists = h->n_lists;
+            mj.cand_off = ws.cand_off.as<int64_t>(); mj.list_beg = h->lay.d_beg();
+            mj.row_ids = h->row_ids.as<int>(); mj.mask = d_mask; mj.max_row_nrm = h->max_nrm.as<float>();
+            mj.mins = ws.mins.as<float>(); mj.thr = ws.thr_d.as<float>(); mj.queue = reinterpret_cast<int2*>(ws.queue.p);
+            mj.queue_len = ws.queue_cnt.as<int>(); mj.queue_cap = queue_cap; mj.overflow = ws.flag.as<int>();
+            mj.k = kmax; mj.k_out = k; mj.take_sqrt = sm == VDB_EUCLIDEAN_DIRECT;
+            mj.out_d = d_out_d + (int64_t)q0 * k; mj.out_rows = d_out_i + (int64_t)q0 * k;
+            mj.out_order = d_out_order ? d_out_order + (int64_t)q0 * k : nullptr;
+            mj.timed = true;
+            VDB_TRY(launch_ivf_mfma_search(mj, s));
+        }
         StreamJob j{};
         j.data = m->r.data; j.ld = m->r.ld; j.dim = m->r.dim; j.plan = m->r.plan;
         j.op = op_of_metric(sm); j.post = post_of_metric(sm);
         if (j.post == POST_SQRT) j.post = POST_NONE;      // the selection below takes the root (CandJob::sqrt_here)
-        j.q = q + (int64_t)q0 * m->r.ld; j.ldq = m->r.ld; j.group = group; j.n_seg = h->n_lists;
+        j.q = q + (int64_t)q0 * m->r.ld; j.ldq = m->r.ld; j.group = scan_group; j.n_seg = h->n_lists;
         j.seg_row_off = h->lay.d_beg(); j.seg_q_off = b.seg_q_off; j.seg_item_off = b.seg_item_off;
         j.sq_qid = b.sq_qid; j.sq_out = b.sq_out; j.items = b.items; j.items_cap = b.items_cap;
-        j.out = ws.cand.as<float>(); j.timed = true;
+        j.out = ws.cand.as<float>(); j.timed = !mfma; j.run_if = run_if;
         VDB_TRY(launch_stream_sums(j, s));
 
         const int splits = cand_splits(avg_tiles, nb);
@@ -2156,13 +2285,14 @@ static int ivf_search_impl(vdb_ivf* h, const float* d_q, int nq, int k, int n_pr
             c.row_sq = m->r.sq; c.row_nrm = m->r.nrm;
             c.lb_d = done > 0 ? ws.lb_d.as<float>() : nullptr; c.lb_k = done > 0 ? ws.lb_k.as<int64_t>() : nullptr;
             c.k = kk; c.splits = splits; c.part_d = ws.part_d.as<float>(); c.part_i = ws.part_i.as<int>();
+            c.run_if = run_if;
             VDB_TRY(launch_topk_cand(c, s));
             SelectOut o{d_out_d + (int64_t)q0 * k, nullptr, ws.slots.as<int>() + (int64_t)q0 * k, k, (int)done,
-                        multi ? ws.lb_d.as<float>() : nullptr, multi ? ws.lb_k.as<int64_t>() : nullptr};
+                        multi ? ws.lb_d.as<float>() : nullptr, multi ? ws.lb_k.as<int64_t>() : nullptr, run_if};
             VDB_TRY(launch_select(ws.part_d.as<float>(), ws.part_i.as<int>(), nb, n_cand, kk, 1 << 30, nullptr, 0, o, s, ws.mid));
             VDB_TRY(launch_ivf_rows(ws.slots.as<int>() + (int64_t)q0 * k, nb, kk, k, (int)done, probes, n_probe, h->n_lists,
                                     ws.cand_off.as<int64_t>(), h->lay.d_beg(), h->row_ids.as<int>(),
-                                    d_out_i + (int64_t)q0 * k, d_out_order ? d_out_order + (int64_t)q0 * k : nullptr, s));
+                                    d_out_i + (int64_t)q0 * k, d_out_order ? d_out_order + (int64_t)q0 * k : nullptr, s, run_if));
         }
     }
     return VDB_OK;
@@ -2222,6 +2352,34 @@ int vdb_ivf_probe(vdb_ivf* h, const float* queries, int nq, int n_probe, int32_t
     if (out_lists) VDB_HIP(hipMemcpyAsync(out_lists, ws.probes.p, (size_t)nq * n_probe * sizeof(int), hipMemcpyDeviceToHost, s));
     if (out_dist) VDB_HIP(hipMemcpyAsync(out_dist, ws.probe_d.p, (size_t)nq * n_probe * sizeof(float), hipMemcpyDeviceToHost, s));
     VDB_HIP(hipStreamSynchronize(s));
+    return VDB_OK;
+}
+
+int vdb_ivf_set_prefilter(vdb_ivf* h, int mode) {
+    VDB_REQUIRE(h && mode >= VDB_PREFILTER_NONE && mode <= VDB_PREFILTER_AUTO, "unknown prefilter mode %d", mode);
+    Entry g(h);
+    h->prefilter = mode;
+    if (mode == VDB_PREFILTER_NONE) {
+        (void)hipStreamSynchronize(h->stream);
+        if (h->last_stream && h->last_stream != h->stream) (void)hipStreamSynchronize(h->last_stream);
+        h->shadow16.release();
+        h->shadow_cap = 0;
+        h->shadow_stale = true;
+        h->shadow_dirty.clear();
+    }
+    return VDB_OK;
+}
+
+int vdb_ivf_search_stats(vdb_ivf* h, int* used_matrix_scan, int* overflowed) {
+    VDB_REQUIRE(h && used_matrix_scan && overflowed, "null argument");
+    Entry g(h);
+    *used_matrix_scan = h->last_used_mfma ? 1 : 0;
+    *overflowed = 0;
+    if (h->last_used_mfma && h->ws.flag.p) {
+        hipStream_t s = h->last_stream ? h->last_stream : h->stream;
+        VDB_HIP(hipMemcpyAsync(overflowed, h->ws.flag.p, sizeof(int), hipMemcpyDeviceToHost, s));
+        VDB_HIP(hipStreamSynchronize(s));
+    }
     return VDB_OK;
 }
 

@@ -1,0 +1,409 @@
+// Batched IVF list scan on the matrix cores, behind an exact recomputation.
+//
+// The reference scans the probed lists with the per-pair scalar distance (index/ivf.py:619-628: for Euclidean
+// sqrt(sum((q - c)^2)), distance/metrics.py:43) and sorts the candidates (:631).  What a batch needs from the scan
+// is each query's k best; everything else of the ~n_probe * n / n_lists distances per query is thrown away.  So:
+//
+//   1. bound pass  (ivf_approx_kernel<MODE_BOUND>): over each query's nearest probed lists (until 1024 rows), the
+//      approximate key  |q|^2 + |c|^2 - 2 bf16(q).bf16(c)  of every row on v_mfma_f32_32x32x16_bf16, reduced to 64
+//      minima over disjoint row subsets; the k-th smallest of them is not below the k-th smallest key of those rows.
+//   2. ivf_threshold_kernel: that value, widened by what the approximate key can differ from the reference's
+//      float32 sum (bf16 rounding of both operands, the float32 roundings of both forms), and widened again for
+//      the test itself: every row that can be among the reference's k best has a key within the threshold.
+//   3. scan pass   (ivf_approx_kernel<MODE_SCAN>): the same keys for every (probed list row, query) pair, list-major
+//      (a list chunk is read once for up to 32 queries that probe it); pairs within the threshold (and passing the
+//      filter bit) are appended to the query's queue as (candidate slot, stored position).
+//   4. ivf_exact_select_kernel: one wave per query recomputes the queued pairs in the reference's own arithmetic
+//      (element-wise float32 q - c, square, NumPy's pairwise summation order, sqrtf) and keeps the k best under
+//      (distance, candidate slot) = (distance, visiting order of index/ivf.py:619-628).
+//
+// Rows, order and distance bits equal those of the scalar scan, because every returned value is computed by the same
+// float32 operations on the same float32 rows; the matrix cores only decide which pairs get computed.  A queue that
+// overflows raises a device flag, and the streaming scan repeats the batch behind that flag.
+#include "vdb_internal.h"
+#include "vdb_device.h"
+#include "flat_math.h"
+
+#include <cstdio>
+#include <cstdlib>
+#include <vector>
+
+namespace vdb {
+
+static constexpr int IA_NT = 256;          // threads per block: four independent waves
+static constexpr int IA_SUBSETS = 64;      // disjoint row subsets whose key minima bound a query's k-th best
+
+enum { MODE_BOUND = 0, MODE_SCAN = 1 };
+
+struct IvfApproxParams {
+    const uint16_t* rows16; int ld16;      // bf16 copies of the stored rows, [positions][ld16]
+    int n_chunks;                          // column chunks of KS * 16 elements per row
+    const float* row_sq;                   // |c|^2 of the float32 rows, by position
+    const uint16_t* q16;                   // bf16 copies of the queries, [nq][ld16]
+    const float* q_sq;                     // |q|^2 of the float32 queries
+    const StreamItem* items; const int64_t* seg_item_off; int n_seg; int64_t items_cap;
+    const int* sq_qid; const int64_t* sq_out; const int* sq_rank;     // per (list, query): query, first slot, probe rank | bound flag << 16
+    int64_t cand_stride;                   // sq_out = query * cand_stride + slot of the list's first row
+    const float* thr;                      // MODE_SCAN: per query, pairs with key <= thr are queued
+    int2* queue; int* queue_len; int queue_cap; int* overflow;
+    float* mins;                           // MODE_BOUND: [nq][IA_SUBSETS], smallest key per subset (non-negative floats)
+    const int* row_ids; const uint32_t* mask;
+};
+
+typedef int i4v __attribute__((ext_vector_type(4)));
+typedef int i8v __attribute__((ext_vector_type(8)));
+
+template <class T> __device__ __forceinline__ T uniform_load(const T* p) {
+    return *reinterpret_cast<const __attribute__((address_space(4))) T*>(reinterpret_cast<uintptr_t>(p));
+}
+
+// One wave per item = (chunk of up to 256 stored rows of one list, up to 32 of the queries that probe the list).
+// A operand: 32 rows, lane (row = lane % 32, half = lane / 32) holds its row's columns [half * 8 KS, half * 8 KS + 8 KS)
+// of the current column chunk as KS 16-byte pieces, loaded straight from global memory; k step j multiplies piece j of
+// both halves, i.e. the columns are visited in a permuted order, the same for rows and queries (the sum does not care).
+// B operand: the item's queries in the same layout.  The 32 x 32 accumulator gives lane (query = lane % 32) sixteen
+// rows: 8 g + 4 half + i.
+typedef float f4u __attribute__((ext_vector_type(4), aligned(4)));      // four floats at any dword address
+
+template <int KS, bool MULTI, int MODE>
+__global__ __launch_bounds__(IA_NT) void ivf_approx_kernel(IvfApproxParams p) {
+    const int lane = threadIdx.x & 63;
+    const int n = lane & 31, h = lane >> 5;
+    const int64_t n_waves = (int64_t)gridDim.x * (IA_NT / 64);
+    const int64_t wave0 = (int64_t)blockIdx.x * (IA_NT / 64) + (threadIdx.x >> 6);
+    const int64_t total = min(uniform_load(p.seg_item_off + p.n_seg), p.items_cap);
+    constexpr int CE = KS * 16;                    // elements per column chunk
+    for (int64_t item = wave0; item < total; item += n_waves) {
+        const i8v w = uniform_load(reinterpret_cast<const i8v*>(p.items + item));
+        const int64_t row0 = ((int64_t)(uint32_t)w[1] << 32) | (uint32_t)w[0];
+        const int64_t out_rel = ((int64_t)(uint32_t)w[3] << 32) | (uint32_t)w[2];
+        const int rows = w[4], qbeg = w[5], qcnt = w[6];
+        const bool live = n < qcnt;
+        const int qslot = qbeg + (live ? n : 0);
+        const int qid = p.sq_qid[qslot];
+        const int rank = p.sq_rank[qslot];
+        if (MODE == MODE_BOUND) {
+            // only queries for which this list is one of the nearest (flagged by the plan) take part
+            if (__ballot(live && (rank >> 16)) == 0ull) continue;
+        }
+        const bool mine = live && (MODE == MODE_SCAN || (rank >> 16));
+        const float q_sq = p.q_sq[qid];
+        const float thr = (MODE == MODE_SCAN && mine) ? p.thr[qid] : -INFINITY;
+        const int slot0 = (int)(p.sq_out[qslot] - (int64_t)qid * p.cand_stride + out_rel);
+        const int n_tiles = (rows + 31) >> 5;
+        const uint16_t* arow = p.rows16 + (row0 + n) * p.ld16 + h * (CE / 2);
+        const uint16_t* brow = p.q16 + (int64_t)qid * p.ld16 + h * (CE / 2);
+        i4v a[KS], b[KS];
+        if (!MULTI) {
+#pragma unroll
+            for (int j = 0; j < KS; ++j) b[j] = *reinterpret_cast<const i4v*>(brow + j * 8);
+#pragma unroll
+            for (int j = 0; j < KS; ++j) a[j] = *reinterpret_cast<const i4v*>(arow + j * 8);
+        }
+        for (int t = 0; t < n_tiles; ++t) {
+            float best = INFINITY;
+            const int64_t pos_t = row0 + t * 32;
+            // the row terms first, then the coming tile's rows: waiting for the former leaves the latter in flight
+            f4u cs[4];
+#pragma unroll
+            for (int g = 0; g < 4; ++g) cs[g] = *reinterpret_cast<const f4u*>(p.row_sq + pos_t + 8 * g + 4 * h);
+            f32x16 acc;
+#pragma unroll
+            for (int e = 0; e < 16; ++e) acc[e] = 0.0f;
+            if (MULTI) {
+                for (int c = 0; c < p.n_chunks; ++c) {
+#pragma unroll
+                    for (int j = 0; j < KS; ++j) a[j] = *reinterpret_cast<const i4v*>(arow + ((int64_t)t * 32) * p.ld16 + c * CE + j * 8);
+#pragma unroll
+                    for (int j = 0; j < KS; ++j) b[j] = *reinterpret_cast<const i4v*>(brow + c * CE + j * 8);
+#pragma unroll
+                    for (int j = 0; j < KS; ++j)
+                        acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, a[j]), __builtin_bit_cast(bf16x8, b[j]),
+                                                                      acc, 0, 0, 0);
+                }
+            } else {
+                i4v an[KS];
+                // (the last tile refetches itself: no branch around the loads)
+                const uint16_t* nxt = arow + (int64_t)min(t + 1, n_tiles - 1) * 32 * p.ld16;
+#pragma unroll
+                for (int j = 0; j < KS; ++j) an[j] = *reinterpret_cast<const i4v*>(nxt + j * 8);
+#pragma unroll
+                for (int j = 0; j < KS; ++j)
+                    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, a[j]), __builtin_bit_cast(bf16x8, b[j]),
+                                                                  acc, 0, 0, 0);
+#pragma unroll
+                for (int j = 0; j < KS; ++j) a[j] = an[j];
+            }
+            // keys of this lane's sixteen rows
+            uint32_t hits = 0;
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    const int r = t * 32 + 8 * g + 4 * h + i;
+                    const float key = __fmaf_rn(-2.0f, acc[g * 4 + i], q_sq + cs[g][i]);
+                    if (MODE == MODE_SCAN) {
+                        if (key <= thr && r < rows) hits |= 1u << (g * 4 + i);
+                    } else {
+                        bool ok = mine && r < rows;
+                        if (ok && p.mask) {
+                            const int id = p.row_ids[pos_t + 8 * g + 4 * h + i];
+                            ok = (p.mask[id >> 5] >> (id & 31)) & 1u;
+                        }
+                        // a key below zero counts as zero: the k-th smallest of larger values is still a bound
+                        if (ok) best = fminf(best, fmaxf(key, 0.0f));
+                    }
+                }
+            }
+            if (MODE == MODE_SCAN && __ballot(hits != 0) != 0ull) {
+                while (hits) {
+                    const int e = __builtin_ctz(hits);
+                    hits &= hits - 1;
+                    const int r = t * 32 + 8 * (e >> 2) + 4 * h + (e & 3);
+                    const int64_t pos = row0 + r;
+                    if (p.mask) {
+                        const int id = p.row_ids[pos];
+                        if (!((p.mask[id >> 5] >> (id & 31)) & 1u)) continue;
+                    }
+                    const int at = atomicAdd(&p.queue_len[qid], 1);
+                    if (at < p.queue_cap) p.queue[(int64_t)qid * p.queue_cap + at] = make_int2(slot0 + r, (int)pos);
+                    else *p.overflow = 1;
+                }
+            }
+            if (MODE == MODE_BOUND && mine && best < INFINITY) {
+                // the rows of a list fall into 64 subsets by (32-row tile of the list) mod 32 and half; lists share them
+                const int subset = h * 32 + (int)(((out_rel >> 5) + t) & 31);
+                atomicMin(reinterpret_cast<int*>(p.mins) + (int64_t)qid * IA_SUBSETS + subset, __float_as_int(best));
+            }
+        }
+    }
+}
+
+// --------------------------------------------------------------------------
+// Per query: B = the k-th smallest of its subset minima (an upper bound of the k-th smallest approximate key over the
+// rows of its nearest lists), then the threshold of the scan pass.
+//
+// Let d be the squared distance in real arithmetic, R the reference's float32 sum of squared differences and A the
+// approximate key, u = 2^-24.
+//   |A - d| <= 2 E + (D + 4) u (|q|^2 + |c|^2): E bounds the error of the bf16 dot product as the matrix cores form it,
+//              (2^-7 + 2^-16) |q||c| for rounding both operands to 8 significant bits plus D 2^-22 |q||c| for the
+//              float32 accumulation; the rest are the roundings of the two norm sums, their sum and the final fma;
+//   |R - d| <= (D + 2) u d (1 + ...) <= 2 (D + 2) u (|q|^2 + |c|^2): two roundings per term, D - 1 in the sum.
+// With S = 2 E + (4 D + 16) u (|q|^2 + max|c|^2) every row has |A - R| <= S.  k rows have A <= B, hence R <= B + S, so
+// the reference's k-th smallest sum is at most B + S; rows that tie it after the square root lie within one part in
+// 2^22 of it; and any row with R <= (B + S)(1 + 2^-21) has A <= (B + S)(1 + 2^-21) + S, which is the threshold.
+// Norms whose squares or products could leave float32 (or are not numbers) raise the overflow flag instead.
+__global__ __launch_bounds__(256) void ivf_threshold_kernel(const float* __restrict__ mins, int nq, int k, int dim,
+                                                            const float* __restrict__ q_sq, const float* __restrict__ q_nrm,
+                                                            const float* __restrict__ max_row_nrm, float* __restrict__ thr,
+                                                            int* __restrict__ overflow) {
+    const int lane = threadIdx.x & 63;
+    const int q = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (q >= nq) return;
+    WaveTopK top;
+    top.init(k);
+    const float v = mins[(int64_t)q * IA_SUBSETS + lane];
+    top.offer(v < INFINITY, v, lane, lane);
+    if (lane != 0) return;
+    const float qn = q_nrm[q], big = *max_row_nrm;
+    if (!(qn < 1e18f) || !(big < 1e18f)) { *overflow = 1; thr[q] = INFINITY; return; }
+    const float e_dot = (0.0078278f + (float)dim * 2.4e-7f) * 1.0001f * qn * big + sqrtf((float)dim) * 1.2e-38f * (qn + big) + 1e-30f;
+    const float s = 2.0f * e_dot + (4.0f * (float)dim + 16.0f) * 6.0e-8f * 1.01f * (q_sq[q] + big * big);
+    const float b = top.thr;                     // +inf while fewer than k subsets saw a row
+    thr[q] = b < INFINITY ? ((b + s) * 1.000001f + s) : INFINITY;
+}
+
+// --------------------------------------------------------------------------
+// The reference's sum of squared differences of one (query, row) pair: float32 q - c, its square, np.sum's pairwise
+// order (leaves of at most 128 terms with eight strided partial sums, folded pairwise; distance/metrics.py:43).
+__device__ static float exact_sqdiff(const float* __restrict__ x, const float* __restrict__ q, const SumPlan& plan) {
+    float stack[8];
+    int sp = 0, off = 0;
+    for (int l = 0; l < plan.n_leaves; ++l) {
+        const int len = plan.leaf_len[l];
+        float res;
+        if (len < 8) {
+            res = 0.0f;
+            for (int i = 0; i < len; ++i) { const float d = q[off + i] - x[off + i]; res = res + d * d; }
+        } else {
+            float r[8];
+#pragma unroll
+            for (int j = 0; j < 8; ++j) { const float d = q[off + j] - x[off + j]; r[j] = d * d; }
+            int i = 8;
+            for (; i + 8 <= len; i += 8) {
+#pragma unroll
+                for (int j = 0; j < 8; ++j) { const float d = q[off + i + j] - x[off + i + j]; r[j] = r[j] + d * d; }
+            }
+            res = ((r[0] + r[1]) + (r[2] + r[3])) + ((r[4] + r[5]) + (r[6] + r[7]));
+            for (; i < len; ++i) { const float d = q[off + i] - x[off + i]; res = res + d * d; }
+        }
+        off += len;
+        stack[sp++] = res;
+        for (int f = 0; f < plan.folds[l]; ++f) {
+            const float b = stack[--sp];
+            const float a = stack[--sp];
+            stack[sp++] = a + b;
+        }
+    }
+    return stack[0];
+}
+
+struct IvfExactParams {
+    const float* rows; int ld; SumPlan plan;     // the float32 rows, by position
+    const float* q; int ldq;                     // the float32 queries (padded rows)
+    int take_sqrt;                               // VDB_EUCLIDEAN_DIRECT: the distance is the root of the sum
+    const int2* queue; int* queue_len; int queue_cap;
+    int nq, k, k_out;
+    const int* probes; int n_probe; int n_lists;
+    const int64_t* cand_off; const int64_t* list_beg; const int* row_ids;
+    float* out_d; int64_t* out_rows; int64_t* out_order;
+};
+
+__global__ __launch_bounds__(256) void ivf_exact_select_kernel(IvfExactParams p) {
+    const int lane = threadIdx.x & 63;
+    const int q = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (q >= p.nq) return;
+    const int len = min(p.queue_len[q], p.queue_cap);
+    const float* qrow = p.q + (int64_t)q * p.ldq;
+    WaveTopK top;
+    top.init(p.k);
+    for (int base = 0; base < len; base += 64) {
+        const bool have = base + lane < len;
+        const int2 e = have ? p.queue[(int64_t)q * p.queue_cap + base + lane] : make_int2(EMPTY_IDX, 0);
+        float d = INFINITY;
+        if (have) {
+            const float sum = exact_sqdiff(p.rows + (int64_t)e.y * p.ld, qrow, p.plan);
+            d = p.take_sqrt ? sqrtf(sum) : sum;
+        }
+        top.offer(have, d, e.x, lane);
+    }
+    if (lane >= p.k) return;                     // result slots past k keep what the caller filled them with
+    const int64_t at = (int64_t)q * p.k_out + lane;
+    const int slot = top.eid;
+    if (slot == EMPTY_IDX) {
+        p.out_d[at] = INFINITY;
+        p.out_rows[at] = -1;
+        if (p.out_order) p.out_order[at] = -1;
+        return;
+    }
+    const int64_t* co = p.cand_off + (int64_t)q * (p.n_probe + 1);
+    int lo = 0, hi = p.n_probe;                  // co[lo] <= slot < co[hi]
+    while (hi - lo > 1) {
+        const int mid = (lo + hi) >> 1;
+        if (co[mid] <= slot) lo = mid; else hi = mid;
+    }
+    const int l = p.probes[(int64_t)q * p.n_probe + lo];
+    p.out_d[at] = top.e;
+    p.out_rows[at] = (l >= 0 && l < p.n_lists) ? (int64_t)p.row_ids[p.list_beg[l] + (slot - co[lo])] : -1;
+    if (p.out_order) p.out_order[at] = ((int64_t)lo << 32) | (int64_t)(slot - co[lo]);
+}
+
+__global__ void ivf_fill_mins_kernel(float* mins, int64_t n, int* queue_len, int nq, int* overflow) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) mins[i] = INFINITY;
+    if (i < nq) queue_len[i] = 0;
+    if (i == 0) *overflow = 0;
+}
+
+// fp32 rows -> bf16 (round to nearest even), zero padded to ld16 columns
+__global__ void ivf_round_rows_kernel(const float* __restrict__ src, int64_t src_ld, int dim, int64_t n,
+                                      uint16_t* __restrict__ dst16, int ld16) {
+    const int64_t total = n * ld16;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t r = i / ld16;
+        const int c = (int)(i - r * ld16);
+        uint32_t b = 0;
+        if (c < dim) {
+            const uint32_t x = __float_as_uint(src[r * src_ld + c]);
+            b = ((x & 0x7fffffffu) > 0x7f800000u) ? ((x >> 16) | 0x40u) : ((x + 0x7fffu + ((x >> 16) & 1u)) >> 16);
+        }
+        dst16[i] = (uint16_t)b;
+    }
+}
+
+int ivf_mfma_pitch(int dim) { return dim <= 128 ? round_up(dim, 32) : round_up(dim, 128); }
+
+int launch_ivf_round_rows(const float* src, int64_t src_ld, int dim, int64_t n, uint16_t* dst16, int ld16, hipStream_t s) {
+    if (n <= 0) return VDB_OK;
+    const int64_t total = n * ld16;
+    hipLaunchKernelGGL(ivf_round_rows_kernel, dim3((unsigned)std::min<int64_t>((total + 255) / 256, 65536)), dim3(256), 0, s,
+                       src, src_ld, dim, n, dst16, ld16);
+    VDB_HIP(hipGetLastError());
+    return VDB_OK;
+}
+
+template <int MODE>
+static int launch_approx(const IvfApproxParams& p, hipStream_t s) {
+    const int ks = std::min(p.ld16, 128) / 16;
+    const int grid = ctx().num_cus * 3;                      // twelve waves per CU keep enough row bytes in flight
+    if (p.n_chunks > 1) {
+        hipLaunchKernelGGL((ivf_approx_kernel<8, true, MODE>), dim3(grid), dim3(IA_NT), 0, s, p);
+    } else {
+        switch (ks) {
+            case 2: hipLaunchKernelGGL((ivf_approx_kernel<2, false, MODE>), dim3(grid), dim3(IA_NT), 0, s, p); break;
+            case 4: hipLaunchKernelGGL((ivf_approx_kernel<4, false, MODE>), dim3(grid), dim3(IA_NT), 0, s, p); break;
+            case 6: hipLaunchKernelGGL((ivf_approx_kernel<6, false, MODE>), dim3(grid), dim3(IA_NT), 0, s, p); break;
+            case 8: hipLaunchKernelGGL((ivf_approx_kernel<8, false, MODE>), dim3(grid), dim3(IA_NT), 0, s, p); break;
+            default: set_error("bf16 row pitch %d has no matrix-core list scan", p.ld16); return VDB_ERR_INVALID;
+        }
+    }
+    VDB_HIP(hipGetLastError());
+    return VDB_OK;
+}
+
+int launch_ivf_mfma_search(const IvfMfmaJob& j, hipStream_t s) {
+    VDB_REQUIRE(j.k >= 1 && j.k <= 64 && j.k_out >= j.k, "matrix-core list scan: k in 1..64");
+    VDB_REQUIRE(j.ld16 % 32 == 0 && (j.ld16 <= 128 || j.ld16 % 128 == 0), "bad bf16 row pitch %d", j.ld16);
+    IvfApproxParams p{};
+    p.rows16 = j.rows16; p.ld16 = j.ld16; p.n_chunks = j.ld16 <= 128 ? 1 : j.ld16 / 128;
+    p.row_sq = j.row_sq; p.q16 = j.q16; p.q_sq = j.q_sq;
+    p.items = j.plan.items; p.seg_item_off = j.plan.seg_item_off; p.n_seg = j.n_lists; p.items_cap = j.plan.items_cap;
+    p.sq_qid = j.plan.sq_qid; p.sq_out = j.plan.sq_out; p.sq_rank = j.sq_rank; p.cand_stride = j.cand_stride;
+    p.thr = j.thr; p.queue = j.queue; p.queue_len = j.queue_len; p.queue_cap = j.queue_cap; p.overflow = j.overflow;
+    p.mins = j.mins; p.row_ids = j.row_ids; p.mask = j.mask;
+    const int64_t n_mins = (int64_t)j.nq * IA_SUBSETS;
+    hipLaunchKernelGGL(ivf_fill_mins_kernel, dim3((unsigned)((std::max<int64_t>(n_mins, j.nq) + 255) / 256)), dim3(256), 0, s,
+                       j.mins, n_mins, j.queue_len, j.nq, j.overflow);
+    VDB_HIP(hipGetLastError());
+    VDB_TRY(launch_approx<MODE_BOUND>(p, s));
+    hipLaunchKernelGGL(ivf_threshold_kernel, dim3((j.nq + 3) / 4), dim3(256), 0, s, j.mins, j.nq, j.k, j.dim, j.q_sq, j.q_nrm,
+                       j.max_row_nrm, j.thr, j.overflow);
+    VDB_HIP(hipGetLastError());
+    {
+        KernelTimer timer(s, j.timed);
+        VDB_TRY(launch_approx<MODE_SCAN>(p, s));
+    }
+    static const bool debug = getenv("VDB_IVF_DEBUG") != nullptr;
+    if (debug) {
+        std::vector<float> thr((size_t)j.nq);
+        std::vector<int> len((size_t)j.nq);
+        int flag = 0;
+        float big = 0;
+        (void)hipStreamSynchronize(s);
+        (void)hipMemcpy(thr.data(), j.thr, thr.size() * sizeof(float), hipMemcpyDeviceToHost);
+        (void)hipMemcpy(len.data(), j.queue_len, len.size() * sizeof(int), hipMemcpyDeviceToHost);
+        (void)hipMemcpy(&flag, j.overflow, sizeof(int), hipMemcpyDeviceToHost);
+        (void)hipMemcpy(&big, j.max_row_nrm, sizeof(float), hipMemcpyDeviceToHost);
+        int inf = 0, mx = 0; long long tot = 0; float tmin = INFINITY, tmax = 0;
+        for (int q = 0; q < j.nq; ++q) {
+            if (!(thr[q] < INFINITY)) ++inf; else { tmin = std::min(tmin, thr[q]); tmax = std::max(tmax, thr[q]); }
+            mx = std::max(mx, len[q]); tot += len[q];
+        }
+        fprintf(stderr, "[ivf mfma] nq=%d k=%d ld16=%d max|c|=%g thr: %d inf, finite %g..%g; queue: max %d, mean %.1f (cap %d); flag=%d\n",
+                j.nq, j.k, j.ld16, big, inf, tmin, tmax, mx, (double)tot / j.nq, j.queue_cap, flag);
+    }
+    IvfExactParams e{};
+    e.rows = j.rows; e.ld = j.ld; e.plan = j.sum_plan; e.q = j.q; e.ldq = j.ldq; e.take_sqrt = j.take_sqrt ? 1 : 0;
+    e.queue = j.queue; e.queue_len = j.queue_len; e.queue_cap = j.queue_cap;
+    e.nq = j.nq; e.k = j.k; e.k_out = j.k_out;
+    e.probes = j.probes; e.n_probe = j.n_probe; e.n_lists = j.n_lists;
+    e.cand_off = j.cand_off; e.list_beg = j.list_beg; e.row_ids = j.row_ids;
+    e.out_d = j.out_d; e.out_rows = j.out_rows; e.out_order = j.out_order;
+    hipLaunchKernelGGL(ivf_exact_select_kernel, dim3((j.nq + 3) / 4), dim3(256), 0, s, e);
+    VDB_HIP(hipGetLastError());
+    return VDB_OK;
+}
+
+int ivf_mfma_subsets() { return IA_SUBSETS; }
+
+}  // namespace vdb

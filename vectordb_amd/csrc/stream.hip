@@ -1094,20 +1094,23 @@ __global__ __launch_bounds__(1024) void ivf_plan_scan_kernel(const int* __restri
 
 __global__ void ivf_plan_fill_kernel(const int* __restrict__ probes, int nq, int n_probe, int n_lists, int64_t cand_stride,
                                      const int64_t* __restrict__ cand_off, int* __restrict__ cursor,
-                                     int* __restrict__ sq_qid, int64_t* __restrict__ sq_out) {
+                                     int* __restrict__ sq_qid, int64_t* __restrict__ sq_out, int* __restrict__ sq_rank,
+                                     int64_t bound_rows) {
     const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (t >= (int64_t)nq * n_probe) return;
     const int q = (int)(t / n_probe), pr = (int)(t - (int64_t)q * n_probe);
     const int l = probes[t];
     if (l < 0 || l >= n_lists) return;
     const int slot = atomicAdd(&cursor[l], 1);
+    const int64_t before = cand_off[(int64_t)q * (n_probe + 1) + pr];
     sq_qid[slot] = q;
-    sq_out[slot] = (int64_t)q * cand_stride + cand_off[(int64_t)q * (n_probe + 1) + pr];
+    sq_out[slot] = (int64_t)q * cand_stride + before;
+    if (sq_rank) sq_rank[slot] = min(pr, 0xffff) | (before < bound_rows ? 1 << 16 : 0);
 }
 
 int launch_ivf_plan(const int* probes, int nq, int n_probe, const int64_t* list_beg, const int64_t* list_end, int n_lists, int group,
                     int64_t cand_stride, int* list_cnt, int* cursor, int64_t* cand_off, int* tile_off,
-                    const StreamPlanBufs& b, hipStream_t s) {
+                    const StreamPlanBufs& b, hipStream_t s, int* sq_rank, int64_t bound_rows) {
     VDB_HIP(hipMemsetAsync(list_cnt, 0, (size_t)n_lists * sizeof(int), s));
     hipLaunchKernelGGL(ivf_plan_count_kernel, dim3((nq + 255) / 256), dim3(256), 0, s, probes, nq, n_probe, n_lists,
                        list_beg, list_end, list_cnt, cand_off, tile_off);
@@ -1115,7 +1118,7 @@ int launch_ivf_plan(const int* probes, int nq, int n_probe, const int64_t* list_
                        b.seg_item_off, cursor);
     const int64_t total = (int64_t)nq * n_probe;
     hipLaunchKernelGGL(ivf_plan_fill_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, probes, nq, n_probe,
-                       n_lists, cand_stride, cand_off, cursor, b.sq_qid, b.sq_out);
+                       n_lists, cand_stride, cand_off, cursor, b.sq_qid, b.sq_out, sq_rank, bound_rows);
     VDB_HIP(hipGetLastError());
     return launch_build_items(b, list_beg, list_end, n_lists, group, s);
 }
@@ -1733,7 +1736,8 @@ int launch_range_collect(const RangeJob& j, const int64_t* block_off, int64_t ca
 __global__ void ivf_rows_kernel(const int* __restrict__ slots, int nq, int k, int out_stride, int out_off,
                                 const int* __restrict__ probes, int n_probe, int n_lists, const int64_t* __restrict__ cand_off,
                                 const int64_t* __restrict__ list_beg, const int* __restrict__ row_ids,
-                                int64_t* __restrict__ out_rows, int64_t* __restrict__ out_order) {
+                                int64_t* __restrict__ out_rows, int64_t* __restrict__ out_order, const int* __restrict__ run_if) {
+    if (run_if && *run_if == 0) return;
     const int t = blockIdx.x * blockDim.x + threadIdx.x;
     if (t >= nq * k) return;
     const int q = t / k, r = t - q * k;
@@ -1754,10 +1758,10 @@ __global__ void ivf_rows_kernel(const int* __restrict__ slots, int nq, int k, in
 
 int launch_ivf_rows(const int* slots, int nq, int k, int out_stride, int out_off, const int* probes, int n_probe, int n_lists,
                     const int64_t* cand_off, const int64_t* list_beg, const int* row_ids, int64_t* out_rows,
-                    int64_t* out_order, hipStream_t s) {
+                    int64_t* out_order, hipStream_t s, const int* run_if) {
     if (nq <= 0 || k <= 0) return VDB_OK;
     hipLaunchKernelGGL(ivf_rows_kernel, dim3((nq * k + 255) / 256), dim3(256), 0, s, slots, nq, k, out_stride, out_off,
-                       probes, n_probe, n_lists, cand_off, list_beg, row_ids, out_rows, out_order);
+                       probes, n_probe, n_lists, cand_off, list_beg, row_ids, out_rows, out_order, run_if);
     VDB_HIP(hipGetLastError());
     return VDB_OK;
 }

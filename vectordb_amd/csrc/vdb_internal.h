@@ -249,9 +249,11 @@ int stream_batch_group(int dim, int ld, const SumPlan& plan, int op, int nq, int
 int launch_row_norms(const float* data, int ld, int dim, int64_t n, const SumPlan& plan, const StreamPlanBufs& b,
                      float* sq, float* nrm, hipStream_t s);
 int launch_flat_plan(int64_t n, int nq, int group, int64_t out_stride, const StreamPlanBufs& b, hipStream_t s);
+// sq_rank (optional, one int per (list, query) entry like sq_qid): the probe's rank in its query's ranking, with
+// bit 16 set while fewer than bound_rows rows precede the list in the query's visiting order
 int launch_ivf_plan(const int* probes, int nq, int n_probe, const int64_t* list_beg, const int64_t* list_end, int n_lists, int group,
                     int64_t cand_stride, int* list_cnt, int* cursor, int64_t* cand_off, int* tile_off,
-                    const StreamPlanBufs& b, hipStream_t s);
+                    const StreamPlanBufs& b, hipStream_t s, int* sq_rank = nullptr, int64_t bound_rows = 0);
 // in-place distance finish of a [nq][n] matrix of streamed sums (identity-form L2 and cosine only)
 int launch_finish_dist(int metric, const float* q_sq, const float* q_nrm, const float* row_sq, const float* row_nrm,
                        float cos_eps, float* v, int nq, int64_t n, hipStream_t s);
@@ -297,12 +299,33 @@ int launch_range_collect(const RangeJob& j, const int64_t* block_off, int64_t ca
                          float* out_d, int64_t* out_row, hipStream_t s);
 int launch_ivf_rows(const int* slots, int nq, int k, int out_stride, int out_off, const int* probes, int n_probe, int n_lists,
                     const int64_t* cand_off, const int64_t* list_beg, const int* row_ids, int64_t* out_rows,
-                    int64_t* out_order, hipStream_t s);
+                    int64_t* out_order, hipStream_t s, const int* run_if = nullptr);
 
 // final selection: per query, the k best of n_cand ascending candidate lists of k,
 // layout [nq][n_cand][k], under the (distance, tie key) order with
 // tie key = (candidate list / tie_group) << 32 | idx.  idx_map (optional)
 // translates a selected idx to a row number; idx_offset is added afterwards.
+// Batched IVF list scan on the matrix cores behind an exact recomputation (ivf_mfma.hip): bound pass, threshold,
+// scan pass into per-query queues, exact selection.  `plan` is the list-major plan of launch_ivf_plan (items of at
+// most 32 queries) with sq_rank beside sq_qid / sq_out; outputs are written for k results per query at stride k_out.
+struct IvfMfmaJob {
+    const uint16_t* rows16; int ld16; const float* row_sq;     // bf16 copies of the stored rows and |c|^2 of the fp32 rows
+    const float* rows; int ld; int dim; SumPlan sum_plan;      // the fp32 rows
+    const float* q; int ldq; const uint16_t* q16; const float* q_sq; const float* q_nrm; int nq;
+    StreamPlanBufs plan; const int* sq_rank; int64_t cand_stride;
+    const int* probes; int n_probe; int n_lists; const int64_t* cand_off; const int64_t* list_beg;
+    const int* row_ids; const uint32_t* mask;
+    const float* max_row_nrm;                                  // device float: the largest |c| over the stored rows
+    float* mins; float* thr; int2* queue; int* queue_len; int queue_cap; int* overflow;   // workspaces
+    int k, k_out; bool take_sqrt;
+    float* out_d; int64_t* out_rows; int64_t* out_order;
+    bool timed;
+};
+int launch_ivf_mfma_search(const IvfMfmaJob& j, hipStream_t s);
+int ivf_mfma_pitch(int dim);            // bf16 elements per row of the copy
+int ivf_mfma_subsets();                 // floats of `mins` per query
+int launch_ivf_round_rows(const float* src, int64_t src_ld, int dim, int64_t n, uint16_t* dst16, int ld16, hipStream_t s);
+
 struct SelectOut {
     float* out_d; int64_t* out_i; int* out_i32;   // any of the index outputs may be null
     int out_stride; int out_off;                  // result r of query q goes to [q*out_stride + out_off + r]

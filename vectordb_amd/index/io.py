@@ -30,7 +30,7 @@ FORMAT_VERSION = 1
 def _pack_flat(ix: FlatIndex) -> Dict[str, Any]:
     small = {"index_type": ix.index_type.value, "dimension": ix._dimension, "metric": ix._metric,
              "config": {"normalize": ix.config.normalize, "use_matrix": ix.config.use_matrix,
-                        "initial_capacity": ix.config.initial_capacity},
+                        "initial_capacity": ix.config.initial_capacity, "storage": ix._storage, "prefilter": ix._prefilter},
              "ids": list(ix._ids), "metadata": {i: m for i, m in ix._metadata.items()}}
     return {"small": small, "vectors": np.ascontiguousarray(ix._vectors[:ix._size], dtype=np.float32)}
 
@@ -50,7 +50,7 @@ def _pack_ivf(ix: IVFIndex) -> Dict[str, Any]:
                if slots else np.zeros((0, ix._dimension), np.float32))
     small = {"index_type": ix.index_type.value, "dimension": ix._dimension, "metric": ix._metric,
              "config": {"n_clusters": ix.config.n_clusters, "n_probe": ix.config.n_probe, "n_iter": ix.config.n_iter,
-                        "normalize": ix.config.normalize, "seed": ix.config.seed},
+                        "normalize": ix.config.normalize, "seed": ix.config.seed, "prefilter": ix._prefilter},
              "is_trained": bool(ix._is_trained), "ids": ids, "metadata": {i: ix._metadata[i] for i in ids}}
     out = {"small": small, "vectors": vectors, "lists": np.asarray(lists, dtype=np.int32)}
     if ix._centroids is not None:

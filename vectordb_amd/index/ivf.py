@@ -178,8 +178,16 @@ class IVFIndex(BaseIndex):
     """index/ivf.py:240-1061"""
 
     def __init__(self, dimension: int, metric: str = "euclidean", n_clusters: int = 100, n_probe: int = 10,
-                 n_iter: int = 20, normalize: bool = False, seed: Optional[int] = None, verbose: bool = False, **kwargs):
+                 n_iter: int = 20, normalize: bool = False, seed: Optional[int] = None, verbose: bool = False,
+                 prefilter: Optional[str] = "auto", **kwargs):
+        """``prefilter`` is not a reference argument: batched Euclidean searches scan a bf16 copy of the member rows on
+        the matrix cores and recompute the few remaining candidates in the reference's arithmetic; results are bit for
+        bit those of the plain scan.  "auto" (default) keeps the copy while it leaves a tenth of the device memory
+        free, "bf16" always, None never."""
         super().__init__(dimension, metric, **kwargs)
+        if prefilter not in N.PREFILTER:
+            raise ValueError(f"prefilter must be None, 'bf16' or 'auto', got {prefilter!r}")
+        self._prefilter = prefilter
         self.config = IVFConfig(dimension=dimension, metric=metric, n_clusters=n_clusters, n_probe=n_probe,
                                 n_iter=n_iter, normalize=normalize, seed=seed, verbose=verbose)
         get_metric(metric)                                     # KeyError for unknown metrics (ivf.py:332)
@@ -336,6 +344,7 @@ class IVFIndex(BaseIndex):
     def _device(self) -> N.IvfLists:
         if self._dev is None:
             self._dev = N.IvfLists(self._dimension, _CODES[self._canon])
+            self._dev.set_prefilter(self._prefilter)
             self._dev.set_centroids(self._centroids)
             self._dev_dirty = True
         if self._dev_dirty:
@@ -520,7 +529,8 @@ class IVFIndex(BaseIndex):
                  for c, slots in self._lists.items()}
         return {"index_type": self.index_type.value, "dimension": self._dimension, "metric": self._metric,
                 "config": {"n_clusters": self.config.n_clusters, "n_probe": self.config.n_probe,
-                           "n_iter": self.config.n_iter, "normalize": self.config.normalize, "seed": self.config.seed},
+                           "n_iter": self.config.n_iter, "normalize": self.config.normalize, "seed": self.config.seed,
+                           "prefilter": self._prefilter},
                 "is_trained": self._is_trained,
                 "centroids": self._centroids.tolist() if self._centroids is not None else None,
                 "inverted_lists": lists}
@@ -530,7 +540,7 @@ class IVFIndex(BaseIndex):
         cfg = data.get("config", {})
         index = cls(dimension=data["dimension"], metric=data["metric"], n_clusters=cfg.get("n_clusters", 100),
                     n_probe=cfg.get("n_probe", 10), n_iter=cfg.get("n_iter", 20), normalize=cfg.get("normalize", False),
-                    seed=cfg.get("seed"))
+                    seed=cfg.get("seed"), prefilter=cfg.get("prefilter", "auto"))
         if data.get("centroids") is not None:
             index._set_centroids(np.array(data["centroids"], dtype=np.float32))
             index._is_trained = data.get("is_trained", True)
