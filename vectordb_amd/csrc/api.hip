@@ -241,11 +241,11 @@ struct Workspace {
     // item table of the last flat scan, kept between calls: it depends on (rows, queries, group) only
     DevBuf fp_seg_row_off, fp_seg_q_off, fp_seg_item_off, fp_sq_qid, fp_sq_out, fp_items;
     int64_t fp_n = -1; int fp_nq = -1, fp_group = -1;
-    DevBuf round32, q16, cand, seg_row_off, seg_q_off, seg_item_off, sq_qid, sq_out, sq_rank, cand_off, tile_off, list_cnt, cursor, slots, items;
+    DevBuf round32, q16, cand, seg_row_off, seg_q_off, seg_item_off, sq_qid, sq_out, cand_off, tile_off, list_cnt, cursor, slots, items;
     template <class F> void each(F&& f) {
         DevBuf* all[] = {&q_buf, &q_sq, &q_nrm, &part_d, &part_i, &lb_d, &lb_k, &thr_d, &thr_k, &mask, &out_d, &out_i, &dist,
                          &probes, &probe_d, &lut, &stage, &round32, &q16, &cand, &seg_row_off, &seg_q_off, &seg_item_off, &sq_qid, &sq_out,
-                         &cand_off, &tile_off, &list_cnt, &cursor, &slots, &items, &sq_rank,
+                         &cand_off, &tile_off, &list_cnt, &cursor, &slots, &items,
                          &queue, &queue_cnt, &flag, &mins, &ticket, &mid[0], &mid[1], &mid[2], &mid[3],
                          &fp_seg_row_off, &fp_seg_q_off, &fp_seg_item_off, &fp_sq_qid, &fp_sq_out, &fp_items};
         for (DevBuf* b : all) f(b);
@@ -2142,7 +2142,6 @@ static int ivf_shadow_sync(vdb_ivf* h, hipStream_t s) {
 
 static constexpr int IVF_MFMA_GROUP = 32;           // queries per item: the columns of one 32 x 32 accumulator
 static constexpr int IVF_MFMA_QUEUE = 8192;         // most (slot, position) entries per query
-static constexpr int64_t IVF_BOUND_ROWS = 1024;     // rows of a query's nearest lists its bound is taken from
 
 static bool ivf_mfma_ok(const vdb_ivf* h, int sm, int nq, int64_t k_eff) {
     static const bool off = getenv("VDB_IVF_NO_MFMA") != nullptr;
@@ -2216,11 +2215,10 @@ static int ivf_search_impl(vdb_ivf* h, const float* d_q, int nq, int k, int n_pr
     // a queue as long as a query's candidates cannot overflow; longer ones are cut at IVF_MFMA_QUEUE entries
     const int queue_cap = (int)std::min<int64_t>(cand_stride, IVF_MFMA_QUEUE);
     if (mfma) {
-        VDB_TRY(ws.sq_rank.reserve((size_t)q_block * n_probe * sizeof(int)));
         VDB_TRY(ws.q16.reserve((size_t)nq * ld16 * 2));
         VDB_TRY(ws.mins.reserve((size_t)q_block * ivf_mfma_subsets() * sizeof(float)));
         VDB_TRY(ws.thr_d.reserve((size_t)q_block * sizeof(float)));
-        VDB_TRY(ws.queue.reserve((size_t)q_block * queue_cap * sizeof(int2)));
+        VDB_TRY(ws.queue.reserve((size_t)q_block * queue_cap * 3 * sizeof(int)));      // slots, positions, distances
         VDB_TRY(ws.queue_cnt.reserve((size_t)q_block * sizeof(int)));
         VDB_TRY(ws.flag.reserve(sizeof(int)));
         VDB_TRY(launch_ivf_round_rows(q, m->r.ld, m->r.dim, nq, ws.q16.as<uint16_t>(), ld16, s));
@@ -2231,19 +2229,21 @@ static int ivf_search_impl(vdb_ivf* h, const float* d_q, int nq, int k, int n_pr
         const int nb = std::min(q_block, nq - q0);
         const int* probes = ws.probes.as<int>() + (int64_t)q0 * n_probe;
         VDB_TRY(launch_ivf_plan(probes, nb, n_probe, h->lay.d_beg(), h->lay.d_end(), h->n_lists, group, cand_stride,
-                                ws.list_cnt.as<int>(), ws.cursor.as<int>(), ws.cand_off.as<int64_t>(), ws.tile_off.as<int>(), b, s,
-                                mfma ? ws.sq_rank.as<int>() : nullptr, IVF_BOUND_ROWS));
+                                ws.list_cnt.as<int>(), ws.cursor.as<int>(), ws.cand_off.as<int64_t>(), ws.tile_off.as<int>(), b, s));
         if (mfma) {
             IvfMfmaJob mj{};
             mj.rows16 = h->shadow16.as<uint16_t>(); mj.ld16 = ld16; mj.row_sq = m->r.sq;
             mj.rows = m->r.data; mj.ld = m->r.ld; mj.dim = m->r.dim; mj.sum_plan = m->r.plan;
             mj.q = q + (int64_t)q0 * m->r.ld; mj.ldq = m->r.ld; mj.q16 = ws.q16.as<uint16_t>() + (int64_t)q0 * ld16;
             mj.q_sq = ws.q_sq.as<float>() + q0; mj.q_nrm = ws.q_nrm.as<float>() + q0; mj.nq = nb;
-            mj.plan = b; mj.sq_rank = ws.sq_rank.as<int>(); mj.cand_stride = cand_stride;
+            mj.plan = b; mj.cand_stride = cand_stride;
             mj.probes = probes; mj.n_probe = n_probe; mj.n_lists = h->n_lists;
             mj.cand_off = ws.cand_off.as<int64_t>(); mj.list_beg = h->lay.d_beg();
             mj.row_ids = h->row_ids.as<int>(); mj.mask = d_mask; mj.max_row_nrm = h->max_nrm.as<float>();
-            mj.mins = ws.mins.as<float>(); mj.thr = ws.thr_d.as<float>(); mj.queue = reinterpret_cast<int2*>(ws.queue.p);
+            mj.mins = ws.mins.as<float>(); mj.thr = ws.thr_d.as<float>(); mj.queue_slot = ws.queue.as<int>();
+            mj.queue_pos = ws.queue.as<int>() + (size_t)q_block * queue_cap;
+            mj.queue_d = ws.queue.as<float>() + (size_t)2 * q_block * queue_cap;
+            mj.slots = ws.slots.as<int>() + (int64_t)q0 * k;
             mj.queue_len = ws.queue_cnt.as<int>(); mj.queue_cap = queue_cap; mj.overflow = ws.flag.as<int>();
             mj.k = kmax; mj.k_out = k; mj.take_sqrt = sm == VDB_EUCLIDEAN_DIRECT;
             mj.out_d = d_out_d + (int64_t)q0 * k; mj.out_rows = d_out_i + (int64_t)q0 * k;

@@ -4,17 +4,17 @@
 // sqrt(sum((q - c)^2)), distance/metrics.py:43) and sorts the candidates (:631).  What a batch needs from the scan
 // is each query's k best; everything else of the ~n_probe * n / n_lists distances per query is thrown away.  So:
 //
-//   1. bound pass  (ivf_approx_kernel<MODE_BOUND>): over each query's nearest probed lists (until 1024 rows), the
-//      approximate key  |q|^2 + |c|^2 - 2 bf16(q).bf16(c)  of every row on v_mfma_f32_32x32x16_bf16, reduced to 64
+//   1. bound pass  (ivf_bound_kernel): over the first 2048 rows a query visits (its nearest probed lists), the
+//      approximate key  |q|^2 + |c|^2 - 2 bf16(q).bf16(c)  of every row on v_mfma_f32_32x32x16_bf16, reduced to 128
 //      minima over disjoint row subsets; the k-th smallest of them is not below the k-th smallest key of those rows.
 //   2. ivf_threshold_kernel: that value, widened by what the approximate key can differ from the reference's
 //      float32 sum (bf16 rounding of both operands, the float32 roundings of both forms), and widened again for
 //      the test itself: every row that can be among the reference's k best has a key within the threshold.
-//   3. scan pass   (ivf_approx_kernel<MODE_SCAN>): the same keys for every (probed list row, query) pair, list-major
+//   3. scan pass   (ivf_approx_kernel): the same keys for every (probed list row, query) pair, list-major
 //      (a list chunk is read once for up to 32 queries that probe it); pairs within the threshold (and passing the
 //      filter bit) are appended to the query's queue as (candidate slot, stored position).
-//   4. ivf_exact_select_kernel: one wave per query recomputes the queued pairs in the reference's own arithmetic
-//      (element-wise float32 q - c, square, NumPy's pairwise summation order, sqrtf) and keeps the k best under
+//   4. ivf_exact_dist_kernel recomputes the queued pairs in the reference's own arithmetic (element-wise float32
+//      q - c, square, NumPy's pairwise summation order, sqrtf); one block per query then keeps the k best under
 //      (distance, candidate slot) = (distance, visiting order of index/ivf.py:619-628).
 //
 // Rows, order and distance bits equal those of the scalar scan, because every returned value is computed by the same
@@ -31,9 +31,8 @@
 namespace vdb {
 
 static constexpr int IA_NT = 256;          // threads per block: four independent waves
-static constexpr int IA_SUBSETS = 64;      // disjoint row subsets whose key minima bound a query's k-th best
-
-enum { MODE_BOUND = 0, MODE_SCAN = 1 };
+static constexpr int IB_UNITS = 8;         // bound pass: 256-row units of a query's visiting order (2048 rows)
+static constexpr int IA_SUBSETS = IB_UNITS * 16;   // disjoint row subsets (32-row tile x half) whose key minima bound the k-th best
 
 struct IvfApproxParams {
     const uint16_t* rows16; int ld16;      // bf16 copies of the stored rows, [positions][ld16]
@@ -42,11 +41,10 @@ struct IvfApproxParams {
     const uint16_t* q16;                   // bf16 copies of the queries, [nq][ld16]
     const float* q_sq;                     // |q|^2 of the float32 queries
     const StreamItem* items; const int64_t* seg_item_off; int n_seg; int64_t items_cap;
-    const int* sq_qid; const int64_t* sq_out; const int* sq_rank;     // per (list, query): query, first slot, probe rank | bound flag << 16
+    const int* sq_qid; const int64_t* sq_out;                         // per (list, query): query, first candidate slot
     int64_t cand_stride;                   // sq_out = query * cand_stride + slot of the list's first row
-    const float* thr;                      // MODE_SCAN: per query, pairs with key <= thr are queued
-    int2* queue; int* queue_len; int queue_cap; int* overflow;
-    float* mins;                           // MODE_BOUND: [nq][IA_SUBSETS], smallest key per subset (non-negative floats)
+    const float* thr;                      // per query: pairs with key <= thr are queued
+    int* queue_slot; int* queue_pos; int* queue_len; int queue_cap; int* overflow;    // [nq][queue_cap] each
     const int* row_ids; const uint32_t* mask;
 };
 
@@ -65,7 +63,7 @@ template <class T> __device__ __forceinline__ T uniform_load(const T* p) {
 // rows: 8 g + 4 half + i.
 typedef float f4u __attribute__((ext_vector_type(4), aligned(4)));      // four floats at any dword address
 
-template <int KS, bool MULTI, int MODE>
+template <int KS, bool MULTI>
 __global__ __launch_bounds__(IA_NT) void ivf_approx_kernel(IvfApproxParams p) {
     const int lane = threadIdx.x & 63;
     const int n = lane & 31, h = lane >> 5;
@@ -81,15 +79,9 @@ __global__ __launch_bounds__(IA_NT) void ivf_approx_kernel(IvfApproxParams p) {
         const bool live = n < qcnt;
         const int qslot = qbeg + (live ? n : 0);
         const int qid = p.sq_qid[qslot];
-        const int rank = p.sq_rank[qslot];
-        if (MODE == MODE_BOUND) {
-            // only queries for which this list is one of the nearest (flagged by the plan) take part
-            if (__ballot(live && (rank >> 16)) == 0ull) continue;
-        }
-        const bool mine = live && (MODE == MODE_SCAN || (rank >> 16));
-        const float q_sq = p.q_sq[qid];
-        const float thr = (MODE == MODE_SCAN && mine) ? p.thr[qid] : -INFINITY;
         const int slot0 = (int)(p.sq_out[qslot] - (int64_t)qid * p.cand_stride + out_rel);
+        const float q_sq = p.q_sq[qid];
+        const float thr = live ? p.thr[qid] : -INFINITY;
         const int n_tiles = (rows + 31) >> 5;
         const uint16_t* arow = p.rows16 + (row0 + n) * p.ld16 + h * (CE / 2);
         const uint16_t* brow = p.q16 + (int64_t)qid * p.ld16 + h * (CE / 2);
@@ -101,7 +93,6 @@ __global__ __launch_bounds__(IA_NT) void ivf_approx_kernel(IvfApproxParams p) {
             for (int j = 0; j < KS; ++j) a[j] = *reinterpret_cast<const i4v*>(arow + j * 8);
         }
         for (int t = 0; t < n_tiles; ++t) {
-            float best = INFINITY;
             const int64_t pos_t = row0 + t * 32;
             // the row terms first, then the coming tile's rows: waiting for the former leaves the latter in flight
             f4u cs[4];
@@ -142,20 +133,10 @@ __global__ __launch_bounds__(IA_NT) void ivf_approx_kernel(IvfApproxParams p) {
                 for (int i = 0; i < 4; ++i) {
                     const int r = t * 32 + 8 * g + 4 * h + i;
                     const float key = __fmaf_rn(-2.0f, acc[g * 4 + i], q_sq + cs[g][i]);
-                    if (MODE == MODE_SCAN) {
-                        if (key <= thr && r < rows) hits |= 1u << (g * 4 + i);
-                    } else {
-                        bool ok = mine && r < rows;
-                        if (ok && p.mask) {
-                            const int id = p.row_ids[pos_t + 8 * g + 4 * h + i];
-                            ok = (p.mask[id >> 5] >> (id & 31)) & 1u;
-                        }
-                        // a key below zero counts as zero: the k-th smallest of larger values is still a bound
-                        if (ok) best = fminf(best, fmaxf(key, 0.0f));
-                    }
+                    if (key <= thr && r < rows) hits |= 1u << (g * 4 + i);
                 }
             }
-            if (MODE == MODE_SCAN && __ballot(hits != 0) != 0ull) {
+            if (__ballot(hits != 0) != 0ull) {
                 while (hits) {
                     const int e = __builtin_ctz(hits);
                     hits &= hits - 1;
@@ -166,16 +147,100 @@ __global__ __launch_bounds__(IA_NT) void ivf_approx_kernel(IvfApproxParams p) {
                         if (!((p.mask[id >> 5] >> (id & 31)) & 1u)) continue;
                     }
                     const int at = atomicAdd(&p.queue_len[qid], 1);
-                    if (at < p.queue_cap) p.queue[(int64_t)qid * p.queue_cap + at] = make_int2(slot0 + r, (int)pos);
-                    else *p.overflow = 1;
+                    if (at < p.queue_cap) {
+                        p.queue_slot[(int64_t)qid * p.queue_cap + at] = slot0 + r;
+                        p.queue_pos[(int64_t)qid * p.queue_cap + at] = (int)pos;
+                    } else {
+                        *p.overflow = 1;
+                    }
                 }
             }
-            if (MODE == MODE_BOUND && mine && best < INFINITY) {
-                // the rows of a list fall into 64 subsets by (32-row tile of the list) mod 32 and half; lists share them
-                const int subset = h * 32 + (int)(((out_rel >> 5) + t) & 31);
-                atomicMin(reinterpret_cast<int*>(p.mins) + (int64_t)qid * IA_SUBSETS + subset, __float_as_int(best));
+        }
+    }
+}
+
+// --------------------------------------------------------------------------
+// Bound pass.  One wave per (query, unit): unit u covers candidate slots [256 u, 256 u + 256) of the query's visiting
+// order, i.e. rows of its nearest probed lists; every lane finds the stored position of its own slot (slots of one tile
+// may straddle two lists).  The query sits in every column of B, so lanes 0 and 32 hold the keys of the tile's rows
+// 8 g + i and 8 g + 4 + i; each writes the smallest key of its sixteen rows that exist and pass the filter (a key below
+// zero counts as zero: the k-th smallest of larger values is still a bound) to the subset (unit, tile, half).
+struct IvfBoundParams {
+    const uint16_t* rows16; int ld16; int n_chunks;
+    const float* row_sq; const uint16_t* q16; const float* q_sq;
+    const int* probes; int n_probe; int n_lists; const int64_t* cand_off; const int64_t* list_beg;
+    const int* row_ids; const uint32_t* mask;
+    float* mins;                           // [nq][IA_SUBSETS]
+    int nq;
+};
+
+template <int KS, bool MULTI>
+__global__ __launch_bounds__(IA_NT) void ivf_bound_kernel(IvfBoundParams p) {
+    const int lane = threadIdx.x & 63;
+    const int n = lane & 31, h = lane >> 5;
+    const int w = blockIdx.x * (IA_NT / 64) + (threadIdx.x >> 6);
+    const int q = w / IB_UNITS, u = w - q * IB_UNITS;
+    if (q >= p.nq) return;
+    constexpr int CE = KS * 16;
+    const int64_t* co = p.cand_off + (int64_t)q * (p.n_probe + 1);
+    const int64_t total = co[p.n_probe];
+    const float q_sq = p.q_sq[q];
+    const uint16_t* brow = p.q16 + (int64_t)q * p.ld16 + h * (CE / 2);
+    i4v b[KS];
+    if (!MULTI) {
+#pragma unroll
+        for (int j = 0; j < KS; ++j) b[j] = *reinterpret_cast<const i4v*>(brow + j * 8);
+    }
+    int pr = 0;                                    // the probe this lane's slot lies in (slots only grow)
+    for (int t = 0; t < 8; ++t) {
+        const int64_t slot = (int64_t)u * 256 + t * 32 + n;
+        bool ok = slot < total;
+        int64_t pos = 0;
+        if (ok) {
+            while (co[pr + 1] <= slot) ++pr;       // empty lists have equal offsets and are stepped over
+            const int l = p.probes[(int64_t)q * p.n_probe + pr];
+            pos = p.list_beg[l] + (slot - co[pr]);
+            if (p.mask) {
+                const int id = p.row_ids[pos];
+                ok = (p.mask[id >> 5] >> (id & 31)) & 1u;
             }
         }
+        const unsigned long long okm = __ballot(ok);
+        if ((int64_t)u * 256 + t * 32 >= total) {              // the same for the whole wave: nothing left to visit
+            if (n == 0) p.mins[(int64_t)q * IA_SUBSETS + (u * 8 + t) * 2 + h] = INFINITY;
+            continue;
+        }
+        const float csq_own = p.row_sq[pos];
+        const uint16_t* arow = p.rows16 + pos * p.ld16 + h * (CE / 2);
+        f32x16 acc;
+#pragma unroll
+        for (int e = 0; e < 16; ++e) acc[e] = 0.0f;
+        const int chunks = MULTI ? p.n_chunks : 1;
+        for (int c = 0; c < chunks; ++c) {
+            i4v a[KS];
+#pragma unroll
+            for (int j = 0; j < KS; ++j) a[j] = *reinterpret_cast<const i4v*>(arow + c * CE + j * 8);
+            if (MULTI) {
+#pragma unroll
+                for (int j = 0; j < KS; ++j) b[j] = *reinterpret_cast<const i4v*>(brow + c * CE + j * 8);
+            }
+#pragma unroll
+            for (int j = 0; j < KS; ++j)
+                acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, a[j]), __builtin_bit_cast(bf16x8, b[j]),
+                                                              acc, 0, 0, 0);
+        }
+        float best = INFINITY;
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const int r = 8 * g + 4 * h + i;               // the tile's row: lane r (and r + 32) looked it up
+                const float csq = __shfl(csq_own, r);
+                const float key = __fmaf_rn(-2.0f, acc[g * 4 + i], q_sq + csq);
+                if ((okm >> r) & 1ull) best = fminf(best, fmaxf(key, 0.0f));
+            }
+        }
+        if (n == 0) p.mins[(int64_t)q * IA_SUBSETS + (u * 8 + t) * 2 + h] = best;
     }
 }
 
@@ -202,8 +267,10 @@ __global__ __launch_bounds__(256) void ivf_threshold_kernel(const float* __restr
     if (q >= nq) return;
     WaveTopK top;
     top.init(k);
-    const float v = mins[(int64_t)q * IA_SUBSETS + lane];
-    top.offer(v < INFINITY, v, lane, lane);
+    for (int s0 = 0; s0 < IA_SUBSETS; s0 += 64) {
+        const float v = mins[(int64_t)q * IA_SUBSETS + s0 + lane];
+        top.offer(v < INFINITY, v, s0 + lane, lane);
+    }
     if (lane != 0) return;
     const float qn = q_nrm[q], big = *max_row_nrm;
     if (!(qn < 1e18f) || !(big < 1e18f)) { *overflow = 1; thr[q] = INFINITY; return; }
@@ -216,29 +283,50 @@ __global__ __launch_bounds__(256) void ivf_threshold_kernel(const float* __restr
 // --------------------------------------------------------------------------
 // The reference's sum of squared differences of one (query, row) pair: float32 q - c, its square, np.sum's pairwise
 // order (leaves of at most 128 terms with eight strided partial sums, folded pairwise; distance/metrics.py:43).
-__device__ static float exact_sqdiff(const float* __restrict__ x, const float* __restrict__ q, const SumPlan& plan) {
+// Two neighbouring lanes (m = 0, 1) share one pair: lane m keeps partial sums 4m .. 4m + 3 of the eight and reads its
+// rows sixteen bytes at a time; the halves ((r0+r1)+(r2+r3)) and ((r4+r5)+(r6+r7)) meet through a lane swap.  Both
+// lanes return the sum.
+__device__ __forceinline__ f4u sqdiff4(const float* __restrict__ x, const float* __restrict__ q) {
+    const f4u xv = *reinterpret_cast<const f4u*>(x);
+    const f4u qv = *reinterpret_cast<const f4u*>(q);
+    const f4u d = qv - xv;
+    return d * d;
+}
+
+__device__ __forceinline__ float leaf_sqdiff(const float* __restrict__ x, const float* __restrict__ q, int len, int m) {
+    if (len < 8) {
+        float res = 0.0f;
+        for (int i = 0; i < len; ++i) { const float d = q[i] - x[i]; res = res + d * d; }
+        return res;
+    }
+    f4u r = sqdiff4(x + 4 * m, q + 4 * m);
+    int i = 8;
+    // four groups of eight at a time: their loads are in flight together, the sums stay in order
+    for (; i + 32 <= len; i += 32) {
+        f4u xv[4], qv[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            xv[u] = *reinterpret_cast<const f4u*>(x + i + 8 * u + 4 * m);
+            qv[u] = *reinterpret_cast<const f4u*>(q + i + 8 * u + 4 * m);
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u) { const f4u d = qv[u] - xv[u]; r = r + d * d; }
+    }
+    for (; i + 8 <= len; i += 8) r = r + sqdiff4(x + i + 4 * m, q + i + 4 * m);
+    const float half = (r[0] + r[1]) + (r[2] + r[3]);
+    float res = half + __shfl_xor(half, 1);                // the same value in both lanes: addition commutes
+    for (; i < len; ++i) { const float d = q[i] - x[i]; res = res + d * d; }
+    return res;
+}
+
+__device__ static float exact_sqdiff(const float* __restrict__ x, const float* __restrict__ q, const SumPlan& plan, int m) {
+    if (plan.n_leaves == 1) return leaf_sqdiff(x, q, plan.leaf_len[0], m);
     float stack[8];
     int sp = 0, off = 0;
     for (int l = 0; l < plan.n_leaves; ++l) {
         const int len = plan.leaf_len[l];
-        float res;
-        if (len < 8) {
-            res = 0.0f;
-            for (int i = 0; i < len; ++i) { const float d = q[off + i] - x[off + i]; res = res + d * d; }
-        } else {
-            float r[8];
-#pragma unroll
-            for (int j = 0; j < 8; ++j) { const float d = q[off + j] - x[off + j]; r[j] = d * d; }
-            int i = 8;
-            for (; i + 8 <= len; i += 8) {
-#pragma unroll
-                for (int j = 0; j < 8; ++j) { const float d = q[off + i + j] - x[off + i + j]; r[j] = r[j] + d * d; }
-            }
-            res = ((r[0] + r[1]) + (r[2] + r[3])) + ((r[4] + r[5]) + (r[6] + r[7]));
-            for (; i < len; ++i) { const float d = q[off + i] - x[off + i]; res = res + d * d; }
-        }
+        stack[sp++] = leaf_sqdiff(x + off, q + off, len, m);
         off += len;
-        stack[sp++] = res;
         for (int f = 0; f < plan.folds[l]; ++f) {
             const float b = stack[--sp];
             const float a = stack[--sp];
@@ -252,55 +340,25 @@ struct IvfExactParams {
     const float* rows; int ld; SumPlan plan;     // the float32 rows, by position
     const float* q; int ldq;                     // the float32 queries (padded rows)
     int take_sqrt;                               // VDB_EUCLIDEAN_DIRECT: the distance is the root of the sum
-    const int2* queue; int* queue_len; int queue_cap;
-    int nq, k, k_out;
-    const int* probes; int n_probe; int n_lists;
-    const int64_t* cand_off; const int64_t* list_beg; const int* row_ids;
-    float* out_d; int64_t* out_rows; int64_t* out_order;
+    const int* queue_pos; const int* queue_len; int queue_cap;
+    float* queue_d;                              // out [nq][queue_cap]: the reference's distance of every queued pair
 };
 
-__global__ __launch_bounds__(256) void ivf_exact_select_kernel(IvfExactParams p) {
-    const int lane = threadIdx.x & 63;
-    const int q = blockIdx.x * 4 + (threadIdx.x >> 6);
-    if (q >= p.nq) return;
+// grid (queries, entry slices): a pair of lanes per queued (query, row) pair
+__global__ __launch_bounds__(256) void ivf_exact_dist_kernel(IvfExactParams p) {
+    const int q = blockIdx.x;
     const int len = min(p.queue_len[q], p.queue_cap);
+    const int m = threadIdx.x & 1;
     const float* qrow = p.q + (int64_t)q * p.ldq;
-    WaveTopK top;
-    top.init(p.k);
-    for (int base = 0; base < len; base += 64) {
-        const bool have = base + lane < len;
-        const int2 e = have ? p.queue[(int64_t)q * p.queue_cap + base + lane] : make_int2(EMPTY_IDX, 0);
-        float d = INFINITY;
-        if (have) {
-            const float sum = exact_sqdiff(p.rows + (int64_t)e.y * p.ld, qrow, p.plan);
-            d = p.take_sqrt ? sqrtf(sum) : sum;
-        }
-        top.offer(have, d, e.x, lane);
+    for (int e = blockIdx.y * 128 + (threadIdx.x >> 1); e < len; e += 128 * gridDim.y) {
+        const int64_t at = (int64_t)q * p.queue_cap + e;
+        const float sum = exact_sqdiff(p.rows + (int64_t)p.queue_pos[at] * p.ld, qrow, p.plan, m);
+        if (m == 0) p.queue_d[at] = p.take_sqrt ? sqrtf(sum) : sum;
     }
-    if (lane >= p.k) return;                     // result slots past k keep what the caller filled them with
-    const int64_t at = (int64_t)q * p.k_out + lane;
-    const int slot = top.eid;
-    if (slot == EMPTY_IDX) {
-        p.out_d[at] = INFINITY;
-        p.out_rows[at] = -1;
-        if (p.out_order) p.out_order[at] = -1;
-        return;
-    }
-    const int64_t* co = p.cand_off + (int64_t)q * (p.n_probe + 1);
-    int lo = 0, hi = p.n_probe;                  // co[lo] <= slot < co[hi]
-    while (hi - lo > 1) {
-        const int mid = (lo + hi) >> 1;
-        if (co[mid] <= slot) lo = mid; else hi = mid;
-    }
-    const int l = p.probes[(int64_t)q * p.n_probe + lo];
-    p.out_d[at] = top.e;
-    p.out_rows[at] = (l >= 0 && l < p.n_lists) ? (int64_t)p.row_ids[p.list_beg[l] + (slot - co[lo])] : -1;
-    if (p.out_order) p.out_order[at] = ((int64_t)lo << 32) | (int64_t)(slot - co[lo]);
 }
 
-__global__ void ivf_fill_mins_kernel(float* mins, int64_t n, int* queue_len, int nq, int* overflow) {
-    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i < n) mins[i] = INFINITY;
+__global__ void ivf_clear_queues_kernel(int* queue_len, int nq, int* overflow) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i < nq) queue_len[i] = 0;
     if (i == 0) *overflow = 0;
 }
@@ -332,19 +390,17 @@ int launch_ivf_round_rows(const float* src, int64_t src_ld, int dim, int64_t n, 
     return VDB_OK;
 }
 
-template <int MODE>
-static int launch_approx(const IvfApproxParams& p, hipStream_t s) {
-    const int ks = std::min(p.ld16, 128) / 16;
-    const int grid = ctx().num_cus * 3;                      // twelve waves per CU keep enough row bytes in flight
-    if (p.n_chunks > 1) {
-        hipLaunchKernelGGL((ivf_approx_kernel<8, true, MODE>), dim3(grid), dim3(IA_NT), 0, s, p);
+template <class P, class K2, class K4, class K6, class K8, class KM>
+static int launch_by_pitch(const P& p, int ld16, int n_chunks, dim3 grid, hipStream_t s, K2 k2, K4 k4, K6 k6, K8 k8, KM km) {
+    if (n_chunks > 1) {
+        hipLaunchKernelGGL(km, grid, dim3(IA_NT), 0, s, p);
     } else {
-        switch (ks) {
-            case 2: hipLaunchKernelGGL((ivf_approx_kernel<2, false, MODE>), dim3(grid), dim3(IA_NT), 0, s, p); break;
-            case 4: hipLaunchKernelGGL((ivf_approx_kernel<4, false, MODE>), dim3(grid), dim3(IA_NT), 0, s, p); break;
-            case 6: hipLaunchKernelGGL((ivf_approx_kernel<6, false, MODE>), dim3(grid), dim3(IA_NT), 0, s, p); break;
-            case 8: hipLaunchKernelGGL((ivf_approx_kernel<8, false, MODE>), dim3(grid), dim3(IA_NT), 0, s, p); break;
-            default: set_error("bf16 row pitch %d has no matrix-core list scan", p.ld16); return VDB_ERR_INVALID;
+        switch (ld16 / 16) {
+            case 2: hipLaunchKernelGGL(k2, grid, dim3(IA_NT), 0, s, p); break;
+            case 4: hipLaunchKernelGGL(k4, grid, dim3(IA_NT), 0, s, p); break;
+            case 6: hipLaunchKernelGGL(k6, grid, dim3(IA_NT), 0, s, p); break;
+            case 8: hipLaunchKernelGGL(k8, grid, dim3(IA_NT), 0, s, p); break;
+            default: set_error("bf16 row pitch %d has no matrix-core list scan", ld16); return VDB_ERR_INVALID;
         }
     }
     VDB_HIP(hipGetLastError());
@@ -354,24 +410,32 @@ static int launch_approx(const IvfApproxParams& p, hipStream_t s) {
 int launch_ivf_mfma_search(const IvfMfmaJob& j, hipStream_t s) {
     VDB_REQUIRE(j.k >= 1 && j.k <= 64 && j.k_out >= j.k, "matrix-core list scan: k in 1..64");
     VDB_REQUIRE(j.ld16 % 32 == 0 && (j.ld16 <= 128 || j.ld16 % 128 == 0), "bad bf16 row pitch %d", j.ld16);
-    IvfApproxParams p{};
-    p.rows16 = j.rows16; p.ld16 = j.ld16; p.n_chunks = j.ld16 <= 128 ? 1 : j.ld16 / 128;
-    p.row_sq = j.row_sq; p.q16 = j.q16; p.q_sq = j.q_sq;
-    p.items = j.plan.items; p.seg_item_off = j.plan.seg_item_off; p.n_seg = j.n_lists; p.items_cap = j.plan.items_cap;
-    p.sq_qid = j.plan.sq_qid; p.sq_out = j.plan.sq_out; p.sq_rank = j.sq_rank; p.cand_stride = j.cand_stride;
-    p.thr = j.thr; p.queue = j.queue; p.queue_len = j.queue_len; p.queue_cap = j.queue_cap; p.overflow = j.overflow;
-    p.mins = j.mins; p.row_ids = j.row_ids; p.mask = j.mask;
-    const int64_t n_mins = (int64_t)j.nq * IA_SUBSETS;
-    hipLaunchKernelGGL(ivf_fill_mins_kernel, dim3((unsigned)((std::max<int64_t>(n_mins, j.nq) + 255) / 256)), dim3(256), 0, s,
-                       j.mins, n_mins, j.queue_len, j.nq, j.overflow);
+    const int n_chunks = j.ld16 <= 128 ? 1 : j.ld16 / 128;
+    hipLaunchKernelGGL(ivf_clear_queues_kernel, dim3((j.nq + 255) / 256), dim3(256), 0, s, j.queue_len, j.nq, j.overflow);
     VDB_HIP(hipGetLastError());
-    VDB_TRY(launch_approx<MODE_BOUND>(p, s));
+    IvfBoundParams bp{};
+    bp.rows16 = j.rows16; bp.ld16 = j.ld16; bp.n_chunks = n_chunks; bp.row_sq = j.row_sq; bp.q16 = j.q16; bp.q_sq = j.q_sq;
+    bp.probes = j.probes; bp.n_probe = j.n_probe; bp.n_lists = j.n_lists; bp.cand_off = j.cand_off; bp.list_beg = j.list_beg;
+    bp.row_ids = j.row_ids; bp.mask = j.mask; bp.mins = j.mins; bp.nq = j.nq;
+    VDB_TRY(launch_by_pitch(bp, j.ld16, n_chunks, dim3((unsigned)(((int64_t)j.nq * IB_UNITS + 3) / 4)), s,
+                            ivf_bound_kernel<2, false>, ivf_bound_kernel<4, false>, ivf_bound_kernel<6, false>,
+                            ivf_bound_kernel<8, false>, ivf_bound_kernel<8, true>));
     hipLaunchKernelGGL(ivf_threshold_kernel, dim3((j.nq + 3) / 4), dim3(256), 0, s, j.mins, j.nq, j.k, j.dim, j.q_sq, j.q_nrm,
                        j.max_row_nrm, j.thr, j.overflow);
     VDB_HIP(hipGetLastError());
+    IvfApproxParams p{};
+    p.rows16 = j.rows16; p.ld16 = j.ld16; p.n_chunks = n_chunks;
+    p.row_sq = j.row_sq; p.q16 = j.q16; p.q_sq = j.q_sq;
+    p.items = j.plan.items; p.seg_item_off = j.plan.seg_item_off; p.n_seg = j.n_lists; p.items_cap = j.plan.items_cap;
+    p.sq_qid = j.plan.sq_qid; p.sq_out = j.plan.sq_out; p.cand_stride = j.cand_stride;
+    p.thr = j.thr; p.queue_slot = j.queue_slot; p.queue_pos = j.queue_pos; p.queue_len = j.queue_len; p.queue_cap = j.queue_cap;
+    p.overflow = j.overflow; p.row_ids = j.row_ids; p.mask = j.mask;
     {
         KernelTimer timer(s, j.timed);
-        VDB_TRY(launch_approx<MODE_SCAN>(p, s));
+        // twelve waves per CU keep enough row bytes in flight
+        VDB_TRY(launch_by_pitch(p, j.ld16, n_chunks, dim3(ctx().num_cus * 3), s, ivf_approx_kernel<2, false>,
+                                ivf_approx_kernel<4, false>, ivf_approx_kernel<6, false>, ivf_approx_kernel<8, false>,
+                                ivf_approx_kernel<8, true>));
     }
     static const bool debug = getenv("VDB_IVF_DEBUG") != nullptr;
     if (debug) {
@@ -394,14 +458,15 @@ int launch_ivf_mfma_search(const IvfMfmaJob& j, hipStream_t s) {
     }
     IvfExactParams e{};
     e.rows = j.rows; e.ld = j.ld; e.plan = j.sum_plan; e.q = j.q; e.ldq = j.ldq; e.take_sqrt = j.take_sqrt ? 1 : 0;
-    e.queue = j.queue; e.queue_len = j.queue_len; e.queue_cap = j.queue_cap;
-    e.nq = j.nq; e.k = j.k; e.k_out = j.k_out;
-    e.probes = j.probes; e.n_probe = j.n_probe; e.n_lists = j.n_lists;
-    e.cand_off = j.cand_off; e.list_beg = j.list_beg; e.row_ids = j.row_ids;
-    e.out_d = j.out_d; e.out_rows = j.out_rows; e.out_order = j.out_order;
-    hipLaunchKernelGGL(ivf_exact_select_kernel, dim3((j.nq + 3) / 4), dim3(256), 0, s, e);
+    e.queue_pos = j.queue_pos; e.queue_len = j.queue_len; e.queue_cap = j.queue_cap; e.queue_d = j.queue_d;
+    const int slices = std::max(1, std::min(8, (j.queue_cap + 127) / 128));
+    hipLaunchKernelGGL(ivf_exact_dist_kernel, dim3(j.nq, slices), dim3(256), 0, s, e);
     VDB_HIP(hipGetLastError());
-    return VDB_OK;
+    // the k best of every queue under (distance, slot) = (distance, visiting order), then slots -> rows
+    SelectOut o{j.out_d, nullptr, j.slots, j.k_out, 0, nullptr, nullptr, nullptr};
+    VDB_TRY(launch_select_packed(j.queue_d, j.queue_slot, j.nq, j.queue_cap, j.k, o, s, j.queue_len));
+    return launch_ivf_rows(j.slots, j.nq, j.k, j.k_out, 0, j.probes, j.n_probe, j.n_lists, j.cand_off, j.list_beg, j.row_ids,
+                           j.out_rows, j.out_order, s);
 }
 
 int ivf_mfma_subsets() { return IA_SUBSETS; }

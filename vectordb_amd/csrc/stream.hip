@@ -1026,25 +1026,42 @@ static int launch_build_items(const StreamPlanBufs& b, const int64_t* seg_row_be
 // in which the reference visits its candidates (index/ivf.py:619-628).
 // A probe entry outside [0, n_lists) (a query whose centroid distances are all NaN has
 // no ranking) stands for an empty list.
-__global__ void ivf_plan_count_kernel(const int* __restrict__ probes, int nq, int n_probe, int n_lists,
-                                      const int64_t* __restrict__ list_beg, const int64_t* __restrict__ list_end,
-                                      int* __restrict__ list_cnt, int64_t* __restrict__ cand_off, int* __restrict__ tile_off) {
-    const int q = blockIdx.x * blockDim.x + threadIdx.x;
+__global__ __launch_bounds__(256) void ivf_plan_count_kernel(const int* __restrict__ probes, int nq, int n_probe, int n_lists,
+                                                             const int64_t* __restrict__ list_beg, const int64_t* __restrict__ list_end,
+                                                             int* __restrict__ list_cnt, int64_t* __restrict__ cand_off,
+                                                             int* __restrict__ tile_off) {
+    // one wave per query: the lanes take 64 probes at a time and a prefix sum gives every probe its offsets
+    const int lane = threadIdx.x & 63;
+    const int q = blockIdx.x * 4 + (threadIdx.x >> 6);
     if (q >= nq) return;
     int64_t run = 0;
     int tiles = 0;
-    for (int pr = 0; pr < n_probe; ++pr) {
-        const int l = probes[(int64_t)q * n_probe + pr];
-        cand_off[(int64_t)q * (n_probe + 1) + pr] = run;
-        tile_off[(int64_t)q * (n_probe + 1) + pr] = tiles;
-        if (l < 0 || l >= n_lists) continue;
-        const int64_t len = list_end[l] - list_beg[l];
-        run += len;
-        tiles += (int)((len + LIST_NT - 1) / LIST_NT);
-        atomicAdd(&list_cnt[l], 1);
+    for (int base = 0; base < n_probe; base += 64) {
+        const int pr = base + lane;
+        const int l = pr < n_probe ? probes[(int64_t)q * n_probe + pr] : -1;
+        const bool ok = l >= 0 && l < n_lists;
+        const int64_t len = ok ? list_end[l] - list_beg[l] : 0;
+        const int t = (int)((len + LIST_NT - 1) / LIST_NT);
+        int64_t sum_len = len;
+        int sum_t = t;
+#pragma unroll
+        for (int off = 1; off < 64; off <<= 1) {
+            const int64_t a = __shfl_up(sum_len, off);
+            const int b = __shfl_up(sum_t, off);
+            if (lane >= off) { sum_len += a; sum_t += b; }
+        }
+        if (pr < n_probe) {
+            cand_off[(int64_t)q * (n_probe + 1) + pr] = run + sum_len - len;
+            tile_off[(int64_t)q * (n_probe + 1) + pr] = tiles + sum_t - t;
+        }
+        if (ok) atomicAdd(&list_cnt[l], 1);
+        run += __shfl(sum_len, 63);
+        tiles += __shfl(sum_t, 63);
     }
-    cand_off[(int64_t)q * (n_probe + 1) + n_probe] = run;
-    tile_off[(int64_t)q * (n_probe + 1) + n_probe] = tiles;
+    if (lane == 0) {
+        cand_off[(int64_t)q * (n_probe + 1) + n_probe] = run;
+        tile_off[(int64_t)q * (n_probe + 1) + n_probe] = tiles;
+    }
 }
 
 // exclusive scans over the lists: query entries and items (single block)
@@ -1094,31 +1111,28 @@ __global__ __launch_bounds__(1024) void ivf_plan_scan_kernel(const int* __restri
 
 __global__ void ivf_plan_fill_kernel(const int* __restrict__ probes, int nq, int n_probe, int n_lists, int64_t cand_stride,
                                      const int64_t* __restrict__ cand_off, int* __restrict__ cursor,
-                                     int* __restrict__ sq_qid, int64_t* __restrict__ sq_out, int* __restrict__ sq_rank,
-                                     int64_t bound_rows) {
+                                     int* __restrict__ sq_qid, int64_t* __restrict__ sq_out) {
     const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (t >= (int64_t)nq * n_probe) return;
     const int q = (int)(t / n_probe), pr = (int)(t - (int64_t)q * n_probe);
     const int l = probes[t];
     if (l < 0 || l >= n_lists) return;
     const int slot = atomicAdd(&cursor[l], 1);
-    const int64_t before = cand_off[(int64_t)q * (n_probe + 1) + pr];
     sq_qid[slot] = q;
-    sq_out[slot] = (int64_t)q * cand_stride + before;
-    if (sq_rank) sq_rank[slot] = min(pr, 0xffff) | (before < bound_rows ? 1 << 16 : 0);
+    sq_out[slot] = (int64_t)q * cand_stride + cand_off[(int64_t)q * (n_probe + 1) + pr];
 }
 
 int launch_ivf_plan(const int* probes, int nq, int n_probe, const int64_t* list_beg, const int64_t* list_end, int n_lists, int group,
                     int64_t cand_stride, int* list_cnt, int* cursor, int64_t* cand_off, int* tile_off,
-                    const StreamPlanBufs& b, hipStream_t s, int* sq_rank, int64_t bound_rows) {
+                    const StreamPlanBufs& b, hipStream_t s) {
     VDB_HIP(hipMemsetAsync(list_cnt, 0, (size_t)n_lists * sizeof(int), s));
-    hipLaunchKernelGGL(ivf_plan_count_kernel, dim3((nq + 255) / 256), dim3(256), 0, s, probes, nq, n_probe, n_lists,
+    hipLaunchKernelGGL(ivf_plan_count_kernel, dim3((nq + 3) / 4), dim3(256), 0, s, probes, nq, n_probe, n_lists,
                        list_beg, list_end, list_cnt, cand_off, tile_off);
     hipLaunchKernelGGL(ivf_plan_scan_kernel, dim3(1), dim3(1024), 0, s, list_cnt, list_beg, list_end, n_lists, group, b.seg_q_off,
                        b.seg_item_off, cursor);
     const int64_t total = (int64_t)nq * n_probe;
     hipLaunchKernelGGL(ivf_plan_fill_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, probes, nq, n_probe,
-                       n_lists, cand_stride, cand_off, cursor, b.sq_qid, b.sq_out, sq_rank, bound_rows);
+                       n_lists, cand_stride, cand_off, cursor, b.sq_qid, b.sq_out);
     VDB_HIP(hipGetLastError());
     return launch_build_items(b, list_beg, list_end, n_lists, group, s);
 }

@@ -249,11 +249,9 @@ int stream_batch_group(int dim, int ld, const SumPlan& plan, int op, int nq, int
 int launch_row_norms(const float* data, int ld, int dim, int64_t n, const SumPlan& plan, const StreamPlanBufs& b,
                      float* sq, float* nrm, hipStream_t s);
 int launch_flat_plan(int64_t n, int nq, int group, int64_t out_stride, const StreamPlanBufs& b, hipStream_t s);
-// sq_rank (optional, one int per (list, query) entry like sq_qid): the probe's rank in its query's ranking, with
-// bit 16 set while fewer than bound_rows rows precede the list in the query's visiting order
 int launch_ivf_plan(const int* probes, int nq, int n_probe, const int64_t* list_beg, const int64_t* list_end, int n_lists, int group,
                     int64_t cand_stride, int* list_cnt, int* cursor, int64_t* cand_off, int* tile_off,
-                    const StreamPlanBufs& b, hipStream_t s, int* sq_rank = nullptr, int64_t bound_rows = 0);
+                    const StreamPlanBufs& b, hipStream_t s);
 // in-place distance finish of a [nq][n] matrix of streamed sums (identity-form L2 and cosine only)
 int launch_finish_dist(int metric, const float* q_sq, const float* q_nrm, const float* row_sq, const float* row_nrm,
                        float cos_eps, float* v, int nq, int64_t n, hipStream_t s);
@@ -312,11 +310,12 @@ struct IvfMfmaJob {
     const uint16_t* rows16; int ld16; const float* row_sq;     // bf16 copies of the stored rows and |c|^2 of the fp32 rows
     const float* rows; int ld; int dim; SumPlan sum_plan;      // the fp32 rows
     const float* q; int ldq; const uint16_t* q16; const float* q_sq; const float* q_nrm; int nq;
-    StreamPlanBufs plan; const int* sq_rank; int64_t cand_stride;
+    StreamPlanBufs plan; int64_t cand_stride;
     const int* probes; int n_probe; int n_lists; const int64_t* cand_off; const int64_t* list_beg;
     const int* row_ids; const uint32_t* mask;
     const float* max_row_nrm;                                  // device float: the largest |c| over the stored rows
-    float* mins; float* thr; int2* queue; int* queue_len; int queue_cap; int* overflow;   // workspaces
+    float* mins; float* thr; int* queue_slot; int* queue_pos; float* queue_d; int* queue_len; int queue_cap; int* overflow;   // workspaces
+    int* slots;                                                // workspace [nq][k_out]: the selected candidate slots
     int k, k_out; bool take_sqrt;
     float* out_d; int64_t* out_rows; int64_t* out_order;
     bool timed;
