@@ -234,7 +234,7 @@ struct PinBuf {
 struct Workspace {
     PinBuf pin_in, pin_out;             // host ends of the small transfers of the host-pointer entry points
     DevBuf q_buf, q_sq, q_nrm, part_d, part_i, lb_d, lb_k, thr_d, thr_k, mask, out_d, out_i, dist, probes, probe_d, lut, stage;
-    DevBuf queue, queue_cnt, flag, mins;
+    DevBuf queue, queue_cnt, flag, mins, seg, seg_len;
     DevBuf ticket;                      // one int per query, zero between launches (topk_cand's last-block merge)
     void* ticket_zeroed = nullptr;      // the allocation that has been cleared
     DevBuf mid[4];                      // intermediate levels of a hierarchical list merge (launch_select)
@@ -246,7 +246,7 @@ struct Workspace {
         DevBuf* all[] = {&q_buf, &q_sq, &q_nrm, &part_d, &part_i, &lb_d, &lb_k, &thr_d, &thr_k, &mask, &out_d, &out_i, &dist,
                          &probes, &probe_d, &lut, &stage, &round32, &q16, &cand, &seg_row_off, &seg_q_off, &seg_item_off, &sq_qid, &sq_out,
                          &cand_off, &tile_off, &list_cnt, &cursor, &slots, &items,
-                         &queue, &queue_cnt, &flag, &mins, &ticket, &mid[0], &mid[1], &mid[2], &mid[3],
+                         &queue, &queue_cnt, &flag, &mins, &seg, &seg_len, &ticket, &mid[0], &mid[1], &mid[2], &mid[3],
                          &fp_seg_row_off, &fp_seg_q_off, &fp_seg_item_off, &fp_sq_qid, &fp_sq_out, &fp_items};
         for (DevBuf* b : all) f(b);
     }
@@ -2118,12 +2118,13 @@ static int ivf_shadow_sync(vdb_ivf* h, hipStream_t s) {
             if (free_b + h->shadow16.cap < want + std::max<size_t>(total_b / 10, (size_t)2 << 30)) return VDB_ERR_NOMEM;
         }
         // positions past the copy's old end are converted below (they are new, hence noted or stale)
-        VDB_TRY(h->shadow16.reserve_keep(want, h->shadow_stale ? 0 : (size_t)std::min(h->shadow_cap, r.n) * ld16 * 2, s));
+        // (whole tiles of 32 positions: the copy interleaves the rows of a tile)
+        VDB_TRY(h->shadow16.reserve_keep(want, h->shadow_stale ? 0 : (size_t)round_up64(std::min(h->shadow_cap, r.n), 32) * ld16 * 2, s));
         h->shadow_cap = r.cap;
     }
     uint16_t* dst = h->shadow16.as<uint16_t>();
     if (h->shadow_stale) {
-        VDB_TRY(launch_ivf_round_rows(r.data, r.ld, r.dim, r.n, dst, ld16, s));
+        VDB_TRY(launch_ivf_round_rows_tiled(r.data, r.ld, r.dim, 0, r.n, dst, ld16, s));
         VDB_HIP(hipMemsetAsync(h->max_nrm.p, 0, sizeof(float), s));
         VDB_TRY(launch_max_norm(r.nrm, 0, r.n, h->max_nrm.as<float>(), s));
         h->shadow_stale = false;
@@ -2131,7 +2132,7 @@ static int ivf_shadow_sync(vdb_ivf* h, hipStream_t s) {
         for (const auto& d : h->shadow_dirty) {
             const int64_t from = std::max<int64_t>(d.first, 0), to = std::min(d.second, r.n);
             if (to <= from) continue;
-            VDB_TRY(launch_ivf_round_rows(r.data + from * r.ld, r.ld, r.dim, to - from, dst + from * ld16, ld16, s));
+            VDB_TRY(launch_ivf_round_rows_tiled(r.data + from * r.ld, r.ld, r.dim, from, to - from, dst, ld16, s));
             // a running maximum: a row that was overwritten may leave it larger than needed, never smaller
             VDB_TRY(launch_max_norm(r.nrm, from, to, h->max_nrm.as<float>(), s));
         }
@@ -2141,7 +2142,8 @@ static int ivf_shadow_sync(vdb_ivf* h, hipStream_t s) {
 }
 
 static constexpr int IVF_MFMA_GROUP = 32;           // queries per item: the columns of one 32 x 32 accumulator
-static constexpr int IVF_MFMA_QUEUE = 8192;         // most (slot, position) entries per query
+static constexpr int IVF_MFMA_QUEUE = 8192;         // most (slot, distance) entries per query
+static constexpr int IVF_MFMA_SEGMENT = 2048;       // kept pairs per wave of the scan pass
 
 static bool ivf_mfma_ok(const vdb_ivf* h, int sm, int nq, int64_t k_eff) {
     static const bool off = getenv("VDB_IVF_NO_MFMA") != nullptr;
@@ -2218,8 +2220,10 @@ static int ivf_search_impl(vdb_ivf* h, const float* d_q, int nq, int k, int n_pr
         VDB_TRY(ws.q16.reserve((size_t)nq * ld16 * 2));
         VDB_TRY(ws.mins.reserve((size_t)q_block * ivf_mfma_subsets() * sizeof(float)));
         VDB_TRY(ws.thr_d.reserve((size_t)q_block * sizeof(float)));
-        VDB_TRY(ws.queue.reserve((size_t)q_block * queue_cap * 3 * sizeof(int)));      // slots, positions, distances
-        VDB_TRY(ws.queue_cnt.reserve((size_t)q_block * sizeof(int)));
+        VDB_TRY(ws.queue.reserve((size_t)q_block * queue_cap * 2 * sizeof(int)));      // slots, distances
+        VDB_TRY(ws.seg.reserve((size_t)ivf_mfma_scan_waves() * IVF_MFMA_SEGMENT * sizeof(int4)));
+        VDB_TRY(ws.seg_len.reserve((size_t)ivf_mfma_scan_waves() * sizeof(int)));
+        VDB_TRY(ws.queue_cnt.reserve((size_t)q_block * ivf_mfma_len_stride() * sizeof(int)));
         VDB_TRY(ws.flag.reserve(sizeof(int)));
         VDB_TRY(launch_ivf_round_rows(q, m->r.ld, m->r.dim, nq, ws.q16.as<uint16_t>(), ld16, s));
         run_if = ws.flag.as<int>();
@@ -2241,8 +2245,8 @@ static int ivf_search_impl(vdb_ivf* h, const float* d_q, int nq, int k, int n_pr
             mj.cand_off = ws.cand_off.as<int64_t>(); mj.list_beg = h->lay.d_beg();
             mj.row_ids = h->row_ids.as<int>(); mj.mask = d_mask; mj.max_row_nrm = h->max_nrm.as<float>();
             mj.mins = ws.mins.as<float>(); mj.thr = ws.thr_d.as<float>(); mj.queue_slot = ws.queue.as<int>();
-            mj.queue_pos = ws.queue.as<int>() + (size_t)q_block * queue_cap;
-            mj.queue_d = ws.queue.as<float>() + (size_t)2 * q_block * queue_cap;
+            mj.queue_d = ws.queue.as<float>() + (size_t)q_block * queue_cap;
+            mj.seg = reinterpret_cast<int4*>(ws.seg.p); mj.seg_len = ws.seg_len.as<int>(); mj.seg_cap = IVF_MFMA_SEGMENT;
             mj.slots = ws.slots.as<int>() + (int64_t)q0 * k;
             mj.queue_len = ws.queue_cnt.as<int>(); mj.queue_cap = queue_cap; mj.overflow = ws.flag.as<int>();
             mj.k = kmax; mj.k_out = k; mj.take_sqrt = sm == VDB_EUCLIDEAN_DIRECT;

@@ -31,11 +31,14 @@
 namespace vdb {
 
 static constexpr int IA_NT = 256;          // threads per block: four independent waves
+static constexpr int IA_SETS = 4;          // scan pass: register sets of one 32-row tile per wave (IA_SETS - 1 tiles in flight)
+static constexpr int IA_LEN_STRIDE = 32;   // ints between the queue lengths of two queries: one 128-byte line each (they are hit by atomics)
+static constexpr int IA_RUN = 4;           // scan pass: consecutive items (256-row chunks) one wave takes at a time
 static constexpr int IB_UNITS = 8;         // bound pass: 256-row units of a query's visiting order (2048 rows)
 static constexpr int IA_SUBSETS = IB_UNITS * 16;   // disjoint row subsets (32-row tile x half) whose key minima bound the k-th best
 
 struct IvfApproxParams {
-    const uint16_t* rows16; int ld16;      // bf16 copies of the stored rows, [positions][ld16]
+    const uint16_t* rows16; int ld16;      // bf16 copies of the stored rows in the tiled layout (tiled_at), ld16 columns each
     int n_chunks;                          // column chunks of KS * 16 elements per row
     const float* row_sq;                   // |c|^2 of the float32 rows, by position
     const uint16_t* q16;                   // bf16 copies of the queries, [nq][ld16]
@@ -43,120 +46,186 @@ struct IvfApproxParams {
     const StreamItem* items; const int64_t* seg_item_off; int n_seg; int64_t items_cap;
     const int* sq_qid; const int64_t* sq_out;                         // per (list, query): query, first candidate slot
     int64_t cand_stride;                   // sq_out = query * cand_stride + slot of the list's first row
-    const float* thr;                      // per query: pairs with key <= thr are queued
-    int* queue_slot; int* queue_pos; int* queue_len; int queue_cap; int* overflow;    // [nq][queue_cap] each
+    const float* thr;                      // per query: pairs with key <= thr are kept
+    int4* seg; int* seg_len; int seg_cap;  // per wave of the launch: its kept pairs (query, slot, position, -), and how many
+    int* overflow;
     const int* row_ids; const uint32_t* mask;
 };
 
 typedef int i4v __attribute__((ext_vector_type(4)));
 typedef int i8v __attribute__((ext_vector_type(8)));
+typedef int i8v_u __attribute__((ext_vector_type(8), aligned(4)));       // eight dwords at any dword address
 
 template <class T> __device__ __forceinline__ T uniform_load(const T* p) {
     return *reinterpret_cast<const __attribute__((address_space(4))) T*>(reinterpret_cast<uintptr_t>(p));
 }
 
-// One wave per item = (chunk of up to 256 stored rows of one list, up to 32 of the queries that probe the list).
-// A operand: 32 rows, lane (row = lane % 32, half = lane / 32) holds its row's columns [half * 8 KS, half * 8 KS + 8 KS)
-// of the current column chunk as KS 16-byte pieces, loaded straight from global memory; k step j multiplies piece j of
-// both halves, i.e. the columns are visited in a permuted order, the same for rows and queries (the sum does not care).
-// B operand: the item's queries in the same layout.  The 32 x 32 accumulator gives lane (query = lane % 32) sixteen
-// rows: 8 g + 4 half + i.
+// The bf16 copy is laid out for the matrix cores, not row by row: positions go in tiles of 32, and inside a tile the
+// 16-byte pieces (8 columns) of the 32 rows are interleaved, piece c of row r at element ((tile * pieces + c) * 32 + r) * 8.
+// A wave loads piece c of 32 consecutive rows as 512 contiguous bytes.
+__device__ __forceinline__ int64_t tiled_at(int64_t pos, int piece, int pieces) {
+    return (((pos >> 5) * pieces + piece) * 32 + (pos & 31)) * 8;
+}
+
+// One wave per run of consecutive items = (rows of one list, up to 32 of the queries that probe the list); a run is up to
+// IA_RUN 256-row chunks that follow each other in memory and share their query group.
+// A operand: 32 rows, lane (row = lane % 32, half = lane / 32) loads pieces 2 j + half (j = 0 .. KS - 1) of its row's
+// current column chunk straight from global memory: one load instruction reads 1 KiB in two (or, for a run that does
+// not start on a tile boundary, four) contiguous stretches.  k step j multiplies piece 2 j of one half with piece 2 j + 1
+// of the other, i.e. the columns are visited in a permuted order, the same for rows and queries (the sum does not care).
+// B operand: the queries (row-major) in the same piece order.  The 32 x 32 accumulator gives lane (query = lane % 32)
+// sixteen rows: 8 g + 4 half + i.
 typedef float f4u __attribute__((ext_vector_type(4), aligned(4)));      // four floats at any dword address
 
+struct ItemHeader { int64_t row0, out_rel; int rows, qbeg, qcnt; };
+__device__ __forceinline__ ItemHeader load_header(const StreamItem* items, int64_t item) {
+    const i8v w = uniform_load(reinterpret_cast<const i8v*>(items + item));
+    ItemHeader it;
+    it.row0 = ((int64_t)(uint32_t)w[1] << 32) | (uint32_t)w[0];
+    it.out_rel = ((int64_t)(uint32_t)w[3] << 32) | (uint32_t)w[2];
+    it.rows = w[4]; it.qbeg = w[5]; it.qcnt = w[6];
+    return it;
+}
+
 template <int KS, bool MULTI>
-__global__ __launch_bounds__(IA_NT) void ivf_approx_kernel(IvfApproxParams p) {
+__global__ __launch_bounds__(IA_NT, 2) void ivf_approx_kernel(IvfApproxParams p) {
     const int lane = threadIdx.x & 63;
     const int n = lane & 31, h = lane >> 5;
     const int64_t n_waves = (int64_t)gridDim.x * (IA_NT / 64);
-    const int64_t wave0 = (int64_t)blockIdx.x * (IA_NT / 64) + (threadIdx.x >> 6);
+    // (the wave number through readfirstlane: what derives from it, items and row addresses, stays in scalar registers)
+    const int64_t wave0 = (int64_t)blockIdx.x * (IA_NT / 64) + __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
     const int64_t total = min(uniform_load(p.seg_item_off + p.n_seg), p.items_cap);
     constexpr int CE = KS * 16;                    // elements per column chunk
-    for (int64_t item = wave0; item < total; item += n_waves) {
-        const i8v w = uniform_load(reinterpret_cast<const i8v*>(p.items + item));
-        const int64_t row0 = ((int64_t)(uint32_t)w[1] << 32) | (uint32_t)w[0];
-        const int64_t out_rel = ((int64_t)(uint32_t)w[3] << 32) | (uint32_t)w[2];
-        const int rows = w[4], qbeg = w[5], qcnt = w[6];
-        const bool live = n < qcnt;
-        const int qslot = qbeg + (live ? n : 0);
-        const int qid = p.sq_qid[qslot];
-        const int slot0 = (int)(p.sq_out[qslot] - (int64_t)qid * p.cand_stride + out_rel);
-        const float q_sq = p.q_sq[qid];
-        const float thr = live ? p.thr[qid] : -INFINITY;
-        const int n_tiles = (rows + 31) >> 5;
-        const uint16_t* arow = p.rows16 + (row0 + n) * p.ld16 + h * (CE / 2);
-        const uint16_t* brow = p.q16 + (int64_t)qid * p.ld16 + h * (CE / 2);
-        i4v a[KS], b[KS];
-        if (!MULTI) {
+    const int pieces = p.ld16 >> 3;
+    int4* my_seg = p.seg + wave0 * p.seg_cap;
+    int seg_n = 0;
+    for (int64_t unit = wave0 * IA_RUN; unit < total; unit += n_waves * IA_RUN) {
+        const int64_t unit_end = min(unit + IA_RUN, total);
+        int64_t item = unit;
+        ItemHeader next = load_header(p.items, item);
+        while (item < unit_end) {
+            // the run: this item and the ones behind it that continue its rows for the same queries
+            const ItemHeader first = next;
+            int rows = first.rows;
+            ++item;
+            while (item < unit_end) {
+                next = load_header(p.items, item);
+                if (next.qbeg != first.qbeg || next.row0 != first.row0 + rows || (rows & 255) != 0) break;
+                rows += next.rows;
+                ++item;
+            }
+            const int64_t row0 = first.row0;
+            const bool live = n < first.qcnt;
+            const int qslot = first.qbeg + (live ? n : 0);
+            const int qid = p.sq_qid[qslot];
+            const int slot0 = (int)(p.sq_out[qslot] - (int64_t)qid * p.cand_stride + first.out_rel);
+            const float q_sq = p.q_sq[qid];
+            const float thr = live ? p.thr[qid] : -INFINITY;
+            const int n_tiles = (rows + 31) >> 5;
+            const uint16_t* arow = p.rows16 + tiled_at(row0 + n, h, pieces);          // piece h of this lane's first row
+            const uint16_t* brow = p.q16 + (int64_t)qid * p.ld16 + h * 8;
+            const int64_t tile_step = (int64_t)32 * p.ld16;                            // elements from a tile to the next
+            i4v b[KS];
+            // |c|^2 of 256 rows at a time: lane l holds rows 4 l .. 4 l + 3 of the current 256, the next 256 are on their way
+            f4u cs4 = *reinterpret_cast<const f4u*>(p.row_sq + row0 + 4 * lane);
+            f4u cs4_next = cs4;
+            // keys of one tile's rows from its accumulator; pairs within the threshold go to this wave's segment
+            auto finish_tile = [&](int t, const f32x16& acc) {
+                uint32_t hits = 0;
 #pragma unroll
-            for (int j = 0; j < KS; ++j) b[j] = *reinterpret_cast<const i4v*>(brow + j * 8);
+                for (int g = 0; g < 4; ++g) {
 #pragma unroll
-            for (int j = 0; j < KS; ++j) a[j] = *reinterpret_cast<const i4v*>(arow + j * 8);
-        }
-        for (int t = 0; t < n_tiles; ++t) {
-            const int64_t pos_t = row0 + t * 32;
-            // the row terms first, then the coming tile's rows: waiting for the former leaves the latter in flight
-            f4u cs[4];
-#pragma unroll
-            for (int g = 0; g < 4; ++g) cs[g] = *reinterpret_cast<const f4u*>(p.row_sq + pos_t + 8 * g + 4 * h);
-            f32x16 acc;
-#pragma unroll
-            for (int e = 0; e < 16; ++e) acc[e] = 0.0f;
+                    for (int i = 0; i < 4; ++i) {
+                        const int r = t * 32 + 8 * g + 4 * h + i;
+                        // |c|^2 of row r sits in lane (r mod 256) / 4, component i
+                        const float csq = __shfl(cs4[i], (t & 7) * 8 + 2 * g + h);
+                        const float key = __fmaf_rn(-2.0f, acc[g * 4 + i], q_sq + csq);
+                        if (key <= thr && r < rows) hits |= 1u << (g * 4 + i);
+                    }
+                }
+                // kept pairs go to this wave's own segment: places are handed out by ballot, no atomic and nothing to wait for
+                unsigned long long pending = __ballot(hits != 0);
+                while (pending != 0ull) {
+                    const bool has = hits != 0;
+                    const int e = has ? __builtin_ctz(hits) : 0;
+                    hits &= hits - 1;
+                    const int r = t * 32 + 8 * (e >> 2) + 4 * h + (e & 3);
+                    const int64_t pos = row0 + r;
+                    bool keep = has;
+                    if (keep && p.mask) {
+                        const int id = p.row_ids[pos];
+                        keep = (p.mask[id >> 5] >> (id & 31)) & 1u;
+                    }
+                    const unsigned long long km = __ballot(keep);
+                    const int at = seg_n + __popcll(km & ((1ull << lane) - 1ull));
+                    if (keep) {
+                        if (at < p.seg_cap) my_seg[at] = make_int4(qid, slot0 + r, (int)pos, 0);
+                        else *p.overflow = 1;
+                    }
+                    seg_n += __popcll(km);
+                    pending = __ballot(hits != 0);
+                }
+            };
+            auto next_row_terms = [&](int t) {           // at the first tile of every 256 rows
+                cs4 = cs4_next;
+                if ((t + 8) * 32 < rows) cs4_next = *reinterpret_cast<const f4u*>(p.row_sq + row0 + (int64_t)(t + 8) * 32 + 4 * lane);
+            };
             if (MULTI) {
-                for (int c = 0; c < p.n_chunks; ++c) {
+                for (int t = 0; t < n_tiles; ++t) {
+                    if ((t & 7) == 0) next_row_terms(t);
+                    f32x16 acc;
 #pragma unroll
-                    for (int j = 0; j < KS; ++j) a[j] = *reinterpret_cast<const i4v*>(arow + ((int64_t)t * 32) * p.ld16 + c * CE + j * 8);
+                    for (int e = 0; e < 16; ++e) acc[e] = 0.0f;
+                    for (int c = 0; c < p.n_chunks; ++c) {
+                        i4v a[KS];
 #pragma unroll
-                    for (int j = 0; j < KS; ++j) b[j] = *reinterpret_cast<const i4v*>(brow + c * CE + j * 8);
+                        for (int j = 0; j < KS; ++j)
+                            a[j] = *reinterpret_cast<const i4v*>(arow + t * tile_step + (int64_t)(c * (CE / 8) + 2 * j) * 256);
+#pragma unroll
+                        for (int j = 0; j < KS; ++j) b[j] = *reinterpret_cast<const i4v*>(brow + c * CE + j * 16);
+#pragma unroll
+                        for (int j = 0; j < KS; ++j)
+                            acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, a[j]), __builtin_bit_cast(bf16x8, b[j]),
+                                                                          acc, 0, 0, 0);
+                    }
+                    finish_tile(t, acc);
+                }
+            } else {
+                // IA_SETS register sets of one tile each: while a tile is multiplied the next IA_SETS - 1 are on their way.
+                // A tile past the end refetches the last one: no branch around the loads.
+                i4v a[IA_SETS][KS];
+                auto load_rows = [&](int t, i4v* a) {
+                    const uint16_t* src = arow + min(t, n_tiles - 1) * tile_step;
+#pragma unroll
+                    for (int j = 0; j < KS; ++j) a[j] = *reinterpret_cast<const i4v*>(src + j * 512);
+                };
+                auto multiply = [&](int t, const i4v* a) {
+                    f32x16 acc;
+#pragma unroll
+                    for (int e = 0; e < 16; ++e) acc[e] = 0.0f;
 #pragma unroll
                     for (int j = 0; j < KS; ++j)
                         acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, a[j]), __builtin_bit_cast(bf16x8, b[j]),
                                                                       acc, 0, 0, 0);
-                }
-            } else {
-                i4v an[KS];
-                // (the last tile refetches itself: no branch around the loads)
-                const uint16_t* nxt = arow + (int64_t)min(t + 1, n_tiles - 1) * 32 * p.ld16;
+                    finish_tile(t, acc);
+                };
 #pragma unroll
-                for (int j = 0; j < KS; ++j) an[j] = *reinterpret_cast<const i4v*>(nxt + j * 8);
+                for (int j = 0; j < KS; ++j) b[j] = *reinterpret_cast<const i4v*>(brow + j * 16);
 #pragma unroll
-                for (int j = 0; j < KS; ++j)
-                    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, a[j]), __builtin_bit_cast(bf16x8, b[j]),
-                                                                  acc, 0, 0, 0);
+                for (int u = 0; u < IA_SETS - 1; ++u) load_rows(u, a[u]);
+                for (int t = 0; t < n_tiles; t += IA_SETS) {
+                    if ((t & 7) == 0) next_row_terms(t);
 #pragma unroll
-                for (int j = 0; j < KS; ++j) a[j] = an[j];
-            }
-            // keys of this lane's sixteen rows
-            uint32_t hits = 0;
-#pragma unroll
-            for (int g = 0; g < 4; ++g) {
-#pragma unroll
-                for (int i = 0; i < 4; ++i) {
-                    const int r = t * 32 + 8 * g + 4 * h + i;
-                    const float key = __fmaf_rn(-2.0f, acc[g * 4 + i], q_sq + cs[g][i]);
-                    if (key <= thr && r < rows) hits |= 1u << (g * 4 + i);
-                }
-            }
-            if (__ballot(hits != 0) != 0ull) {
-                while (hits) {
-                    const int e = __builtin_ctz(hits);
-                    hits &= hits - 1;
-                    const int r = t * 32 + 8 * (e >> 2) + 4 * h + (e & 3);
-                    const int64_t pos = row0 + r;
-                    if (p.mask) {
-                        const int id = p.row_ids[pos];
-                        if (!((p.mask[id >> 5] >> (id & 31)) & 1u)) continue;
-                    }
-                    const int at = atomicAdd(&p.queue_len[qid], 1);
-                    if (at < p.queue_cap) {
-                        p.queue_slot[(int64_t)qid * p.queue_cap + at] = slot0 + r;
-                        p.queue_pos[(int64_t)qid * p.queue_cap + at] = (int)pos;
-                    } else {
-                        *p.overflow = 1;
+                    for (int u = 0; u < IA_SETS; ++u) {
+                        if (t + u >= n_tiles) break;
+                        load_rows(t + u + IA_SETS - 1, a[(u + IA_SETS - 1) % IA_SETS]);
+                        multiply(t + u, a[u]);
                     }
                 }
             }
         }
     }
+    if (lane == 0) p.seg_len[wave0] = min(seg_n, p.seg_cap);
 }
 
 // --------------------------------------------------------------------------
@@ -185,11 +254,11 @@ __global__ __launch_bounds__(IA_NT) void ivf_bound_kernel(IvfBoundParams p) {
     const int64_t* co = p.cand_off + (int64_t)q * (p.n_probe + 1);
     const int64_t total = co[p.n_probe];
     const float q_sq = p.q_sq[q];
-    const uint16_t* brow = p.q16 + (int64_t)q * p.ld16 + h * (CE / 2);
+    const uint16_t* brow = p.q16 + (int64_t)q * p.ld16 + h * 8;
     i4v b[KS];
     if (!MULTI) {
 #pragma unroll
-        for (int j = 0; j < KS; ++j) b[j] = *reinterpret_cast<const i4v*>(brow + j * 8);
+        for (int j = 0; j < KS; ++j) b[j] = *reinterpret_cast<const i4v*>(brow + j * 16);
     }
     int pr = 0;                                    // the probe this lane's slot lies in (slots only grow)
     for (int t = 0; t < 8; ++t) {
@@ -211,7 +280,7 @@ __global__ __launch_bounds__(IA_NT) void ivf_bound_kernel(IvfBoundParams p) {
             continue;
         }
         const float csq_own = p.row_sq[pos];
-        const uint16_t* arow = p.rows16 + pos * p.ld16 + h * (CE / 2);
+        const uint16_t* arow = p.rows16 + tiled_at(pos, h, p.ld16 >> 3);
         f32x16 acc;
 #pragma unroll
         for (int e = 0; e < 16; ++e) acc[e] = 0.0f;
@@ -219,10 +288,10 @@ __global__ __launch_bounds__(IA_NT) void ivf_bound_kernel(IvfBoundParams p) {
         for (int c = 0; c < chunks; ++c) {
             i4v a[KS];
 #pragma unroll
-            for (int j = 0; j < KS; ++j) a[j] = *reinterpret_cast<const i4v*>(arow + c * CE + j * 8);
+            for (int j = 0; j < KS; ++j) a[j] = *reinterpret_cast<const i4v*>(arow + (int64_t)(c * (CE / 8) + 2 * j) * 256);
             if (MULTI) {
 #pragma unroll
-                for (int j = 0; j < KS; ++j) b[j] = *reinterpret_cast<const i4v*>(brow + c * CE + j * 8);
+                for (int j = 0; j < KS; ++j) b[j] = *reinterpret_cast<const i4v*>(brow + c * CE + j * 16);
             }
 #pragma unroll
             for (int j = 0; j < KS; ++j)
@@ -340,26 +409,34 @@ struct IvfExactParams {
     const float* rows; int ld; SumPlan plan;     // the float32 rows, by position
     const float* q; int ldq;                     // the float32 queries (padded rows)
     int take_sqrt;                               // VDB_EUCLIDEAN_DIRECT: the distance is the root of the sum
-    const int* queue_pos; const int* queue_len; int queue_cap;
-    float* queue_d;                              // out [nq][queue_cap]: the reference's distance of every queued pair
+    const int4* seg; const int* seg_len; int seg_cap;
+    float* queue_d; int* queue_slot; int* queue_len; int queue_cap; int* overflow;   // per query: [nq][queue_cap]
 };
 
-// grid (queries, entry slices): a pair of lanes per queued (query, row) pair
+// Blocks (segment of the scan pass, slice), a pair of lanes per kept (query, row) pair: the reference's distance, then a
+// place in the query's queue (an atomic per pair, spread over thousands of waves that have nothing else to wait for).
 __global__ __launch_bounds__(256) void ivf_exact_dist_kernel(IvfExactParams p) {
-    const int q = blockIdx.x;
-    const int len = min(p.queue_len[q], p.queue_cap);
+    const int len = min(p.seg_len[blockIdx.x], p.seg_cap);
     const int m = threadIdx.x & 1;
-    const float* qrow = p.q + (int64_t)q * p.ldq;
+    const int4* seg = p.seg + (int64_t)blockIdx.x * p.seg_cap;
     for (int e = blockIdx.y * 128 + (threadIdx.x >> 1); e < len; e += 128 * gridDim.y) {
-        const int64_t at = (int64_t)q * p.queue_cap + e;
-        const float sum = exact_sqdiff(p.rows + (int64_t)p.queue_pos[at] * p.ld, qrow, p.plan, m);
-        if (m == 0) p.queue_d[at] = p.take_sqrt ? sqrtf(sum) : sum;
+        const int4 ent = seg[e];
+        const float sum = exact_sqdiff(p.rows + (int64_t)ent.z * p.ld, p.q + (int64_t)ent.x * p.ldq, p.plan, m);
+        if (m == 0) {
+            const int at = atomicAdd(&p.queue_len[ent.x * IA_LEN_STRIDE], 1);
+            if (at < p.queue_cap) {
+                p.queue_d[(int64_t)ent.x * p.queue_cap + at] = p.take_sqrt ? sqrtf(sum) : sum;
+                p.queue_slot[(int64_t)ent.x * p.queue_cap + at] = ent.y;
+            } else {
+                *p.overflow = 1;
+            }
+        }
     }
 }
 
 __global__ void ivf_clear_queues_kernel(int* queue_len, int nq, int* overflow) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i < nq) queue_len[i] = 0;
+    if (i < nq) queue_len[i * IA_LEN_STRIDE] = 0;
     if (i == 0) *overflow = 0;
 }
 
@@ -377,6 +454,43 @@ __global__ void ivf_round_rows_kernel(const float* __restrict__ src, int64_t src
         }
         dst16[i] = (uint16_t)b;
     }
+}
+
+// fp32 rows [pos0, pos0 + n) of a store -> the tiled bf16 copy (tiled_at).  A thread converts one 16-byte piece; threads
+// run over (tile, piece, row of the tile), so 32 neighbours write 512 contiguous bytes.
+__global__ void ivf_round_rows_tiled_kernel(const float* __restrict__ src, int64_t src_ld, int dim, int64_t pos0, int64_t n,
+                                            uint16_t* __restrict__ dst16, int ld16) {
+    const int pieces = ld16 >> 3;
+    const int64_t first_tile = pos0 >> 5;
+    const int64_t total = (((pos0 + n + 31) >> 5) - first_tile) * pieces * 32;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+        const int r = (int)(i & 31);
+        const int c = (int)((i >> 5) % pieces);
+        const int64_t pos = (first_tile + (i >> 5) / pieces) * 32 + r;
+        if (pos < pos0 || pos >= pos0 + n) continue;
+        const float* x = src + (pos - pos0) * src_ld + c * 8;
+        uint32_t w[4];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            uint32_t b = 0;
+            if (c * 8 + e < dim) {
+                const uint32_t v = __float_as_uint(x[e]);
+                b = ((v & 0x7fffffffu) > 0x7f800000u) ? ((v >> 16) | 0x40u) : ((v + 0x7fffu + ((v >> 16) & 1u)) >> 16);
+            }
+            if (e & 1) w[e >> 1] |= b << 16; else w[e >> 1] = b & 0xffffu;
+        }
+        *reinterpret_cast<uint4*>(dst16 + tiled_at(pos, c, pieces)) = make_uint4(w[0], w[1], w[2], w[3]);
+    }
+}
+
+int launch_ivf_round_rows_tiled(const float* src, int64_t src_ld, int dim, int64_t pos0, int64_t n, uint16_t* dst16, int ld16,
+                                hipStream_t s) {
+    if (n <= 0) return VDB_OK;
+    const int64_t total = (n + 64) * (ld16 >> 3);
+    hipLaunchKernelGGL(ivf_round_rows_tiled_kernel, dim3((unsigned)std::min<int64_t>((total + 255) / 256, 65536)), dim3(256), 0, s,
+                       src, src_ld, dim, pos0, n, dst16, ld16);
+    VDB_HIP(hipGetLastError());
+    return VDB_OK;
 }
 
 int ivf_mfma_pitch(int dim) { return dim <= 128 ? round_up(dim, 32) : round_up(dim, 128); }
@@ -428,47 +542,51 @@ int launch_ivf_mfma_search(const IvfMfmaJob& j, hipStream_t s) {
     p.row_sq = j.row_sq; p.q16 = j.q16; p.q_sq = j.q_sq;
     p.items = j.plan.items; p.seg_item_off = j.plan.seg_item_off; p.n_seg = j.n_lists; p.items_cap = j.plan.items_cap;
     p.sq_qid = j.plan.sq_qid; p.sq_out = j.plan.sq_out; p.cand_stride = j.cand_stride;
-    p.thr = j.thr; p.queue_slot = j.queue_slot; p.queue_pos = j.queue_pos; p.queue_len = j.queue_len; p.queue_cap = j.queue_cap;
+    p.thr = j.thr; p.seg = j.seg; p.seg_len = j.seg_len; p.seg_cap = j.seg_cap;
     p.overflow = j.overflow; p.row_ids = j.row_ids; p.mask = j.mask;
+    const int scan_blocks = ivf_mfma_scan_waves() / (IA_NT / 64);
     {
         KernelTimer timer(s, j.timed);
-        // twelve waves per CU keep enough row bytes in flight
-        VDB_TRY(launch_by_pitch(p, j.ld16, n_chunks, dim3(ctx().num_cus * 3), s, ivf_approx_kernel<2, false>,
+        VDB_TRY(launch_by_pitch(p, j.ld16, n_chunks, dim3(scan_blocks), s, ivf_approx_kernel<2, false>,
                                 ivf_approx_kernel<4, false>, ivf_approx_kernel<6, false>, ivf_approx_kernel<8, false>,
                                 ivf_approx_kernel<8, true>));
     }
     static const bool debug = getenv("VDB_IVF_DEBUG") != nullptr;
     if (debug) {
         std::vector<float> thr((size_t)j.nq);
-        std::vector<int> len((size_t)j.nq);
+        std::vector<int> len((size_t)ivf_mfma_scan_waves());
         int flag = 0;
         float big = 0;
         (void)hipStreamSynchronize(s);
         (void)hipMemcpy(thr.data(), j.thr, thr.size() * sizeof(float), hipMemcpyDeviceToHost);
-        (void)hipMemcpy(len.data(), j.queue_len, len.size() * sizeof(int), hipMemcpyDeviceToHost);
+        (void)hipMemcpy(len.data(), j.seg_len, len.size() * sizeof(int), hipMemcpyDeviceToHost);
         (void)hipMemcpy(&flag, j.overflow, sizeof(int), hipMemcpyDeviceToHost);
         (void)hipMemcpy(&big, j.max_row_nrm, sizeof(float), hipMemcpyDeviceToHost);
         int inf = 0, mx = 0; long long tot = 0; float tmin = INFINITY, tmax = 0;
         for (int q = 0; q < j.nq; ++q) {
             if (!(thr[q] < INFINITY)) ++inf; else { tmin = std::min(tmin, thr[q]); tmax = std::max(tmax, thr[q]); }
-            mx = std::max(mx, len[q]); tot += len[q];
         }
-        fprintf(stderr, "[ivf mfma] nq=%d k=%d ld16=%d max|c|=%g thr: %d inf, finite %g..%g; queue: max %d, mean %.1f (cap %d); flag=%d\n",
-                j.nq, j.k, j.ld16, big, inf, tmin, tmax, mx, (double)tot / j.nq, j.queue_cap, flag);
+        for (int v : len) { mx = std::max(mx, v); tot += v; }
+        fprintf(stderr, "[ivf mfma] nq=%d k=%d ld16=%d max|c|=%g thr: %d inf, finite %g..%g; kept pairs: %lld (%.1f per query), "
+                "largest segment %d of %d; flag=%d\n", j.nq, j.k, j.ld16, big, inf, tmin, tmax, tot, (double)tot / j.nq, mx, j.seg_cap, flag);
     }
     IvfExactParams e{};
     e.rows = j.rows; e.ld = j.ld; e.plan = j.sum_plan; e.q = j.q; e.ldq = j.ldq; e.take_sqrt = j.take_sqrt ? 1 : 0;
-    e.queue_pos = j.queue_pos; e.queue_len = j.queue_len; e.queue_cap = j.queue_cap; e.queue_d = j.queue_d;
-    const int slices = std::max(1, std::min(8, (j.queue_cap + 127) / 128));
-    hipLaunchKernelGGL(ivf_exact_dist_kernel, dim3(j.nq, slices), dim3(256), 0, s, e);
+    e.seg = j.seg; e.seg_len = j.seg_len; e.seg_cap = j.seg_cap;
+    e.queue_d = j.queue_d; e.queue_slot = j.queue_slot; e.queue_len = j.queue_len; e.queue_cap = j.queue_cap; e.overflow = j.overflow;
+    // (a segment's pairs over several blocks: segments differ in length by an order of magnitude)
+    hipLaunchKernelGGL(ivf_exact_dist_kernel, dim3(ivf_mfma_scan_waves(), 8), dim3(256), 0, s, e);
     VDB_HIP(hipGetLastError());
     // the k best of every queue under (distance, slot) = (distance, visiting order), then slots -> rows
     SelectOut o{j.out_d, nullptr, j.slots, j.k_out, 0, nullptr, nullptr, nullptr};
-    VDB_TRY(launch_select_packed(j.queue_d, j.queue_slot, j.nq, j.queue_cap, j.k, o, s, j.queue_len));
+    VDB_TRY(launch_select_packed(j.queue_d, j.queue_slot, j.nq, j.queue_cap, j.k, o, s, j.queue_len, IA_LEN_STRIDE));
     return launch_ivf_rows(j.slots, j.nq, j.k, j.k_out, 0, j.probes, j.n_probe, j.n_lists, j.cand_off, j.list_beg, j.row_ids,
                            j.out_rows, j.out_order, s);
 }
 
 int ivf_mfma_subsets() { return IA_SUBSETS; }
+int ivf_mfma_len_stride() { return IA_LEN_STRIDE; }
+// waves of the scan pass (eight per CU, three tiles in flight each) = segments of kept pairs
+int ivf_mfma_scan_waves() { return ctx().num_cus * 2 * (IA_NT / 64); }
 
 }  // namespace vdb

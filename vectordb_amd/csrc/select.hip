@@ -264,7 +264,7 @@ __global__ __launch_bounds__(256) void merge_wave_kernel(const float* __restrict
 }
 
 __global__ void merge_block_kernel(const float* __restrict__ d, const int* __restrict__ idx, int area, int k, SelectOut o,
-                                   int* __restrict__ queue_len, int lists_of_k);
+                                   int* __restrict__ queue_len, int lists_of_k, int len_stride);
 static constexpr int MB_WAVES = 16;
 
 int launch_select(const float* part_d, const int* part_i, int nq, int n_cand, int k, int tie_group,
@@ -287,7 +287,7 @@ int launch_select(const float* part_d, const int* part_i, int nq, int n_cand, in
     if (nq <= 8 && idx_map == nullptr && idx_offset == 0 && (int64_t)n_cand * k <= (1 << 17)) {
         // a handful of queries: one block of sixteen waves per query walks the lists as one run of entries, instead of
         // two or three dependent launches of list merges
-        hipLaunchKernelGGL(merge_block_kernel, dim3(nq), dim3(64 * MB_WAVES), 0, s, part_d, part_i, n_cand * k, k, o, (int*)nullptr, 1);
+        hipLaunchKernelGGL(merge_block_kernel, dim3(nq), dim3(64 * MB_WAVES), 0, s, part_d, part_i, n_cand * k, k, o, (int*)nullptr, 1, 1);
         VDB_HIP(hipGetLastError());
         return VDB_OK;
     }
@@ -329,7 +329,7 @@ int launch_select(const float* part_d, const int* part_i, int nq, int n_cand, in
 // waves busy), each keeps its k best in registers, and wave 0 merges the waves' lists through LDS.
 __global__ __launch_bounds__(64 * MB_WAVES) void merge_block_kernel(const float* __restrict__ d, const int* __restrict__ idx,
                                                                     int area, int k, SelectOut o, int* __restrict__ queue_len,
-                                                                    int lists_of_k) {
+                                                                    int lists_of_k, int len_stride) {
     __shared__ float sh_d[MB_WAVES * 64];
     __shared__ int sh_i[MB_WAVES * 64];
     __shared__ float sh_thr[MB_WAVES];
@@ -337,6 +337,7 @@ __global__ __launch_bounds__(64 * MB_WAVES) void merge_block_kernel(const float*
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int q = blockIdx.x;
     if (o.run_if && *o.run_if == 0) return;
+    if (queue_len) queue_len += (int64_t)q * len_stride - q;     // a query's length lies len_stride ints from its neighbour's
     const int total = queue_len ? min(__builtin_amdgcn_readfirstlane(queue_len[q]), area) : area;
     const int waves = max(1, min(MB_WAVES, (total + 255) / 256));
     const float* dq = d + (int64_t)q * area;
@@ -441,10 +442,10 @@ __global__ __launch_bounds__(64 * MB_WAVES) void merge_block_kernel(const float*
 }
 
 int launch_select_packed(const float* part_d, const int* part_i, int nq, int area, int k, const SelectOut& o, hipStream_t s,
-                         int* queue_len) {
+                         int* queue_len, int len_stride) {
     if (nq <= 0) return VDB_OK;
     VDB_REQUIRE(k >= 1 && k <= 64 && queue_len, "packed selection: k in 1..64 and a queue length per query");
-    hipLaunchKernelGGL(merge_block_kernel, dim3(nq), dim3(64 * MB_WAVES), 0, s, part_d, part_i, area, k, o, queue_len, 0);
+    hipLaunchKernelGGL(merge_block_kernel, dim3(nq), dim3(64 * MB_WAVES), 0, s, part_d, part_i, area, k, o, queue_len, 0, len_stride);
     VDB_HIP(hipGetLastError());
     return VDB_OK;
 }

@@ -314,7 +314,8 @@ struct IvfMfmaJob {
     const int* probes; int n_probe; int n_lists; const int64_t* cand_off; const int64_t* list_beg;
     const int* row_ids; const uint32_t* mask;
     const float* max_row_nrm;                                  // device float: the largest |c| over the stored rows
-    float* mins; float* thr; int* queue_slot; int* queue_pos; float* queue_d; int* queue_len; int queue_cap; int* overflow;   // workspaces
+    float* mins; float* thr; int4* seg; int* seg_len; int seg_cap;                                       // workspaces
+    int* queue_slot; float* queue_d; int* queue_len; int queue_cap; int* overflow;
     int* slots;                                                // workspace [nq][k_out]: the selected candidate slots
     int k, k_out; bool take_sqrt;
     float* out_d; int64_t* out_rows; int64_t* out_order;
@@ -323,7 +324,12 @@ struct IvfMfmaJob {
 int launch_ivf_mfma_search(const IvfMfmaJob& j, hipStream_t s);
 int ivf_mfma_pitch(int dim);            // bf16 elements per row of the copy
 int ivf_mfma_subsets();                 // floats of `mins` per query
+int ivf_mfma_len_stride();              // ints of `queue_len` per query
+int ivf_mfma_scan_waves();              // segments of `seg` / entries of `seg_len`
 int launch_ivf_round_rows(const float* src, int64_t src_ld, int dim, int64_t n, uint16_t* dst16, int ld16, hipStream_t s);
+// rows [pos0, pos0 + n) of a store (src = its row pos0) into the tiled bf16 copy `dst16` (the copy's base address)
+int launch_ivf_round_rows_tiled(const float* src, int64_t src_ld, int dim, int64_t pos0, int64_t n, uint16_t* dst16, int ld16,
+                                hipStream_t s);
 
 struct SelectOut {
     float* out_d; int64_t* out_i; int* out_i32;   // any of the index outputs may be null
@@ -336,9 +342,9 @@ struct SelectOut {
 int launch_select(const float* part_d, const int* part_i, int nq, int n_cand, int k, int tie_group,
                   const int* idx_map, int64_t idx_offset, const SelectOut& o, hipStream_t s, DevBuf* mid);
 // a few queries: the k best of every query's packed candidate area (queue_len[q] of `area` entries, any order),
-// one block per query; sets queue_len[q] back to zero
+// one block per query; sets queue_len[q] back to zero (query q's length at queue_len[q * len_stride])
 int launch_select_packed(const float* part_d, const int* part_i, int nq, int area, int k, const SelectOut& o, hipStream_t s,
-                         int* queue_len);
+                         int* queue_len, int len_stride = 1);
 // lists laid out [n_lists][nq][k] with int64 ids (negative = empty), ordered by (distance, id);
 // with a payload of the same layout the payload of every selected entry is written instead of its id.
 // List l of the distances starts at d + l * stride_d, of the ids and the payload at i + l * stride_i
