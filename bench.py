@@ -36,6 +36,14 @@ sample of the queries is checked against that oracle at every N.
             bit for bit with the former) and bf16 storage, batch 1024
             (queries/s, kernel ms, fraction of the MFMA peak of the kernel's
             type), with a spot check of the returned distances against the oracle;
+  c4        configs[3]: IVF nlist=4096 nprobe=32 over 10M x 128: IVFIndex.train on 256 x 4096 rows (k-means++ and 20
+            Lloyd steps, seed 42), assignment of all rows, inverted lists spread over the ranks by whole lists
+            (ShardedIVF), batch 1024 and single queries, the scan kernel against the HBM roofline, a sample of the
+            queries against the oracle and the oracle timed on the host cores;
+  c5        configs[4]: PQ m=16 nbits=8 ADC scan over 100M codes (rows / N per GPU, HipPqBackend), batch 1 and 8, no
+            filter / 50 % / 1 % bitmask resident in HBM, the scan kernel against the HBM roofline, the oracle on a
+            sample of the codes; the PQIndex class with a filter callable (first and repeated search); Manhattan
+            1M x 128 batch 1 and 1024 beside it;
   c1        configs[0]: 10k x 128 euclidean, 100 single queries, through the
             Collection.search-shaped path and as bare distances + top-k, on the
             GPU and on the host oracle (N = 1 only);
@@ -147,7 +155,8 @@ def main() -> None:
     ap.add_argument("--dim", type=int, default=DIM)
     ap.add_argument("--queries", type=int, default=N_QUERIES)
     ap.add_argument("--cpu-sample", type=int, default=48, help="queries timed on the host oracle at N = 1 (0 = skip)")
-    ap.add_argument("--no-extra", action="store_true", help="skip the side measurements (c3, c1, ceilings)")
+    ap.add_argument("--no-extra", action="store_true", help="skip the side measurements (prefilter, c3, c4, c5, c1, ceilings)")
+    ap.add_argument("--skip", default="", help="side measurements to leave out, e.g. c3,c5")
     args = ap.parse_args()
 
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
@@ -267,10 +276,20 @@ def main() -> None:
     extra = None
     if not args.no_extra:
         extra = {"prefilter": prefilter}
-        try:
-            extra["c3"] = bench_c3(world, rank, dev, gen, barrier, max_over_ranks, _native)
-        except Exception as e:          # a side measurement must not take the headline line with it
-            extra["c3"] = {"error": f"{type(e).__name__}: {e}"}
+        skip = set(filter(None, args.skip.split(",")))
+        if "c3" not in skip:
+            try:
+                extra["c3"] = bench_c3(world, rank, dev, gen, barrier, max_over_ranks, _native)
+            except Exception as e:          # a side measurement must not take the headline line with it
+                extra["c3"] = {"error": f"{type(e).__name__}: {e}"}
+        for name, fn in (("c4", bench_c4), ("c5", bench_c5)):
+            if name in skip:
+                continue
+            try:
+                extra[name] = fn(world, rank, dev, gen, barrier, max_over_ranks, _native)
+            except Exception as e:
+                extra[name] = {"error": f"{type(e).__name__}: {e}"}
+            torch.cuda.empty_cache()
         if world == 1:
             for name, fn in (("c1", bench_c1), ("ceilings", bench_ceilings)):
                 try:
@@ -348,6 +367,305 @@ def bench_c3(world, rank, dev, gen, barrier, max_over_ranks, native, steps=5, wa
         del index, backend
         torch.cuda.empty_cache()
     return out
+
+
+C4_ROWS, C4_DIM, C4_LISTS, C4_PROBE = 10_000_000, 128, 4096, 32
+C5_ROWS, C5_M = 100_000_000, 16
+
+
+def hbm_roofline(nbytes: float, kernel_s: float, **more) -> dict:
+    gbs = nbytes / kernel_s / 1e9 if kernel_s and kernel_s == kernel_s and kernel_s > 0 else 0.0
+    return {"bound": "hbm", "achieved": round(gbs, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+            "frac": round(gbs / HBM_PEAK_GBS, 4), "bytes_per_launch": int(nbytes), **more}
+
+
+class _Probed:
+    """ShardedIVF behind the (queries, k) call that timed_steps makes."""
+
+    def __init__(self, index, n_probe):
+        self.index, self.n_probe = index, n_probe
+
+    def search(self, queries, k):
+        return self.index.search(queries, k, self.n_probe)
+
+
+class _Masked:
+    """ShardedFlat with this rank's filter words bound."""
+
+    def __init__(self, index, words):
+        self.index, self.words = index, words
+
+    def search(self, queries, k):
+        return self.index.search(queries, k, self.words)
+
+
+def bench_c4(world, rank, dev, gen, barrier, max_over_ranks, native, cpu_sample=16):
+    """BASELINE.json configs[3]: IVF nlist=4096 nprobe=32 over 10M x 128 standard-normal rows, k = 10.  Training is the
+    reference's: k-means++ and 20 Lloyd steps over 256 rows per cluster (index/ivf.py:126-231 through IVFIndex.train),
+    then every row goes to its nearest centroid (ivf.py:553-565).  Whole lists are dealt to the ranks by length; a step
+    is: rank all centroids, scan the probed lists this rank owns [-> all-gather -> merge by (distance, visiting order)]."""
+    from oracle import ref_numpy as R
+    from vectordb_amd.index import IVFIndex
+    from vectordb_amd.sharded import HipIvfBackend, ShardedIVF, assign_lists_balanced, local_ivf_layout
+    n, d, nlist, nprobe, k = C4_ROWS, C4_DIM, C4_LISTS, C4_PROBE, TOP_K
+    x = np.empty((n, d), np.float32)
+    for c0 in range(0, n, 16 * GEN_BLOCK):
+        c1 = min(n, c0 + 16 * GEN_BLOCK)
+        x[c0:c1] = block_rows(c0, c1, d, 777, dev, gen).cpu().numpy()
+    ix = IVFIndex(dimension=d, metric="euclidean", n_clusters=nlist, n_probe=nprobe, n_iter=20, seed=42)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    ix.train(x[:256 * nlist])
+    train_s = time.perf_counter() - t0
+    ph = dict(ix._last_kmeans.phase_seconds)
+    cent = ix.centroids
+    t0 = time.perf_counter()
+    assign, _ = native.assign(x, cent, native.EUCLIDEAN)
+    assign_s = time.perf_counter() - t0
+    lengths = np.bincount(assign, minlength=nlist)
+    owner = assign_lists_balanced(lengths, world)
+    t0 = time.perf_counter()
+    mine, list_rows_local, offsets = local_ivf_layout(assign, nlist, owner, rank)
+    backend = HipIvfBackend(d, native.EUCLIDEAN, cent, x[mine], list_rows_local, offsets, mine)
+    build_s = time.perf_counter() - t0
+    index = _Probed(ShardedIVF(backend, rank, world), nprobe)
+    out = {"workload": f"IVF nlist={nlist} nprobe={nprobe}, {n} x {d} fp32, k={k}, whole lists dealt to {world} GPU(s) (BASELINE configs[3])",
+           "train": {"what": f"IVFIndex.train: k-means++ + 20 Lloyd steps over {256 * nlist} rows, {nlist} clusters, seed 42",
+                     "seconds": round(train_s, 3), "init_pp_s": round(ph.get("init_pp", 0.0), 3), "lloyd_s": round(ph.get("lloyd", 0.0), 3),
+                     "lloyd_steps": ph.get("lloyd_steps")},
+           "assign_all_rows_s": round(assign_s, 3), "build_lists_s": round(build_s, 3),
+           "rows_on_this_gpu": int(len(mine)), "longest_list": int(lengths.max())}
+    gen.manual_seed(999)
+    queries = torch.randn((N_QUERIES, d), device=dev, dtype=torch.float32, generator=gen)
+    results = None
+    for nq, steps, warmup in ((N_QUERIES, 10, 3), (1, 50, 5)):
+        q = queries[:nq].contiguous()
+        elapsed, kernel_ms, launches, (od, orow) = timed_steps(index, q, k, steps, warmup, barrier, native)
+        elapsed = max_over_ranks(elapsed)
+        used_mfma, overflow = backend.lists.search_stats()
+        scanned = backend.lists.last_scan_rows()                     # (row, query) pairs this rank scanned in one step
+        per_step_ms = kernel_ms / steps
+        if used_mfma:
+            # the timed kernel is the matrix-core pass over the bf16 copy.  A chunk of a list is read once for all the
+            # queries of the batch that probe it, so what HBM must deliver is every probed list once: at most this
+            # GPU's whole copy (2 bytes per element), and not more than one read per scanned (row, query) pair
+            roof = hbm_roofline(min(scanned, len(mine)) * d * 2.0, per_step_ms * 1e-3,
+                                kernel="ivf_approx_kernel (bf16 copy of the member rows)",
+                                kernel_ms=round(per_step_ms, 4), launches_per_step=launches // steps,
+                                per_query_fp32_bytes_times_queries=int(scanned * d * 4 + nq * nlist * d * 4))
+        else:
+            roof = hbm_roofline(scanned * d * 4.0 + nq * nlist * d * 4.0, elapsed / steps,
+                                kernel="centroid ranking + list scan + selection (whole step)", kernel_ms_timed=round(per_step_ms, 4),
+                                launches_per_step=launches // steps)
+        out[f"batch_{nq}"] = {"queries_per_s": round(nq * steps / elapsed, 1), "ms_per_step": round(elapsed / steps * 1e3, 4),
+                              "row_query_pairs_scanned_on_this_gpu": int(scanned), "matrix_core_scan": used_mfma,
+                              "queue_overflow": overflow, "roofline": roof}
+        if nq == N_QUERIES:
+            results = (od.cpu().numpy(), orow.cpu().numpy())
+    # parity sample and the host baseline: the oracle's IVFIndex.search over all 10M rows, one query at a time
+    if rank == 0 and cpu_sample > 0:
+        order = np.argsort(assign, kind="stable")
+        offs = np.searchsorted(assign[order], np.arange(nlist + 1))
+        members = [order[offs[l]:offs[l + 1]] for l in range(nlist)]
+        qh = queries[:cpu_sample].cpu().numpy()
+        R.ivf_search(qh[0], x, cent, members, k, nprobe, "euclidean")
+        t0 = time.perf_counter()
+        ref = [R.ivf_search(qh[i], x, cent, members, k, nprobe, "euclidean") for i in range(cpu_sample)]
+        cpu_s = time.perf_counter() - t0
+        same = all(np.array_equal(results[1][i], ref[i][0]) and np.array_equal(results[0][i], ref[i][1].astype(np.float32))
+                   for i in range(cpu_sample))
+        out["identical_to_oracle"] = bool(same)
+        if world == 1:
+            out["cpu_baseline"] = {"value": round(cpu_sample / cpu_s, 2), "unit": "queries/s", "cores": host_threads(), "kind": "port",
+                                   "sample": f"{cpu_sample} of the queries, one at a time, over all {n} rows (vectorised NumPy restatement "
+                                             "of IVFIndex.search; the reference itself loops over the members in Python)"}
+    backend.lists.close()
+    return out
+
+
+def pq_block(lo: int, hi: int, m: int, seed: int, dev, gen, block: int = 1_000_000) -> "torch.Tensor":
+    """Codes of global rows [lo, hi): uniform bytes, block b of `block` rows from seed + b (the same at every world size)."""
+    parts = []
+    for b in range(lo // block, (hi + block - 1) // block):
+        gen.manual_seed(seed + b)
+        blk = torch.randint(0, 256, (block, m), device=dev, dtype=torch.uint8, generator=gen)
+        b0 = b * block
+        parts.append(blk[max(lo - b0, 0):min(hi - b0, block)])
+    return (parts[0] if len(parts) == 1 else torch.cat(parts)).contiguous()
+
+
+def keep_bits(lo: int, hi: int, fraction: float, seed: int, dev, gen, block: int = 1_000_000) -> "torch.Tensor":
+    """Filter outcome (bool) of global rows [lo, hi): row kept with probability `fraction`, block-seeded like the codes."""
+    parts = []
+    for b in range(lo // block, (hi + block - 1) // block):
+        gen.manual_seed(seed + b)
+        blk = torch.rand(block, device=dev, generator=gen) < fraction
+        b0 = b * block
+        parts.append(blk[max(lo - b0, 0):min(hi - b0, block)])
+    return parts[0] if len(parts) == 1 else torch.cat(parts)
+
+
+def pack_bits(bits: "torch.Tensor") -> "torch.Tensor":
+    """bool [n] -> int32 words, bit i of word i // 32 = bits[i] (the layout every *_search entry point takes)."""
+    n = bits.numel()
+    padded = torch.zeros(((n + 31) // 32) * 32, device=bits.device, dtype=torch.int64)
+    padded[:n] = bits
+    weights = 2 ** torch.arange(32, device=bits.device, dtype=torch.int64)
+    return (padded.view(-1, 32) * weights).sum(1).to(torch.int32).contiguous()          # wraps to the same 32 bits
+
+
+def bench_c5(world, rank, dev, gen, barrier, max_over_ranks, native, cpu_codes=2_000_000, cpu_queries=4):
+    """BASELINE.json configs[4]: PQ m=16 nbits=8 ADC scan over 100M codes (1.6 GB) with a filter bitmask, k = 10,
+    rows / world per GPU; a step is: lookup tables -> scan of this rank's codes under its slice of the bitmask ->
+    selection [-> all-gather -> merge].  Beside it the PQIndex class with a filter callable, and Manhattan 1M x 128."""
+    from oracle import ref_numpy as R
+    from vectordb_amd.sharded import HipFlatBackend, HipPqBackend, ShardedFlat, shard_range
+    n, m, d, k = C5_ROWS, C5_M, C4_DIM, TOP_K
+    lo, hi = shard_range(n, world, rank)
+    book = np.random.default_rng(7).standard_normal((m, 256, d // m), dtype=np.float32)
+    backend = HipPqBackend(d, m, 256, book)
+    for c0 in range(lo, hi, 10_000_000):
+        backend.add_device(pq_block(c0, min(hi, c0 + 10_000_000), m, 5000, dev, gen))
+        torch.cuda.synchronize()
+    index = ShardedFlat(backend, n, rank, world)
+    gen.manual_seed(555)
+    queries = torch.randn((8, d), device=dev, dtype=torch.float32, generator=gen)
+    out = {"workload": f"PQ m={m} nbits=8 ADC scan, {n} codes, k={k}, rows/{world} per GPU (BASELINE configs[4])",
+           "codes_on_this_gpu": hi - lo, "scans": []}
+    checks = {}
+    for sel in (None, 0.5, 0.01):
+        words = None
+        if sel is not None:
+            words = pack_bits(keep_bits(lo, hi, sel, 9000, dev, gen))
+        for nq in (1, 8):
+            q = queries[:nq].contiguous()
+            elapsed, kernel_ms, launches, (od, orow) = timed_steps(_Masked(index, words), q, k, 10, 3, barrier, native)
+            elapsed = max_over_ranks(elapsed)
+            kern = kernel_ms / max(launches, 1)
+            passes = (nq + 3) // 4                           # four queries share one pass over the codes (one launch covers all passes)
+            nbytes = passes * ((hi - lo) * m + ((hi - lo) // 8 if words is not None else 0))
+            out["scans"].append({"batch": nq, "filter": sel, "queries_per_s": round(nq * 10 / elapsed, 2),
+                                 "ms_per_step": round(elapsed / 10 * 1e3, 4), "passes_over_the_codes": passes,
+                                 "roofline": hbm_roofline(nbytes, kern * 1e-3, kernel="pq_scan_kernel", kernel_ms=round(kern, 4))})
+            if nq == 8:
+                checks[sel] = (od.cpu().numpy(), orow.cpu().numpy())
+        del words
+    # the oracle on the first cpu_codes rows: the device result restricted to them must be a prefix-compatible subset, so the
+    # check searches a second store holding just those rows (rank 0, one GPU's worth of work, not timed)
+    if rank == 0:
+        small = HipPqBackend(d, m, 256, book)
+        codes_s = pq_block(0, cpu_codes, m, 5000, dev, gen)
+        small.add_device(codes_s)
+        codes_h = codes_s.cpu().numpy()
+        keep_h = keep_bits(0, cpu_codes, 0.01, 9000, dev, gen)
+        words_s = pack_bits(keep_h)
+        keep_h = keep_h.cpu().numpy()
+        qh = queries[:cpu_queries].cpu().numpy()
+        sd = torch.empty((cpu_queries, k), device=dev, dtype=torch.float32)
+        sr = torch.empty((cpu_queries, k), device=dev, dtype=torch.int64)
+        ok = True
+        t_cpu = 0.0
+        for mask_h, words in ((None, None), (keep_h, words_s)):
+            small.local_search(queries[:cpu_queries].contiguous(), k, sd, sr, words)
+            torch.cuda.synchronize()
+            for i in range(cpu_queries):
+                t0 = time.perf_counter()
+                rows_ref, dist_ref = R.pq_search(qh[i], book, codes_h, k, mask_h)
+                if mask_h is None:
+                    t_cpu += time.perf_counter() - t0
+                ok &= bool(np.array_equal(sr[i].cpu().numpy(), rows_ref)) and bool(np.array_equal(sd[i].cpu().numpy(), dist_ref))
+        out["identical_to_oracle_on_sample"] = bool(ok)
+        if world == 1:
+            out["cpu_baseline"] = {"value": round(cpu_queries / t_cpu * cpu_codes / n, 4), "unit": "queries/s", "cores": host_threads(),
+                                   "kind": "port", "measured_queries_per_s_on_sample": round(cpu_queries / t_cpu, 3),
+                                   "sample": f"{cpu_queries} single queries over the first {cpu_codes} of the {n} codes, no filter, scaled "
+                                             "linearly in the code count (vectorised NumPy restatement of PQIndex.search; the reference "
+                                             "itself scans in a Python loop)"}
+        small.codes.close()
+        del small, codes_s, words_s
+    backend.codes.close()
+    del index, backend
+    torch.cuda.empty_cache()
+
+    if world == 1:
+        out["pq_index_class"] = pq_class_filtered(native)
+
+    # Manhattan side-check: Flat 1M x 128, rows / world per GPU, batch 1 and 1024
+    n1, d1 = N_ROWS, C4_DIM
+    lo, hi = shard_range(n1, world, rank)
+    flat = HipFlatBackend(d1, native.MANHATTAN, prefilter=None)
+    fill_store(flat, lo, hi, d1, 808, dev, gen)
+    findex = ShardedFlat(flat, n1, rank, world)
+    gen.manual_seed(556)
+    q_all = torch.randn((N_QUERIES, d1), device=dev, dtype=torch.float32, generator=gen)
+    man = {"workload": f"Flat manhattan {n1} x {d1} fp32, k={k}, rows/{world} per GPU"}
+    for nq, steps in ((1, 20), (N_QUERIES, 5)):
+        q = q_all[:nq].contiguous()
+        elapsed, kernel_ms, launches, (od, orow) = timed_steps(findex, q, k, steps, 2, barrier, native)
+        elapsed = max_over_ranks(elapsed)
+        kern = kernel_ms / max(launches, 1)
+        entry = {"queries_per_s": round(nq * steps / elapsed, 1), "ms_per_step": round(elapsed / steps * 1e3, 4),
+                 "kernel_ms_avg": round(kern, 4), "kernels_per_step": launches // steps}
+        if nq == 1:
+            entry["roofline"] = hbm_roofline((hi - lo) * d1 * 4.0, kern * 1e-3, kernel="streaming row scan")
+        else:
+            entry["valu_tops"] = round(3.0 * nq * (hi - lo) * d1 * steps / elapsed / 1e12, 2)     # subtract, abs, add per element pair
+        if rank == 0 and nq == 1:
+            rows_h = np.empty((n1, d1), np.float32)
+            for c0 in range(0, n1, 16 * GEN_BLOCK):
+                rows_h[c0:c0 + 16 * GEN_BLOCK] = block_rows(c0, min(n1, c0 + 16 * GEN_BLOCK), d1, 808, dev, gen).cpu().numpy()
+            qh = q_all[:4].cpu().numpy()
+            t0 = time.perf_counter()
+            ref = [R.flat_search(qh[i], rows_h, k, "manhattan") for i in range(4)]
+            cpu_s = time.perf_counter() - t0
+            entry["identical_rows_to_oracle"] = bool(np.array_equal(orow[0].cpu().numpy(), ref[0][0]))
+            entry["distances_ok"] = bool(np.allclose(od[0].cpu().numpy(), ref[0][1], rtol=1e-4, atol=1e-4))
+            if world == 1:
+                entry["cpu_queries_per_s"] = round(4 / cpu_s, 2)
+            del rows_h
+        man[f"batch_{nq}"] = entry
+    out["manhattan"] = man
+    flat.store.close()
+    return out
+
+
+def pq_class_filtered(native, n=1_000_000, d=C4_DIM, m=C5_M):
+    """PQIndex.search with a filter callable, as a user of the reference's class calls it (index/pq.py:247-318), on 1M rows:
+    the first filtered search runs the callable over every row and uploads the packed words; repeats of the same filter
+    find the words in HBM (the callable is not called again until a write)."""
+    from vectordb_amd.index import PQIndex
+    rng = np.random.default_rng(31)
+    x = rng.standard_normal((n, d), dtype=np.float32)
+    ix = PQIndex(dimension=d, n_subvectors=m, n_bits=8, n_iter=5, seed=1)
+    ix.train(x[:20_000])
+    t0 = time.perf_counter()
+    ix.add_batch([f"r{i}" for i in range(n)], x, [{"cat": i % 100} for i in range(n)])
+    add_s = time.perf_counter() - t0
+    calls = [0]
+
+    def only_cat_7(_id, meta):
+        calls[0] += 1
+        return meta["cat"] == 7
+
+    q = rng.standard_normal(d, dtype=np.float32)
+    ix.search(q, 10)
+    t0 = time.perf_counter()
+    first = ix.search(q, 10, filter_fn=only_cat_7)
+    first_ms = (time.perf_counter() - t0) * 1e3
+    calls_first = calls[0]
+    t0 = time.perf_counter()
+    for _ in range(20):
+        again = ix.search(q, 10, filter_fn=only_cat_7)
+    repeat_ms = (time.perf_counter() - t0) * 1e3 / 20
+    t0 = time.perf_counter()
+    for _ in range(20):
+        ix.search(q, 10)
+    plain_ms = (time.perf_counter() - t0) * 1e3 / 20
+    return {"what": f"PQIndex.search(filter_fn=...) over {n} rows, 1 % of the rows pass", "add_batch_s": round(add_s, 2),
+            "first_filtered_search_ms": round(first_ms, 2), "filter_calls_first": calls_first,
+            "repeated_filtered_search_ms": round(repeat_ms, 3), "filter_calls_in_20_repeats": calls[0] - calls_first,
+            "unfiltered_search_ms": round(plain_ms, 3),
+            "same_results": [r.id for r in first] == [r.id for r in again]}
 
 
 def bench_c1(dev, native, n=10_000, d=128, nq=100, k=10):

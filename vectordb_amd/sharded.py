@@ -31,6 +31,15 @@ def shard_range(n_total: int, world: int, rank: int) -> Tuple[int, int]:
     return (rank * n_total) // world, ((rank + 1) * n_total) // world
 
 
+def _mask_ptr(mask_words: Optional[torch.Tensor], n_rows: int) -> int:
+    if mask_words is None:
+        return 0
+    if not (mask_words.is_cuda and mask_words.is_contiguous() and mask_words.element_size() == 4
+            and mask_words.numel() * 32 >= n_rows):
+        raise ValueError(f"a filter over {n_rows} local rows takes {(n_rows + 31) // 32} contiguous 32-bit words on the GPU")
+    return mask_words.data_ptr()
+
+
 class HipFlatBackend:
     """Local search and merge on the GPU through the C ABI."""
 
@@ -48,9 +57,12 @@ class HipFlatBackend:
         self.store.append_device(rows.data_ptr(), rows.shape[0], rows.shape[1],
                                  torch.cuda.current_stream().cuda_stream)
 
-    def local_search(self, queries: torch.Tensor, k: int, out_dist: torch.Tensor, out_rows: torch.Tensor) -> None:
+    def local_search(self, queries: torch.Tensor, k: int, out_dist: torch.Tensor, out_rows: torch.Tensor,
+                     mask_words: Optional[torch.Tensor] = None) -> None:
+        """mask_words: packed filter bits over this rank's LOCAL rows (bit i of word i // 32), resident on the GPU."""
         self.store.search_device(queries.data_ptr(), queries.shape[0], k, self.metric,
                                  out_dist.data_ptr(), out_rows.data_ptr(),
+                                 mask_ptr=_mask_ptr(mask_words, len(self.store)),
                                  stream=torch.cuda.current_stream().cuda_stream)
 
     def merge(self, all_dist: torch.Tensor, all_rows: torch.Tensor, k: int,
@@ -80,8 +92,10 @@ class HipPqBackend:
         assert codes.is_cuda and codes.dtype == torch.uint8 and codes.is_contiguous()
         self.codes.append_codes_device(codes.data_ptr(), codes.shape[0], torch.cuda.current_stream().cuda_stream)
 
-    def local_search(self, queries: torch.Tensor, k: int, out_dist: torch.Tensor, out_rows: torch.Tensor) -> None:
+    def local_search(self, queries: torch.Tensor, k: int, out_dist: torch.Tensor, out_rows: torch.Tensor,
+                     mask_words: Optional[torch.Tensor] = None) -> None:
         self.codes.search_device(queries.data_ptr(), queries.shape[0], k, out_dist.data_ptr(), out_rows.data_ptr(),
+                                 mask_ptr=_mask_ptr(mask_words, len(self.codes)),
                                  stream=torch.cuda.current_stream().cuda_stream)
 
     merge = HipFlatBackend.merge
@@ -120,10 +134,14 @@ class ShardedFlat:
                               torch.empty((nq, k), device=device, dtype=torch.int64))
         return self._buf[key]
 
-    def search(self, queries: torch.Tensor, k: int) -> Tuple[torch.Tensor, torch.Tensor]:
+    def search(self, queries: torch.Tensor, k: int, mask_words: Optional[torch.Tensor] = None) -> Tuple[torch.Tensor, torch.Tensor]:
+        """mask_words: this rank's slice of the filter, packed over its local rows (see the backends)."""
         nq = queries.shape[0]
         local, gathered, ld, lr, gd, gr, base, od, orow = self._buffers(nq, k, queries.device)
-        self.backend.local_search(queries, k, ld, lr)
+        if mask_words is None:
+            self.backend.local_search(queries, k, ld, lr)
+        else:
+            self.backend.local_search(queries, k, ld, lr, mask_words)
         if self.world == 1:
             return ld, lr
         dist.all_gather_into_tensor(gathered, local, group=self.group)
