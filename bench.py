@@ -73,6 +73,12 @@ HBM_PEAK_GBS = 8000.0
 GEN_BLOCK = 15625                      # rows per generation block: 1M = 64 blocks, 10M = 640 blocks
 
 
+def note(msg: str) -> None:
+    """Progress on stderr (rank 0): the JSON line on stdout stays the only stdout output."""
+    if os.environ.get("RANK", "0") == "0":
+        print(f"[bench {time.strftime('%H:%M:%S')}] {msg}", file=sys.stderr, flush=True)
+
+
 def host_threads() -> int:
     try:
         from threadpoolctl import threadpool_info
@@ -88,7 +94,7 @@ def launch_ranks(n: int) -> int:
     """Start n ranks of this script under torch.distributed.run as a child process.
     Called before any GPU call of this process (device_count does not initialise the GPU)."""
     visible = torch.cuda.device_count()
-    if visible < n:
+    if visible < n and os.environ.get("VDB_BENCH_BACKEND", "nccl") == "nccl":
         print(f"bench.py: --gpus {n} asked, {visible} GPU(s) visible on this node", file=sys.stderr)
         return 2
     with socket.socket() as s:
@@ -157,6 +163,7 @@ def main() -> None:
     ap.add_argument("--cpu-sample", type=int, default=48, help="queries timed on the host oracle at N = 1 (0 = skip)")
     ap.add_argument("--no-extra", action="store_true", help="skip the side measurements (prefilter, c3, c4, c5, c1, ceilings)")
     ap.add_argument("--skip", default="", help="side measurements to leave out, e.g. c3,c5")
+    ap.add_argument("--side-scale", type=float, default=1.0, help="scale the row counts of c4 and c5 (rehearsals only)")
     args = ap.parse_args()
 
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
@@ -169,10 +176,25 @@ def main() -> None:
         print(f"warning: --gpus {args.gpus} but WORLD_SIZE={world}; using WORLD_SIZE", file=sys.stderr)
 
     import torch.distributed as dist
+    # VDB_BENCH_BACKEND=gloo rehearses the N-rank code on fewer GPUs than ranks (ranks share devices, the gathers go
+    # through the host): a logic check, not a measurement
+    dist_backend = os.environ.get("VDB_BENCH_BACKEND", "nccl")
+    if dist_backend != "nccl":
+        local_rank %= max(torch.cuda.device_count(), 1)
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     if world > 1:
-        dist.init_process_group(backend="nccl", device_id=dev)
+        if dist_backend == "nccl":
+            dist.init_process_group(backend="nccl", device_id=dev)
+        else:
+            dist.init_process_group(backend=dist_backend)
+            gather = dist.all_gather_into_tensor
+
+            def gather_through_host(out, inp, group=None):          # gloo does not gather device tensors
+                staged = torch.empty(out.shape, dtype=out.dtype)
+                gather(staged, inp.cpu(), group=group)
+                out.copy_(staged)
+            dist.all_gather_into_tensor = gather_through_host
 
     from vectordb_amd import _native
     from vectordb_amd.sharded import HipFlatBackend, ShardedFlat, shard_range
@@ -185,7 +207,7 @@ def main() -> None:
     def max_over_ranks(x: float) -> float:
         if world == 1:
             return x
-        t = torch.tensor([x], device=dev, dtype=torch.float64)
+        t = torch.tensor([x], device=dev if dist_backend == "nccl" else "cpu", dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         return float(t.item())
 
@@ -199,7 +221,9 @@ def main() -> None:
     fill_store(backend, lo, hi, d, 42, dev, gen)
     index = ShardedFlat(backend, n_total, rank, world)
 
+    note(f"rows resident ({hi - lo} on this GPU), timing the headline")
     elapsed, kernel_ms, launches, (out_d, out_r) = timed_steps(index, queries, k, args.steps, args.warmup, barrier, _native)
+    note("headline timed")
     used_queue, _ = backend.store.search_stats()          # which kernel the library took for this shard size
     elapsed = max_over_ranks(elapsed)
     ms_per_step = elapsed / args.steps * 1e3
@@ -278,6 +302,7 @@ def main() -> None:
         extra = {"prefilter": prefilter}
         skip = set(filter(None, args.skip.split(",")))
         if "c3" not in skip:
+            note("side measurement c3")
             try:
                 extra["c3"] = bench_c3(world, rank, dev, gen, barrier, max_over_ranks, _native)
             except Exception as e:          # a side measurement must not take the headline line with it
@@ -285,8 +310,9 @@ def main() -> None:
         for name, fn in (("c4", bench_c4), ("c5", bench_c5)):
             if name in skip:
                 continue
+            note(f"side measurement {name}")
             try:
-                extra[name] = fn(world, rank, dev, gen, barrier, max_over_ranks, _native)
+                extra[name] = fn(world, rank, dev, gen, barrier, max_over_ranks, _native, scale=args.side_scale)
             except Exception as e:
                 extra[name] = {"error": f"{type(e).__name__}: {e}"}
             torch.cuda.empty_cache()
@@ -303,6 +329,7 @@ def main() -> None:
             "value": round(qps, 1), "unit": "queries/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(ms_per_step, 4), "higher_is_better": True,
             "scaling": "strong", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            **({"rehearsal": f"{dist_backend} process group, ranks sharing GPUs: not a measurement"} if dist_backend != "nccl" else {}),
             "config": {"workload": "Flat cosine 1M x 384 fp32, batch 1024 queries, k=10 (BASELINE configs[1])",
                        "rows": n_total, "dim": d, "queries_per_step": nq, "k": k,
                        "sharding": f"rows/{world}" + (" + all-gather top-k merge" if world > 1 else "")},
@@ -399,7 +426,7 @@ class _Masked:
         return self.index.search(queries, k, self.words)
 
 
-def bench_c4(world, rank, dev, gen, barrier, max_over_ranks, native, cpu_sample=16):
+def bench_c4(world, rank, dev, gen, barrier, max_over_ranks, native, cpu_sample=16, scale=1.0):
     """BASELINE.json configs[3]: IVF nlist=4096 nprobe=32 over 10M x 128 standard-normal rows, k = 10.  Training is the
     reference's: k-means++ and 20 Lloyd steps over 256 rows per cluster (index/ivf.py:126-231 through IVFIndex.train),
     then every row goes to its nearest centroid (ivf.py:553-565).  Whole lists are dealt to the ranks by length; a step
@@ -407,7 +434,7 @@ def bench_c4(world, rank, dev, gen, barrier, max_over_ranks, native, cpu_sample=
     from oracle import ref_numpy as R
     from vectordb_amd.index import IVFIndex
     from vectordb_amd.sharded import HipIvfBackend, ShardedIVF, assign_lists_balanced, local_ivf_layout
-    n, d, nlist, nprobe, k = C4_ROWS, C4_DIM, C4_LISTS, C4_PROBE, TOP_K
+    n, d, nlist, nprobe, k = int(C4_ROWS * scale), C4_DIM, max(int(C4_LISTS * scale), 64), C4_PROBE, TOP_K
     x = np.empty((n, d), np.float32)
     for c0 in range(0, n, 16 * GEN_BLOCK):
         c1 = min(n, c0 + 16 * GEN_BLOCK)
@@ -417,6 +444,7 @@ def bench_c4(world, rank, dev, gen, barrier, max_over_ranks, native, cpu_sample=
     t0 = time.perf_counter()
     ix.train(x[:256 * nlist])
     train_s = time.perf_counter() - t0
+    note(f"c4: trained {nlist} centroids in {train_s:.2f} s")
     ph = dict(ix._last_kmeans.phase_seconds)
     cent = ix.centroids
     t0 = time.perf_counter()
@@ -428,6 +456,7 @@ def bench_c4(world, rank, dev, gen, barrier, max_over_ranks, native, cpu_sample=
     mine, list_rows_local, offsets = local_ivf_layout(assign, nlist, owner, rank)
     backend = HipIvfBackend(d, native.EUCLIDEAN, cent, x[mine], list_rows_local, offsets, mine)
     build_s = time.perf_counter() - t0
+    note(f"c4: lists built ({len(mine)} rows on this GPU)")
     index = _Probed(ShardedIVF(backend, rank, world), nprobe)
     out = {"workload": f"IVF nlist={nlist} nprobe={nprobe}, {n} x {d} fp32, k={k}, whole lists dealt to {world} GPU(s) (BASELINE configs[3])",
            "train": {"what": f"IVFIndex.train: k-means++ + 20 Lloyd steps over {256 * nlist} rows, {nlist} clusters, seed 42",
@@ -514,13 +543,14 @@ def pack_bits(bits: "torch.Tensor") -> "torch.Tensor":
     return (padded.view(-1, 32) * weights).sum(1).to(torch.int32).contiguous()          # wraps to the same 32 bits
 
 
-def bench_c5(world, rank, dev, gen, barrier, max_over_ranks, native, cpu_codes=2_000_000, cpu_queries=4):
+def bench_c5(world, rank, dev, gen, barrier, max_over_ranks, native, cpu_codes=2_000_000, cpu_queries=4, scale=1.0):
     """BASELINE.json configs[4]: PQ m=16 nbits=8 ADC scan over 100M codes (1.6 GB) with a filter bitmask, k = 10,
     rows / world per GPU; a step is: lookup tables -> scan of this rank's codes under its slice of the bitmask ->
     selection [-> all-gather -> merge].  Beside it the PQIndex class with a filter callable, and Manhattan 1M x 128."""
     from oracle import ref_numpy as R
     from vectordb_amd.sharded import HipFlatBackend, HipPqBackend, ShardedFlat, shard_range
-    n, m, d, k = C5_ROWS, C5_M, C4_DIM, TOP_K
+    n, m, d, k = int(C5_ROWS * scale), C5_M, C4_DIM, TOP_K
+    cpu_codes = min(cpu_codes, n)
     lo, hi = shard_range(n, world, rank)
     book = np.random.default_rng(7).standard_normal((m, 256, d // m), dtype=np.float32)
     backend = HipPqBackend(d, m, 256, book)
@@ -528,6 +558,7 @@ def bench_c5(world, rank, dev, gen, barrier, max_over_ranks, native, cpu_codes=2
         backend.add_device(pq_block(c0, min(hi, c0 + 10_000_000), m, 5000, dev, gen))
         torch.cuda.synchronize()
     index = ShardedFlat(backend, n, rank, world)
+    note(f"c5: {hi - lo} codes resident")
     gen.manual_seed(555)
     queries = torch.randn((8, d), device=dev, dtype=torch.float32, generator=gen)
     out = {"workload": f"PQ m={m} nbits=8 ADC scan, {n} codes, k={k}, rows/{world} per GPU (BASELINE configs[4])",
@@ -588,7 +619,9 @@ def bench_c5(world, rank, dev, gen, barrier, max_over_ranks, native, cpu_codes=2
     torch.cuda.empty_cache()
 
     if world == 1:
+        note("c5: PQIndex class with a filter callable")
         out["pq_index_class"] = pq_class_filtered(native)
+    note("c5: Manhattan")
 
     # Manhattan side-check: Flat 1M x 128, rows / world per GPU, batch 1 and 1024
     n1, d1 = N_ROWS, C4_DIM
