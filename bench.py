@@ -573,11 +573,14 @@ def bench_c5(world, rank, dev, gen, barrier, max_over_ranks, native, cpu_codes=2
             elapsed, kernel_ms, launches, (od, orow) = timed_steps(_Masked(index, words), q, k, 10, 3, barrier, native)
             elapsed = max_over_ranks(elapsed)
             kern = kernel_ms / max(launches, 1)
-            passes = (nq + 3) // 4                           # four queries share one pass over the codes (one launch covers all passes)
+            byte_tables, gave_up = backend.codes.search_stats()
+            # queries that share one pass over the codes: eight on the one-byte tables, four on the fp32 tables
+            passes = (nq + 7) // 8 if byte_tables else (nq + 3) // 4
             nbytes = passes * ((hi - lo) * m + ((hi - lo) // 8 if words is not None else 0))
             out["scans"].append({"batch": nq, "filter": sel, "queries_per_s": round(nq * 10 / elapsed, 2),
                                  "ms_per_step": round(elapsed / 10 * 1e3, 4), "passes_over_the_codes": passes,
-                                 "roofline": hbm_roofline(nbytes, kern * 1e-3, kernel="pq_scan_kernel", kernel_ms=round(kern, 4))})
+                                 "byte_tables": byte_tables, "fp32_scan_repeated_the_batch": gave_up,
+                                 "roofline": hbm_roofline(nbytes, kern * 1e-3, kernel="pq_scan8_kernel" if byte_tables else "pq_scan_kernel", kernel_ms=round(kern, 4))})
             if nq == 8:
                 checks[sel] = (od.cpu().numpy(), orow.cpu().numpy())
         del words

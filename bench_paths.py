@@ -338,9 +338,10 @@ def main():
                 od, orow = outputs(nq, 10)
                 mp = mask.data_ptr() if mask is not None else 0
                 wall, kern, launches = timed(lambda: pq.search_device(q.data_ptr(), nq, 10, od.data_ptr(), orow.data_ptr(), mask_ptr=mp), 10)
-                passes = (nq + 3) // 4          # four queries share one pass over the codes
+                # queries that share one pass over the codes: eight on the one-byte tables, four on the fp32 tables
+                passes = (nq + 7) // 8 if pq.search_stats()[0] else (nq + 3) // 4
                 nbytes = passes * (n * m + (n // 8 if mask is not None else 0))
-                emit("pq", workload=f"PQ m={m} nbits=8 ADC scan, {n} codes, batch {nq}, filter={sel}",
+                emit("pq", workload=f"PQ m={m} nbits=8 ADC scan, {n} codes, batch {nq}, filter={sel}", byte_tables=pq.search_stats()[0],
                      qps=round(nq / wall, 2), ms_per_batch=round(wall * 1e3, 4), kernel_ms=round(kern * 1e3, 4),
                      roofline={"bound": "hbm", "achieved": round(nbytes / kern / 1e9, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                                "frac": round(nbytes / kern / 1e9 / HBM_PEAK_GBS, 4), "bytes_per_launch": nbytes})

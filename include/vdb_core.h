@@ -343,6 +343,13 @@ int vdb_pq_search_dev(vdb_pq* h, const float* d_queries, int nq, int k,
 /* vdb_pq_search with a resident mask (index/pq.py:287-297, the filter_fn test inside the ADC scan) */
 int vdb_pq_search_masked(vdb_pq* h, const float* queries, int nq, int k,
                          const vdb_mask* mask, float* out_dist, int64_t* out_row);
+/* Diagnostics of the last search on this handle.  Batches of two queries and more over large code sets (8-bit
+ * codes, m in {4, 8, 16, 32}, k <= 32) pass over the codes eight queries at a time on one-byte tables that bound
+ * the fp32 table entries from below, and take the reference's fp32 sums (index/pq.py:296-297) only for the rows
+ * those bounds cannot exclude: same rows, same distance bits.  *used_byte_tables = 1 when the search went that way,
+ * *overflowed = 1 when it could not answer the batch (no bound for a query, too many rows left) and the fp32 scan
+ * repeated it.  Waits for the search.  No counterpart in the reference. */
+int vdb_pq_search_stats(vdb_pq* h, int* used_byte_tables, int* overflowed);
 
 /* ---- IVF-PQ (HybridIndex, index/hybrid.py:41-536) ----------------------------
  * Coarse k-means centroids + a PQ codebook trained on residuals.  Rows live as

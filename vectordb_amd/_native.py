@@ -109,6 +109,7 @@ SIGNATURES = {
     "vdb_ivf_last_scan_rows": (C.c_int, [C.c_void_p, c_i64_p]),
     "vdb_ivf_set_prefilter": (C.c_int, [C.c_void_p, C.c_int]),
     "vdb_ivf_search_stats": (C.c_int, [C.c_void_p, C.POINTER(C.c_int), C.POINTER(C.c_int)]),
+    "vdb_pq_search_stats": (C.c_int, [C.c_void_p, C.POINTER(C.c_int), C.POINTER(C.c_int)]),
     "vdb_pq_encode": (C.c_int, [c_float_p, C.c_int64, c_float_p, C.c_int, C.c_int, C.c_int, c_u8_p]),
     "vdb_pq_create": (C.c_int, [C.POINTER(C.c_void_p), C.c_int, C.c_int, C.c_int]),
     "vdb_pq_destroy": (C.c_int, [C.c_void_p]),
@@ -740,6 +741,12 @@ class PqCodes:
             check(self.lib.vdb_pq_search(self.h, fptr(q), nq, k, u32ptr(mask_words), fptr(dist),
                                          rows.ctypes.data_as(c_i64_p)))
         return dist, rows
+
+    def search_stats(self):
+        """(went through the byte-table pass, that pass gave up and the fp32 scan repeated the batch) of the last search."""
+        a, b = C.c_int(0), C.c_int(0)
+        check(self.lib.vdb_pq_search_stats(self.h, C.byref(a), C.byref(b)))
+        return bool(a.value), bool(b.value)
 
     def search_device(self, q_ptr: int, nq: int, k: int, out_dist_ptr: int, out_row_ptr: int,
                       mask_ptr: int = 0, stream: int = 0) -> None:

@@ -1014,6 +1014,8 @@ struct vdb_pq : Handle {
     DevBuf codes;                       // uint8 [cap][m]
     int64_t n = 0, cap = 0;
     hipStream_t last_stream = nullptr;  // stream of the last *_dev call
+    bool last_used_bytes = false;       // the last search went through the byte-table pass
+    int* last_flag = nullptr;           // its overflow flag (device)
     Workspace ws;
     Workspace io;                       // staging of the host-pointer entry points
 };
@@ -2601,7 +2603,9 @@ static int pq_search_impl(vdb_pq* h, const float* d_q, int nq, int k, const uint
     VDB_TRY(ws.lut.reserve((size_t)nq * h->m * h->ksub * sizeof(float)));
     VDB_TRY(ws.queue_cnt.reserve((size_t)nq * sizeof(int)));
     int* qlen = ws.queue_cnt.as<int>();          // entries in every query's packed candidate area; the table kernel clears it
-    VDB_TRY(launch_pq_lut(d_q, h->dim, nq, h->book.as<float>(), h->m, h->ksub, h->dsub, h->plan, ws.lut.as<float>(), s, qlen));
+    VDB_TRY(ws.round32.reserve((size_t)nq * h->m * sizeof(float)));          // the smallest entry of every table row
+    VDB_TRY(launch_pq_lut(d_q, h->dim, nq, h->book.as<float>(), h->m, h->ksub, h->dsub, h->plan, ws.lut.as<float>(), s, qlen,
+                          ws.round32.as<float>()));
     const int64_t ntiles = (h->n + 255) / 256;
     const int splits = (int)std::max<int64_t>(1, std::min<int64_t>((ntiles + 15) / 16, (8 * ctx().num_cus + nq - 1) / nq));
     const int n_cand = splits * pq_scan_lists_per_split();
@@ -2624,27 +2628,77 @@ static int pq_search_impl(vdb_pq* h, const float* d_q, int nq, int k, const uint
     const float* bound_d = nullptr;
     static const bool no_bound = getenv("VDB_PQ_NO_BOUND") != nullptr;
     // VDB_PQ_BOUND_MIN_TILES: the smallest code set (in tiles of 256 rows) that gets a bound pass (tests lower it)
-    static const int64_t bound_min_tiles = getenv("VDB_PQ_BOUND_MIN_TILES") ? atoll(getenv("VDB_PQ_BOUND_MIN_TILES")) : PQ_BOUND_MIN_TILES;
-    const bool bounded = !multi && !no_bound && nq < 4 && ntiles >= bound_min_tiles;
+    const char* min_tiles_env = getenv("VDB_PQ_BOUND_MIN_TILES");         // read per call: tests change it between searches
+    const int64_t bound_min_tiles = min_tiles_env ? atoll(min_tiles_env) : PQ_BOUND_MIN_TILES;
+    // Two queries and more: eight queries per pass on one-byte tables behind the same bound, the fp32 sums of the rows
+    // that pass recomputed (pq_scan8.hip); the fp32 scan below then runs only behind the overflow flag.
+    static const bool no_bytes = getenv("VDB_PQ_NO_BYTE_TABLES") != nullptr;
+    const bool bytes = !multi && !no_bound && !no_bytes && !getenv("VDB_PQ_NO_BYTE_TABLES_NOW") && nq >= 2 && pq_scan8_supports(h->m, h->ksub) && ntiles >= bound_min_tiles;
+    const bool bounded = !multi && !no_bound && (nq < 4 || bytes) && ntiles >= bound_min_tiles;
     if (bounded) {
-        const int bsplits = (int)std::min<int64_t>(PQ_BOUND_SPLITS, splits);
+        // (the byte-table pass needs the same sample for any batch size: one query per block in its bound pass)
+        const int bsplits = (int)std::min<int64_t>(PQ_BOUND_SPLITS, bytes ? (ntiles + 15) / 16 : splits);
         const int64_t n_s = std::min<int64_t>(h->n, PQ_BOUND_TILES_PER_BLOCK * bsplits * 256);
         const int area = bsplits * pq_scan_lists_per_split();
         if (area >= 4 * kmax) {
+            VDB_TRY(ws.part_d.reserve((size_t)nq * area * sizeof(float)));
+            VDB_TRY(ws.part_i.reserve((size_t)nq * area * sizeof(int)));
             VDB_TRY(launch_pq_scan(h->codes.as<uint8_t>(), n_s, h->m, h->ksub, ws.lut.as<float>(), nq, 1, d_mask, nullptr, nullptr,
-                                   bsplits, ws.part_d.as<float>(), ws.part_i.as<int>(), nullptr, s, nullptr, 0, false, qlen));
+                                   bsplits, ws.part_d.as<float>(), ws.part_i.as<int>(), nullptr, s, nullptr, 0, false,
+                                   bytes ? nullptr : qlen, nullptr, bytes ? 1 : 4));
             SelectOut o{d_out_d, d_out_i, nullptr, k, 0, nullptr, nullptr};
-            VDB_TRY(launch_select_packed(ws.part_d.as<float>(), ws.part_i.as<int>(), nq, area, kmax, o, s, qlen));
+            // (eight queries and more: every wave's row at its own place instead of an atomic per wave and query)
+            if (bytes) VDB_TRY(launch_select_area(ws.part_d.as<float>(), ws.part_i.as<int>(), nq, area, kmax, o, s));
+            else VDB_TRY(launch_select_packed(ws.part_d.as<float>(), ws.part_i.as<int>(), nq, area, kmax, o, s, qlen));
             bound_d = d_out_d + (kmax - 1);
         }
+    }
+    const int* run_if = nullptr;
+    int64_t bound_stride = k;
+    h->last_used_bytes = false;
+    if (bytes && bound_d) {
+        constexpr int Q_BLOCK = 64, AREA = 32768, SEG_CAP = 512, LEN_STRIDE = 32;
+        const int qb = std::min(nq, Q_BLOCK);
+        const int bsplits = pq_scan8_splits(h->n, qb);
+        const int n_seg = pq_scan8_groups(qb) * bsplits * 4;
+        VDB_TRY(ws.q16.reserve(pq_scan8_table_bytes(qb, h->m)));
+        VDB_TRY(ws.thr_d.reserve((size_t)nq * sizeof(float)));
+        VDB_TRY(ws.mins.reserve((size_t)nq * sizeof(float)));
+        VDB_TRY(ws.seg.reserve((size_t)n_seg * SEG_CAP * sizeof(int2)));
+        VDB_TRY(ws.seg_len.reserve((size_t)n_seg * sizeof(int)));
+        VDB_TRY(ws.queue.reserve((size_t)qb * AREA * (sizeof(float) + sizeof(int))));
+        VDB_TRY(ws.cursor.reserve(((size_t)qb * LEN_STRIDE + 1) * sizeof(int)));
+        int* counters = ws.cursor.as<int>();
+        int* flag = counters + (size_t)qb * LEN_STRIDE;
+        VDB_HIP(hipMemsetAsync(counters, 0, ((size_t)qb * LEN_STRIDE + 1) * sizeof(int), s));
+        for (int q0 = 0; q0 < nq; q0 += Q_BLOCK) {
+            const int nb = std::min(Q_BLOCK, nq - q0);
+            PqScan8Job j{};
+            j.codes = h->codes.as<uint8_t>(); j.n = h->n; j.m = h->m;
+            j.lut = ws.lut.as<float>() + (size_t)q0 * h->m * h->ksub; j.nq = nb;
+            j.lut_mins = ws.round32.as<float>() + (size_t)q0 * h->m;
+            j.bound_d = bound_d + (int64_t)q0 * k; j.bound_stride = k; j.mask = d_mask;
+            j.splits = pq_scan8_splits(h->n, nb);
+            j.t8 = ws.q16.p; j.thr = ws.thr_d.as<float>() + q0; j.bound_keep = ws.mins.as<float>() + q0;
+            j.seg = ws.seg.p; j.seg_len = ws.seg_len.as<int>(); j.seg_cap = SEG_CAP;
+            j.area_d = ws.queue.as<float>(); j.area_i = ws.queue.as<int>() + (size_t)qb * AREA; j.area = AREA;
+            j.queue_len = counters; j.len_stride = LEN_STRIDE; j.overflow = flag; j.timed = true;
+            VDB_TRY(launch_pq_scan8(j, s));
+            SelectOut o{d_out_d + (int64_t)q0 * k, d_out_i + (int64_t)q0 * k, nullptr, k, 0, nullptr, nullptr};
+            VDB_TRY(launch_select_packed(j.area_d, j.area_i, nb, AREA, kmax, o, s, counters, LEN_STRIDE));
+        }
+        run_if = flag;
+        bound_d = ws.mins.as<float>(); bound_stride = 1;     // the outputs that held the bounds have been written
+        h->last_used_bytes = true; h->last_flag = flag;
     }
     for (int64_t done = 0; done < k_eff; done += KMAX_FUSED) {
         const int kk = (int)std::min<int64_t>(KMAX_FUSED, k_eff - done);
         VDB_TRY(launch_pq_scan(h->codes.as<uint8_t>(), h->n, h->m, h->ksub, ws.lut.as<float>(), nq, kk, d_mask,
                                done > 0 ? ws.lb_d.as<float>() : nullptr, done > 0 ? ws.lb_k.as<int64_t>() : nullptr, splits,
-                               ws.part_d.as<float>(), ws.part_i.as<int>(), nullptr, s, bound_d, k, true, bound_d ? qlen : nullptr));
+                               ws.part_d.as<float>(), ws.part_i.as<int>(), nullptr, s, bound_d, bound_stride, run_if == nullptr,
+                               bound_d ? qlen : nullptr, run_if));
         SelectOut o{d_out_d, d_out_i, nullptr, k, (int)done,
-                    multi ? ws.lb_d.as<float>() : nullptr, multi ? ws.lb_k.as<int64_t>() : nullptr};
+                    multi ? ws.lb_d.as<float>() : nullptr, multi ? ws.lb_k.as<int64_t>() : nullptr, run_if};
         if (bound_d) VDB_TRY(launch_select_packed(ws.part_d.as<float>(), ws.part_i.as<int>(), nq, n_cand * kk, kk, o, s, qlen));
         else VDB_TRY(launch_select(ws.part_d.as<float>(), ws.part_i.as<int>(), nq, n_cand, kk, 1 << 30, nullptr, 0, o, s, ws.mid));
     }
@@ -2670,6 +2724,21 @@ static int pq_search_host(vdb_pq* h, const float* queries, int nq, int k, const 
                         [&](const float* dq, float* dd, int64_t* di) {
                             return pq_search_impl(h, dq, nq, k, d_mask, dd, di, s);
                         });
+}
+
+int vdb_pq_search_stats(vdb_pq* h, int* used_byte_tables, int* overflowed) {
+    VDB_REQUIRE(h && used_byte_tables && overflowed, "null argument");
+    Entry g(h);
+    *used_byte_tables = h->last_used_bytes ? 1 : 0;
+    *overflowed = 0;
+    if (h->last_used_bytes && h->last_flag) {
+        hipStream_t s = h->last_stream ? h->last_stream : h->stream;
+        VDB_HIP(hipStreamSynchronize(s));
+        int f = 0;
+        VDB_HIP(hipMemcpy(&f, h->last_flag, sizeof(int), hipMemcpyDeviceToHost));
+        *overflowed = f != 0;
+    }
+    return VDB_OK;
 }
 
 int vdb_pq_search(vdb_pq* h, const float* queries, int nq, int k, const uint32_t* mask, float* out_dist, int64_t* out_row) {

@@ -58,15 +58,26 @@ __device__ static float np_sum_sqdiff(const float* a, const float* b, int n, con
 // ---------------------------------------------------------------- tables
 __global__ __launch_bounds__(256) void pq_lut_kernel(const float* __restrict__ q, int ldq,
                                                      const float* __restrict__ book, int m, int ksub, int dsub,
-                                                     SumPlan plan, float* __restrict__ lut, int* __restrict__ zero_counts) {
+                                                     SumPlan plan, float* __restrict__ lut, int* __restrict__ zero_counts,
+                                                     float* __restrict__ mins) {
     extern __shared__ __align__(16) float qs[];
+    __shared__ float wave_min[4];
     const int sub = blockIdx.x, qi = blockIdx.y;
     if (zero_counts && sub == 0 && threadIdx.x == 0) zero_counts[qi] = 0;    // the scan's per-query queue lengths
     for (int i = threadIdx.x; i < dsub; i += blockDim.x) qs[i] = q[(int64_t)qi * ldq + sub * dsub + i];
     __syncthreads();
+    float least = INFINITY;
     for (int c = threadIdx.x; c < ksub; c += blockDim.x) {
         const float* cw = book + ((int64_t)sub * ksub + c) * dsub;
-        lut[((int64_t)qi * m + sub) * ksub + c] = np_sum_sqdiff(cw, qs, dsub, plan);
+        const float v = np_sum_sqdiff(cw, qs, dsub, plan);
+        lut[((int64_t)qi * m + sub) * ksub + c] = v;
+        least = fminf(least, v);                 // fminf skips NaN entries
+    }
+    if (mins) {                                  // the smallest entry of the table row (the byte tables start from it)
+        for (int o = 32; o > 0; o >>= 1) least = fminf(least, __shfl_xor(least, o));
+        if ((threadIdx.x & 63) == 0) wave_min[threadIdx.x >> 6] = least;
+        __syncthreads();
+        if (threadIdx.x == 0) mins[(int64_t)qi * m + sub] = fminf(fminf(wave_min[0], wave_min[1]), fminf(wave_min[2], wave_min[3]));
     }
 }
 
@@ -118,6 +129,7 @@ struct PqScanParams {
     int* queue_len;                  // optional [nq]: a wave appends its list's entries at part_*[q][queue_len[q]...]
     float* dist_out;                 // optional [nq][n]
     const float* bound_d; int64_t bound_stride;   // optional: query q's k-th best is not above bound_d[q * bound_stride]
+    const int* run_if;               // optional device flag: the launch does nothing while it is zero
 };
 
 static constexpr int PQ_WAVES = 4;       // waves of a split: one candidate list each
@@ -132,6 +144,7 @@ static constexpr int PQ_WAVES = 4;       // waves of a split: one candidate list
 template <int M, int Q, int KSUB = 0, int PQ_UNROLL = 4>
 __global__ __launch_bounds__(256) void pq_scan_kernel(PqScanParams p) {
     extern __shared__ __align__(16) float sm[];
+    if (p.run_if && *p.run_if == 0) return;
     const int m = M > 0 ? M : p.m;
     const int ksub = KSUB > 0 ? KSUB : p.ksub;
     float* T = sm;                                  // [m][ksub][Q]
@@ -478,10 +491,10 @@ int launch_ivfpq_scan(const float* q, int ldq, int dim, int nq, const float* cen
 
 // ---------------------------------------------------------------- launchers
 int launch_pq_lut(const float* q, int ldq, int nq, const float* book, int m, int ksub, int dsub,
-                  const SumPlan& plan, float* lut, hipStream_t s, int* zero_counts) {
+                  const SumPlan& plan, float* lut, hipStream_t s, int* zero_counts, float* mins) {
     if (nq <= 0) return VDB_OK;
     hipLaunchKernelGGL(pq_lut_kernel, dim3(m, nq), dim3(256), (size_t)dsub * sizeof(float), s,
-                       q, ldq, book, m, ksub, dsub, plan, lut, zero_counts);
+                       q, ldq, book, m, ksub, dsub, plan, lut, zero_counts, mins);
     VDB_HIP(hipGetLastError());
     return VDB_OK;
 }
@@ -515,10 +528,10 @@ int launch_pq_encode(const float* x, int64_t n, int ldx, const float* book, int 
 int launch_pq_scan(const uint8_t* codes, int64_t n, int m, int ksub, const float* lut, int nq, int k,
                    const uint32_t* mask, const float* lb_d, const int64_t* lb_k, int splits,
                    float* part_d, int* part_i, float* dist_out, hipStream_t s, const float* bound_d, int64_t bound_stride,
-                   bool timed, int* queue_len) {
+                   bool timed, int* queue_len, const int* run_if, int max_q) {
     VDB_REQUIRE(k >= 0 && k <= 64, "scan supports k <= 64, got %d", k);
     VDB_REQUIRE(n < (int64_t)0x7fffffff, "at most 2^31-1 codes per device");
-    PqScanParams p{codes, n, m, ksub, lut, nq, mask, lb_d, lb_k, k, splits, part_d, part_i, queue_len, dist_out, bound_d, bound_stride};
+    PqScanParams p{codes, n, m, ksub, lut, nq, mask, lb_d, lb_k, k, splits, part_d, part_i, queue_len, dist_out, bound_d, bound_stride, run_if};
     const size_t table = (size_t)m * ksub * sizeof(float);
     VDB_REQUIRE(table <= 160 * 1024, "%d sub-spaces x %d codewords need %zu bytes of LDS", m, ksub, table);
     // queries per pass: as many tables as fit while two blocks still share a CU
@@ -527,6 +540,7 @@ int launch_pq_scan(const uint8_t* codes, int64_t n, int m, int ksub, const float
     else if (nq >= 2 && 2 * table <= 80 * 1024) Q = 2;
     const bool fixed_m = m == 4 || m == 8 || m == 16 || m == 32 || m == 64;
     if (!fixed_m) Q = 1;
+    Q = std::min(Q, std::max(max_q, 1));
     const size_t lds = table * Q;
     const dim3 grid(splits, (nq + Q - 1) / Q);
     KernelTimer timer(s, timed);

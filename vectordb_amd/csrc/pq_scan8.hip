@@ -1,0 +1,379 @@
+// PQ ADC scan for batches: up to eight queries per pass over the codes on one-byte tables, the survivors recomputed
+// with the fp32 tables in the reference's arithmetic (index/pq.py:285-297: sequential fp32 sum over the sub-spaces,
+// sqrt), so the results are those of pq_scan_kernel bit for bit.
+//
+// Why: with fp32 tables a pass for four queries reads 16 bytes of LDS per (row, sub-space) and is bound by the LDS
+// (bank conflicts between the lanes of a gather).  One-byte entries put eight queries into one 8-byte LDS read and
+// make the sums packed 16-bit adds.
+//
+// The bytes are lower bounds.  For query q with a distance B that k rows of the set are known not to exceed
+// (the bound pass of the caller), a result row has sqrtf(S) <= B for its fp32 sum S, hence S <= thr (B squared, a
+// few ulps up), and the real-number sum of its table entries is at most thr * (1 + 16 * 2^-24).  With
+// min_j = the smallest entry of sub-space j,  thr' = thr - sum_j min_j  and  step = thr' / 254,  the byte of an
+// entry t is  clamp(floor((t - min_j) / step) - 1, 0, 255)  (float64; the "- 1" covers the rounding of the
+// quotient), so  byte * step <= t - min_j  and for a result row  sum_j byte_j <= thr' / step = 254: a row whose byte
+// sum is above 254 is in no query's result and is dropped; an entry of 255 alone does that (saturation is harmless).
+// Rows at or below 254 are queued per wave with the bits of the queries they passed for; pq_exact8_kernel takes the
+// fp32 sums of exactly those and hands (distance, row) to the per-query selection.
+//
+// A query without a finite bound, a full wave segment or a full candidate area set the overflow flag: the caller's
+// fp32 scan then runs for the batch (it is launched behind the flag either way).
+#include <type_traits>
+#include "vdb_internal.h"
+#include "vdb_device.h"
+
+namespace vdb {
+
+typedef unsigned short pq_u16x2 __attribute__((ext_vector_type(2)));
+
+template <int N, int I = 0, class F>
+__device__ __forceinline__ void static_for(F&& f) {
+    if constexpr (I < N) {
+        f(std::integral_constant<int, I>{});
+        static_for<N, I + 1>(f);
+    }
+}
+
+static constexpr int P8_Q = 8;             // queries per pass
+static constexpr int P8_LIMIT = 254;       // largest byte sum of a row that may be in a result
+static constexpr int P8_UNROLL = 2;        // row tiles of 256 whose code loads and table reads are in flight together
+
+// ---------------------------------------------------------------- byte tables
+struct PqQuantParams {
+    const float* lut; int nq; int m;            // [nq][m][256]
+    const float* lut_mins;                      // [nq][m]
+    const float* bound_d; int64_t bound_stride; // query q's k-th best distance is not above bound_d[q * bound_stride]
+    uint2* t8;                                  // [groups][m][256]: byte b of an entry = query 8 * group + b
+    float* thr;                                 // [nq]: the bound on the fp32 sum
+    float* bound_keep;                          // [nq]: the bounds themselves, for a scan that follows (bound_d may be overwritten)
+    int* overflow;
+};
+
+// one block per (group of eight queries, sub-space); thread c owns codeword c
+__global__ __launch_bounds__(256) void pq_quantise_kernel(PqQuantParams p) {
+    __shared__ double inv_step[P8_Q];
+    __shared__ float least[P8_Q];
+    const int g = blockIdx.x, j = blockIdx.y, c = threadIdx.x;
+    const int m = p.m;
+    if (c < P8_Q) {
+        const int q = g * P8_Q + c;
+        double inv = 0.0;                       // 0: a query that is not there (its bytes are 255)
+        float mine = 0.0f;
+        if (q < p.nq) {
+            const float b = p.bound_d[(int64_t)q * p.bound_stride];
+            const float t2 = fmaxf(__fmaf_rn(b * b, 4e-7f, b * b), 1e-36f);       // what the fp32 scan compares its sums with
+            double rest = (double)t2 * (1.0 + 4e-6);
+            for (int jj = 0; jj < m; ++jj) rest -= (double)p.lut_mins[(int64_t)q * m + jj];
+            mine = p.lut_mins[(int64_t)q * m + j];
+            const double step = rest / (double)P8_LIMIT;
+            const bool usable = (b == b) && (t2 < INFINITY) && (step > 0.0) && (step < 1e300);
+            if (j == 0) {
+                p.thr[q] = t2;
+                p.bound_keep[q] = b;
+                // no usable bound: fewer than k rows passed the filter in the bound pass, NaN or infinite tables, or
+                // a bound below the sum of the minima (which only rounding can produce)
+                if (!usable) *p.overflow = 1;
+            }
+            inv = usable ? 1.0 / step : -1.0;   // -1: every byte 0
+        }
+        inv_step[c] = inv;
+        least[c] = mine;
+    }
+    __syncthreads();
+    uint32_t w[2] = {0u, 0u};
+#pragma unroll
+    for (int qi = 0; qi < P8_Q; ++qi) {
+        const int q = g * P8_Q + qi;
+        const double inv = inv_step[qi];
+        uint32_t byte = 255u;
+        if (inv < 0.0) byte = 0u;
+        else if (inv > 0.0) {
+            const double v = ((double)p.lut[((int64_t)q * m + j) * 256 + c] - (double)least[qi]) * inv;
+            if (v < 256.0) byte = (uint32_t)max(0, (int)floor(v) - 1);
+            else if (!(v == v)) byte = 0u;                  // NaN entry: the fp32 sums decide
+        }
+        w[qi >> 2] |= byte << (8 * (qi & 3));
+    }
+    p.t8[((int64_t)g * m + j) * 256 + c] = make_uint2(w[0], w[1]);
+}
+
+// ---------------------------------------------------------------- scan
+struct PqScan8Params {
+    const uint8_t* codes; int64_t n; int splits;
+    const uint2* t8;
+    const uint32_t* mask;
+    int2* seg; int* seg_len; int seg_cap;       // one segment per wave: (row, bits of the group's queries it may belong to)
+    int* overflow;
+};
+
+// 8 * (byte B of w): the byte offset of a code's entry in its sub-space's table, in one instruction (the byte
+// select of the SDWA encoding; `three` is a register that holds 3)
+template <int B>
+__device__ __forceinline__ uint32_t code_offset(uint32_t w, uint32_t three) {
+    uint32_t r;
+    if constexpr (B == 0)
+        asm("v_lshlrev_b32_sdwa %0, %1, %2 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:BYTE_0" : "=v"(r) : "v"(three), "v"(w));
+    else if constexpr (B == 1)
+        asm("v_lshlrev_b32_sdwa %0, %1, %2 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:BYTE_1" : "=v"(r) : "v"(three), "v"(w));
+    else if constexpr (B == 2)
+        asm("v_lshlrev_b32_sdwa %0, %1, %2 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:BYTE_2" : "=v"(r) : "v"(three), "v"(w));
+    else
+        asm("v_lshlrev_b32_sdwa %0, %1, %2 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:BYTE_3" : "=v"(r) : "v"(three), "v"(w));
+    return r;
+}
+
+// eight bytes of LDS at a byte offset from the start of the workgroup's LDS, and the offset of a pointer into it
+__device__ __forceinline__ uint2 lds_entry_at(uint32_t off) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    typedef __attribute__((address_space(3))) const unsigned long long lds_u64;
+    const unsigned long long v = *reinterpret_cast<lds_u64*>((uintptr_t)off);
+    return make_uint2((uint32_t)v, (uint32_t)(v >> 32));
+#else
+    (void)off;
+    return make_uint2(0u, 0u);
+#endif
+}
+__device__ __forceinline__ uint32_t lds_offset_of(const void* p) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    return (uint32_t)(uintptr_t)(__attribute__((address_space(3))) const void*)p;
+#else
+    (void)p;
+    return 0u;
+#endif
+}
+
+template <int M>
+__global__ __launch_bounds__(256) void pq_scan8_kernel(PqScan8Params p) {
+    extern __shared__ __align__(16) uint2 T8[];             // [M][256]
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int split = blockIdx.x, g = blockIdx.y;
+    const int wave_id = (g * p.splits + split) * 4 + wave;
+    if (*p.overflow != 0) {                                  // the fp32 scan answers this batch
+        if (lane == 0) p.seg_len[wave_id] = 0;
+        return;
+    }
+    // the table reads below address the LDS by offset alone (one instruction per code); this kernel has no other LDS
+    // variables, so its dynamic block starts at 0, and if that ever changes the fp32 scan answers instead
+    if (lds_offset_of(T8) != 0u) {
+        if (tid == 0) *p.overflow = 1;
+        if (lane == 0) p.seg_len[wave_id] = 0;
+        return;
+    }
+    const uint2* src_t = p.t8 + (int64_t)g * M * 256;
+    for (int i = tid; i < M * 256; i += 256) T8[i] = src_t[i];
+    __syncthreads();
+
+    const int64_t ntiles = (p.n + 255) / 256;
+    const int64_t per = (ntiles + p.splits - 1) / p.splits;
+    const int64_t t0 = min((int64_t)split * per, ntiles), t1 = min(t0 + per, ntiles);
+    constexpr int WN = M / 4;
+    const uint32_t* mask_src = p.mask ? p.mask : reinterpret_cast<const uint32_t*>(p.codes);
+    int2* seg = p.seg + (int64_t)wave_id * p.seg_cap;
+    int kept = 0;                                            // wave-uniform
+    bool full = false;
+    uint32_t three = 3;
+    asm volatile("" : "+v"(three));                          // stays in a vector register
+
+    auto fetch = [&](int64_t tbx, uint32_t (&wx)[P8_UNROLL][WN], uint32_t (&mwx)[P8_UNROLL]) {
+#pragma unroll
+        for (int u = 0; u < P8_UNROLL; ++u) {
+            const int64_t row = min((tbx + u) * 256 + tid, p.n - 1);          // past the end: the last row again, unused
+            if constexpr (M % 16 == 0) {
+                const uint4* src = reinterpret_cast<const uint4*>(p.codes + row * M);
+#pragma unroll
+                for (int i = 0; i < M / 16; ++i) {
+                    const uint4 v = src[i];
+                    wx[u][4 * i] = v.x; wx[u][4 * i + 1] = v.y; wx[u][4 * i + 2] = v.z; wx[u][4 * i + 3] = v.w;
+                }
+            } else if constexpr (M % 8 == 0) {
+                const uint2* src = reinterpret_cast<const uint2*>(p.codes + row * M);
+#pragma unroll
+                for (int i = 0; i < M / 8; ++i) { const uint2 v = src[i]; wx[u][2 * i] = v.x; wx[u][2 * i + 1] = v.y; }
+            } else {
+                const uint32_t* src = reinterpret_cast<const uint32_t*>(p.codes + row * M);
+#pragma unroll
+                for (int i = 0; i < M / 4; ++i) wx[u][i] = src[i];
+            }
+            mwx[u] = mask_src[p.mask ? (row >> 5) : 0];
+        }
+    };
+
+    uint32_t wn[P8_UNROLL][WN], mwn[P8_UNROLL];
+    fetch(min(t0, ntiles - 1), wn, mwn);
+    for (int64_t tb = t0; tb < t1; tb += P8_UNROLL) {
+        uint32_t w[P8_UNROLL][WN], mw[P8_UNROLL];
+#pragma unroll
+        for (int u = 0; u < P8_UNROLL; ++u) {
+            mw[u] = p.mask ? mwn[u] : 0xffffffffu;
+#pragma unroll
+            for (int i = 0; i < WN; ++i) w[u][i] = wn[u][i];
+        }
+        fetch(tb + P8_UNROLL, wn, mwn);
+        // Per 32-bit word of an entry (four queries): `all` adds the word as two 16-bit lanes (odd byte * 256 + even
+        // byte each), `odd` adds the odd bytes alone; the even sums are all - 256 * odd (mod 2^16; M * 255 < 2^16).
+        pq_u16x2 all_lo[P8_UNROLL], odd_lo[P8_UNROLL], all_hi[P8_UNROLL], odd_hi[P8_UNROLL];
+#pragma unroll
+        for (int u = 0; u < P8_UNROLL; ++u) { all_lo[u] = 0; odd_lo[u] = 0; all_hi[u] = 0; odd_hi[u] = 0; }
+        auto look_up = [&](auto jc) {
+            constexpr int j = decltype(jc)::value;
+#pragma unroll
+            for (int u = 0; u < P8_UNROLL; ++u) {
+                const uint32_t off = code_offset<j & 3>(w[u][j >> 2], three);
+                const uint2 t = lds_entry_at(off + j * 2048);                  // the tables start at LDS offset 0
+                const pq_u16x2 lo = __builtin_bit_cast(pq_u16x2, t.x), hi = __builtin_bit_cast(pq_u16x2, t.y);
+                all_lo[u] += lo; odd_lo[u] += lo >> 8;
+                all_hi[u] += hi; odd_hi[u] += hi >> 8;
+            }
+            // the scheduler may not move table reads across every fourth sub-space: sixteen reads in flight are
+            // enough, and all of them in flight cost a wave per SIMD in registers
+            if constexpr ((j & 3) == 3) __builtin_amdgcn_sched_barrier(0);
+        };
+        static_for<M>(look_up);
+#pragma unroll
+        for (int u = 0; u < P8_UNROLL; ++u) {
+            const int64_t row = (tb + u) * 256 + tid;
+            const pq_u16x2 even_lo = all_lo[u] - (odd_lo[u] << 8), even_hi = all_hi[u] - (odd_hi[u] << 8);
+            const pq_u16x2 mn2 = __builtin_elementwise_min(__builtin_elementwise_min(even_lo, odd_lo[u]),
+                                                           __builtin_elementwise_min(even_hi, odd_hi[u]));
+            const unsigned mn = min((unsigned)mn2.x, (unsigned)mn2.y);
+            const bool pass = (tb + u) < t1 && row < p.n && ((mw[u] >> (row & 31)) & 1u) && mn <= (unsigned)P8_LIMIT;
+            const unsigned long long votes = __ballot(pass);
+            if (votes != 0ull) {                                                   // rare
+                const int cnt = __popcll(votes);
+                if (kept + cnt > p.seg_cap) {
+                    full = true;
+                } else if (pass) {
+                    // queries 0, 2 (even bytes of the low word), 1, 3 (odd), then the high word's 4, 6, 5, 7
+                    unsigned bits = 0;
+                    bits |= (even_lo.x <= P8_LIMIT) ? 1u : 0u;   bits |= (odd_lo[u].x <= P8_LIMIT) ? 2u : 0u;
+                    bits |= (even_lo.y <= P8_LIMIT) ? 4u : 0u;   bits |= (odd_lo[u].y <= P8_LIMIT) ? 8u : 0u;
+                    bits |= (even_hi.x <= P8_LIMIT) ? 16u : 0u;  bits |= (odd_hi[u].x <= P8_LIMIT) ? 32u : 0u;
+                    bits |= (even_hi.y <= P8_LIMIT) ? 64u : 0u;  bits |= (odd_hi[u].y <= P8_LIMIT) ? 128u : 0u;
+                    seg[kept + __popcll(votes & ((1ull << lane) - 1ull))] = make_int2((int)row, (int)bits);
+                }
+                if (!full) kept += cnt;
+            }
+        }
+    }
+    if (lane == 0) {
+        p.seg_len[wave_id] = kept;
+        if (full) *p.overflow = 1;
+    }
+}
+
+// ---------------------------------------------------------------- the survivors in fp32
+struct PqExact8Params {
+    const uint8_t* codes; int m;
+    const float* lut; int nq;                   // [nq][m][256]
+    const float* thr;                           // [nq]
+    const int2* seg; const int* seg_len; int seg_cap; int n_seg; int segs_per_group;
+    float* area_d; int* area_i; int area;       // [nq][area]
+    int* queue_len; int len_stride;
+    int* overflow;
+};
+
+// One wave per segment, a lane per kept row.  The row's fp32 sums for all of its queries are taken at once (the
+// table reads of a round are independent of each other), then lanes 0..7 reserve room in the eight candidate areas
+// with one atomic each and the rows within a query's bound are written there.
+template <int M>
+__global__ __launch_bounds__(256) void pq_exact8_kernel(PqExact8Params p) {
+    const int lane = threadIdx.x & 63;
+    const int s = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (s >= p.n_seg) return;
+    const int len = __builtin_amdgcn_readfirstlane(p.seg_len[s]);
+    if (len == 0 || *p.overflow != 0) return;
+    const int q0 = (s / p.segs_per_group) * P8_Q;
+    const int2* seg = p.seg + (int64_t)s * p.seg_cap;
+    for (int i0 = 0; i0 < len; i0 += 64) {
+        const bool have = i0 + lane < len;
+        const int2 e = have ? seg[i0 + lane] : make_int2(0, 0);
+        uint32_t w[M / 4];
+        const uint32_t* src = reinterpret_cast<const uint32_t*>(p.codes + (int64_t)e.x * M);
+#pragma unroll
+        for (int i = 0; i < M / 4; ++i) w[i] = src[i];
+        float d[P8_Q];
+        unsigned long long votes[P8_Q];
+#pragma unroll
+        for (int qi = 0; qi < P8_Q; ++qi) {
+            const bool mine = have && ((e.y >> qi) & 1);     // a set bit implies q0 + qi < nq (absent queries have bytes of 255)
+            bool in = false;
+            d[qi] = 0.0f;
+            if (mine) {
+                const float* t = p.lut + (int64_t)(q0 + qi) * M * 256;
+                float acc = t[w[0] & 0xffu];
+#pragma unroll
+                for (int j = 1; j < M; ++j) acc = acc + t[j * 256 + ((w[j >> 2] >> (8 * (j & 3))) & 0xffu)];
+                in = acc <= p.thr[q0 + qi];
+                d[qi] = sqrtf(acc);
+            }
+            votes[qi] = __ballot(in);
+        }
+        int at = 0;
+#pragma unroll
+        for (int qi = 0; qi < P8_Q; ++qi)
+            if (lane == qi && votes[qi] != 0ull) at = atomicAdd(p.queue_len + (int64_t)(q0 + qi) * p.len_stride, __popcll(votes[qi]));
+#pragma unroll
+        for (int qi = 0; qi < P8_Q; ++qi) {
+            if (votes[qi] == 0ull) continue;                 // wave-uniform
+            const int base = __shfl(at, qi);
+            if (base + __popcll(votes[qi]) > p.area) {
+                if (lane == 0) *p.overflow = 1;
+            } else if ((votes[qi] >> lane) & 1ull) {
+                const int64_t o = (int64_t)(q0 + qi) * p.area + base + __popcll(votes[qi] & ((1ull << lane) - 1ull));
+                p.area_d[o] = d[qi];
+                p.area_i[o] = e.x;
+            }
+        }
+    }
+}
+
+// ---------------------------------------------------------------- launcher
+bool pq_scan8_supports(int m, int ksub) { return ksub == 256 && (m == 4 || m == 8 || m == 16 || m == 32); }
+int pq_scan8_groups(int nq) { return (nq + P8_Q - 1) / P8_Q; }
+int pq_scan8_splits(int64_t n, int nq) {
+    const int64_t ntiles = (n + 255) / 256;
+    const int groups = pq_scan8_groups(nq);
+    return (int)std::max<int64_t>(1, std::min<int64_t>((ntiles + 15) / 16, (8 * (int64_t)ctx().num_cus + groups - 1) / groups));
+}
+size_t pq_scan8_table_bytes(int nq, int m) { return (size_t)pq_scan8_groups(nq) * m * 256 * sizeof(uint2); }
+
+int launch_pq_scan8(const PqScan8Job& j, hipStream_t s) {
+    VDB_REQUIRE(pq_scan8_supports(j.m, 256), "byte-table scan: m in {4, 8, 16, 32}");
+    VDB_REQUIRE(j.n > 0 && j.n < (int64_t)0x7fffffff && j.nq > 0, "byte-table scan: 1 .. 2^31-1 codes, at least one query");
+    const int groups = pq_scan8_groups(j.nq);
+    const int n_seg = groups * j.splits * 4;
+    PqQuantParams qp{j.lut, j.nq, j.m, j.lut_mins, j.bound_d, j.bound_stride, reinterpret_cast<uint2*>(j.t8), j.thr, j.bound_keep,
+                     j.overflow};
+    hipLaunchKernelGGL(pq_quantise_kernel, dim3(groups, j.m), dim3(256), 0, s, qp);
+    PqScan8Params sp{j.codes, j.n, j.splits, reinterpret_cast<const uint2*>(j.t8), j.mask,
+                     reinterpret_cast<int2*>(j.seg), j.seg_len, j.seg_cap, j.overflow};
+    const size_t lds = (size_t)j.m * 256 * sizeof(uint2);
+    {
+        KernelTimer timer(s, j.timed);
+#define VDB_LAUNCH_P8(MM)                                                                      \
+    case MM: {                                                                                 \
+        auto kern = pq_scan8_kernel<MM>;                                                       \
+        VDB_TRY(raise_dynamic_lds(reinterpret_cast<const void*>(kern), lds));                  \
+        hipLaunchKernelGGL(kern, dim3(j.splits, groups), dim3(256), lds, s, sp);               \
+    } break;
+        switch (j.m) {
+            VDB_LAUNCH_P8(4)
+            VDB_LAUNCH_P8(8)
+            VDB_LAUNCH_P8(16)
+            VDB_LAUNCH_P8(32)
+        }
+#undef VDB_LAUNCH_P8
+    }
+    PqExact8Params ep{j.codes, j.m, j.lut, j.nq, j.thr, reinterpret_cast<const int2*>(j.seg), j.seg_len, j.seg_cap, n_seg,
+                      j.splits * 4, j.area_d, j.area_i, j.area, j.queue_len, j.len_stride, j.overflow};
+    switch (j.m) {
+        case 4: hipLaunchKernelGGL(pq_exact8_kernel<4>, dim3((n_seg + 3) / 4), dim3(256), 0, s, ep); break;
+        case 8: hipLaunchKernelGGL(pq_exact8_kernel<8>, dim3((n_seg + 3) / 4), dim3(256), 0, s, ep); break;
+        case 16: hipLaunchKernelGGL(pq_exact8_kernel<16>, dim3((n_seg + 3) / 4), dim3(256), 0, s, ep); break;
+        case 32: hipLaunchKernelGGL(pq_exact8_kernel<32>, dim3((n_seg + 3) / 4), dim3(256), 0, s, ep); break;
+    }
+    VDB_HIP(hipGetLastError());
+    return VDB_OK;
+}
+
+}  // namespace vdb

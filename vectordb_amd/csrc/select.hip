@@ -450,6 +450,15 @@ int launch_select_packed(const float* part_d, const int* part_i, int nq, int are
     return VDB_OK;
 }
 
+// the k best of every query's area of `area` entries in any order, empty ones marked by their id
+int launch_select_area(const float* part_d, const int* part_i, int nq, int area, int k, const SelectOut& o, hipStream_t s) {
+    if (nq <= 0) return VDB_OK;
+    VDB_REQUIRE(k >= 1 && k <= 64, "area selection: k in 1..64");
+    hipLaunchKernelGGL(merge_block_kernel, dim3(nq), dim3(64 * MB_WAVES), 0, s, part_d, part_i, area, k, o, (int*)nullptr, 0, 1);
+    VDB_HIP(hipGetLastError());
+    return VDB_OK;
+}
+
 // lists laid out [n_lists][nq][k] (the shape an all-gather of per-shard results produces); list l of
 // the distances starts at d + l * stride_d, of the ids (and payload) at i + l * stride_i
 int launch_select_i64(const float* d, const int64_t* i, const int64_t* payload, int64_t stride_d, int64_t stride_i,

@@ -345,6 +345,8 @@ int launch_select(const float* part_d, const int* part_i, int nq, int n_cand, in
 // one block per query; sets queue_len[q] back to zero (query q's length at queue_len[q * len_stride])
 int launch_select_packed(const float* part_d, const int* part_i, int nq, int area, int k, const SelectOut& o, hipStream_t s,
                          int* queue_len, int len_stride = 1);
+// the same over whole areas (every entry present or marked empty by its id): no lengths
+int launch_select_area(const float* part_d, const int* part_i, int nq, int area, int k, const SelectOut& o, hipStream_t s);
 // lists laid out [n_lists][nq][k] with int64 ids (negative = empty), ordered by (distance, id);
 // with a payload of the same layout the payload of every selected entry is written instead of its id.
 // List l of the distances starts at d + l * stride_d, of the ids and the payload at i + l * stride_i
@@ -357,7 +359,7 @@ int launch_row_sort_topk(const float* dist, int nq, int n, int k, float* out_d, 
 
 // PQ
 int launch_pq_lut(const float* q, int ldq, int nq, const float* book, int m, int ksub, int dsub,
-                  const SumPlan& plan, float* lut, hipStream_t s, int* zero_counts = nullptr);
+                  const SumPlan& plan, float* lut, hipStream_t s, int* zero_counts = nullptr, float* mins = nullptr);
 int launch_pq_encode(const float* x, int64_t n, int ldx, const float* book, int m, int ksub, int dsub,
                      const SumPlan& plan, uint8_t* codes, hipStream_t s);
 // candidate lists come out as [nq][splits * pq_scan_lists_per_split()][k]
@@ -365,7 +367,32 @@ int pq_scan_lists_per_split();
 int launch_pq_scan(const uint8_t* codes, int64_t n, int m, int ksub, const float* lut, int nq, int k,
                    const uint32_t* mask, const float* lb_d, const int64_t* lb_k, int splits,
                    float* part_d, int* part_i, float* dist_out, hipStream_t s, const float* bound_d = nullptr,
-                   int64_t bound_stride = 0, bool timed = true, int* queue_len = nullptr);
+                   int64_t bound_stride = 0, bool timed = true, int* queue_len = nullptr, const int* run_if = nullptr,
+                   int max_q = 4);
+// Batches of two queries and more: eight queries per pass on one-byte tables (lower bounds derived from bound_d),
+// then the fp32 sums of the rows that pass, into per-query candidate areas [nq][area] of queue_len[q * len_stride]
+// entries.  `overflow` (one int, zero on entry) is set when the pass cannot answer the batch.  pq_scan8.hip
+struct PqScan8Job {
+    const uint8_t* codes; int64_t n; int m;
+    const float* lut; int nq;                      // fp32 tables [nq][m][256]
+    const float* lut_mins;                         // [nq][m]: the smallest entry of every table row (launch_pq_lut)
+    const float* bound_d; int64_t bound_stride;    // per query: a distance that k rows of the set do not exceed
+    const uint32_t* mask;
+    int splits;                                    // pq_scan8_splits(n, nq)
+    void* t8;                                      // pq_scan8_table_bytes(nq, m)
+    float* thr;                                    // [nq]
+    float* bound_keep;                             // [nq]: copy of the bounds (bound_d may lie in the output buffer)
+    void* seg; int* seg_len; int seg_cap;          // groups * splits * 4 segments of seg_cap (row, query bits) pairs
+    float* area_d; int* area_i; int area;
+    int* queue_len; int len_stride;
+    int* overflow;
+    bool timed;
+};
+bool pq_scan8_supports(int m, int ksub);
+int pq_scan8_groups(int nq);
+int pq_scan8_splits(int64_t n, int nq);
+size_t pq_scan8_table_bytes(int nq, int m);
+int launch_pq_scan8(const PqScan8Job& j, hipStream_t s);
 // IVF-PQ (index/hybrid.py): residuals, and the per-(query, probe) table + list scan into candidate slots
 int launch_residual(const float* x, int64_t ldx, const float* cent, int ldc, const int* list, int dim, int64_t n,
                     float* out, hipStream_t s);
