@@ -278,3 +278,18 @@ def test_prefilter_recovers_from_an_overwritten_outlier(nat):
     store.set_row(123, rng.standard_normal(d).astype(np.float32))
     both_ways(nat, store, q, 10, "dot", expect_overflow=False)
     store.close()
+
+
+def test_worst_case_rounding_is_inside_the_slack(native):
+    """tests/worstcase_prefilter.py: every element half a bf16 step from its rounded value, the errors of a dot product
+    all of one sign, the true k best separated from the rows that bf16 prefers by almost twice a row's largest error.
+    In a process of its own: the Flat bound pass must read every row (VDB_PREFILTER_SAMPLE is read once)."""
+    import os
+    import subprocess
+    import sys
+    here = os.path.dirname(os.path.abspath(__file__))
+    env = dict(os.environ, VDB_PREFILTER_SAMPLE="64")
+    r = subprocess.run([sys.executable, os.path.join(here, "worstcase_prefilter.py")], capture_output=True, text=True,
+                       timeout=300, env=env)
+    tail = "\n".join((r.stdout + r.stderr).splitlines()[-15:])
+    assert r.returncode == 0 and "no failure" in r.stdout, tail

@@ -165,6 +165,61 @@ def test_flat_index_add_and_search_from_threads():
             assert index.search(extra[t, i], k=1)[0].id == f"t{t}_{i}"
 
 
+def test_searches_of_one_index_overlap_and_never_see_moved_rows():
+    """Searches hold the index lock shared: two of them are inside their device calls at once (both must reach a
+    barrier placed in front of the device search, which a lock held exclusively for the whole search would never
+    allow).  Removals swap rows on the device; mixed with searches, every result still carries the distance of the
+    vector that belongs to the returned id."""
+    import threading
+    from vectordb_amd.index import FlatIndex, IVFIndex, PQIndex
+    rng = np.random.RandomState(11)
+    d, n = 16, 3000
+    x = rng.randn(n, d).astype(np.float32)
+    ids = [f"v{i}" for i in range(n)]
+    by_id = dict(zip(ids, x))
+    q = rng.randn(40, d).astype(np.float32)
+
+    flat = FlatIndex(d, metric="euclidean")
+    flat.add_batch(ids, x)
+    ivf = IVFIndex(dimension=d, metric="euclidean", n_clusters=16, n_probe=16, seed=1)
+    ivf.train(x[:1000])
+    ivf.add_batch(ids, x)
+    pq = PQIndex(dimension=d, n_subvectors=4, n_bits=8, n_iter=3, seed=1)
+    pq.train(x[:1000])
+    pq.add_batch(ids, x)
+    for index, dev_of in ((flat, lambda: flat._store), (ivf, lambda: ivf._dev), (pq, lambda: pq._dev)):
+        index.search(q[0], k=3)                                   # the device copy exists and is in step
+        dev = dev_of()
+        real = dev.search
+        both_inside = threading.Barrier(2, timeout=20)
+
+        def met(*a, _real=real, **kw):
+            both_inside.wait()
+            return _real(*a, **kw)
+        dev.search = met
+        try:
+            run_threads([lambda i=i: index.search(q[i], k=3) for i in range(2)])
+        finally:
+            del dev.search
+        assert not both_inside.broken
+
+    def remover():
+        for i in range(0, 1500, 3):
+            assert flat.remove(ids[i]) and ivf.remove(ids[i])
+
+    def searcher(t):
+        def f():
+            for i in range(t, len(q), 4):
+                for index in (flat, ivf):
+                    for r in index.search(q[i], k=5):
+                        want = np.sqrt(np.sum((q[i] - by_id[r.id]) ** 2, dtype=np.float32))
+                        assert abs(r.distance - float(want)) <= 1e-4 * max(1.0, float(want)), (r.id, r.distance, want)
+        return f
+
+    run_threads([remover] + [searcher(t) for t in range(4)])
+    assert len(flat) == n - 500 and len(ivf) == n - 500
+
+
 def test_init_refuses_a_second_device(nat):
     """vdb_init fixes the device at the first call: the same device again is a no-op, another one is refused
     (handles, streams and buffers would stay behind on the first)."""

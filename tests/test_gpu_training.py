@@ -174,3 +174,42 @@ def test_trainer_odd_shapes(nat):
     want = (new[fed].astype(np.float64) / counts[fed, None].astype(np.float64)).astype(np.float32)
     np.testing.assert_array_equal(tr.centroids()[fed], want)
     tr.close(); store.close()
+
+
+def test_full_size_lloyd_steps_against_the_oracle(nat):
+    """BASELINE configs[3] at its stated size: 1 048 576 x 128 rows, 4096 clusters, two Lloyd steps from 4096 rows of
+    the set.  Per step: the assignments of 2000 sampled rows against KMeans._assign (index/ivf.py:228-231: identity-form
+    distances, clamp, sqrt, argmin; a row may differ only where its two nearest centroids tie to rounding), and the new
+    centroids of 16 sampled clusters against the reference's update (ivf.py:177-190: fp32 sums in row order, divided by
+    the float64 count), bit for bit."""
+    rng = np.random.default_rng(42)
+    n, d, k = 1_048_576, 128, 4096
+    x = rng.standard_normal((n, d), dtype=np.float32)
+    store, tr = trainer_for(nat, x, 0, d, k)
+    tr.init_rows(np.sort(rng.choice(n, k, replace=False)))
+    sample = np.sort(rng.choice(n, 2000, replace=False))
+    clusters = rng.choice(k, 16, replace=False)
+    for step in range(2):
+        cent = tr.centroids()
+        a = tr.assignments()
+        ref = R.kmeans_assign(x[sample], cent)
+        moved = np.flatnonzero(a[sample] != ref)
+        if len(moved):
+            dist = R.pairwise_euclidean(x[sample[moved]], cent)
+            got, want = dist[np.arange(len(moved)), a[sample[moved]]], dist[np.arange(len(moved)), ref[moved]]
+            assert len(moved) <= 2 and np.allclose(got, want, rtol=1e-6), f"step {step}: {len(moved)} sampled rows in another cluster"
+        counts, shift = tr.step(nat.KMEANS_IVF)
+        assert counts.sum() == n and shift > 0
+        np.testing.assert_array_equal(counts, np.bincount(a, minlength=k))
+        tr.commit()
+        new = tr.centroids()
+        for c in clusters:
+            members = np.flatnonzero(a == c)
+            acc = np.zeros(d, np.float32)
+            for r in members:                                  # sample order, one fp32 addition per row and column
+                acc = acc + x[r]
+            want = acc.copy()
+            if len(members):
+                want /= np.float64(len(members))               # fp32 row /= float64 count, cast back (ivf.py:186-187)
+                np.testing.assert_array_equal(new[c], want, err_msg=f"step {step}, cluster {c}")
+    tr.close(); store.close()

@@ -560,6 +560,7 @@ class IvfLists:
         self.lib = load()
         self.dim = int(dim)
         self.h = C.c_void_p()
+        self._mu = threading.Lock()
         check(self.lib.vdb_ivf_create(C.byref(self.h), self.dim, metric))
 
     def close(self):
@@ -616,19 +617,24 @@ class IvfLists:
         check(self.lib.vdb_ivf_layout(self.h, C.byref(a), C.byref(b), C.byref(c)))
         return a.value, b.value, c.value
 
-    def search(self, queries: np.ndarray, k: int, n_probe: int, mask_words=None):
+    def search(self, queries: np.ndarray, k: int, n_probe: int, mask_words=None, with_scan_rows: bool = False):
+        """-> (distances, rows), and with ``with_scan_rows`` the number of list rows this search scanned (the two
+        calls as one step, so that searches of other threads on this handle do not come between them)."""
         q = f32(queries)
         if q.ndim == 1:
             q = q[None, :]
         nq = q.shape[0]
         dist = np.empty((nq, k), np.float32)
         rows = np.empty((nq, k), np.int64)
-        if isinstance(mask_words, DeviceMask):
-            check(self.lib.vdb_ivf_search_masked(self.h, fptr(q), nq, k, n_probe, mask_words.h, fptr(dist),
-                                                 rows.ctypes.data_as(c_i64_p)))
-        else:
-            check(self.lib.vdb_ivf_search(self.h, fptr(q), nq, k, n_probe, u32ptr(mask_words), fptr(dist),
-                                          rows.ctypes.data_as(c_i64_p)))
+        with self._mu:
+            if isinstance(mask_words, DeviceMask):
+                check(self.lib.vdb_ivf_search_masked(self.h, fptr(q), nq, k, n_probe, mask_words.h, fptr(dist),
+                                                     rows.ctypes.data_as(c_i64_p)))
+            else:
+                check(self.lib.vdb_ivf_search(self.h, fptr(q), nq, k, n_probe, u32ptr(mask_words), fptr(dist),
+                                              rows.ctypes.data_as(c_i64_p)))
+            if with_scan_rows:
+                return dist, rows, self.last_scan_rows()
         return dist, rows
 
     def search_device(self, q_ptr: int, nq: int, k: int, n_probe: int, out_dist_ptr: int, out_row_ptr: int,

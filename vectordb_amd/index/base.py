@@ -5,6 +5,7 @@ containers and the abstract interface of the reference's ``index.base``
 from __future__ import annotations
 
 import threading
+from contextlib import contextmanager
 from abc import ABC, abstractmethod
 from dataclasses import dataclass, field
 from enum import Enum
@@ -77,6 +78,90 @@ class SearchResult:                                              # index/base.py
         return f"SearchResult(id='{self.id}', distance={self.distance:.4f})"
 
 
+class IndexLock:
+    """The lock of an index: writes exclusive and re-entrant (``with lock:``, as the ``threading.RLock`` of
+    index/base.py:125), searches shared (``acquire_shared`` / ``release_shared``), so searches of one index do not wait
+    for each other.  A writer can turn its hold into a shared one without letting another writer in between
+    (``downgrade``): a search that first has to bring the device copy up to date does that and then searches on.
+    Waiting writers go before new searches.  A thread that holds the lock for writing may also take it shared."""
+
+    def __init__(self):
+        self._cond = threading.Condition(threading.Lock())
+        self._readers = 0
+        self._writer = None          # thread id of the exclusive holder
+        self._depth = 0              # its nesting depth
+        self._waiting = 0            # writers waiting
+        self._local = threading.local()
+
+    # -- exclusive
+    def acquire(self) -> bool:
+        me = threading.get_ident()
+        with self._cond:
+            if self._writer == me:
+                self._depth += 1
+                return True
+            if getattr(self._local, "shared", 0):
+                raise RuntimeError("a thread that is searching an index cannot write to it")
+            self._waiting += 1
+            try:
+                while self._writer is not None or self._readers:
+                    self._cond.wait()
+            finally:
+                self._waiting -= 1
+            self._writer, self._depth = me, 1
+        return True
+
+    def release(self) -> None:
+        with self._cond:
+            if self._writer != threading.get_ident():
+                raise RuntimeError("release of an index lock that this thread does not hold")
+            self._depth -= 1
+            if self._depth == 0:
+                self._writer = None
+                self._cond.notify_all()
+
+    __enter__ = acquire
+
+    def __exit__(self, *exc) -> None:
+        self.release()
+
+    # -- shared
+    def acquire_shared(self) -> str:
+        """-> the token ``release_shared`` takes back ("w": this thread holds the lock for writing anyway)."""
+        me = threading.get_ident()
+        with self._cond:
+            if self._writer == me:
+                self._depth += 1
+                return "w"
+            nested = getattr(self._local, "shared", 0)
+            while self._writer is not None or (self._waiting and not nested):
+                self._cond.wait()
+            self._readers += 1
+            self._local.shared = nested + 1
+        return "r"
+
+    def release_shared(self, token: str) -> None:
+        if token == "w":
+            self.release()
+            return
+        with self._cond:
+            self._readers -= 1
+            self._local.shared -= 1
+            if self._readers == 0:
+                self._cond.notify_all()
+
+    def downgrade(self) -> str:
+        """The exclusive hold of this thread (depth 1) becomes a shared one; -> its token."""
+        with self._cond:
+            if self._writer != threading.get_ident() or self._depth != 1:
+                raise RuntimeError("downgrade needs exactly one exclusive hold by this thread")
+            self._writer, self._depth = None, 0
+            self._readers += 1
+            self._local.shared = getattr(self._local, "shared", 0) + 1
+            self._cond.notify_all()
+        return "r"
+
+
 class BaseIndex(ABC):
     """index/base.py:128-485"""
 
@@ -87,8 +172,43 @@ class BaseIndex(ABC):
         self._metric = metric
         self._is_trained = False
         self._build_time = 0.0
-        self._lock = threading.RLock()
+        self._lock = IndexLock()
         self._filters = FilterCache(self.filter_cache_slots)
+
+    # ---- searches hold the lock shared; the device copy is brought up to date under an exclusive hold first
+    def _mirror_stale(self) -> bool:
+        """True while the device copy lacks writes of the host side (subclasses with a device copy override)."""
+        return False
+
+    def _sync_mirror(self) -> None:
+        """Bring the device copy up to date; runs under the exclusive lock."""
+
+    @contextmanager
+    def _searching(self):
+        """Shared hold of the index lock around a device search and the mapping of its rows to ids.  The reference's
+        searches take no lock at all (index/flat.py:288-343); here rows move on the device when a write swaps them,
+        so a search excludes writes, but not other searches."""
+        lock = self._lock
+        token = lock.acquire_shared()
+        try:
+            if self._mirror_stale():
+                if token == "w":
+                    self._sync_mirror()
+                else:
+                    lock.release_shared(token)
+                    token = None
+                    lock.acquire()
+                    try:
+                        if self._mirror_stale():
+                            self._sync_mirror()
+                    except BaseException:
+                        lock.release()
+                        raise
+                    token = lock.downgrade()
+            yield
+        finally:
+            if token is not None:
+                lock.release_shared(token)
 
     @property
     def dimension(self) -> int:
@@ -239,36 +359,56 @@ class FilterCache:
         self.version = 0                 # bumped by every write of the owning index
         self._entries: list = []         # (key, version, packed host words, DeviceMask, any row passes); newest last
         self.evaluations = 0             # filters evaluated over all rows (a cache hit does not count)
+        self._mu = threading.Lock()      # searches of one index run side by side and share this cache
 
     def touch(self) -> None:
-        self.version += 1
-        if self._entries:
-            self.drop()
+        """A write to the index (under its exclusive lock: no search is using an entry)."""
+        with self._mu:
+            self.version += 1
+            self._drop()
 
     def drop(self) -> None:
+        with self._mu:
+            self._drop()
+
+    def _drop(self) -> None:
         for e in self._entries:
             e[3].close()
         self._entries = []
 
     def lookup(self, key, build):
-        """(host words, resident mask, any) for ``key``; ``build()`` -> boolean row mask runs on a miss."""
-        if self.slots <= 0 and self._entries:
-            self.drop()
-        for i, e in enumerate(self._entries):
-            if e[1] == self.version and (e[0] is key or (isinstance(key, str) and isinstance(e[0], str) and e[0] == key)):
-                self._entries.append(self._entries.pop(i))
-                return e[2], e[3], e[4]
+        """(host words, resident mask, any) for ``key``; ``build()`` -> boolean row mask runs on a miss.  An entry
+        that makes room for a new one is only forgotten, not closed: a search in another thread may still be using
+        its mask, which frees its device memory when the last reference goes."""
+        def find():
+            for i, e in enumerate(self._entries):
+                if e[1] == self.version and (e[0] is key or (isinstance(key, str) and isinstance(e[0], str) and e[0] == key)):
+                    self._entries.append(self._entries.pop(i))
+                    return e
+            return None
+
+        with self._mu:
+            if self.slots <= 0 and self._entries:
+                self._entries = []
+            e = find()
+            version = self.version
+        if e is not None:
+            return e[2], e[3], e[4]
         from .. import _native as N
-        mask = np.asarray(build(), dtype=bool)
-        self.evaluations += 1
+        mask = np.asarray(build(), dtype=bool)          # the caller's callable runs outside the cache's own lock
         words = N.pack_mask(mask)
-        if self.slots <= 0:
-            return words, None, bool(mask.any())
-        dev = N.DeviceMask(words, n_bits=len(mask))
-        while len(self._entries) >= self.slots:
-            self._entries.pop(0)[3].close()
-        self._entries.append((key, self.version, words, dev, bool(mask.any())))
-        return words, dev, bool(mask.any())
+        with self._mu:
+            self.evaluations += 1
+            if self.slots <= 0 or version != self.version:
+                return words, None, bool(mask.any())
+            e = find()                                  # another search evaluated the same filter meanwhile
+            if e is not None:
+                return e[2], e[3], e[4]
+            dev = N.DeviceMask(words, n_bits=len(mask))
+            while len(self._entries) >= self.slots:
+                self._entries.pop(0)
+            self._entries.append((key, self.version, words, dev, bool(mask.any())))
+            return words, dev, bool(mask.any())
 
 
 def filter_mask(filter_fn: Optional[FilterFunction], ids, metadata_of) -> Optional[np.ndarray]:

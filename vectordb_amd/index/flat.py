@@ -88,6 +88,12 @@ class FlatIndex(BaseIndex):
             self._synced = self._size
         return self._store
 
+    def _mirror_stale(self) -> bool:
+        return self._store is None or self._synced < self._size
+
+    def _sync_mirror(self) -> None:
+        self._device()
+
     def _metric_code(self) -> int:
         if self._metric not in _QUERY_METRICS:
             raise ValueError(f"Unknown metric: {self._metric}")          # distance/metrics.py:493 via flat.py:331
@@ -170,13 +176,13 @@ class FlatIndex(BaseIndex):
         if k <= 0:
             return []
         code = self._metric_code()
-        # mirror sync, device call and row -> id mapping under the index lock: a concurrent add or
-        # remove must not move rows between the search and the mapping
-        with self._lock:
+        # device call and row -> id mapping under a shared hold of the index lock: a concurrent add or remove must
+        # not move rows between the search and the mapping; other searches may run
+        with self._searching():
             k = min(k, self._size)
             if k <= 0:
                 return []
-            dist, rows = self._device().search(query, k, code, self._mask_words(filter_fn))
+            dist, rows = self._store.search(query, k, code, self._mask_words(filter_fn))
             return self._results(dist[0], rows[0], include_vectors, include_metadata)
 
     def search_batch(self, queries, k: int = 10, filter_fn: Optional[FilterFunction] = None) -> List[List[SearchResult]]:
@@ -187,11 +193,11 @@ class FlatIndex(BaseIndex):
             return [[] for _ in range(len(queries))]
         if self.config.normalize:
             queries = unit_rows(queries)
-        with self._lock:
+        with self._searching():
             k = min(k, self._size)
             if k <= 0 or len(queries) == 0:
                 return [[] for _ in range(len(queries))]
-            dist, rows = self._device().search(queries, k, self._metric_code(), self._mask_words(filter_fn))
+            dist, rows = self._store.search(queries, k, self._metric_code(), self._mask_words(filter_fn))
             return [self._results(dist[i], rows[i], False, True) for i in range(len(queries))]
 
     def search_by_id(self, id: str, k: int = 10, exclude_self: bool = True,
@@ -214,10 +220,10 @@ class FlatIndex(BaseIndex):
         query = self._validate_vector(query)
         if self.config.normalize:
             query = unit_vector(query)
-        with self._lock:
+        with self._searching():
             if self._size == 0:
                 return []
-            dist, rows = self._device().range_search(query, radius, self._metric_code(), self._mask_words(filter_fn, host_words=True),
+            dist, rows = self._store.range_search(query, radius, self._metric_code(), self._mask_words(filter_fn, host_words=True),
                                                      cap=max_results or self._size)
             return self._results(dist, rows, False, True)
 

@@ -207,6 +207,12 @@ class HybridIndex(BaseIndex):
                     self._dirty = True
         self._synced = n_rows
 
+    def _mirror_stale(self) -> bool:
+        return self._dirty or self._synced < len(self._row_ids)
+
+    def _sync_mirror(self) -> None:
+        self._sync()
+
     def _mask_words(self, filter_fn: Optional[FilterFunction]):
         return self._filter_for_device(filter_fn, self._row_ids, lambda i: self._metadata.get(i, {}))
 
@@ -243,8 +249,7 @@ class HybridIndex(BaseIndex):
 
     def _search_rows(self, queries, k, filter_fn, n_probe, include_vectors, include_metadata):
         n_probe = n_probe or self.config.n_probe
-        with self._lock:
-            self._sync()
+        with self._searching():
             k_eff = min(k, self._size)
             if k_eff <= 0:
                 return [[] for _ in range(len(queries))]

@@ -14,6 +14,7 @@ index is searched after a change.
 
 from __future__ import annotations
 
+import threading
 import time
 from dataclasses import dataclass
 from typing import Any, Dict, Iterator, List, Optional, Tuple
@@ -205,6 +206,7 @@ class IVFIndex(BaseIndex):
         self._id_to_position: Dict[str, int] = {}
         self._build_start = time.time()
         self._n_distance_computations = 0
+        self._stats_mu = threading.Lock()
         self._rng = np.random.RandomState(seed)
         # Device mirror.  A device row number is a slot of the host table.  After the first build, adds go to the
         # tails of their lists (`_pending` until the next search) and removes swap inside one list, as the host
@@ -379,6 +381,12 @@ class IVFIndex(BaseIndex):
         if dead > live + 4096:              # more abandoned places than rows: pack the lists again at the next search
             self._dev_dirty = True
 
+    def _mirror_stale(self) -> bool:
+        return self._dev is None or self._dev_dirty or bool(self._pending)
+
+    def _sync_mirror(self) -> None:
+        self._device()
+
     # ------------------------------------------------------------ search
     def _mask_words(self, filter_fn: Optional[FilterFunction]):
         return self._filter_for_device(filter_fn, self._slot_id, lambda i: self._metadata.get(i, {}))
@@ -405,15 +413,16 @@ class IVFIndex(BaseIndex):
         if self.config.normalize:
             query = unit_vector(query)
         n_probe = min(n_probe or self.config.n_probe, self.config.n_clusters)      # ivf.py:607-608
-        # list upload, device call and row -> id mapping under the index lock (a concurrent write
-        # swaps the device row numbering)
-        with self._lock:
+        # device call and row -> id mapping under a shared hold of the index lock (a concurrent write swaps the
+        # device row numbering; other searches may run)
+        with self._searching():
             k = min(k, self.size)
             if k <= 0:
                 return []
-            dev = self._device()
-            dist, rows = dev.search(query, k, n_probe, self._mask_words(filter_fn))
-            self._n_distance_computations += dev.last_scan_rows()
+            dev = self._dev
+            dist, rows, scanned = dev.search(query, k, n_probe, self._mask_words(filter_fn), with_scan_rows=True)
+            with self._stats_mu:
+                self._n_distance_computations += scanned
             return self._results(dist[0], rows[0], include_vectors, include_metadata)
 
     def search_batch(self, queries, k: int = 10, filter_fn: Optional[FilterFunction] = None,
@@ -427,13 +436,14 @@ class IVFIndex(BaseIndex):
         if self.config.normalize:
             queries = unit_rows(queries)
         n_probe = min(n_probe or self.config.n_probe, self.config.n_clusters)
-        with self._lock:
+        with self._searching():
             k = min(k, self.size)
             if k <= 0:
                 return [[] for _ in range(len(queries))]
-            dev = self._device()
-            dist, rows = dev.search(queries, k, n_probe, self._mask_words(filter_fn))
-            self._n_distance_computations += dev.last_scan_rows()
+            dev = self._dev
+            dist, rows, scanned = dev.search(queries, k, n_probe, self._mask_words(filter_fn), with_scan_rows=True)
+            with self._stats_mu:
+                self._n_distance_computations += scanned
             return [self._results(dist[i], rows[i], False, True) for i in range(len(queries))]
 
     def search_with_scores(self, query, k: int = 10, n_probe: Optional[int] = None) -> Tuple[List[str], List[float]]:

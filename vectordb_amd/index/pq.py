@@ -178,6 +178,12 @@ class PQIndex(BaseIndex):
                 self._dev.append_codes(self._codes_arr[:self.size])
             self._synced = self.size
 
+    def _mirror_stale(self) -> bool:
+        return self._synced != self.size
+
+    def _sync_mirror(self) -> None:
+        self._sync()
+
     # ------------------------------------------------------------ search
     def _mask_words(self, filter_fn: Optional[FilterFunction]):
         return self._filter_for_device(filter_fn, self._ids, lambda i: self._metadata.get(i, {}))
@@ -200,13 +206,12 @@ class PQIndex(BaseIndex):
         if self.size == 0:
             return []
         query = self._validate_vector(query)
-        # mirror sync, device call and row -> id mapping under the index lock (a concurrent add or
-        # remove renumbers rows)
-        with self._lock:
+        # device call and row -> id mapping under a shared hold of the index lock (a concurrent add or remove
+        # renumbers rows; other searches may run)
+        with self._searching():
             k = min(k, self.size)
             if k <= 0:
                 return []
-            self._sync()
             dist, rows = self._dev.search(query, k, self._mask_words(filter_fn))
             return self._results(dist[0], rows[0], include_vectors, include_metadata)
 
@@ -216,11 +221,10 @@ class PQIndex(BaseIndex):
         queries = self._validate_vectors(queries)
         if self.size == 0 or len(queries) == 0:
             return [[] for _ in range(len(queries))]
-        with self._lock:
+        with self._searching():
             k = min(k, self.size)
             if k <= 0:
                 return [[] for _ in range(len(queries))]
-            self._sync()
             dist, rows = self._dev.search(queries, k, self._mask_words(filter_fn))
             return [self._results(dist[i], rows[i], False, True) for i in range(len(queries))]
 
