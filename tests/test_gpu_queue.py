@@ -119,6 +119,55 @@ def test_queue_overflow_falls_back_to_lists(nat, metric):
     store.close()
 
 
+def test_one_overflowing_query_is_searched_again_alone(nat):
+    """4000 rows sit next to one point, none of them in a sampled tile: the query at that point gets a bound from
+    ordinary rows, its queues overflow, and it alone goes through the list kernel again.  The other 1023 queries keep
+    the results they have without it (bit for bit), the unlucky one matches the oracle, and the batch costs little
+    more than a clean one (a repeat of the whole batch through the list kernel costs more than twice)."""
+    import time
+    rng = np.random.default_rng(21)
+    n, d, nq, k = 1024 * 1024, 64, 1024, 10
+    x = rng.standard_normal((n, d), dtype=np.float32)
+    point = rng.standard_normal(d).astype(np.float32)
+    tiles = np.arange(n) // 128
+    free = np.flatnonzero(tiles % 4 != 0)                      # whatever the sample stride (a multiple of 4 here), not sampled
+    spot = rng.choice(free, 4000, replace=False)
+    x[spot] = (point + 0.05 * rng.standard_normal((len(spot), d))).astype(np.float32)
+    q = rng.standard_normal((nq, d), dtype=np.float32)
+    bad = 517
+    q_bad = q.copy()
+    q_bad[bad] = point
+    store = nat.RowStore(d)
+    store.append(x)
+    for mode in (None, "bf16"):
+        store.set_prefilter(mode)
+        code = nat.METRIC_CODES["euclidean"]
+        d_clean, r_clean = store.search(q, k, code)
+        assert store.search_stats() == (True, False)
+        d_bad, r_bad = store.search(q_bad, k, code)
+        assert store.search_stats() == (True, True)
+        others = np.arange(nq) != bad
+        np.testing.assert_array_equal(r_bad[others], r_clean[others])
+        np.testing.assert_array_equal(d_bad[others].view(np.uint32), d_clean[others].view(np.uint32))
+        ref_rows, ref_dist = R.flat_search(point, x, k, "euclidean")
+        full = R.query_distances(point, x, "euclidean")
+        assert same_ids_or_near_ties(r_bad[bad], ref_rows, lambda r: full[r], float(ref_dist[-1]), rtol=RTOL,
+                                     atol=ids_atol("euclidean", point, x, float(ref_dist[-1])))
+        assert_close("euclidean", d_bad[bad], ref_dist, point, x)
+        if mode is None:
+            def best_of(queries):
+                t = []
+                for _ in range(7):
+                    t0 = time.perf_counter()
+                    store.search(queries, k, code)
+                    t.append(time.perf_counter() - t0)
+                return min(t)
+            t_clean, t_bad = best_of(q), best_of(q_bad)
+            print(f"clean batch {t_clean * 1e3:.3f} ms, with one overflowing query {t_bad * 1e3:.3f} ms ({t_bad / t_clean:.2f}x)")
+            assert t_bad < 1.35 * t_clean
+    store.close()
+
+
 def test_queue_search_bf16_storage(nat):
     """bf16 rows: the fp32 bars hold against the oracle on the rounded inputs."""
     rng = np.random.default_rng(9)

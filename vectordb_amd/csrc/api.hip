@@ -243,6 +243,7 @@ struct Workspace {
     PinBuf pin_in, pin_out;             // host ends of the small transfers of the host-pointer entry points
     DevBuf q_buf, q_sq, q_nrm, part_d, part_i, lb_d, lb_k, thr_d, thr_k, mask, out_d, out_i, dist, probes, probe_d, lut, stage;
     DevBuf queue, queue_cnt, flag, mins, seg, seg_len;
+    DevBuf redo_mark, redo_list, redo_q, redo_terms, redo_out;    // queries whose queues overflowed, searched again alone
     DevBuf ticket;                      // one int per query, zero between launches (topk_cand's last-block merge)
     void* ticket_zeroed = nullptr;      // the allocation that has been cleared
     DevBuf mid[4];                      // intermediate levels of a hierarchical list merge (launch_select)
@@ -254,7 +255,7 @@ struct Workspace {
         DevBuf* all[] = {&q_buf, &q_sq, &q_nrm, &part_d, &part_i, &lb_d, &lb_k, &thr_d, &thr_k, &mask, &out_d, &out_i, &dist,
                          &probes, &probe_d, &lut, &stage, &round32, &q16, &cand, &seg_row_off, &seg_q_off, &seg_item_off, &sq_qid, &sq_out,
                          &cand_off, &tile_off, &list_cnt, &cursor, &slots, &items,
-                         &queue, &queue_cnt, &flag, &mins, &seg, &seg_len, &ticket, &mid[0], &mid[1], &mid[2], &mid[3],
+                         &queue, &queue_cnt, &flag, &mins, &seg, &seg_len, &redo_mark, &redo_list, &redo_q, &redo_terms, &redo_out, &ticket, &mid[0], &mid[1], &mid[2], &mid[3],
                          &fp_seg_row_off, &fp_seg_q_off, &fp_seg_item_off, &fp_sq_qid, &fp_sq_out, &fp_items};
         for (DevBuf* b : all) f(b);
     }
@@ -675,7 +676,12 @@ static int flat_search_impl(vdb_rows* h, int metric, const float* d_q, int nq, i
     static const bool no_queue = getenv("VDB_NO_QUEUE") != nullptr;
     const bool will_queue = sample_tiles > 0 && !multi && !no_queue;
     bool flag_cleared = false;
+    // Queries whose queues overflow are marked one by one and searched again alone by the list kernel (fp32 rows):
+    // one unlucky query does not cost the batch a second search.  bf16 storage keeps the whole-batch repeat.
+    const bool redo_some = will_queue && !r.bf16;
     if (will_queue) VDB_TRY(ws.flag.reserve(sizeof(int)));
+    if (redo_some) VDB_TRY(ws.redo_mark.reserve((size_t)nq * sizeof(int)));
+    int* marks = redo_some ? ws.redo_mark.as<int>() : nullptr;
     // Filter pass on bf16 copies, exact selection in fp32 (vdb_rows_set_prefilter): only where the 256 x 256 bf16
     // kernel can read the copy, and never from the entry point that must not allocate (the copy is allocated here)
     Rows rf = r;
@@ -729,7 +735,7 @@ static int flat_search_impl(vdb_rows* h, int metric, const float* d_q, int nq, i
                 VDB_TRY(launch_flat_min_sample(rb, metric, qb + (size_t)q0 * q_pitch, ws.q_sq.as<float>() + q0,
                                                ws.q_nrm.as<float>() + q0, nb, kmax, d_mask, sample_tiles, sample_stride,
                                                ws.mins.as<float>(), ws.thr_d.as<float>() + q0,
-                                               will_queue ? ws.flag.as<int>() : nullptr, s));
+                                               will_queue ? ws.flag.as<int>() : nullptr, s, marks ? marks + q0 : nullptr));
             }
             flag_cleared = will_queue;
         } else {
@@ -749,10 +755,13 @@ static int flat_search_impl(vdb_rows* h, int metric, const float* d_q, int nq, i
     if (will_queue) {
         h->last_used_queue = true;
         h->last_flag = ws.flag.as<int>();
-        if (!flag_cleared) VDB_HIP(hipMemsetAsync(ws.flag.p, 0, sizeof(int), s));
+        if (!flag_cleared) {
+            VDB_HIP(hipMemsetAsync(ws.flag.p, 0, sizeof(int), s));
+            if (marks) VDB_HIP(hipMemsetAsync(marks, 0, (size_t)nq * sizeof(int), s));
+        }
         if (prefilter)
             VDB_TRY(launch_prefilter_slack(metric, ws.q_nrm.as<float>(), h->max_nrm.as<float>(), nq, r.dim, h->slack.as<float>(),
-                                           thr_from_copies ? ws.thr_d.as<float>() : nullptr, ws.flag.as<int>(), s));
+                                           thr_from_copies ? ws.thr_d.as<float>() : nullptr, ws.flag.as<int>(), s, marks));
         const Rows& rq = prefilter ? rf : r;
         const char* qb = prefilter ? ws.q16.as<char>() : reinterpret_cast<const char*>(q);
         const size_t q_pitch = rq.bf16 ? (size_t)rq.ld16 * 2 : (size_t)r.ld * 4;
@@ -767,9 +776,48 @@ static int flat_search_impl(vdb_rows* h, int metric, const float* d_q, int nq, i
                                       nb, kmax, d_mask, thr_init + q0, n_slabs, cap, ws.queue.p, ws.queue_cnt.as<int>(),
                                       ws.flag.as<int>(), d_out_d ? d_out_d + (int64_t)q0 * k : nullptr,
                                       d_out_i ? d_out_i + (int64_t)q0 * k : nullptr,
-                                      d_out_i32 ? d_out_i32 + (int64_t)q0 * k : nullptr, s, prefilter ? &pf : nullptr));
+                                      d_out_i32 ? d_out_i32 + (int64_t)q0 * k : nullptr, s, prefilter ? &pf : nullptr,
+                                      marks ? marks + q0 : nullptr));
         }
         run_if = ws.flag.as<int>();
+    }
+    if (redo_some) {
+        // Compact the marked queries (their padded rows, norm terms and fp32 bounds), search those with the list
+        // kernel on a grid laid out for one query tile (so that a handful of queries still fills the GPU), select into
+        // compact results and move them to their queries' places.  More marked queries than a tile holds: the whole
+        // batch again, as before (the loop below, behind the second flag).  Everything is launched either way and
+        // returns at once while its flag or count is zero.
+        const float* qf = reinterpret_cast<const float*>(q);
+        const int lim = std::min(nq, flat_gemm_query_tile());
+        int n_cand_redo = 0;
+        VDB_TRY(flat_gemm_num_cand(r.n, lim, k, &n_cand_redo));
+        const size_t d_bytes = ((size_t)lim * k * sizeof(float) + 7) / 8 * 8;
+        VDB_TRY(ws.redo_list.reserve(((size_t)nq + 2) * sizeof(int)));
+        VDB_TRY(ws.redo_q.reserve((size_t)lim * r.ld * sizeof(float)));
+        VDB_TRY(ws.redo_terms.reserve((size_t)lim * 3 * sizeof(float)));
+        VDB_TRY(ws.redo_out.reserve(d_bytes + (size_t)lim * k * (sizeof(int64_t) + sizeof(int))));
+        VDB_TRY(ws.part_d.reserve((size_t)lim * n_cand_redo * kmax * sizeof(float)));
+        VDB_TRY(ws.part_i.reserve((size_t)lim * n_cand_redo * kmax * sizeof(int)));
+        int* list = ws.redo_list.as<int>();
+        int* count = list + nq;
+        int* all_flag = count + 1;
+        float* t_sq = ws.redo_terms.as<float>();
+        float* t_nrm = t_sq + lim;
+        float* t_thr = t_nrm + lim;
+        float* c_d = ws.redo_out.as<float>();
+        int64_t* c_i = reinterpret_cast<int64_t*>(ws.redo_out.as<char>() + d_bytes);
+        int* c_i32 = reinterpret_cast<int*>(c_i + (size_t)lim * k);
+        // (a bound found on the bf16 copies was widened for them; the list kernel takes none then)
+        const float* thr_f32 = (thr_init && !thr_from_copies) ? thr_init : nullptr;
+        VDB_TRY(launch_redo_gather(run_if, marks, nq, qf, r.ld, ws.q_sq.as<float>(), ws.q_nrm.as<float>(), thr_f32, list, count,
+                                   ws.redo_q.as<float>(), t_sq, t_nrm, t_thr, lim, all_flag, s));
+        VDB_TRY(launch_flat_gemm_topk(r, metric, ws.redo_q.as<float>(), t_sq, t_nrm, lim, kmax, d_mask, nullptr, nullptr,
+                                      thr_f32 ? t_thr : nullptr, 0, 1, ws.part_d.as<float>(), ws.part_i.as<int>(), n_cand_redo, s,
+                                      run_if, count));
+        SelectOut o{c_d, d_out_i ? c_i : nullptr, d_out_i32 ? c_i32 : nullptr, k, 0, nullptr, nullptr, run_if};
+        VDB_TRY(launch_select(ws.part_d.as<float>(), ws.part_i.as<int>(), lim, n_cand_redo, kmax, 1 << 30, nullptr, 0, o, s, ws.mid));
+        VDB_TRY(launch_redo_scatter(list, count, lim, k, c_d, c_i, c_i32, d_out_d, d_out_i, d_out_i32, s));
+        run_if = all_flag;
     }
 
     for (int64_t done = 0; done < k_eff; done += KMAX_FUSED) {

@@ -43,6 +43,7 @@ struct GemmParams {
     float* part_d; int* part_i; int n_cand;
     float* dist_out;
     const int* run_if;              // optional device flag: the launch does nothing while it is zero
+    const int* q_count;             // optional device count: only the first *q_count queries are there
     float cos_eps;                  // cosine: norms below it count as 1 (1e-8 for searches)
 };
 
@@ -60,6 +61,10 @@ __global__ __launch_bounds__(NT, 2) void flat_gemm_kernel(GemmParams p) {
     int* Li = reinterpret_cast<int*>(Ld + (TOPK ? p.k : 0) * NT);
 
     if (p.run_if && *p.run_if == 0) return;
+    if (p.q_count) {
+        p.nq = min(p.nq, *p.q_count);
+        if (p.nq <= 0) return;
+    }
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int wave = tid >> 6;
@@ -84,6 +89,7 @@ __global__ __launch_bounds__(NT, 2) void flat_gemm_kernel(GemmParams p) {
     }
     const int tile0 = slab * p.tiles_per_slab;
     const int tile1 = min(tile0 + p.tiles_per_slab, p.n_tiles);
+    if (qt * TQ >= p.nq) return;                 // a query tile beyond the queries that are there (q_count)
 
     const int my_q = qt * TQ + wave * 32 + col;
     const bool q_ok = my_q < p.nq;
@@ -311,6 +317,8 @@ int flat_gemm_num_cand(int64_t n, int nq, int k, int* n_cand) {
     return VDB_OK;
 }
 
+int flat_gemm_query_tile() { return TQ; }
+
 int flat_gemm_num_cand_tiles(int n_tiles, int nq, int* n_cand) {
     int nqt, ns, tps;
     plan_grid(n_tiles, nq, ctx().num_cus, &nqt, &ns, &tps);
@@ -363,7 +371,7 @@ static int launch_gemm(int metric, GemmParams& p, hipStream_t s) {
 int launch_flat_gemm_topk(const Rows& r, int metric, const void* q, const float* q_sq, const float* q_nrm,
                           int nq, int k, const uint32_t* mask, const float* lb_d, const int64_t* lb_k,
                           const float* thr_init, int sample_tiles, int tile_stride,
-                          float* part_d, int* part_i, int n_cand, hipStream_t s, const int* run_if) {
+                          float* part_d, int* part_i, int n_cand, hipStream_t s, const int* run_if, const int* q_count) {
     VDB_REQUIRE(k >= 1 && k <= KMAX_FUSED, "fused selection supports 1 <= k <= %d, got %d", KMAX_FUSED, k);
     VDB_REQUIRE(r.n >= 1 && nq >= 1, "empty search");
     GemmParams p{};
@@ -373,7 +381,7 @@ int launch_flat_gemm_topk(const Rows& r, int metric, const void* q, const float*
     p.mask = mask; p.lb_d = lb_d; p.lb_k = lb_k; p.thr_init = thr_init; p.k = k;
     p.n_tiles = sample_tiles > 0 ? sample_tiles : (int)((r.n + TM - 1) / TM);
     p.tile_stride = sample_tiles > 0 ? tile_stride : 1;
-    p.part_d = part_d; p.part_i = part_i; p.n_cand = n_cand; p.dist_out = nullptr; p.run_if = run_if;
+    p.part_d = part_d; p.part_i = part_i; p.n_cand = n_cand; p.dist_out = nullptr; p.run_if = run_if; p.q_count = q_count;
     p.cos_eps = 1e-8f;
     return r.bf16 ? launch_gemm<true, true>(metric, p, s) : launch_gemm<true, false>(metric, p, s);
 }
@@ -389,6 +397,90 @@ int launch_flat_gemm_dist(const Rows& r, int metric, const void* q, const float*
     p.n_tiles = (int)((r.n + TM - 1) / TM);
     p.tile_stride = 1;
     return r.bf16 ? launch_gemm<false, true>(metric, p, s) : launch_gemm<false, false>(metric, p, s);
+}
+
+// ---------------------------------------------------------------- searching overflowed queries again, alone
+__global__ __launch_bounds__(1024) void redo_gather_kernel(const int* __restrict__ flag, const int* __restrict__ mark, int nq,
+                                                           const float* __restrict__ q, int ldq, const float* __restrict__ q_sq,
+                                                           const float* __restrict__ q_nrm, const float* __restrict__ thr,
+                                                           int* __restrict__ list, int* __restrict__ count,
+                                                           float* __restrict__ q_out, float* __restrict__ q_sq_out,
+                                                           float* __restrict__ q_nrm_out, float* __restrict__ thr_out,
+                                                           int limit, int* __restrict__ all_flag) {
+    __shared__ int wave_sum[16];
+    __shared__ int base;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    if (*flag == 0) {
+        if (tid == 0) { *count = 0; *all_flag = 0; }
+        return;
+    }
+    if (tid == 0) base = 0;
+    __syncthreads();
+    for (int q0 = 0; q0 < nq; q0 += 1024) {                 // ascending query order
+        const int qi = q0 + tid;
+        const bool hit = qi < nq && mark[qi] != 0;
+        const unsigned long long votes = __ballot(hit);
+        if (lane == 0) wave_sum[wave] = __popcll(votes);
+        __syncthreads();
+        int before = base;
+        for (int w = 0; w < wave; ++w) before += wave_sum[w];
+        if (hit) list[before + __popcll(votes & ((1ull << lane) - 1ull))] = qi;
+        __syncthreads();
+        if (tid == 0) {
+            int t = base;
+            for (int w = 0; w < 16; ++w) t += wave_sum[w];
+            base = t;
+        }
+        __syncthreads();
+    }
+    int n = base;
+    if (n > limit || n == 0) {                                // too many for one query tile (or a flag without a mark): the whole batch again
+        if (tid == 0) { *count = 0; *all_flag = 1; }
+        return;
+    }
+    if (tid == 0) { *count = n; *all_flag = 0; }
+    __syncthreads();                                          // the list is written (same block: LDS barrier + global writes)
+    __threadfence_block();
+    for (int j = tid; j < n; j += 1024) {
+        const int src = list[j];
+        q_sq_out[j] = q_sq[src];
+        q_nrm_out[j] = q_nrm[src];
+        thr_out[j] = thr ? thr[src] : INFINITY;
+    }
+    for (int64_t e = tid; e < (int64_t)n * ldq; e += 1024) {
+        const int j = (int)(e / ldq);
+        q_out[e] = q[(int64_t)list[j] * ldq + (e - (int64_t)j * ldq)];
+    }
+}
+
+__global__ void redo_scatter_kernel(const int* __restrict__ list, const int* __restrict__ count, int k,
+                                    const float* __restrict__ d, const int64_t* __restrict__ i64, const int* __restrict__ i32,
+                                    float* __restrict__ out_d, int64_t* __restrict__ out_i, int* __restrict__ out_i32) {
+    const int n = *count;
+    for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < (int64_t)n * k; e += (int64_t)gridDim.x * blockDim.x) {
+        const int j = (int)(e / k);
+        const int64_t to = (int64_t)list[j] * k + (e - (int64_t)j * k);
+        if (out_d) out_d[to] = d[e];
+        if (out_i) out_i[to] = i64[e];
+        if (out_i32) out_i32[to] = i32[e];
+    }
+}
+
+int launch_redo_gather(const int* flag, const int* ovf_mark, int nq, const float* q, int ldq, const float* q_sq, const float* q_nrm,
+                       const float* thr, int* list, int* count, float* q_out, float* q_sq_out, float* q_nrm_out, float* thr_out,
+                       int limit, int* all_flag, hipStream_t s) {
+    hipLaunchKernelGGL(redo_gather_kernel, dim3(1), dim3(1024), 0, s, flag, ovf_mark, nq, q, ldq, q_sq, q_nrm, thr, list, count,
+                       q_out, q_sq_out, q_nrm_out, thr_out, limit, all_flag);
+    VDB_HIP(hipGetLastError());
+    return VDB_OK;
+}
+
+int launch_redo_scatter(const int* list, const int* count, int nq, int k, const float* d, const int64_t* i64, const int* i32,
+                        float* out_d, int64_t* out_i, int* out_i32, hipStream_t s) {
+    const int blocks = (int)std::min<int64_t>(((int64_t)nq * k + 255) / 256, 256);
+    hipLaunchKernelGGL(redo_scatter_kernel, dim3(blocks), dim3(256), 0, s, list, count, k, d, i64, i32, out_d, out_i, out_i32);
+    VDB_HIP(hipGetLastError());
+    return VDB_OK;
 }
 
 }  // namespace vdb

@@ -468,6 +468,7 @@ struct QueueSelectParams {
     int nq, k;
     float* out_d; int64_t* out_i; int* out_i32;
     int* overflow;                  // set to 1 when a queue held more survivors than it has slots
+    int* ovf_mark;                  // optional [nq]: 1 for the queries whose queues did
 };
 
 template <int METRIC>
@@ -518,7 +519,10 @@ __global__ __launch_bounds__(256) void queue_select_kernel(QueueSelectParams p) 
             }
         }
     }
-    if (over) *p.overflow = 1;
+    if (__ballot(over) != 0ull && lane == 0) {
+        *p.overflow = 1;
+        if (p.ovf_mark) p.ovf_mark[q] = 1;
+    }
     if (lane < p.k) {
         const bool empty = top.eid == EMPTY_IDX;
         const int64_t at = (int64_t)q * p.k + lane;
@@ -548,6 +552,7 @@ struct PrefilterSelectParams {
     int nq, k;
     float* out_d; int64_t* out_i; int* out_i32;
     int* overflow;
+    int* ovf_mark;
 };
 
 template <int METRIC>
@@ -717,7 +722,10 @@ __global__ __launch_bounds__(256) void prefilter_select_kernel(PrefilterSelectPa
     }
     if (nc > 0) refine(nc);
 
-    if (over) *p.overflow = 1;
+    if (__ballot(over) != 0ull && lane == 0) {
+        *p.overflow = 1;
+        if (p.ovf_mark) p.ovf_mark[q] = 1;
+    }
     if (lane < p.k) {
         const bool empty = top.eid == EMPTY_IDX;
         const int64_t at = (int64_t)q * p.k + lane;
@@ -735,14 +743,17 @@ __global__ __launch_bounds__(256) void prefilter_select_kernel(PrefilterSelectPa
 // row norm.  Products that could overflow, or norms that are not numbers, send the search to the fp32 kernel.
 __global__ void prefilter_slack_kernel(int metric, const float* __restrict__ q_nrm, const float* __restrict__ max_row_nrm,
                                        int nq, int dim, float* __restrict__ slack, float* __restrict__ widen_thr,
-                                       int* __restrict__ overflow) {
+                                       int* __restrict__ overflow, int* __restrict__ ovf_mark) {
     const int q = blockIdx.x * blockDim.x + threadIdx.x;
     if (q >= nq) return;
     const float qn = q_nrm[q];
     const float big = *max_row_nrm;
     const float rel = (0.0078278f + (float)dim * 2.4e-7f) * 1.0001f;
     const float prod = qn * big;
-    if (!(prod < 1e37f)) *overflow = 1;
+    if (!(prod < 1e37f)) {
+        *overflow = 1;
+        if (ovf_mark) ovf_mark[q] = 1;
+    }
     const float tiny = sqrtf((float)dim) * 1.2e-38f * (qn + big) + 1e-30f;
     const float sl = (metric == VDB_COSINE) ? rel * qn : rel * prod + tiny;
     slack[q] = sl;
@@ -770,9 +781,9 @@ __global__ void max_norm_kernel(const float* __restrict__ nrm, int64_t n0, int64
 }
 
 int launch_prefilter_slack(int metric, const float* q_nrm, const float* max_row_nrm, int nq, int dim, float* slack,
-                           float* widen_thr, int* overflow, hipStream_t s) {
+                           float* widen_thr, int* overflow, hipStream_t s, int* ovf_mark) {
     hipLaunchKernelGGL(prefilter_slack_kernel, dim3((nq + 255) / 256), dim3(256), 0, s, metric, q_nrm, max_row_nrm, nq, dim,
-                       slack, widen_thr, overflow);
+                       slack, widen_thr, overflow, ovf_mark);
     VDB_HIP(hipGetLastError());
     return VDB_OK;
 }
@@ -790,11 +801,13 @@ int launch_max_norm(const float* row_nrm, int64_t n0, int64_t n1, float* max_nrm
 // minimum is the distance of a real row, and minima of different lanes belong to different rows, so
 // the k-th smallest of them is at least the k-th best distance of the whole row set.
 __global__ __launch_bounds__(256) void kth_of_minima_kernel(const float* __restrict__ mins, int n_lists, int nq, int k,
-                                                            float* __restrict__ thr, int* __restrict__ clear) {
+                                                            float* __restrict__ thr, int* __restrict__ clear,
+                                                            int* __restrict__ clear_marks) {
     const int lane = threadIdx.x & 63;
     const int q = blockIdx.x * 4 + (threadIdx.x >> 6);
     if (clear && blockIdx.x == 0 && threadIdx.x == 0) *clear = 0;      // the overflow flag of the pass that follows
     if (q >= nq) return;
+    if (clear_marks && lane == 0) clear_marks[q] = 0;                   // and its per-query marks
     WaveTopK top;
     top.init(k);
     for (int l0 = 0; l0 < n_lists; l0 += 64) {
@@ -846,7 +859,8 @@ static int launch_min_pass(int metric, QueueParams& p, hipStream_t s) {
 }
 
 int launch_flat_min_sample(const Rows& r, int metric, const void* q, const float* q_sq, const float* q_nrm, int nq, int k,
-                           const uint32_t* mask, int sample_tiles, int tile_stride, float* mins, float* thr, int* clear_flag, hipStream_t s) {
+                           const uint32_t* mask, int sample_tiles, int tile_stride, float* mins, float* thr, int* clear_flag, hipStream_t s,
+                           int* clear_marks) {
     VDB_REQUIRE(flat_queue_fast_ok(r) && sample_tiles >= 1 && k >= 1 && k <= 64, "bad bound pass arguments");
     QueueParams p{};
     p.rows = r.bf16 ? (const void*)r.data16 : (const void*)r.data; p.n = r.n;
@@ -855,7 +869,7 @@ int launch_flat_min_sample(const Rows& r, int metric, const void* q, const float
     p.n_tiles = sample_tiles; p.tile_stride = tile_stride; p.min_out = mins;
     plan_grid(p.n_tiles, nq, ctx().num_cus, &p.n_qtiles, &p.n_slabs, &p.tiles_per_slab);
     VDB_TRY(r.bf16 ? launch_min_pass<true>(metric, p, s) : launch_min_pass<false>(metric, p, s));
-    hipLaunchKernelGGL(kth_of_minima_kernel, dim3((nq + 3) / 4), dim3(256), 0, s, mins, 2 * p.n_slabs, nq, k, thr, clear_flag);
+    hipLaunchKernelGGL(kth_of_minima_kernel, dim3((nq + 3) / 4), dim3(256), 0, s, mins, 2 * p.n_slabs, nq, k, thr, clear_flag, clear_marks);
     VDB_HIP(hipGetLastError());
     return VDB_OK;
 }
@@ -906,7 +920,8 @@ static int launch_queue(int metric, QueueParams& p, bool fast, hipStream_t s) {
 
 int launch_flat_queue(const Rows& r, int metric, const void* q, const float* q_sq, const float* q_nrm, int nq, int k,
                       const uint32_t* mask, const float* thr, int n_slabs, int cap, void* queue, int* counts,
-                      int* overflow, float* out_d, int64_t* out_i, int* out_i32, hipStream_t s, const PrefilterArgs* pf) {
+                      int* overflow, float* out_d, int64_t* out_i, int* out_i32, hipStream_t s, const PrefilterArgs* pf,
+                      int* ovf_mark) {
     VDB_REQUIRE(k >= 1 && k <= 64, "queue selection supports 1 <= k <= 64, got %d", k);
     VDB_REQUIRE(r.n >= 1 && r.n < (1LL << 31) && nq >= 1 && thr != nullptr, "bad queue search arguments");
     QueueParams p{};
@@ -934,7 +949,7 @@ int launch_flat_queue(const Rows& r, int metric, const void* q, const float* q_s
         fp.queue = p.queue; fp.counts = counts; fp.n_slabs = n_slabs; fp.cap = cap;
         fp.rows = pf->rows32; fp.ld = pf->ld32; fp.q = pf->q32; fp.ldq = pf->ldq32;
         fp.row_sq = r.sq; fp.row_nrm = r.nrm; fp.q_sq = q_sq; fp.q_nrm = q_nrm; fp.slack = pf->slack;
-        fp.nq = nq; fp.k = k; fp.out_d = out_d; fp.out_i = out_i; fp.out_i32 = out_i32; fp.overflow = overflow;
+        fp.nq = nq; fp.k = k; fp.out_d = out_d; fp.out_i = out_i; fp.out_i32 = out_i32; fp.overflow = overflow; fp.ovf_mark = ovf_mark;
         const dim3 fgrid((nq + 3) / 4);
         switch (metric) {
             case VDB_EUCLIDEAN: hipLaunchKernelGGL(prefilter_select_kernel<VDB_EUCLIDEAN>, fgrid, dim3(256), 0, s, fp); break;
@@ -948,7 +963,7 @@ int launch_flat_queue(const Rows& r, int metric, const void* q, const float* q_s
     QueueSelectParams sp{};
     sp.queue = p.queue; sp.counts = counts; sp.n_slabs = n_slabs; sp.cap = cap;
     sp.row_sq = r.sq; sp.row_nrm = r.nrm; sp.q_sq = q_sq; sp.q_nrm = q_nrm; sp.nq = nq; sp.k = k;
-    sp.out_d = out_d; sp.out_i = out_i; sp.out_i32 = out_i32; sp.overflow = overflow;
+    sp.out_d = out_d; sp.out_i = out_i; sp.out_i32 = out_i32; sp.overflow = overflow; sp.ovf_mark = ovf_mark;
     const dim3 sgrid((nq + 3) / 4);
     switch (metric) {
         case VDB_EUCLIDEAN: hipLaunchKernelGGL(queue_select_kernel<VDB_EUCLIDEAN>, sgrid, dim3(256), 0, s, sp); break;

@@ -152,7 +152,9 @@ int flat_gemm_sample_plan(int64_t n, int* sample_tiles, int* tile_stride);
 int launch_flat_gemm_topk(const Rows& r, int metric, const void* q, const float* q_sq, const float* q_nrm,
                           int nq, int k, const uint32_t* mask, const float* lb_d, const int64_t* lb_k,
                           const float* thr_init, int sample_tiles, int tile_stride,
-                          float* part_d, int* part_i, int n_cand, hipStream_t s, const int* run_if = nullptr);
+                          float* part_d, int* part_i, int n_cand, hipStream_t s, const int* run_if = nullptr,
+                          const int* q_count = nullptr);
+// `q_count` (device): only the first *q_count of the nq queries are searched (the grid is laid out for nq).
 // MFMA path with a known per-query bound of the k-th best distance (`thr`): survivors of the
 // bound go to queues of `cap` entries per (query, slab) and the k best of them come out directly.
 // `*overflow` is set to 1 when a queue was too small (the caller then repeats the search with
@@ -165,7 +167,7 @@ bool flat_queue_fast_ok(const Rows& r);
 int flat_min_sample_lists(int sample_tiles, int nq, int k, int* n_slabs);
 int launch_flat_min_sample(const Rows& r, int metric, const void* q, const float* q_sq, const float* q_nrm, int nq, int k,
                            const uint32_t* mask, int sample_tiles, int tile_stride, float* mins, float* thr,
-                           int* clear_flag, hipStream_t s);
+                           int* clear_flag, hipStream_t s, int* clear_marks = nullptr);
 int flat_queue_plan(const Rows& r, int nq, int k, int sample_stride, int* n_slabs, int* cap, bool loosened = false);
 // bf16 rows with whole 128-byte column steps and whole readable 256-row tiles take the 256 x 256 kernel
 bool queue_use_wide(const Rows& r);
@@ -184,13 +186,25 @@ struct PrefilterArgs {
 // (per-query bounds of the k-th best distance found on the bf16 copies) every bound is raised to what the exact
 // distances of the same k rows cannot exceed.
 int launch_prefilter_slack(int metric, const float* q_nrm, const float* max_row_nrm, int nq, int dim, float* slack,
-                           float* widen_thr, int* overflow, hipStream_t s);
+                           float* widen_thr, int* overflow, hipStream_t s, int* ovf_mark = nullptr);
 // max over row_nrm[n0, n1) folded into *max_nrm (a device float that starts at 0; a NaN norm wins)
 int launch_max_norm(const float* row_nrm, int64_t n0, int64_t n1, float* max_nrm, hipStream_t s);
 int launch_flat_queue(const Rows& r, int metric, const void* q, const float* q_sq, const float* q_nrm, int nq, int k,
                       const uint32_t* mask, const float* thr, int n_slabs, int cap, void* queue, int* counts,
                       int* overflow, float* out_d, int64_t* out_i, int* out_i32, hipStream_t s,
-                      const PrefilterArgs* pf = nullptr);
+                      const PrefilterArgs* pf = nullptr, int* ovf_mark = nullptr);
+// The queries whose queues overflowed (ovf_mark[q] != 0), searched again alone.  launch_redo_gather (one block) lists
+// them in ascending order, writes their number to *count and copies their padded rows, norm terms and bounds to
+// compact arrays; the list kernel then runs over those (q_count = count, a grid laid out for `limit` queries so that
+// it fills the GPU), the selection writes compact results, and launch_redo_scatter moves result row j to query
+// list[j].  More than `limit` marked queries: *count = 0 and *all_flag = 1, the caller's whole-batch repeat runs behind
+// all_flag instead.  Nothing runs while *flag is zero (*count = 0, *all_flag = 0).
+int flat_gemm_query_tile();
+int launch_redo_gather(const int* flag, const int* ovf_mark, int nq, const float* q, int ldq, const float* q_sq, const float* q_nrm,
+                       const float* thr, int* list, int* count, float* q_out, float* q_sq_out, float* q_nrm_out, float* thr_out,
+                       int limit, int* all_flag, hipStream_t s);
+int launch_redo_scatter(const int* list, const int* count, int nq, int k, const float* d, const int64_t* i64, const int* i32,
+                        float* out_d, int64_t* out_i, int* out_i32, hipStream_t s);
 // MFMA path, full distance matrix out[nq][n]
 int launch_flat_gemm_dist(const Rows& r, int metric, const void* q, const float* q_sq, const float* q_nrm,
                           int nq, float* out, hipStream_t s);
