@@ -2636,7 +2636,7 @@ int vdb_pq_lut(vdb_pq* h, const float* query, float* out_lut) {
 // bound pass of the PQ scan: blocks, tiles of 256 rows per block at most, smallest code set that gets one
 static constexpr int PQ_BOUND_SPLITS = 192;
 static constexpr int64_t PQ_BOUND_TILES_PER_BLOCK = 8;
-static constexpr int64_t PQ_BOUND_MIN_TILES = 16384;
+static constexpr int64_t PQ_BOUND_MIN_TILES = 256;      // 65 536 codes (measured faster from 100 k codes on, one query or eight)
 
 static int pq_search_impl(vdb_pq* h, const float* d_q, int nq, int k, const uint32_t* d_mask,
                           float* d_out_d, int64_t* d_out_i, hipStream_t s) {
