@@ -213,3 +213,12 @@ def test_full_size_lloyd_steps_against_the_oracle(nat):
                 want /= np.float64(len(members))               # fp32 row /= float64 count, cast back (ivf.py:186-187)
                 np.testing.assert_array_equal(new[c], want, err_msg=f"step {step}, cluster {c}")
     tr.close(); store.close()
+
+
+def test_kmeans_pp_over_identical_rows_raises_like_the_reference():
+    """All rows equal: after the first centroid every weight is 0 and the reference's rng.choice(p=0/0) raises
+    ValueError("probabilities contain NaN") (index/ivf.py:224); so does the device path, instead of picking a row."""
+    from vectordb_amd.index.ivf import KMeans
+    x = np.ones((500, 8), dtype=np.float32)
+    with pytest.raises(ValueError, match="probabilities contain NaN"):
+        KMeans(n_clusters=4, n_iter=3, seed=1).fit(x)

@@ -67,12 +67,17 @@ def test_static_scratch_search_equals_allocating_search(nat):
         torch.cuda.synchronize()
         assert nat.device_info()["memory_free"] >= free_before
 
+    # a streamed batch whose [queries][rows] buffer would not fit is cut into blocks of queries that do
+    q_many = torch.randn((300, d), device="cuda", dtype=torch.float32, generator=g)
+    (ad, ar), (sd, sr) = _both(nat, store, q_many, 10, nat.CHEBYSHEV)
+    assert np.array_equal(ar, sr) and np.array_equal(ad, sd)
     # a call whose workspaces exceed the array is refused with a clear error, and the next call still works
-    q_huge = torch.randn((4096, d), device="cuda", dtype=torch.float32, generator=g)
-    od = torch.empty((4096, 10), device="cuda", dtype=torch.float32)
-    orow = torch.empty((4096, 10), device="cuda", dtype=torch.int64)
+    q_huge = torch.randn((65536, d), device="cuda", dtype=torch.float32, generator=g)
+    od = torch.empty((65536, 32), device="cuda", dtype=torch.float32)
+    orow = torch.empty((65536, 32), device="cuda", dtype=torch.int64)
     with pytest.raises(ValueError, match="static scratch"):
-        store.search_device_static(q_huge.data_ptr(), 4096, 10, nat.MANHATTAN, od.data_ptr(), orow.data_ptr())
+        store.search_device_static(q_huge.data_ptr(), 65536, 32, nat.COSINE, od.data_ptr(), orow.data_ptr())
+    del q_huge, od, orow
     (ad, ar), (sd, sr) = _both(nat, store, q_small, 10, nat.COSINE)
     assert np.array_equal(ar, sr) and np.array_equal(ad, sd)
     store.close()

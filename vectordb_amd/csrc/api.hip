@@ -477,7 +477,10 @@ static constexpr int FLAT_BOUND_QUEUE = 4096;     // (distance, row) entries per
 static int stream_flat_search(vdb_rows* h, Workspace& ws, int metric, const float* q, int nq, int k, int64_t k_eff,
                               const uint32_t* d_mask, float* d_out_d, int64_t* d_out_i, int* d_out_i32, hipStream_t s) {
     Rows& r = h->r;
-    const int q_block = (int)std::max<int64_t>(1, std::min<int64_t>(nq, CAND_BUDGET / (r.n * (int64_t)sizeof(float))));
+    // queries per pass: what the candidate buffer [queries][rows] may take; from the static scratch, half of what is left
+    int64_t budget = CAND_BUDGET;
+    if (ws.cand.arena) budget = std::min<int64_t>(budget, (int64_t)(ws.cand.arena->size - std::min(ws.cand.arena->size, ws.cand.arena->used)) / 2);
+    const int q_block = (int)std::max<int64_t>(1, std::min<int64_t>(nq, budget / (r.n * (int64_t)sizeof(float))));
     const int64_t ntiles = (r.n + 255) / 256;
     const int kmax = (int)std::min<int64_t>(KMAX_FUSED, k_eff);
     const bool multi = k_eff > KMAX_FUSED;
@@ -1122,6 +1125,7 @@ int vdb_init(int device) {
     // device address of the static scratch on THIS device (the device is current here); the library
     // never runs on a second device in one process, so one pointer is all there is to keep
     VDB_TRY(resolve_scratch(&c.scratch));
+    if (!c.scratch_done) VDB_HIP(hipEventCreateWithFlags(&c.scratch_done, hipEventDisableTiming));
     c.device = device;
     return VDB_OK;
 }
@@ -1404,7 +1408,23 @@ int vdb_flat_search_static_dev(vdb_rows* h, int metric, const float* d_queries, 
     arena.size = VDB_STATIC_SCRATCH_BYTES;
     Workspace ws;
     ws.bind(&arena);
-    return flat_search_impl(h, metric, d_queries, nq, k, d_mask, d_out_dist, d_out_row, nullptr, pick_stream(stream), &ws);
+    hipStream_t s = pick_stream(stream);
+    // Calls from different streams or handles share the array: each waits on the device for the one before it (an
+    // event made once at initialisation; nothing is allocated here).  A stream that is being captured into a graph
+    // is left alone: the order of the graph's own nodes is the caller's.
+    hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
+    if (hipStreamIsCapturing(s, &cap) != hipSuccess) { (void)hipGetLastError(); cap = hipStreamCaptureStatusNone; }
+    const bool ordered = cap == hipStreamCaptureStatusNone && ctx().scratch_done != nullptr;
+    if (ordered && ctx().scratch_used) VDB_HIP(hipStreamWaitEvent(s, ctx().scratch_done, 0));
+    const int st = flat_search_impl(h, metric, d_queries, nq, k, d_mask, d_out_dist, d_out_row, nullptr, s, &ws);
+    if (ordered) {
+        VDB_HIP(hipEventRecord(ctx().scratch_done, s));
+        ctx().scratch_used = true;
+    }
+    // the overflow flag of this call lies in the shared array, where the next call of any handle writes: it is not
+    // kept (vdb_flat_search_stats reports no overflow for such a call; the results are complete either way)
+    h->last_flag = nullptr;
+    return st;
 }
 
 int vdb_flat_search_stats(vdb_rows* h, int* used_queue, int* overflowed) {
@@ -1674,21 +1694,27 @@ int vdb_kmeans_init_pp(vdb_kmeans* h, int64_t first_row, const double* uniforms,
     const Rows& x = h->x();
     vdb_rows* xs = h->sub ? h->sub : h->train;
     const int k = h->k;
-    VDB_TRY(h->chosen.reserve((size_t)k * sizeof(int64_t)));
+    VDB_TRY(h->chosen.reserve(((size_t)k + 1) * sizeof(int64_t)));        // the chosen rows, then one error word
     VDB_TRY(h->dist.reserve((size_t)x.n * sizeof(float)));
     VDB_TRY(h->nearest.reserve((size_t)x.n * sizeof(float)));
     VDB_TRY(h->bsums.reserve((size_t)km_pp_blocks(x.n) * sizeof(double)));
     VDB_TRY(h->qrow.reserve((size_t)h->dsub * sizeof(float) + 64));
     long long* chosen = h->chosen.as<long long>();
     VDB_HIP(hipMemcpyAsync(chosen, &first_row, sizeof(int64_t), hipMemcpyHostToDevice, s));
+    VDB_HIP(hipMemsetAsync(chosen + k, 0, sizeof(int64_t), s));
     for (int j = 1; j < k; ++j) {
         // distances of every row to the centroid chosen last: pairwise_euclidean against ONE new centroid; the
         // minimum over all chosen ones is kept as a running minimum (min is exact, so the result is the same)
         VDB_TRY(launch_km_gather(x.data, x.ld, h->dsub, chosen + (j - 1), nullptr, 1, h->qrow.as<float>(), nullptr, s));
         VDB_TRY(flat_distances_impl(xs, VDB_EUCLIDEAN, h->qrow.as<float>(), 1, h->dist.as<float>(), s));
         VDB_TRY(launch_km_pp_step(h->dist.as<float>(), x.n, j == 1, h->nearest.as<float>(), h->bsums.as<double>(),
-                                  uniforms[j - 1], chosen + j, s));
+                                  uniforms[j - 1], chosen + j, chosen + k, s));
     }
+    int64_t bad_weights = 0;
+    VDB_HIP(hipMemcpyAsync(&bad_weights, chosen + k, sizeof(int64_t), hipMemcpyDeviceToHost, s));
+    VDB_HIP(hipStreamSynchronize(s));
+    VDB_REQUIRE(bad_weights == 0, "probabilities contain NaN: every training row coincides with a centroid chosen so far "
+                                  "(k-means++ over fewer distinct rows than clusters), or a distance is not a number");
     VDB_TRY(launch_km_gather(x.data, x.ld, h->dsub, chosen, nullptr, k, h->cur32.as<float>(), h->cur64.as<double>(), s));
     if (out_rows) VDB_HIP(hipMemcpyAsync(out_rows, chosen, (size_t)k * sizeof(int64_t), hipMemcpyDeviceToHost, s));
     VDB_HIP(hipStreamSynchronize(s));

@@ -317,7 +317,7 @@ __global__ __launch_bounds__(256) void km_pp_update_kernel(const float* __restri
 // One block: scan of the block sums, then of the 1024 entries of the block the draw falls into.
 __global__ __launch_bounds__(1024) void km_pp_select_kernel(const float* __restrict__ nearest, int64_t n,
                                                             const double* __restrict__ block_sums, int64_t nb, double u,
-                                                            long long* __restrict__ chosen) {
+                                                            long long* __restrict__ chosen, long long* __restrict__ bad_weights) {
     __shared__ double sh[1024];
     __shared__ double carry, total_s, before_s;
     __shared__ long long pick_block;
@@ -333,6 +333,13 @@ __global__ __launch_bounds__(1024) void km_pp_select_kernel(const float* __restr
     if (tid == 0) { total_s = sh[0]; carry = 0.0; pick_block = -1; before_s = 0.0; }
     __syncthreads();
     const double total = total_s;
+    if (!(total > 0.0) || !(total < INFINITY)) {
+        // every row coincides with a chosen centroid (or a distance is not a number): the weights are 0/0, and the
+        // reference's rng.choice raises "probabilities contain NaN" (ivf.py:224).  Row 0 keeps the rounds that are
+        // already enqueued inside the buffers; the caller reports the error.
+        if (tid == 0) { chosen[0] = 0; *bad_weights = 1; }
+        return;
+    }
     for (int64_t b0 = 0; b0 < nb; b0 += 1024) {
         const int64_t b = b0 + tid;
         const double v = b < nb ? block_sums[b] : 0.0;
@@ -462,10 +469,10 @@ int launch_km_assign_f64(const float* x, int ldx, int dsub, int64_t n, const flo
 int64_t km_pp_blocks(int64_t n) { return (n + PP_BLOCK - 1) / PP_BLOCK; }
 
 int launch_km_pp_step(const float* dist, int64_t n, bool first, float* nearest, double* block_sums, double u,
-                      long long* chosen, hipStream_t s) {
+                      long long* chosen, long long* bad_weights, hipStream_t s) {
     const int64_t nb = km_pp_blocks(n);
     hipLaunchKernelGGL(km_pp_update_kernel, dim3((unsigned)nb), dim3(256), 0, s, dist, n, first ? 1 : 0, nearest, block_sums);
-    hipLaunchKernelGGL(km_pp_select_kernel, dim3(1), dim3(1024), 0, s, nearest, n, block_sums, nb, u, chosen);
+    hipLaunchKernelGGL(km_pp_select_kernel, dim3(1), dim3(1024), 0, s, nearest, n, block_sums, nb, u, chosen, bad_weights);
     VDB_HIP(hipGetLastError());
     return VDB_OK;
 }

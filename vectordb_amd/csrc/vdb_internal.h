@@ -48,6 +48,8 @@ struct Context {
     int num_cus = 256;
     float* zeros = nullptr;         // 256 zero bytes in device memory
     void* scratch = nullptr;        // device address of the static scratch array (no-allocation entry point)
+    hipEvent_t scratch_done = nullptr;  // recorded behind the last call that used the array; the next one waits for it
+    bool scratch_used = false;
     std::mutex mu;                  // guards initialisation only
 };
 Context& ctx();
@@ -432,6 +434,6 @@ int launch_km_assign_f64(const float* x, int ldx, int dsub, int64_t n, const flo
                          int k, int* assign, hipStream_t s);
 int64_t km_pp_blocks(int64_t n);
 int launch_km_pp_step(const float* dist, int64_t n, bool first, float* nearest, double* block_sums, double u,
-                      long long* chosen, hipStream_t s);
+                      long long* chosen, long long* bad_weights, hipStream_t s);
 
 }  // namespace vdb

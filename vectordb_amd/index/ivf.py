@@ -160,7 +160,12 @@ class KMeans:
         def body(tr):
             first = self._rng.randint(n)
             uniforms = self._rng.random_sample(self.n_clusters - 1)
-            tr.init_pp(first, uniforms)
+            try:
+                tr.init_pp(first, uniforms)
+            except N.NativeError as e:
+                if "probabilities contain NaN" in str(e):         # what rng.choice raises there (ivf.py:224)
+                    raise ValueError("probabilities contain NaN") from e
+                raise
             return tr.centroids()
 
         return self._with_trainer(vectors, trainer, body)
