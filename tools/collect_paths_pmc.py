@@ -28,7 +28,8 @@ fetch = per_kernel(glob.glob(src + "/pmc_fetch/*/*counter_collection.csv")[0], l
 write = per_kernel(glob.glob(src + "/pmc_write/*/*counter_collection.csv")[0], lambda r: float(r["Counter_Value"]) if r["Counter_Name"] == "WRITE_SIZE" else None)
 rows = []
 for k, ds in dur.items():
-    if not any(s in k for s in ("stream_sums_kernel", "pq_scan_kernel", "topk_cand_kernel")):
+    if not any(s in k for s in ("stream_sums_kernel", "pq_scan_kernel", "pq_scan8_kernel", "topk_cand_kernel", "ivf_approx_kernel",
+                                "ivf_exact_dist_kernel", "ivf_bound_kernel", "rowreg_sums_kernel")):
         continue
     if len(fetch.get(k, [])) != len(ds) or len(write.get(k, [])) != len(ds):
         continue
