@@ -617,6 +617,54 @@ static int shadow_sync(vdb_rows* h, hipStream_t s) {
     return VDB_OK;
 }
 
+// Nearest row of every query of a large batch (k = 1, Euclidean forms, fp32 rows, no filter): k-means assignment and
+// index builds.  The branch-free kernel keeps a running (smallest, second smallest, row) per lane instead of lists
+// (launch_flat_argmin); the few queries whose two best keys are too close for the clamp and square root of the list
+// kernel to tell apart are searched again by the list kernel itself, so every result is the list kernel's.
+static int flat_nearest_row(vdb_rows* h, Workspace& ws, int metric, const float* q, int nq, float* d_out_d, int64_t* d_out_i,
+                            int* d_out_i32, hipStream_t s) {
+    Rows& r = h->r;
+    const int lists = flat_argmin_lists(r, nq);
+    const int lim = std::min(nq, std::max(128, nq / 64));
+    int n_cand = 0, n_cand_redo = 0;
+    VDB_TRY(flat_gemm_num_cand(r.n, nq, 1, &n_cand));
+    VDB_TRY(flat_gemm_num_cand(r.n, lim, 1, &n_cand_redo));
+    const size_t parts = std::max((size_t)nq * n_cand, (size_t)lim * n_cand_redo);
+    const size_t d_bytes = ((size_t)lim * sizeof(float) + 7) / 8 * 8;
+    VDB_TRY(ws.mins.reserve((size_t)nq * lists * sizeof(float4)));
+    VDB_TRY(ws.redo_list.reserve(((size_t)lim + 4) * sizeof(int)));
+    VDB_TRY(ws.redo_q.reserve((size_t)lim * r.ld * sizeof(float)));
+    VDB_TRY(ws.redo_terms.reserve((size_t)lim * 2 * sizeof(float)));
+    VDB_TRY(ws.redo_out.reserve(d_bytes + (size_t)lim * (sizeof(int64_t) + sizeof(int))));
+    VDB_TRY(ws.part_d.reserve(parts * sizeof(float)));
+    VDB_TRY(ws.part_i.reserve(parts * sizeof(int)));
+    int* list = ws.redo_list.as<int>();
+    int* wanted = list + lim;
+    int* q_count = wanted + 1;
+    int* all_flag = wanted + 2;
+    float* t_sq = ws.redo_terms.as<float>();
+    float* t_nrm = t_sq + lim;
+    float* c_d = ws.redo_out.as<float>();
+    int64_t* c_i = reinterpret_cast<int64_t*>(ws.redo_out.as<char>() + d_bytes);
+    int* c_i32 = reinterpret_cast<int*>(c_i + lim);
+    VDB_HIP(hipMemsetAsync(wanted, 0, 3 * sizeof(int), s));
+    VDB_TRY(launch_flat_argmin(r, metric, q, ws.q_sq.as<float>(), nq, ws.mins.p, d_out_d, d_out_i, d_out_i32, 1, list, wanted, lim, s));
+    VDB_TRY(launch_redo_gather_list(list, wanted, lim, q, r.ld, ws.q_sq.as<float>(), ws.q_nrm.as<float>(), ws.redo_q.as<float>(),
+                                    t_sq, t_nrm, q_count, all_flag, s));
+    VDB_TRY(launch_flat_gemm_topk(r, metric, ws.redo_q.as<float>(), t_sq, t_nrm, lim, 1, nullptr, nullptr, nullptr, nullptr, 0, 1,
+                                  ws.part_d.as<float>(), ws.part_i.as<int>(), n_cand_redo, s, nullptr, q_count));
+    {
+        SelectOut o{c_d, d_out_i ? c_i : nullptr, d_out_i32 ? c_i32 : nullptr, 1, 0, nullptr, nullptr, nullptr};
+        VDB_TRY(launch_select(ws.part_d.as<float>(), ws.part_i.as<int>(), lim, n_cand_redo, 1, 1 << 30, nullptr, 0, o, s, ws.mid));
+    }
+    VDB_TRY(launch_redo_scatter(list, q_count, lim, 1, c_d, c_i, c_i32, d_out_d, d_out_i, d_out_i32, s));
+    // more unsure queries than the list holds (duplicated rows, say): the whole batch through the list kernel
+    VDB_TRY(launch_flat_gemm_topk(r, metric, q, ws.q_sq.as<float>(), ws.q_nrm.as<float>(), nq, 1, nullptr, nullptr, nullptr, nullptr,
+                                  0, 1, ws.part_d.as<float>(), ws.part_i.as<int>(), n_cand, s, all_flag));
+    SelectOut o{d_out_d, d_out_i, d_out_i32, 1, 0, nullptr, nullptr, all_flag};
+    return launch_select(ws.part_d.as<float>(), ws.part_i.as<int>(), nq, n_cand, 1, 1 << 30, nullptr, 0, o, s, ws.mid);
+}
+
 // ---- flat search on device pointers ------------------------------------
 // `ws_in` replaces the handle's own workspace (the no-allocation entry point passes one bound to the static scratch)
 static int flat_search_impl(vdb_rows* h, int metric, const float* d_q, int nq, int k, const uint32_t* d_mask,
@@ -647,6 +695,10 @@ static int flat_search_impl(vdb_rows* h, int metric, const float* d_q, int nq, i
         const bool gemm = is_dot_metric(metric) && nq >= GEMM_MIN_NQ;
         if (!gemm) return stream_flat_search(h, ws, metric, qf, nq, k, k_eff, d_mask, d_out_d, d_out_i, d_out_i32, s);
         q = qf;
+        const bool no_argmin = getenv("VDB_NO_ARGMIN") != nullptr;           // read per call: tests compare both paths
+        if (k == 1 && !d_mask && (metric == VDB_EUCLIDEAN || metric == VDB_EUCLIDEAN_SQ) && nq >= 1024 && r.n >= 2 &&
+            flat_queue_fast_ok(r) && ws_in == nullptr && !no_argmin)
+            return flat_nearest_row(h, ws, metric, qf, nq, d_out_d, d_out_i, d_out_i32, s);
     }
 
     int n_cand = 0, sample_tiles = 0, sample_stride = 1, n_cand_sample = 0;

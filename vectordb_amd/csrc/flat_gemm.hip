@@ -475,6 +475,34 @@ int launch_redo_gather(const int* flag, const int* ovf_mark, int nq, const float
     return VDB_OK;
 }
 
+__global__ __launch_bounds__(256) void redo_gather_list_kernel(const int* __restrict__ list, const int* __restrict__ count, int lim,
+                                                               const float* __restrict__ q, int ldq, const float* __restrict__ q_sq,
+                                                               const float* __restrict__ q_nrm, float* __restrict__ q_out,
+                                                               float* __restrict__ q_sq_out, float* __restrict__ q_nrm_out,
+                                                               int* __restrict__ q_count, int* __restrict__ all_flag) {
+    const int wanted = *count;
+    const bool fits = wanted <= lim;
+    if (blockIdx.x == 0 && threadIdx.x == 0) { *q_count = fits ? wanted : 0; *all_flag = fits ? 0 : 1; }
+    if (!fits) return;
+    for (int j = blockIdx.x; j < wanted; j += gridDim.x) {
+        const int src = list[j];
+        if (threadIdx.x == 0) {
+            q_sq_out[j] = q_sq[src];
+            if (q_nrm) q_nrm_out[j] = q_nrm[src];
+        }
+        for (int e = threadIdx.x; e < ldq; e += 256) q_out[(int64_t)j * ldq + e] = q[(int64_t)src * ldq + e];
+    }
+}
+
+int launch_redo_gather_list(const int* list, const int* count, int lim, const float* q, int ldq, const float* q_sq,
+                            const float* q_nrm, float* q_out, float* q_sq_out, float* q_nrm_out, int* q_count, int* all_flag,
+                            hipStream_t s) {
+    hipLaunchKernelGGL(redo_gather_list_kernel, dim3(std::min(lim, 512)), dim3(256), 0, s, list, count, lim, q, ldq, q_sq, q_nrm,
+                       q_out, q_sq_out, q_nrm_out, q_count, all_flag);
+    VDB_HIP(hipGetLastError());
+    return VDB_OK;
+}
+
 int launch_redo_scatter(const int* list, const int* count, int nq, int k, const float* d, const int64_t* i64, const int* i32,
                         float* out_d, int64_t* out_i, int* out_i32, hipStream_t s) {
     const int blocks = (int)std::min<int64_t>(((int64_t)nq * k + 255) / 256, 256);

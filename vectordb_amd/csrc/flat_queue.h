@@ -25,7 +25,12 @@ struct QueueParams {
     // t * tile_stride, and every lane's smallest distance goes to min_out[(query * n_slabs + slab) * 2 + half]
     int tile_stride;
     float* min_out;
+    // nearest-row pass (flat_queue_fast_kernel<..., MODE = QMODE_ARGMIN>): every lane's smallest and second smallest
+    // key and the row of the smallest go to arg_out[(query * n_slabs + slab) * 2 + half] = (key1, key2, row bits, -)
+    float4* arg_out;
 };
+
+enum { QMODE_QUEUE = 0, QMODE_MINPASS = 1, QMODE_ARGMIN = 2 };
 
 // filter_bound<>() for dot products that are only known to within `slack`
 template <int METRIC>
@@ -58,6 +63,35 @@ __device__ __forceinline__ float min_key16(const f32x16& a, const float* rs, int
 #pragma unroll
     for (int e = 1; e < 16; ++e) m = fminf(m, v[e]);
     return m;
+}
+
+// The lane's running smallest key b1 (at row bi) and second smallest b2 over the 16 values of one accumulator,
+// Euclidean forms only: key = the pre-clamp term of finish<>().  Rows reach a lane in ascending order and the
+// comparison is strict, so of equal keys the first row stays.  v_med3 keeps (b1, b2) sorted: the new b2 is the
+// median of (b1, key, b2).
+template <int METRIC, bool MASKED>
+__device__ __forceinline__ void argmin16(const f32x16& a, const float* rs, int s, int half, float q_term, uint32_t avail,
+                                         int row0, float& b1, float& b2, int& bi) {
+    typedef float f2 __attribute__((ext_vector_type(2)));
+    const f2 qq = {q_term, q_term}, m2 = {-2.0f, -2.0f};
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+        const float4 t = *reinterpret_cast<const float4*>(rs + s * 32 + 8 * g + 4 * half);
+        // two keys per packed add and packed fma (the same roundings as the scalar forms)
+        const f2 s01 = qq + f2{t.x, t.y}, s23 = qq + f2{t.z, t.w};
+        const f2 k01 = __builtin_elementwise_fma(m2, f2{a[g * 4], a[g * 4 + 1]}, s01);
+        const f2 k23 = __builtin_elementwise_fma(m2, f2{a[g * 4 + 2], a[g * 4 + 3]}, s23);
+        const float keys[4] = {k01.x, k01.y, k23.x, k23.y};
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            float key = keys[j];
+            if (MASKED && !((avail >> (g * 4 + j)) & 1u)) key = INFINITY;
+            const bool less = key < b1;
+            b2 = __builtin_amdgcn_fmed3f(b1, key, b2);
+            bi = less ? row0 + 8 * g + j : bi;
+            b1 = fminf(b1, key);
+        }
+    }
 }
 
 // per-lane availability bits (value e = 4g + j <-> row 8g + 4*half + j of the 32-row sub-tile at r0)

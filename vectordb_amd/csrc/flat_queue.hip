@@ -239,8 +239,10 @@ __global__ __launch_bounds__(NT, 2) void flat_queue_kernel(QueueParams p) {
 // instructions back to back, so nothing is left for a separate phase to do.)
 #define VDB_FENCE() __builtin_amdgcn_sched_barrier(0)
 
-template <int METRIC, bool BF16, bool MINPASS>
+template <int METRIC, bool BF16, int MODE>
 __global__ __launch_bounds__(NT, 2) void flat_queue_fast_kernel(QueueParams p) {
+    constexpr bool MINPASS = MODE == QMODE_MINPASS;
+    constexpr bool ARGMIN = MODE == QMODE_ARGMIN;
     extern __shared__ __align__(16) float smem[];
     float* As = smem;                                   // [2][TM][LW]
     float* Bs = As + 2 * TM * LW;                       // [2][TQ][LW]
@@ -281,7 +283,9 @@ __global__ __launch_bounds__(NT, 2) void flat_queue_fast_kernel(QueueParams p) {
     float bound = 0.0f;
     float2* my_queue = nullptr;
     float best = INFINITY;                              // bound pass: this lane's smallest key
-    if (!MINPASS) {
+    float best2 = INFINITY;                             // nearest-row pass: its second smallest, and the row of the smallest
+    int best_row = -1;
+    if (MODE == QMODE_QUEUE) {
         bound = filter_bound<METRIC>(p.thr[my_q_ld], q_term);
         if (p.slack) bound = loosen_bound<METRIC>(bound, p.slack[my_q_ld]);
         if (!q_ok) bound = (METRIC == VDB_DOT || METRIC == VDB_COSINE) ? INFINITY : -INFINITY;
@@ -418,6 +422,21 @@ __global__ __launch_bounds__(NT, 2) void flat_queue_fast_kernel(QueueParams p) {
                     const uint32_t avail = masked ? avail16(p.mask, rbase + s * 32, p.n, half) : 0xFFFFu;
                     best = fminf(best, min_key16<METRIC>(acc[s], Rs + (ct & 1) * TM, s, half, q_term, avail));
                 }
+            } else if (ARGMIN) {
+                if constexpr (METRIC == VDB_EUCLIDEAN || METRIC == VDB_EUCLIDEAN_SQ) {
+                    const int64_t rbase = (int64_t)ct * TM;
+                    if ((rbase + TM > p.n) || p.mask != nullptr) {              // the last, partial tile (or a filter)
+#pragma unroll
+                        for (int s = 0; s < 4; ++s)
+                            argmin16<METRIC, true>(acc[s], Rs + (ct & 1) * TM, s, half, q_term, avail16(p.mask, rbase + s * 32, p.n, half),
+                                                   (int)rbase + s * 32 + 4 * half, best, best2, best_row);
+                    } else {
+#pragma unroll
+                        for (int s = 0; s < 4; ++s)
+                            argmin16<METRIC, false>(acc[s], Rs + (ct & 1) * TM, s, half, q_term, 0xFFFFu,
+                                                    (int)rbase + s * 32 + 4 * half, best, best2, best_row);
+                    }
+                }
             } else {
                 queue_epilogue<METRIC>(acc, Rs + (ct & 1) * TM, (int64_t)ct * TM, p.n, p.mask, half, bound, q_term,
                                        my_cnt, my_queue, p.cap);
@@ -454,6 +473,10 @@ __global__ __launch_bounds__(NT, 2) void flat_queue_fast_kernel(QueueParams p) {
             else if (METRIC == VDB_COSINE) d = (1.0f - fminf(fmaxf(-best / q_term, -1.0f), 1.0f)) + 4e-6f;
         }
         if (q_ok) p.min_out[((int64_t)my_q * p.n_slabs + slab) * 2 + half] = d;
+        return;
+    }
+    if (ARGMIN) {
+        if (q_ok) p.arg_out[((int64_t)my_q * p.n_slabs + slab) * 2 + half] = make_float4(best, best2, __int_as_float(best_row), 0.0f);
         return;
     }
     if (tid < TQ && q_base + tid < p.nq) p.counts[(q_base + tid) * p.n_slabs + slab] = Cnt[tid];
@@ -838,7 +861,7 @@ static int launch_min_pass(int metric, QueueParams& p, hipStream_t s) {
     const size_t lds = (size_t)(2 * TM * LW + 2 * TQ * LW + 2 * TM + TQ) * sizeof(float);
 #define VDB_LAUNCH_MIN(M)                                                                      \
     case M: {                                                                                  \
-        auto kern = flat_queue_fast_kernel<M, BF16, true>;                                     \
+        auto kern = flat_queue_fast_kernel<M, BF16, QMODE_MINPASS>;                            \
         VDB_TRY(raise_dynamic_lds(reinterpret_cast<const void*>(kern),                       \
                                     lds));    \
         hipLaunchKernelGGL(kern, grid, dim3(NT), lds, s, p);                                   \
@@ -874,6 +897,80 @@ int launch_flat_min_sample(const Rows& r, int metric, const void* q, const float
     return VDB_OK;
 }
 
+// --------------------------------------------------------------------------
+// Nearest row of every query (k = 1, Euclidean forms, no filter): the branch-free kernel with a per-lane running
+// (smallest key, second smallest, row) instead of queues; then per query the smallest over its lanes' entries.
+// The keys are the list kernel's own pre-clamp values (same matrix instructions in the same order, same fma), so the
+// smallest key names the row the list kernel's argmin of sqrt(max(key, 0)) names, unless keys are so close that the
+// clamp or the square root can make them equal (then the lower row wins there): a second key within 2^-20 of the
+// smallest, or a smallest key that is not positive, puts the query on a list (*count entries wanted, the first `lim`
+// kept), and the caller searches the listed ones again with the list kernel.
+__global__ __launch_bounds__(256) void argmin_finish_kernel(const float4* __restrict__ arg, int lists, int nq, int take_sqrt,
+                                                            float* __restrict__ out_d, int64_t* __restrict__ out_i,
+                                                            int* __restrict__ out_i32, int k_stride,
+                                                            int* __restrict__ list, int* __restrict__ count, int lim) {
+    const int q = blockIdx.x * blockDim.x + threadIdx.x;
+    if (q >= nq) return;
+    float b1 = INFINITY, b2 = INFINITY;
+    int bi = -1;
+    for (int l = 0; l < lists; ++l) {
+        const float4 e = arg[(int64_t)q * lists + l];
+        const int row = __float_as_int(e.z);
+        const bool less = e.x < b1 || (e.x == b1 && row >= 0 && (bi < 0 || row < bi));
+        // the second smallest of everything seen: the old smallest if it is displaced, else the entry's smallest
+        const float other = less ? b1 : e.x;
+        b2 = fminf(fminf(b2, e.y), other);
+        if (less) { b1 = e.x; bi = row; }
+    }
+    const bool unsure = !(b1 > 0.0f) || !(b2 > b1 + fabsf(b1) * 9.5367431640625e-07f) || bi < 0;
+    if (unsure) {                                   // (in any order: every query of the list gets its own result back)
+        const int slot = atomicAdd(count, 1);
+        if (slot < lim) list[slot] = q;
+    }
+    const float sq = fmaxf(b1, 0.0f);
+    const int64_t at = (int64_t)q * k_stride;
+    if (out_d) out_d[at] = bi < 0 ? INFINITY : (take_sqrt ? sqrtf(sq) : sq);
+    if (out_i) out_i[at] = bi;
+    if (out_i32) out_i32[at] = bi;
+}
+
+int flat_argmin_lists(const Rows& r, int nq) {
+    int nqt, ns, tps;
+    plan_grid((int)((r.n + TM - 1) / TM), nq, ctx().num_cus, &nqt, &ns, &tps);
+    return 2 * ns;
+}
+
+int launch_flat_argmin(const Rows& r, int metric, const void* q, const float* q_sq, int nq, void* arg_buf,
+                       float* out_d, int64_t* out_i, int* out_i32, int out_stride, int* list, int* count, int lim, hipStream_t s) {
+    VDB_REQUIRE(!r.bf16 && flat_queue_fast_ok(r) && (metric == VDB_EUCLIDEAN || metric == VDB_EUCLIDEAN_SQ) && nq >= 1 && r.n >= 1,
+                "bad nearest-row pass arguments");
+    QueueParams p{};
+    p.rows = r.data; p.n = r.n; p.ld_bytes = r.ld * 4; p.row_sq = r.sq; p.row_nrm = r.nrm;
+    p.q = q; p.nq = nq; p.q_sq = q_sq; p.q_nrm = nullptr; p.mask = nullptr;
+    p.n_tiles = (int)((r.n + TM - 1) / TM); p.tile_stride = 1;
+    p.arg_out = reinterpret_cast<float4*>(arg_buf);
+    plan_grid(p.n_tiles, nq, ctx().num_cus, &p.n_qtiles, &p.n_slabs, &p.tiles_per_slab);
+    const int groups = (p.n_slabs + 7) / 8;
+    const dim3 grid(p.n_slabs >= 8 ? groups * 8 * p.n_qtiles : p.n_slabs * p.n_qtiles);
+    const size_t lds = (size_t)(2 * TM * LW + 2 * TQ * LW + 2 * TM + TQ) * sizeof(float);
+    {
+        KernelTimer timer(s, true);
+        if (metric == VDB_EUCLIDEAN) {
+            auto kern = flat_queue_fast_kernel<VDB_EUCLIDEAN, false, QMODE_ARGMIN>;
+            VDB_TRY(raise_dynamic_lds(reinterpret_cast<const void*>(kern), lds));
+            hipLaunchKernelGGL(kern, grid, dim3(NT), lds, s, p);
+        } else {
+            auto kern = flat_queue_fast_kernel<VDB_EUCLIDEAN_SQ, false, QMODE_ARGMIN>;
+            VDB_TRY(raise_dynamic_lds(reinterpret_cast<const void*>(kern), lds));
+            hipLaunchKernelGGL(kern, grid, dim3(NT), lds, s, p);
+        }
+    }
+    hipLaunchKernelGGL(argmin_finish_kernel, dim3((nq + 255) / 256), dim3(256), 0, s, p.arg_out, 2 * p.n_slabs, nq,
+                       metric == VDB_EUCLIDEAN ? 1 : 0, out_d, out_i, out_i32, out_stride, list, count, lim);
+    VDB_HIP(hipGetLastError());
+    return VDB_OK;
+}
+
 int flat_queue_plan(const Rows& r, int nq, int k, int sample_stride, int* n_slabs, int* cap, bool loosened) {
     int nqt, tps;
     if (queue_use_wide(r)) plan_grid_wide((int)((r.n + WM - 1) / WM), nq, ctx().num_cus, &nqt, n_slabs, &tps);
@@ -898,7 +995,7 @@ static int launch_queue(int metric, QueueParams& p, bool fast, hipStream_t s) {
     KernelTimer timer(s, true);
 #define VDB_LAUNCH_QUEUE(M)                                                                    \
     case M: {                                                                                  \
-        auto kern = fast ? flat_queue_fast_kernel<M, BF16, false> : flat_queue_kernel<M, BF16>; \
+        auto kern = fast ? flat_queue_fast_kernel<M, BF16, QMODE_QUEUE> : flat_queue_kernel<M, BF16>; \
         VDB_TRY(raise_dynamic_lds(reinterpret_cast<const void*>(kern),                       \
                                     lds));    \
         hipLaunchKernelGGL(kern, grid, dim3(NT), lds, s, p);                                   \

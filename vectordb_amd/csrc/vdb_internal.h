@@ -171,6 +171,18 @@ int launch_flat_min_sample(const Rows& r, int metric, const void* q, const float
                            const uint32_t* mask, int sample_tiles, int tile_stride, float* mins, float* thr,
                            int* clear_flag, hipStream_t s, int* clear_marks = nullptr);
 int flat_queue_plan(const Rows& r, int nq, int k, int sample_stride, int* n_slabs, int* cap, bool loosened = false);
+// Nearest row of every query (k = 1; VDB_EUCLIDEAN or VDB_EUCLIDEAN_SQ; fp32 rows that flat_queue_fast_ok accepts; no
+// filter): out_d / out_i / out_i32 [q * out_stride] get the list kernel's result wherever the smallest key is clear
+// of the second smallest; the other queries are appended to list[] (at most lim of them; *count, zero on entry, counts
+// all) and must be searched again by the list kernel.  arg_buf: nq * flat_argmin_lists(r, nq) * 16 bytes.
+int flat_argmin_lists(const Rows& r, int nq);
+int launch_flat_argmin(const Rows& r, int metric, const void* q, const float* q_sq, int nq, void* arg_buf,
+                       float* out_d, int64_t* out_i, int* out_i32, int out_stride, int* list, int* count, int lim, hipStream_t s);
+// The listed queries' padded rows and norm terms to compact arrays (many blocks); *q_count = their number, or 0 with
+// *all_flag = 1 when more were wanted than the list holds.
+int launch_redo_gather_list(const int* list, const int* count, int lim, const float* q, int ldq, const float* q_sq,
+                            const float* q_nrm, float* q_out, float* q_sq_out, float* q_nrm_out, int* q_count, int* all_flag,
+                            hipStream_t s);
 // bf16 rows with whole 128-byte column steps and whole readable 256-row tiles take the 256 x 256 kernel
 bool queue_use_wide(const Rows& r);
 // Exact search behind a bf16 filter: `r` and `q` of launch_flat_queue are then bf16 copies (rounded to nearest) of
