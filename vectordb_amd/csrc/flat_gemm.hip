@@ -345,7 +345,7 @@ static int launch_gemm(int metric, GemmParams& p, hipStream_t s) {
     const int groups = (p.n_slabs + 7) / 8;
     const dim3 grid(p.n_slabs >= 8 ? groups * 8 * p.n_qtiles : p.n_slabs * p.n_qtiles);
     const size_t lds = (size_t)(2 * TM * LW + TM) * sizeof(float) + (TOPK ? (size_t)p.k * NT * 8 : 0);
-    KernelTimer timer(s, p.tile_stride == 1 && p.run_if == nullptr);
+    KernelTimer timer(s, p.tile_stride == 1 && p.run_if == nullptr && p.q_count == nullptr);
 #define VDB_LAUNCH_GEMM(M)                                                                     \
     case M: {                                                                                  \
         auto kern = (TOPK && p.tile_stride != 1) ? flat_gemm_kernel<M, TOPK, TOPK, BF16> : flat_gemm_kernel<M, TOPK, false, BF16>; \

@@ -371,6 +371,34 @@ __global__ __launch_bounds__(NT, 2) void flat_queue_fast_kernel(QueueParams p) {
 #define VDB_WR_A(PS) *reinterpret_cast<float4*>(wa_ + (PS) * 32 * LW) = ra##PS
 #define VDB_WR_B(PS) *reinterpret_cast<float4*>(wb_ + (PS) * 32 * LW) = rb##PS
 
+    // Nearest-row pass: the finished tile's values are taken one accumulator at a time at the start of the next
+    // tile's first step, each just before that accumulator's first matrix instructions of the new tile, so the vector
+    // ALU work runs under the matrix instructions already issued.  (Taken at the end of the tile, all four waves of a
+    // block, and the block sharing the CU, which runs in step with it, leave the matrix cores idle for its length:
+    // a third of the time at four K steps per tile.)  Rows of one K step (ksteps == 1) keep the plain order: the next
+    // tile's row terms are written at the end of the same step.
+    const bool defer = ARGMIN && ksteps >= 2;
+    auto nearest_of = [&](int s, int t) {
+        if constexpr (ARGMIN && (METRIC == VDB_EUCLIDEAN || METRIC == VDB_EUCLIDEAN_SQ)) {
+            const int64_t rbase = (int64_t)t * TM;
+            if ((rbase + TM > p.n) || p.mask != nullptr)                    // the last, partial tile (or a filter)
+                argmin16<METRIC, true>(acc[s], Rs + (t & 1) * TM, s, half, q_term, avail16(p.mask, rbase + s * 32, p.n, half),
+                                       (int)rbase + s * 32 + 4 * half, best, best2, best_row);
+            else
+                argmin16<METRIC, false>(acc[s], Rs + (t & 1) * TM, s, half, q_term, 0xFFFFu, (int)rbase + s * 32 + 4 * half,
+                                        best, best2, best_row);
+        }
+    };
+#define VDB_HEAD(S)                                                     \
+    do {                                                                \
+        if constexpr (ARGMIN) {                                         \
+            if (defer && ck == 0) {                                     \
+                if (ct > tile0) nearest_of(S, ct - 1);                  \
+                for (int e_ = 0; e_ < 16; ++e_) acc[S][e_] = 0.0f;      \
+            }                                                           \
+        }                                                               \
+    } while (0)
+
     // two steps per trip so that the stage in use is a literal: every LDS address is base + immediate
     for (int st = 0; st < n_steps; st += 2) {
 #pragma unroll
@@ -383,10 +411,10 @@ __global__ __launch_bounds__(NT, 2) void flat_queue_fast_kernel(QueueParams p) {
         float4 bf[4], af[4][4];
         VDB_RD_B(0); VDB_RD_A(0, 0); VDB_RD_A(0, 1); VDB_RD_A(0, 2); VDB_RD_A(0, 3);
         VDB_FENCE();
-        VDB_MFMA4(0, 0); VDB_RD_B(1); VDB_RD_A(1, 0); VDB_FENCE();
-        VDB_MFMA4(0, 1); VDB_RD_A(1, 1); VDB_RD_A(1, 2); VDB_FENCE();
-        VDB_MFMA4(0, 2); VDB_RD_A(1, 3); VDB_RD_B(2); VDB_FENCE();
-        VDB_MFMA4(0, 3); VDB_RD_A(2, 0); VDB_RD_A(2, 1); VDB_FENCE();
+        VDB_HEAD(0); VDB_MFMA4(0, 0); VDB_RD_B(1); VDB_RD_A(1, 0); VDB_FENCE();
+        VDB_HEAD(1); VDB_MFMA4(0, 1); VDB_RD_A(1, 1); VDB_RD_A(1, 2); VDB_FENCE();
+        VDB_HEAD(2); VDB_MFMA4(0, 2); VDB_RD_A(1, 3); VDB_RD_B(2); VDB_FENCE();
+        VDB_HEAD(3); VDB_MFMA4(0, 3); VDB_RD_A(2, 0); VDB_RD_A(2, 1); VDB_FENCE();
         VDB_MFMA4(1, 0); VDB_RD_A(2, 2); VDB_RD_A(2, 3); VDB_FENCE();
         VDB_MFMA4(1, 1); VDB_RD_B(3); VDB_RD_A(3, 0); VDB_FENCE();
         VDB_MFMA4(1, 2); VDB_RD_A(3, 1); VDB_RD_A(3, 2); VDB_FENCE();
@@ -423,19 +451,9 @@ __global__ __launch_bounds__(NT, 2) void flat_queue_fast_kernel(QueueParams p) {
                     best = fminf(best, min_key16<METRIC>(acc[s], Rs + (ct & 1) * TM, s, half, q_term, avail));
                 }
             } else if (ARGMIN) {
-                if constexpr (METRIC == VDB_EUCLIDEAN || METRIC == VDB_EUCLIDEAN_SQ) {
-                    const int64_t rbase = (int64_t)ct * TM;
-                    if ((rbase + TM > p.n) || p.mask != nullptr) {              // the last, partial tile (or a filter)
+                if (!defer) {
 #pragma unroll
-                        for (int s = 0; s < 4; ++s)
-                            argmin16<METRIC, true>(acc[s], Rs + (ct & 1) * TM, s, half, q_term, avail16(p.mask, rbase + s * 32, p.n, half),
-                                                   (int)rbase + s * 32 + 4 * half, best, best2, best_row);
-                    } else {
-#pragma unroll
-                        for (int s = 0; s < 4; ++s)
-                            argmin16<METRIC, false>(acc[s], Rs + (ct & 1) * TM, s, half, q_term, 0xFFFFu,
-                                                    (int)rbase + s * 32 + 4 * half, best, best2, best_row);
-                    }
+                    for (int s = 0; s < 4; ++s) nearest_of(s, ct);
                 }
             } else {
                 queue_epilogue<METRIC>(acc, Rs + (ct & 1) * TM, (int64_t)ct * TM, p.n, p.mask, half, bound, q_term,
@@ -446,10 +464,12 @@ __global__ __launch_bounds__(NT, 2) void flat_queue_fast_kernel(QueueParams p) {
                 if (MINPASS && METRIC == VDB_COSINE) nxt = 1.0f / nxt;
                 Rs[((ct + 1) & 1) * TM + tid] = nxt;
             }
+            if (!(ARGMIN && defer)) {
 #pragma unroll
-            for (int s = 0; s < 4; ++s)
+                for (int s = 0; s < 4; ++s)
 #pragma unroll
-                for (int e = 0; e < 16; ++e) acc[s][e] = 0.0f;
+                    for (int e = 0; e < 16; ++e) acc[s][e] = 0.0f;
+            }
             ck = 0; ++ct;
         } else {
             ++ck;
@@ -457,6 +477,11 @@ __global__ __launch_bounds__(NT, 2) void flat_queue_fast_kernel(QueueParams p) {
         __syncthreads();
       }
     }
+    if (ARGMIN && defer && n_steps > 0) {
+#pragma unroll
+        for (int s = 0; s < 4; ++s) nearest_of(s, tile1 - 1);
+    }
+#undef VDB_HEAD
 #undef VDB_LOAD_STEP
 #undef VDB_MFMA4
 #undef VDB_RD_A
