@@ -889,7 +889,8 @@ static int flat_search_impl(vdb_rows* h, int metric, const float* d_q, int nq, i
     return VDB_OK;
 }
 
-static int flat_distances_impl(vdb_rows* h, int metric, const float* d_q, int nq, float* d_out, hipStream_t s) {
+static int flat_distances_impl(vdb_rows* h, int metric, const float* d_q, int nq, float* d_out, hipStream_t s,
+                               bool back_to_front = false) {
     Rows& r = h->r;
     Workspace& ws = h->ws;
     VDB_REQUIRE(valid_metric(metric), "unknown metric code %d", metric);
@@ -904,7 +905,10 @@ static int flat_distances_impl(vdb_rows* h, int metric, const float* d_q, int nq
     VDB_TRY(prepare_queries(ws, d_q, nq, r.dim, r.ld, r.plan, &q, s));
     if (is_dot_metric(metric) && nq >= GEMM_MIN_NQ)
         return launch_flat_gemm_dist(r, metric, q, ws.q_sq.as<float>(), ws.q_nrm.as<float>(), nq, d_out, s);
-    VDB_TRY(stream_flat_sums(ws, r, metric, q, nq, d_out, s));
+    StreamJob more{};
+    more.timed = true;
+    if (back_to_front && nq == 1) more.reverse_items = (r.n + 255) / 256;      // one query: one item per 256-row chunk
+    VDB_TRY(stream_flat_sums(ws, r, metric, q, nq, d_out, s, false, &more));
     return launch_finish_dist(metric, ws.q_sq.as<float>(), ws.q_nrm.as<float>(), r.sq, r.nrm, r.cos_eps, d_out, nq, r.n, s);
 }
 
@@ -1758,7 +1762,8 @@ int vdb_kmeans_init_pp(vdb_kmeans* h, int64_t first_row, const double* uniforms,
         // distances of every row to the centroid chosen last: pairwise_euclidean against ONE new centroid; the
         // minimum over all chosen ones is kept as a running minimum (min is exact, so the result is the same)
         VDB_TRY(launch_km_gather(x.data, x.ld, h->dsub, chosen + (j - 1), nullptr, 1, h->qrow.as<float>(), nullptr, s));
-        VDB_TRY(flat_distances_impl(xs, VDB_EUCLIDEAN, h->qrow.as<float>(), 1, h->dist.as<float>(), s));
+        // (every other pass back to front: it starts on the rows the pass before left in the memory-side cache)
+        VDB_TRY(flat_distances_impl(xs, VDB_EUCLIDEAN, h->qrow.as<float>(), 1, h->dist.as<float>(), s, (j & 1) != 0));
         VDB_TRY(launch_km_pp_step(h->dist.as<float>(), x.n, j == 1, h->nearest.as<float>(), h->bsums.as<double>(),
                                   uniforms[j - 1], chosen + j, chosen + k, s));
     }

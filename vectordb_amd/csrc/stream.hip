@@ -53,6 +53,7 @@ struct StreamParams {
     const int64_t* seg_item_off;      // [n_seg+1] first item of a segment
     const StreamItem* items;          // [seg_item_off[n_seg]] the decoded items
     int64_t items_cap;
+    int64_t reverse_from;             // >= 0: the items are taken back to front, item i is table entry reverse_from - i
     const int* sq_qid;                // query number
     const int64_t* sq_out;            // where that query's value for the segment's row 0 goes
     float* out;
@@ -142,6 +143,7 @@ struct Item {
 static_assert(sizeof(StreamItem) == 32, "one item is one 32-byte scalar load");
 
 __device__ __forceinline__ Item load_item(const StreamParams& p, int64_t item) {
+    if (p.reverse_from >= 0) item = p.reverse_from - item;
     const i8v w = uload(reinterpret_cast<const i8v*>(p.items + item));
     Item it;
     it.row0 = ((int64_t)(uint32_t)w[1] << 32) | (uint32_t)w[0];
@@ -892,6 +894,7 @@ int launch_stream_sums(const StreamJob& j, hipStream_t s) {
     p.q = j.q; p.ldq = j.ldq; p.zeros = ctx().zeros;
     p.n_seg = j.n_seg; p.seg_row_off = j.seg_row_off; p.seg_q_off = j.seg_q_off; p.seg_item_off = j.seg_item_off;
     p.sq_qid = j.sq_qid; p.sq_out = j.sq_out; p.out = j.out; p.items = j.items; p.items_cap = j.items_cap;
+    p.reverse_from = j.reverse_items > 0 ? j.reverse_items - 1 : -1;
     p.run_if = j.run_if;
     VDB_REQUIRE(j.bound == nullptr || (j.group == RR_GROUP && j.queue_len && j.queue_d && j.queue_i && j.queue_cap > 0 && j.overflow),
                 "the bounded form belongs to the row-resident kernel and needs its queues");

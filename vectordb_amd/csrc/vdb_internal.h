@@ -263,6 +263,10 @@ struct StreamJob {
     float* out;
     bool timed;
     const int* run_if;              // optional device flag: the launch does nothing while it is zero
+    // > 0: the number of items of the table; the blocks then take them back to front.  A scan that is repeated over a
+    // row set larger than the memory-side cache alternates direction, so each pass starts on the rows the last one
+    // ended on (k-means++ runs thousands of such passes)
+    int64_t reverse_items;
     // bounded form (group 128, flat row sets): pairs within bound[query] whose row passes `mask` go to per-query
     // queues of queue_cap (distance, row) entries instead of `out`; *overflow is set when a queue is full
     const float* bound; bool bound_sqrt; const uint32_t* mask;
