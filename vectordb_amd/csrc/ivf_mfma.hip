@@ -579,7 +579,9 @@ int launch_ivf_mfma_search(const IvfMfmaJob& j, hipStream_t s) {
     VDB_HIP(hipGetLastError());
     // the k best of every queue under (distance, slot) = (distance, visiting order), then slots -> rows
     SelectOut o{j.out_d, nullptr, j.slots, j.k_out, 0, nullptr, nullptr, nullptr};
-    VDB_TRY(launch_select_packed(j.queue_d, j.queue_slot, j.nq, j.queue_cap, j.k, o, s, j.queue_len, IA_LEN_STRIDE));
+    // (queues of a few hundred entries: four waves per query keep eight queries on a CU instead of two)
+    VDB_TRY(launch_select_packed(j.queue_d, j.queue_slot, j.nq, j.queue_cap, j.k, o, s, j.queue_len, IA_LEN_STRIDE,
+                                 j.queue_cap <= 2048 || j.nq >= 64 ? 4 : 16));
     return launch_ivf_rows(j.slots, j.nq, j.k, j.k_out, 0, j.probes, j.n_probe, j.n_lists, j.cand_off, j.list_beg, j.row_ids,
                            j.out_rows, j.out_order, s);
 }

@@ -339,7 +339,7 @@ __global__ __launch_bounds__(64 * MB_WAVES) void merge_block_kernel(const float*
     if (o.run_if && *o.run_if == 0) return;
     if (queue_len) queue_len += (int64_t)q * len_stride - q;     // a query's length lies len_stride ints from its neighbour's
     const int total = queue_len ? min(__builtin_amdgcn_readfirstlane(queue_len[q]), area) : area;
-    const int waves = max(1, min(MB_WAVES, (total + 255) / 256));
+    const int waves = max(1, min((int)(blockDim.x >> 6), (total + 255) / 256));
     const float* dq = d + (int64_t)q * area;
     const int* iq = idx + (int64_t)q * area;
     constexpr int AHEAD = 8;
@@ -354,7 +354,7 @@ __global__ __launch_bounds__(64 * MB_WAVES) void merge_block_kernel(const float*
             o.last_key[q] = empty ? INT64_MAX : (int64_t)id;
         }
     };
-    if (lists_of_k && k <= 16 && total <= 64 * MB_WAVES * AHEAD) {            // the same for every thread of the block
+    if (lists_of_k && k <= 16 && total <= (int)blockDim.x * AHEAD) {            // the same for every thread of the block
         if (threadIdx.x == 0) sh_cnt = 0;
         float v[AHEAD];
         int id[AHEAD];
@@ -442,10 +442,11 @@ __global__ __launch_bounds__(64 * MB_WAVES) void merge_block_kernel(const float*
 }
 
 int launch_select_packed(const float* part_d, const int* part_i, int nq, int area, int k, const SelectOut& o, hipStream_t s,
-                         int* queue_len, int len_stride) {
+                         int* queue_len, int len_stride, int waves) {
     if (nq <= 0) return VDB_OK;
     VDB_REQUIRE(k >= 1 && k <= 64 && queue_len, "packed selection: k in 1..64 and a queue length per query");
-    hipLaunchKernelGGL(merge_block_kernel, dim3(nq), dim3(64 * MB_WAVES), 0, s, part_d, part_i, area, k, o, queue_len, 0, len_stride);
+    VDB_REQUIRE(waves >= 1 && waves <= MB_WAVES && waves * k <= 64 * MB_WAVES, "packed selection: 1..%d waves per query", MB_WAVES);
+    hipLaunchKernelGGL(merge_block_kernel, dim3(nq), dim3(64 * waves), 0, s, part_d, part_i, area, k, o, queue_len, 0, len_stride);
     VDB_HIP(hipGetLastError());
     return VDB_OK;
 }

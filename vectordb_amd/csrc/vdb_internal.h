@@ -376,7 +376,7 @@ int launch_select(const float* part_d, const int* part_i, int nq, int n_cand, in
 // a few queries: the k best of every query's packed candidate area (queue_len[q] of `area` entries, any order),
 // one block per query; sets queue_len[q] back to zero (query q's length at queue_len[q * len_stride])
 int launch_select_packed(const float* part_d, const int* part_i, int nq, int area, int k, const SelectOut& o, hipStream_t s,
-                         int* queue_len, int len_stride = 1);
+                         int* queue_len, int len_stride = 1, int waves = 16);
 // the same over whole areas (every entry present or marked empty by its id): no lengths
 int launch_select_area(const float* part_d, const int* part_i, int nq, int area, int k, const SelectOut& o, hipStream_t s);
 // lists laid out [n_lists][nq][k] with int64 ids (negative = empty), ordered by (distance, id);
