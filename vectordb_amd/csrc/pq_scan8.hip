@@ -37,6 +37,7 @@ __device__ __forceinline__ void static_for(F&& f) {
 static constexpr int P8_Q = 8;             // queries per pass
 static constexpr int P8_LIMIT = 254;       // largest byte sum of a row that may be in a result
 static constexpr int P8_UNROLL = 2;        // row tiles of 256 whose code loads and table reads are in flight together
+static constexpr int P8_DEPTH = 4;         // steps (of P8_UNROLL tiles) whose codes are in registers or on their way
 
 // ---------------------------------------------------------------- byte tables
 struct PqQuantParams {
@@ -142,7 +143,7 @@ __device__ __forceinline__ uint32_t lds_offset_of(const void* p) {
 #endif
 }
 
-template <int M>
+template <int M, bool MASKED>
 __global__ __launch_bounds__(256) void pq_scan8_kernel(PqScan8Params p) {
     extern __shared__ __align__(16) uint2 T8[];             // [M][256]
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -163,80 +164,83 @@ __global__ __launch_bounds__(256) void pq_scan8_kernel(PqScan8Params p) {
     for (int i = tid; i < M * 256; i += 256) T8[i] = src_t[i];
     __syncthreads();
 
-    const int64_t ntiles = (p.n + 255) / 256;
-    const int64_t per = (ntiles + p.splits - 1) / p.splits;
-    const int64_t t0 = min((int64_t)split * per, ntiles), t1 = min(t0 + per, ntiles);
+    // rows are numbered in 32 bits (the launcher refuses 2^31 codes and more): a row's address is one 64-bit
+    // shift-and-add, its validity one compare
+    const uint32_t ntiles = (uint32_t)((p.n + 255) / 256);
+    const uint32_t per = (ntiles + p.splits - 1) / p.splits;
+    const uint32_t t0 = min((uint32_t)split * per, ntiles), t1 = min(t0 + per, ntiles);
+    const uint32_t row_end = (uint32_t)min((int64_t)t1 * 256, p.n);      // this block's rows end here
+    const uint32_t last = row_end - 1u;                      // reads past the block's rows repeat its last row
     constexpr int WN = M / 4;
-    const uint32_t* mask_src = p.mask ? p.mask : reinterpret_cast<const uint32_t*>(p.codes);
     int2* seg = p.seg + (int64_t)wave_id * p.seg_cap;
     int kept = 0;                                            // wave-uniform
     bool full = false;
     uint32_t three = 3;
     asm volatile("" : "+v"(three));                          // stays in a vector register
 
-    auto fetch = [&](int64_t tbx, uint32_t (&wx)[P8_UNROLL][WN], uint32_t (&mwx)[P8_UNROLL]) {
+    // the codes (and filter words) of the P8_UNROLL tiles whose first row for this lane is `row0`; rows past the end
+    // of the block's share read its last row again (a cache hit, never used: `row < row_end` fails for them)
+    auto fetch = [&](uint32_t row0, uint32_t (&wx)[P8_UNROLL][WN], uint32_t (&mwx)[P8_UNROLL]) {
 #pragma unroll
         for (int u = 0; u < P8_UNROLL; ++u) {
-            const int64_t row = min((tbx + u) * 256 + tid, p.n - 1);          // past the end: the last row again, unused
+            const uint32_t row = min(row0 + u * 256u, last);
+            const uint8_t* src8 = p.codes + (uint64_t)row * M;
             if constexpr (M % 16 == 0) {
-                const uint4* src = reinterpret_cast<const uint4*>(p.codes + row * M);
+                const uint4* src = reinterpret_cast<const uint4*>(src8);
 #pragma unroll
                 for (int i = 0; i < M / 16; ++i) {
                     const uint4 v = src[i];
                     wx[u][4 * i] = v.x; wx[u][4 * i + 1] = v.y; wx[u][4 * i + 2] = v.z; wx[u][4 * i + 3] = v.w;
                 }
             } else if constexpr (M % 8 == 0) {
-                const uint2* src = reinterpret_cast<const uint2*>(p.codes + row * M);
+                const uint2* src = reinterpret_cast<const uint2*>(src8);
 #pragma unroll
                 for (int i = 0; i < M / 8; ++i) { const uint2 v = src[i]; wx[u][2 * i] = v.x; wx[u][2 * i + 1] = v.y; }
             } else {
-                const uint32_t* src = reinterpret_cast<const uint32_t*>(p.codes + row * M);
+                const uint32_t* src = reinterpret_cast<const uint32_t*>(src8);
 #pragma unroll
                 for (int i = 0; i < M / 4; ++i) wx[u][i] = src[i];
             }
-            mwx[u] = mask_src[p.mask ? (row >> 5) : 0];
+            if constexpr (MASKED) mwx[u] = p.mask[row >> 5];
         }
     };
-
-    uint32_t wn[P8_UNROLL][WN], mwn[P8_UNROLL];
-    fetch(min(t0, ntiles - 1), wn, mwn);
-    for (int64_t tb = t0; tb < t1; tb += P8_UNROLL) {
-        uint32_t w[P8_UNROLL][WN], mw[P8_UNROLL];
-#pragma unroll
-        for (int u = 0; u < P8_UNROLL; ++u) {
-            mw[u] = p.mask ? mwn[u] : 0xffffffffu;
-#pragma unroll
-            for (int i = 0; i < WN; ++i) w[u][i] = wn[u][i];
-        }
-        fetch(tb + P8_UNROLL, wn, mwn);
-        // Per 32-bit word of an entry (four queries): `all` adds the word as two 16-bit lanes (odd byte * 256 + even
-        // byte each), `odd` adds the odd bytes alone; the even sums are all - 256 * odd (mod 2^16; M * 255 < 2^16).
-        pq_u16x2 all_lo[P8_UNROLL], odd_lo[P8_UNROLL], all_hi[P8_UNROLL], odd_hi[P8_UNROLL];
+    // one step: the table sums of the tiles in `w`, then the rows that may be in a result
+    auto step = [&](uint32_t row0, const uint32_t (&w)[P8_UNROLL][WN], const uint32_t (&mw)[P8_UNROLL]) {
+        // Per 32-bit word of an entry (four queries, one byte each): `all` adds the whole words, `odd` adds the odd
+        // bytes as two 16-bit fields. Both are plain 32-bit sums, two sub-spaces per three-operand add: the fields of
+        // `odd` cannot carry into each other (M * 255 < 2^16), and all - 256 * odd (mod 2^32) is exactly the even
+        // bytes' sums in the same two fields, whatever `all` carried on the way.
+        uint32_t all_lo[P8_UNROLL], odd_lo[P8_UNROLL], all_hi[P8_UNROLL], odd_hi[P8_UNROLL];
 #pragma unroll
         for (int u = 0; u < P8_UNROLL; ++u) { all_lo[u] = 0; odd_lo[u] = 0; all_hi[u] = 0; odd_hi[u] = 0; }
+        auto odd_bytes = [](uint32_t v) { return __builtin_bit_cast(uint32_t, __builtin_bit_cast(pq_u16x2, v) >> 8); };
         auto look_up = [&](auto jc) {
-            constexpr int j = decltype(jc)::value;
+            constexpr int j = 2 * decltype(jc)::value;
 #pragma unroll
             for (int u = 0; u < P8_UNROLL; ++u) {
-                const uint32_t off = code_offset<j & 3>(w[u][j >> 2], three);
-                const uint2 t = lds_entry_at(off + j * 2048);                  // the tables start at LDS offset 0
-                const pq_u16x2 lo = __builtin_bit_cast(pq_u16x2, t.x), hi = __builtin_bit_cast(pq_u16x2, t.y);
-                all_lo[u] += lo; odd_lo[u] += lo >> 8;
-                all_hi[u] += hi; odd_hi[u] += hi >> 8;
+                const uint32_t off0 = code_offset<j & 3>(w[u][j >> 2], three);
+                const uint32_t off1 = code_offset<(j + 1) & 3>(w[u][(j + 1) >> 2], three);
+                const uint2 a = lds_entry_at(off0 + j * 2048);                 // the tables start at LDS offset 0
+                const uint2 b = lds_entry_at(off1 + (j + 1) * 2048);
+                all_lo[u] = all_lo[u] + a.x + b.x;  odd_lo[u] = odd_lo[u] + odd_bytes(a.x) + odd_bytes(b.x);
+                all_hi[u] = all_hi[u] + a.y + b.y;  odd_hi[u] = odd_hi[u] + odd_bytes(a.y) + odd_bytes(b.y);
             }
             // the scheduler may not move table reads across every fourth sub-space: sixteen reads in flight are
             // enough, and all of them in flight cost a wave per SIMD in registers
-            if constexpr ((j & 3) == 3) __builtin_amdgcn_sched_barrier(0);
+            if constexpr ((j & 3) == 2) __builtin_amdgcn_sched_barrier(0);
         };
-        static_for<M>(look_up);
+        static_for<M / 2>(look_up);
 #pragma unroll
         for (int u = 0; u < P8_UNROLL; ++u) {
-            const int64_t row = (tb + u) * 256 + tid;
-            const pq_u16x2 even_lo = all_lo[u] - (odd_lo[u] << 8), even_hi = all_hi[u] - (odd_hi[u] << 8);
-            const pq_u16x2 mn2 = __builtin_elementwise_min(__builtin_elementwise_min(even_lo, odd_lo[u]),
-                                                           __builtin_elementwise_min(even_hi, odd_hi[u]));
+            const uint32_t row = row0 + u * 256u;
+            const pq_u16x2 odd_l = __builtin_bit_cast(pq_u16x2, odd_lo[u]), odd_h = __builtin_bit_cast(pq_u16x2, odd_hi[u]);
+            const pq_u16x2 even_lo = __builtin_bit_cast(pq_u16x2, all_lo[u] - (odd_lo[u] << 8));
+            const pq_u16x2 even_hi = __builtin_bit_cast(pq_u16x2, all_hi[u] - (odd_hi[u] << 8));
+            const pq_u16x2 mn2 = __builtin_elementwise_min(__builtin_elementwise_min(even_lo, odd_l),
+                                                           __builtin_elementwise_min(even_hi, odd_h));
             const unsigned mn = min((unsigned)mn2.x, (unsigned)mn2.y);
-            const bool pass = (tb + u) < t1 && row < p.n && ((mw[u] >> (row & 31)) & 1u) && mn <= (unsigned)P8_LIMIT;
+            bool pass = row < row_end && mn <= (unsigned)P8_LIMIT;
+            if constexpr (MASKED) pass = pass && ((mw[u] >> (row & 31u)) & 1u);
             const unsigned long long votes = __ballot(pass);
             if (votes != 0ull) {                                                   // rare
                 const int cnt = __popcll(votes);
@@ -245,16 +249,42 @@ __global__ __launch_bounds__(256) void pq_scan8_kernel(PqScan8Params p) {
                 } else if (pass) {
                     // queries 0, 2 (even bytes of the low word), 1, 3 (odd), then the high word's 4, 6, 5, 7
                     unsigned bits = 0;
-                    bits |= (even_lo.x <= P8_LIMIT) ? 1u : 0u;   bits |= (odd_lo[u].x <= P8_LIMIT) ? 2u : 0u;
-                    bits |= (even_lo.y <= P8_LIMIT) ? 4u : 0u;   bits |= (odd_lo[u].y <= P8_LIMIT) ? 8u : 0u;
-                    bits |= (even_hi.x <= P8_LIMIT) ? 16u : 0u;  bits |= (odd_hi[u].x <= P8_LIMIT) ? 32u : 0u;
-                    bits |= (even_hi.y <= P8_LIMIT) ? 64u : 0u;  bits |= (odd_hi[u].y <= P8_LIMIT) ? 128u : 0u;
+                    bits |= (even_lo.x <= P8_LIMIT) ? 1u : 0u;   bits |= (odd_l.x <= P8_LIMIT) ? 2u : 0u;
+                    bits |= (even_lo.y <= P8_LIMIT) ? 4u : 0u;   bits |= (odd_l.y <= P8_LIMIT) ? 8u : 0u;
+                    bits |= (even_hi.x <= P8_LIMIT) ? 16u : 0u;  bits |= (odd_h.x <= P8_LIMIT) ? 32u : 0u;
+                    bits |= (even_hi.y <= P8_LIMIT) ? 64u : 0u;  bits |= (odd_h.y <= P8_LIMIT) ? 128u : 0u;
                     seg[kept + __popcll(votes & ((1ull << lane) - 1ull))] = make_int2((int)row, (int)bits);
                 }
                 if (!full) kept += cnt;
             }
         }
+    };
+
+    // P8_DEPTH sets of code registers take turns: the codes of a step are asked for P8_DEPTH - 1 steps before their
+    // sums are taken (a step lasts about half a microsecond, a read from HBM under load longer), with no register
+    // copies between steps
+    constexpr uint32_t STEP = P8_UNROLL * 256u;
+    uint32_t w[P8_DEPTH][P8_UNROLL][WN], mk[P8_DEPTH][P8_UNROLL];
+#pragma unroll
+    for (int s = 0; s < P8_DEPTH; ++s)
+#pragma unroll
+        for (int u = 0; u < P8_UNROLL; ++u) mk[s][u] = 0xffffffffu;
+    uint32_t row0 = t0 * 256u + (uint32_t)tid;
+    uint32_t tb = t0;
+    if (t0 >= t1) goto done;
+#pragma unroll
+    for (int s = 0; s < P8_DEPTH - 1; ++s) fetch(row0 + s * STEP, w[s], mk[s]);
+    for (;;) {
+#pragma unroll
+        for (int s = 0; s < P8_DEPTH; ++s) {
+            fetch(row0 + (P8_DEPTH - 1) * STEP, w[(s + P8_DEPTH - 1) % P8_DEPTH], mk[(s + P8_DEPTH - 1) % P8_DEPTH]);
+            step(row0, w[s], mk[s]);
+            row0 += STEP;
+            tb += P8_UNROLL;
+            if (tb >= t1) goto done;                         // wave-uniform
+        }
     }
+done:
     if (lane == 0) {
         p.seg_len[wave_id] = kept;
         if (full) *p.overflow = 1;
@@ -352,7 +382,7 @@ int launch_pq_scan8(const PqScan8Job& j, hipStream_t s) {
         KernelTimer timer(s, j.timed);
 #define VDB_LAUNCH_P8(MM)                                                                      \
     case MM: {                                                                                 \
-        auto kern = pq_scan8_kernel<MM>;                                                       \
+        auto kern = j.mask ? pq_scan8_kernel<MM, true> : pq_scan8_kernel<MM, false>;           \
         VDB_TRY(raise_dynamic_lds(reinterpret_cast<const void*>(kern), lds));                  \
         hipLaunchKernelGGL(kern, dim3(j.splits, groups), dim3(256), lds, s, sp);               \
     } break;
