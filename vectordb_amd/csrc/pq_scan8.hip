@@ -8,12 +8,13 @@
 //
 // The bytes are lower bounds.  For query q with a distance B that k rows of the set are known not to exceed
 // (the bound pass of the caller), a result row has sqrtf(S) <= B for its fp32 sum S, hence S <= thr (B squared, a
-// few ulps up), and the real-number sum of its table entries is at most thr * (1 + 16 * 2^-24).  With
-// min_j = the smallest entry of sub-space j,  thr' = thr - sum_j min_j  and  step = thr' / 254,  the byte of an
-// entry t is  clamp(floor((t - min_j) / step) - 1, 0, 255)  (float64; the "- 1" covers the rounding of the
-// quotient), so  byte * step <= t - min_j  and for a result row  sum_j byte_j <= thr' / step = 254: a row whose byte
-// sum is above 254 is in no query's result and is dropped; an entry of 255 alone does that (saturation is harmless).
-// Rows at or below 254 are queued per wave with the bits of the queries they passed for; pq_exact8_kernel takes the
+// few ulps up), and the real-number sum of its table entries is at most thr * (1 + 32 * 2^-24).  With
+// min_j = the smallest entry of sub-space j,  thr' = thr * (1 + 4e-6) - sum_j min_j  and  step = thr' / 510,  the
+// byte of an entry t is  clamp(floor((t - min_j) / step - 1e-9), 0, 255)  (float64; the 1e-9 covers the rounding of
+// the quotient), so  byte * step <= t - min_j  and for a result row  sum_j byte_j <= thr' / step = 510: a row whose
+// byte sum is above 510 is in no query's result and is dropped.  An entry of half of thr' and more saturates at 255
+// (still a lower bound).  Flooring loses less than one step per sub-space, m / 1020 of thr' on average.
+// Rows at or below 510 are queued per wave with the bits of the queries they passed for; pq_exact8_kernel takes the
 // fp32 sums of exactly those and hands (distance, row) to the per-query selection.
 //
 // A query without a finite bound, a full wave segment or a full candidate area set the overflow flag: the caller's
@@ -35,7 +36,7 @@ __device__ __forceinline__ void static_for(F&& f) {
 }
 
 static constexpr int P8_Q = 8;             // queries per pass
-static constexpr int P8_LIMIT = 254;       // largest byte sum of a row that may be in a result
+static constexpr int P8_LIMIT = 510;       // largest byte sum of a row that may be in a result (m * 255 < 2^16 for the sums)
 static constexpr int P8_UNROLL = 2;        // row tiles of 256 whose code loads and table reads are in flight together
 static constexpr int P8_DEPTH = 4;         // steps (of P8_UNROLL tiles) whose codes are in registers or on their way
 
@@ -90,7 +91,7 @@ __global__ __launch_bounds__(256) void pq_quantise_kernel(PqQuantParams p) {
         if (inv < 0.0) byte = 0u;
         else if (inv > 0.0) {
             const double v = ((double)p.lut[((int64_t)q * m + j) * 256 + c] - (double)least[qi]) * inv;
-            if (v < 256.0) byte = (uint32_t)max(0, (int)floor(v) - 1);
+            if (v < 256.0) byte = (uint32_t)max(0, (int)floor(v - 1e-9));
             else if (!(v == v)) byte = 0u;                  // NaN entry: the fp32 sums decide
         }
         w[qi >> 2] |= byte << (8 * (qi & 3));
@@ -302,57 +303,89 @@ struct PqExact8Params {
     int* overflow;
 };
 
-// One wave per segment, a lane per kept row.  The row's fp32 sums for all of its queries are taken at once (the
-// table reads of a round are independent of each other), then lanes 0..7 reserve room in the eight candidate areas
-// with one atomic each and the rows within a query's bound are written there.
+// A block per 32 consecutive segments of a query group, eight per wave, the kept rows of a wave's segments spread
+// over its lanes.  Nearly every kept row is kept for one query, so the lanes take their queries one set bit at a
+// time, each lane its own query's table (as many rounds as the busiest lane has bits, not eight).  Rows within their
+// query's bound are collected in LDS with their rank among the block's rows of that query; then one atomic per
+// (block, query) reserves the block's room in the query's candidate area.  (An atomic per row, or per wave and
+// query, makes a few thousand returning atomics on each of eight addresses: 50 microseconds.)
+static constexpr int PX_SEGS = 8;          // segments per wave
+static constexpr int PX_CAP = 1024;        // rows within their bounds that a block can hold
+
 template <int M>
 __global__ __launch_bounds__(256) void pq_exact8_kernel(PqExact8Params p) {
-    const int lane = threadIdx.x & 63;
-    const int s = blockIdx.x * 4 + (threadIdx.x >> 6);
-    if (s >= p.n_seg) return;
-    const int len = __builtin_amdgcn_readfirstlane(p.seg_len[s]);
-    if (len == 0 || *p.overflow != 0) return;
-    const int q0 = (s / p.segs_per_group) * P8_Q;
-    const int2* seg = p.seg + (int64_t)s * p.seg_cap;
-    for (int i0 = 0; i0 < len; i0 += 64) {
-        const bool have = i0 + lane < len;
-        const int2 e = have ? seg[i0 + lane] : make_int2(0, 0);
+    __shared__ float sh_d[PX_CAP];
+    __shared__ int sh_row[PX_CAP];
+    __shared__ int sh_meta[PX_CAP];          // query of the group << 16 | rank among the block's rows of that query
+    __shared__ int sh_cnt[P8_Q], sh_base[P8_Q], sh_total, sh_skip;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int g = blockIdx.y, q0 = g * P8_Q;
+    if (tid < P8_Q) sh_cnt[tid] = 0;
+    if (tid == 0) { sh_total = 0; sh_skip = *p.overflow; }
+    __syncthreads();
+    if (sh_skip != 0) return;                                // the fp32 scan answers this batch
+    const int first = (blockIdx.x * 4 + wave) * PX_SEGS;     // of this wave's segments, within the group
+    const int s0 = g * p.segs_per_group + first;
+    // lane l < PX_SEGS: the rows kept in segment first + l, then the running totals over the lanes
+    int incl = (lane < PX_SEGS && first + lane < p.segs_per_group) ? p.seg_len[s0 + lane] : 0;
+#pragma unroll
+    for (int off = 1; off < PX_SEGS; off <<= 1) {
+        const int up = __shfl_up(incl, off);
+        if (lane >= off) incl += up;
+    }
+    int ends[PX_SEGS];
+#pragma unroll
+    for (int i = 0; i < PX_SEGS; ++i) ends[i] = __builtin_amdgcn_readlane(incl, i);
+    const int total = ends[PX_SEGS - 1];
+    for (int i0 = 0; i0 < total; i0 += 64) {
+        const int i = i0 + lane;
+        const bool have = i < total;
+        int which = 0, begin = 0;
+#pragma unroll
+        for (int j = 0; j < PX_SEGS - 1; ++j)
+            if (i >= ends[j]) { which = j + 1; begin = ends[j]; }
+        const int2 e = have ? p.seg[(int64_t)(s0 + which) * p.seg_cap + (i - begin)] : make_int2(0, 0);
         uint32_t w[M / 4];
         const uint32_t* src = reinterpret_cast<const uint32_t*>(p.codes + (int64_t)e.x * M);
 #pragma unroll
-        for (int i = 0; i < M / 4; ++i) w[i] = src[i];
-        float d[P8_Q];
-        unsigned long long votes[P8_Q];
+        for (int j = 0; j < M / 4; ++j) w[j] = src[j];
+        unsigned bits = have ? ((unsigned)e.y & 0xffu) : 0u;   // a set bit implies q0 + qi < nq (absent queries have bytes of 255)
+        while (__ballot(bits != 0u) != 0ull) {
+            const bool mine = bits != 0u;
+            const int qi = mine ? __builtin_ctz(bits) : 0;                   // idle lanes read query q0's table (unused)
+            bits &= bits - 1u;
+            const float* t = p.lut + (int64_t)(q0 + qi) * M * 256;
+            float acc = t[w[0] & 0xffu];
 #pragma unroll
-        for (int qi = 0; qi < P8_Q; ++qi) {
-            const bool mine = have && ((e.y >> qi) & 1);     // a set bit implies q0 + qi < nq (absent queries have bytes of 255)
-            bool in = false;
-            d[qi] = 0.0f;
-            if (mine) {
-                const float* t = p.lut + (int64_t)(q0 + qi) * M * 256;
-                float acc = t[w[0] & 0xffu];
-#pragma unroll
-                for (int j = 1; j < M; ++j) acc = acc + t[j * 256 + ((w[j >> 2] >> (8 * (j & 3))) & 0xffu)];
-                in = acc <= p.thr[q0 + qi];
-                d[qi] = sqrtf(acc);
+            for (int j = 1; j < M; ++j) acc = acc + t[j * 256 + ((w[j >> 2] >> (8 * (j & 3))) & 0xffu)];
+            if (mine && acc <= p.thr[q0 + qi]) {
+                const int slot = atomicAdd(&sh_total, 1);
+                if (slot < PX_CAP) {
+                    sh_d[slot] = sqrtf(acc);
+                    sh_row[slot] = e.x;
+                    sh_meta[slot] = (qi << 16) | atomicAdd(&sh_cnt[qi], 1);
+                }
             }
-            votes[qi] = __ballot(in);
         }
-        int at = 0;
-#pragma unroll
-        for (int qi = 0; qi < P8_Q; ++qi)
-            if (lane == qi && votes[qi] != 0ull) at = atomicAdd(p.queue_len + (int64_t)(q0 + qi) * p.len_stride, __popcll(votes[qi]));
-#pragma unroll
-        for (int qi = 0; qi < P8_Q; ++qi) {
-            if (votes[qi] == 0ull) continue;                 // wave-uniform
-            const int base = __shfl(at, qi);
-            if (base + __popcll(votes[qi]) > p.area) {
-                if (lane == 0) *p.overflow = 1;
-            } else if ((votes[qi] >> lane) & 1ull) {
-                const int64_t o = (int64_t)(q0 + qi) * p.area + base + __popcll(votes[qi] & ((1ull << lane) - 1ull));
-                p.area_d[o] = d[qi];
-                p.area_i[o] = e.x;
-            }
+    }
+    __syncthreads();
+    const int held = sh_total;
+    if (held == 0) return;
+    if (held > PX_CAP) {                                     // (the ranks of the rows that did fit are of no use then)
+        if (tid == 0) *p.overflow = 1;
+        return;
+    }
+    if (tid < P8_Q && sh_cnt[tid] > 0) sh_base[tid] = atomicAdd(p.queue_len + (int64_t)(q0 + tid) * p.len_stride, sh_cnt[tid]);
+    __syncthreads();
+    for (int t = tid; t < held; t += 256) {
+        const int meta = sh_meta[t], qi = meta >> 16;
+        const int at = sh_base[qi] + (meta & 0xffff);
+        if (at >= p.area) {
+            *p.overflow = 1;
+        } else {
+            const int64_t o = (int64_t)(q0 + qi) * p.area + at;
+            p.area_d[o] = sh_d[t];
+            p.area_i[o] = sh_row[t];
         }
     }
 }
@@ -396,11 +429,12 @@ int launch_pq_scan8(const PqScan8Job& j, hipStream_t s) {
     }
     PqExact8Params ep{j.codes, j.m, j.lut, j.nq, j.thr, reinterpret_cast<const int2*>(j.seg), j.seg_len, j.seg_cap, n_seg,
                       j.splits * 4, j.area_d, j.area_i, j.area, j.queue_len, j.len_stride, j.overflow};
+    const dim3 xgrid((j.splits * 4 + 4 * PX_SEGS - 1) / (4 * PX_SEGS), groups);
     switch (j.m) {
-        case 4: hipLaunchKernelGGL(pq_exact8_kernel<4>, dim3((n_seg + 3) / 4), dim3(256), 0, s, ep); break;
-        case 8: hipLaunchKernelGGL(pq_exact8_kernel<8>, dim3((n_seg + 3) / 4), dim3(256), 0, s, ep); break;
-        case 16: hipLaunchKernelGGL(pq_exact8_kernel<16>, dim3((n_seg + 3) / 4), dim3(256), 0, s, ep); break;
-        case 32: hipLaunchKernelGGL(pq_exact8_kernel<32>, dim3((n_seg + 3) / 4), dim3(256), 0, s, ep); break;
+        case 4: hipLaunchKernelGGL(pq_exact8_kernel<4>, xgrid, dim3(256), 0, s, ep); break;
+        case 8: hipLaunchKernelGGL(pq_exact8_kernel<8>, xgrid, dim3(256), 0, s, ep); break;
+        case 16: hipLaunchKernelGGL(pq_exact8_kernel<16>, xgrid, dim3(256), 0, s, ep); break;
+        case 32: hipLaunchKernelGGL(pq_exact8_kernel<32>, xgrid, dim3(256), 0, s, ep); break;
     }
     VDB_HIP(hipGetLastError());
     return VDB_OK;

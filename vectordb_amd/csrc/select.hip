@@ -319,12 +319,11 @@ int launch_select(const float* part_d, const int* part_i, int nq, int n_cand, in
 
 // One block of up to sixteen waves per query picks the k best of the query's packed candidate area (queue_len[q]
 // entries of `area`, in any order).
-//   An area made of sorted lists of k (lists_of_k), up to 8192 entries, k <= 16: every thread takes its entries into
-// registers; a wave's k-th smallest among the list heads (every k-th entry) is a distance that k entries do not
-// exceed, and so is the smallest of the waves' values, B.  The entries within B (little more than k) are gathered in
-// LDS and each finds its place by counting the ones that precede it: no chain of merges.  More than 1024 within B
-// (a bound that does not bind): the general path below.  (Entries in any order leave hundreds within B: the PQ scan's
-// packed areas were slower this way, 41 against 21 microseconds.)
+//   Up to 512 entries per wave, k <= 16: every thread takes its entries into registers; a wave's k-th smallest among
+// its list heads (every k-th entry of an area made of sorted lists of k, lists_of_k; else every lane's smallest
+// entry) is a distance that k entries do not exceed, and so is the smallest of the waves' values, B.  The entries
+// within B (little more than k per wave) are gathered in LDS and each finds its place by counting the ones that
+// precede it: no chain of merges.  More than 1024 within B (a bound that does not bind): the general path below.
 //   Otherwise the waves share out the entries 64 at a time (256 entries or more per wave, so a short queue keeps few
 // waves busy), each keeps its k best in registers, and wave 0 merges the waves' lists through LDS.
 __global__ __launch_bounds__(64 * MB_WAVES) void merge_block_kernel(const float* __restrict__ d, const int* __restrict__ idx,
@@ -354,7 +353,7 @@ __global__ __launch_bounds__(64 * MB_WAVES) void merge_block_kernel(const float*
             o.last_key[q] = empty ? INT64_MAX : (int64_t)id;
         }
     };
-    if (lists_of_k && k <= 16 && total <= (int)blockDim.x * AHEAD) {            // the same for every thread of the block
+    if (k <= 16 && total <= (int)blockDim.x * AHEAD) {                          // the same for every thread of the block
         if (threadIdx.x == 0) sh_cnt = 0;
         float v[AHEAD];
         int id[AHEAD];
@@ -367,16 +366,26 @@ __global__ __launch_bounds__(64 * MB_WAVES) void merge_block_kernel(const float*
                 v[a] = i < total ? dq[i] : INFINITY;
                 id[a] = i < total ? iq[i] : EMPTY_IDX;
             }
+            if (lists_of_k) {
 #pragma unroll
-            for (int a = 0; a < AHEAD; ++a) {
-                const int i = (a * waves + wave) * 64 + lane;
-                if ((a * waves + wave) * 64 < total) heads.template offer<false, false>(id[a] != EMPTY_IDX && i % k == 0, v[a], id[a], lane);
+                for (int a = 0; a < AHEAD; ++a) {
+                    const int i = (a * waves + wave) * 64 + lane;
+                    if ((a * waves + wave) * 64 < total) heads.template offer<false, false>(id[a] != EMPTY_IDX && i % k == 0, v[a], id[a], lane);
+                }
+            } else {
+                // entries in any order: every lane's smallest entry stands in for a list head (64 different entries)
+                float hv = INFINITY;
+                int hid = EMPTY_IDX;
+#pragma unroll
+                for (int a = 0; a < AHEAD; ++a)
+                    if (id[a] != EMPTY_IDX && (hid == EMPTY_IDX || v[a] < hv)) { hv = v[a]; hid = id[a]; }
+                heads.template offer<false, false>(hid != EMPTY_IDX, hv, hid, lane);
             }
         }
         if (lane == 0) sh_thr[wave] = wave < waves ? heads.thr : INFINITY;
         __syncthreads();
         float bound = INFINITY;
-        for (int w = 0; w < MB_WAVES; ++w) bound = fminf(bound, sh_thr[w]);
+        for (int w = 0; w < (int)(blockDim.x >> 6); ++w) bound = fminf(bound, sh_thr[w]);
         if (wave < waves) {
 #pragma unroll
             for (int a = 0; a < AHEAD; ++a) {
