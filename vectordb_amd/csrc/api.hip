@@ -2735,8 +2735,11 @@ static int pq_search_impl(vdb_pq* h, const float* d_q, int nq, int k, const uint
     VDB_TRY(ws.queue_cnt.reserve((size_t)nq * sizeof(int)));
     int* qlen = ws.queue_cnt.as<int>();          // entries in every query's packed candidate area; the table kernel clears it
     VDB_TRY(ws.round32.reserve((size_t)nq * h->m * sizeof(float)));          // the smallest entry of every table row
+    // (the counters and the two flags of the byte-table pass: cleared by the table kernel, the first of the search)
+    constexpr int PQ8_Q_BLOCK = 64, PQ8_LEN_STRIDE = 32, PQ8_COUNTERS = PQ8_Q_BLOCK * PQ8_LEN_STRIDE + 2;
+    VDB_TRY(ws.cursor.reserve((size_t)PQ8_COUNTERS * sizeof(int)));
     VDB_TRY(launch_pq_lut(d_q, h->dim, nq, h->book.as<float>(), h->m, h->ksub, h->dsub, h->plan, ws.lut.as<float>(), s, qlen,
-                          ws.round32.as<float>()));
+                          ws.round32.as<float>(), ws.cursor.as<int>(), PQ8_COUNTERS));
     const int64_t ntiles = (h->n + 255) / 256;
     const int splits = (int)std::max<int64_t>(1, std::min<int64_t>((ntiles + 15) / 16, (8 * ctx().num_cus + nq - 1) / nq));
     const int n_cand = splits * pq_scan_lists_per_split();
@@ -2788,7 +2791,7 @@ static int pq_search_impl(vdb_pq* h, const float* d_q, int nq, int k, const uint
     int64_t bound_stride = k;
     h->last_used_bytes = false;
     if (bytes && bound_d) {
-        constexpr int Q_BLOCK = 64, AREA = 32768, SEG_CAP = 512, LEN_STRIDE = 32;
+        constexpr int Q_BLOCK = PQ8_Q_BLOCK, AREA = 32768, SEG_CAP = 512, LEN_STRIDE = PQ8_LEN_STRIDE;
         const int qb = std::min(nq, Q_BLOCK);
         const int bsplits = pq_scan8_splits(h->n, qb);
         const int n_seg = pq_scan8_groups(qb) * bsplits * 4;
@@ -2798,10 +2801,9 @@ static int pq_search_impl(vdb_pq* h, const float* d_q, int nq, int k, const uint
         VDB_TRY(ws.seg.reserve((size_t)n_seg * SEG_CAP * sizeof(int2)));
         VDB_TRY(ws.seg_len.reserve((size_t)n_seg * sizeof(int)));
         VDB_TRY(ws.queue.reserve((size_t)qb * AREA * (sizeof(float) + sizeof(int))));
-        VDB_TRY(ws.cursor.reserve(((size_t)qb * LEN_STRIDE + 1) * sizeof(int)));
         int* counters = ws.cursor.as<int>();
-        int* flag = counters + (size_t)qb * LEN_STRIDE;
-        VDB_HIP(hipMemsetAsync(counters, 0, ((size_t)qb * LEN_STRIDE + 1) * sizeof(int), s));
+        int* flag = counters + (size_t)Q_BLOCK * LEN_STRIDE;     // some query's rows did not fit: the fp32 scan answers
+        int* redo = flag + 1;                                    // some query's candidates are left to the general selection
         for (int q0 = 0; q0 < nq; q0 += Q_BLOCK) {
             const int nb = std::min(Q_BLOCK, nq - q0);
             PqScan8Job j{};
@@ -2816,7 +2818,7 @@ static int pq_search_impl(vdb_pq* h, const float* d_q, int nq, int k, const uint
             j.queue_len = counters; j.len_stride = LEN_STRIDE; j.overflow = flag; j.timed = true;
             VDB_TRY(launch_pq_scan8(j, s));
             SelectOut o{d_out_d + (int64_t)q0 * k, d_out_i + (int64_t)q0 * k, nullptr, k, 0, nullptr, nullptr};
-            VDB_TRY(launch_select_packed(j.area_d, j.area_i, nb, AREA, kmax, o, s, counters, LEN_STRIDE));
+            VDB_TRY(launch_select_packed(j.area_d, j.area_i, nb, AREA, kmax, o, s, counters, LEN_STRIDE, 16, redo));
         }
         run_if = flag;
         bound_d = ws.mins.as<float>(); bound_stride = 1;     // the outputs that held the bounds have been written

@@ -59,11 +59,13 @@ __device__ static float np_sum_sqdiff(const float* a, const float* b, int n, con
 __global__ __launch_bounds__(256) void pq_lut_kernel(const float* __restrict__ q, int ldq,
                                                      const float* __restrict__ book, int m, int ksub, int dsub,
                                                      SumPlan plan, float* __restrict__ lut, int* __restrict__ zero_counts,
-                                                     float* __restrict__ mins) {
+                                                     float* __restrict__ mins, int* __restrict__ zero_more, int zero_more_n) {
     extern __shared__ __align__(16) float qs[];
     __shared__ float wave_min[4];
     const int sub = blockIdx.x, qi = blockIdx.y;
     if (zero_counts && sub == 0 && threadIdx.x == 0) zero_counts[qi] = 0;    // the scan's per-query queue lengths
+    if (sub == 0 && qi == 0)                                                 // the byte-table pass's counters and flags
+        for (int i = threadIdx.x; i < zero_more_n; i += blockDim.x) zero_more[i] = 0;
     for (int i = threadIdx.x; i < dsub; i += blockDim.x) qs[i] = q[(int64_t)qi * ldq + sub * dsub + i];
     __syncthreads();
     float least = INFINITY;
@@ -491,10 +493,10 @@ int launch_ivfpq_scan(const float* q, int ldq, int dim, int nq, const float* cen
 
 // ---------------------------------------------------------------- launchers
 int launch_pq_lut(const float* q, int ldq, int nq, const float* book, int m, int ksub, int dsub,
-                  const SumPlan& plan, float* lut, hipStream_t s, int* zero_counts, float* mins) {
+                  const SumPlan& plan, float* lut, hipStream_t s, int* zero_counts, float* mins, int* zero_more, int zero_more_n) {
     if (nq <= 0) return VDB_OK;
     hipLaunchKernelGGL(pq_lut_kernel, dim3(m, nq), dim3(256), (size_t)dsub * sizeof(float), s,
-                       q, ldq, book, m, ksub, dsub, plan, lut, zero_counts, mins);
+                       q, ldq, book, m, ksub, dsub, plan, lut, zero_counts, mins, zero_more, zero_more_n);
     VDB_HIP(hipGetLastError());
     return VDB_OK;
 }

@@ -264,7 +264,7 @@ __global__ __launch_bounds__(256) void merge_wave_kernel(const float* __restrict
 }
 
 __global__ void merge_block_kernel(const float* __restrict__ d, const int* __restrict__ idx, int area, int k, SelectOut o,
-                                   int* __restrict__ queue_len, int lists_of_k, int len_stride);
+                                   int* __restrict__ queue_len, int lists_of_k, int len_stride, const int* __restrict__ redo);
 static constexpr int MB_WAVES = 16;
 
 int launch_select(const float* part_d, const int* part_i, int nq, int n_cand, int k, int tie_group,
@@ -287,7 +287,7 @@ int launch_select(const float* part_d, const int* part_i, int nq, int n_cand, in
     if (nq <= 8 && idx_map == nullptr && idx_offset == 0 && (int64_t)n_cand * k <= (1 << 17)) {
         // a handful of queries: one block of sixteen waves per query walks the lists as one run of entries, instead of
         // two or three dependent launches of list merges
-        hipLaunchKernelGGL(merge_block_kernel, dim3(nq), dim3(64 * MB_WAVES), 0, s, part_d, part_i, n_cand * k, k, o, (int*)nullptr, 1, 1);
+        hipLaunchKernelGGL(merge_block_kernel, dim3(nq), dim3(64 * MB_WAVES), 0, s, part_d, part_i, n_cand * k, k, o, (int*)nullptr, 1, 1, (const int*)nullptr);
         VDB_HIP(hipGetLastError());
         return VDB_OK;
     }
@@ -328,7 +328,7 @@ int launch_select(const float* part_d, const int* part_i, int nq, int n_cand, in
 // waves busy), each keeps its k best in registers, and wave 0 merges the waves' lists through LDS.
 __global__ __launch_bounds__(64 * MB_WAVES) void merge_block_kernel(const float* __restrict__ d, const int* __restrict__ idx,
                                                                     int area, int k, SelectOut o, int* __restrict__ queue_len,
-                                                                    int lists_of_k, int len_stride) {
+                                                                    int lists_of_k, int len_stride, const int* __restrict__ redo) {
     __shared__ float sh_d[MB_WAVES * 64];
     __shared__ int sh_i[MB_WAVES * 64];
     __shared__ float sh_thr[MB_WAVES];
@@ -336,8 +336,10 @@ __global__ __launch_bounds__(64 * MB_WAVES) void merge_block_kernel(const float*
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int q = blockIdx.x;
     if (o.run_if && *o.run_if == 0) return;
+    if (redo && *redo == 0) return;                              // select_small_kernel answered every query
     if (queue_len) queue_len += (int64_t)q * len_stride - q;     // a query's length lies len_stride ints from its neighbour's
     const int total = queue_len ? min(__builtin_amdgcn_readfirstlane(queue_len[q]), area) : area;
+    if (redo && total == 0) return;                              // ... or this one (and cleared its length)
     const int waves = max(1, min((int)(blockDim.x >> 6), (total + 255) / 256));
     const float* dq = d + (int64_t)q * area;
     const int* iq = idx + (int64_t)q * area;
@@ -450,12 +452,121 @@ __global__ __launch_bounds__(64 * MB_WAVES) void merge_block_kernel(const float*
     if (lane < k) write_out(lane, top.eid == EMPTY_IDX, top.e, top.eid);
 }
 
+// The k best (k <= 16) of a query's candidate area of up to 512 entries per wave, in any order, empty entries marked by
+// their id: merge_block_kernel's first way alone, in a kernel of a few kilobytes (a block per query starts on a
+// cold instruction cache, and merge_block_kernel is 90 KB of merge networks).  A wave's bound is the k-th smallest of
+// its lanes' smallest entries, found by counting (every lane counts the lanes whose value precedes its own).
+// A longer area, or more than 1024 entries within the bound: `redo` is set and the query's length stays, for
+// merge_block_kernel behind that flag.
+static constexpr int SS_AHEAD = 8;
+static constexpr int SS_HELD = 1024;
+__global__ __launch_bounds__(1024) void select_small_kernel(const float* __restrict__ d, const int* __restrict__ idx, int area,
+                                                            int k, SelectOut o, int* __restrict__ queue_len, int len_stride,
+                                                            int* __restrict__ redo) {
+    __shared__ float sh_d[SS_HELD];
+    __shared__ int sh_i[SS_HELD];
+    __shared__ float sh_thr[16];
+    __shared__ int sh_cnt;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nw = blockDim.x >> 6;
+    const int q = blockIdx.x;
+    if (o.run_if && *o.run_if == 0) return;
+    if (queue_len) queue_len += (int64_t)q * len_stride - q;
+    const int total = queue_len ? min(__builtin_amdgcn_readfirstlane(queue_len[q]), area) : area;
+    if (total > nw * 64 * SS_AHEAD) {                            // the same for every thread of the block
+        if (threadIdx.x == 0) *redo = 1;
+        return;
+    }
+    const int waves = max(1, min(nw, (total + 255) / 256));
+    const float* dq = d + (int64_t)q * area;
+    const int* iq = idx + (int64_t)q * area;
+    if (threadIdx.x == 0) sh_cnt = 0;
+    float v[SS_AHEAD];
+    int id[SS_AHEAD];
+    float thr = INFINITY;
+    if (wave < waves) {
+#pragma unroll
+        for (int a = 0; a < SS_AHEAD; ++a) {
+            const int i = (a * waves + wave) * 64 + lane;
+            v[a] = i < total ? dq[i] : INFINITY;
+            id[a] = i < total ? iq[i] : EMPTY_IDX;
+        }
+        float hv = INFINITY;                                     // lanes without an entry (or with NaN alone) stand at +inf
+#pragma unroll
+        for (int a = 0; a < SS_AHEAD; ++a)
+            if (id[a] != EMPTY_IDX && v[a] < hv) hv = v[a];
+        int before = 0;
+#pragma unroll
+        for (int l = 0; l < 64; ++l) {
+            const float other = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(hv), l));
+            before += (other < hv || (other == hv && l < lane)) ? 1 : 0;
+        }
+        const unsigned long long kth = __ballot(before == k - 1);          // exactly one lane: the counts are a permutation
+        thr = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(hv), __builtin_ctzll(kth)));
+    } else {
+#pragma unroll
+        for (int a = 0; a < SS_AHEAD; ++a) { v[a] = INFINITY; id[a] = EMPTY_IDX; }
+    }
+    if (lane == 0) sh_thr[wave] = thr;
+    __syncthreads();
+    float bound = INFINITY;
+    for (int w = 0; w < nw; ++w) bound = fminf(bound, sh_thr[w]);
+    if (wave < waves) {
+#pragma unroll
+        for (int a = 0; a < SS_AHEAD; ++a) {
+            const bool in = id[a] != EMPTY_IDX && v[a] <= bound;
+            const unsigned long long m = __ballot(in);
+            if (m != 0ull) {
+                int base = 0;
+                if (lane == 0) base = atomicAdd(&sh_cnt, __popcll(m));
+                base = __builtin_amdgcn_readfirstlane(base);
+                const int at = base + __popcll(m & ((1ull << lane) - 1ull));
+                if (in && at < SS_HELD) { sh_d[at] = v[a]; sh_i[at] = id[a]; }
+            }
+        }
+    }
+    __syncthreads();
+    const int within = sh_cnt;
+    if (within > SS_HELD) {                                      // a bound that does not bind
+        if (threadIdx.x == 0) *redo = 1;
+        return;
+    }
+    if (queue_len && threadIdx.x == 0) queue_len[q] = 0;         // every wave has read it (the barriers above)
+    for (int t = threadIdx.x; t < max(within, k); t += blockDim.x) {
+        bool empty = t >= within;
+        float my = 0.0f;
+        int my_id = 0, place = t;
+        if (!empty) {
+            my = sh_d[t];
+            my_id = sh_i[t];
+            place = 0;
+            for (int e = 0; e < within; ++e) place += pair_less(sh_d[e], sh_i[e], my, my_id) ? 1 : 0;
+        } else if (t >= k) {
+            continue;
+        }
+        if (place < k) {
+            const int64_t row = empty ? -1 : (int64_t)my_id;
+            const int64_t at = (int64_t)q * o.out_stride + o.out_off + place;
+            if (o.out_d) o.out_d[at] = empty ? INFINITY : my;
+            if (o.out_i) o.out_i[at] = row;
+            if (o.out_i32) o.out_i32[at] = (int)row;
+            if (place == k - 1 && o.last_d) {
+                o.last_d[q] = empty ? INFINITY : my;
+                o.last_key[q] = empty ? INT64_MAX : (int64_t)my_id;
+            }
+        }
+    }
+}
+
+// `redo` (one int, zero before the call): the short kernel first, merge_block_kernel behind the flag for what it left
 int launch_select_packed(const float* part_d, const int* part_i, int nq, int area, int k, const SelectOut& o, hipStream_t s,
-                         int* queue_len, int len_stride, int waves) {
+                         int* queue_len, int len_stride, int waves, int* redo) {
     if (nq <= 0) return VDB_OK;
     VDB_REQUIRE(k >= 1 && k <= 64 && queue_len, "packed selection: k in 1..64 and a queue length per query");
     VDB_REQUIRE(waves >= 1 && waves <= MB_WAVES && waves * k <= 64 * MB_WAVES, "packed selection: 1..%d waves per query", MB_WAVES);
-    hipLaunchKernelGGL(merge_block_kernel, dim3(nq), dim3(64 * waves), 0, s, part_d, part_i, area, k, o, queue_len, 0, len_stride);
+    if (k > 16) redo = nullptr;
+    if (redo) hipLaunchKernelGGL(select_small_kernel, dim3(nq), dim3(64 * waves), 0, s, part_d, part_i, area, k, o, queue_len, len_stride, redo);
+    hipLaunchKernelGGL(merge_block_kernel, dim3(nq), dim3(64 * waves), 0, s, part_d, part_i, area, k, o, queue_len, 0, len_stride,
+                       (const int*)redo);
     VDB_HIP(hipGetLastError());
     return VDB_OK;
 }
@@ -464,7 +575,14 @@ int launch_select_packed(const float* part_d, const int* part_i, int nq, int are
 int launch_select_area(const float* part_d, const int* part_i, int nq, int area, int k, const SelectOut& o, hipStream_t s) {
     if (nq <= 0) return VDB_OK;
     VDB_REQUIRE(k >= 1 && k <= 64, "area selection: k in 1..64");
-    hipLaunchKernelGGL(merge_block_kernel, dim3(nq), dim3(64 * MB_WAVES), 0, s, part_d, part_i, area, k, o, (int*)nullptr, 0, 1);
+    if (k <= 16 && area <= SS_HELD) {        // everything fits the short kernel's LDS: it cannot leave a query behind
+        const int waves = std::max(1, std::min(MB_WAVES, (area + 255) / 256));
+        hipLaunchKernelGGL(select_small_kernel, dim3(nq), dim3(64 * waves), 0, s, part_d, part_i, area, k, o, (int*)nullptr, 1,
+                           (int*)nullptr);
+    } else {
+        hipLaunchKernelGGL(merge_block_kernel, dim3(nq), dim3(64 * MB_WAVES), 0, s, part_d, part_i, area, k, o, (int*)nullptr, 0, 1,
+                           (const int*)nullptr);
+    }
     VDB_HIP(hipGetLastError());
     return VDB_OK;
 }

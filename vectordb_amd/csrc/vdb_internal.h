@@ -374,9 +374,11 @@ struct SelectOut {
 int launch_select(const float* part_d, const int* part_i, int nq, int n_cand, int k, int tie_group,
                   const int* idx_map, int64_t idx_offset, const SelectOut& o, hipStream_t s, DevBuf* mid);
 // a few queries: the k best of every query's packed candidate area (queue_len[q] of `area` entries, any order),
-// one block per query; sets queue_len[q] back to zero (query q's length at queue_len[q * len_stride])
+// one block per query; sets queue_len[q] back to zero (query q's length at queue_len[q * len_stride]).
+// `redo` (optional: one device int that is zero before the call, k <= 16): a short kernel answers the queries with up
+// to 512 entries per wave first and sets the flag for the others, which the general kernel then answers.
 int launch_select_packed(const float* part_d, const int* part_i, int nq, int area, int k, const SelectOut& o, hipStream_t s,
-                         int* queue_len, int len_stride = 1, int waves = 16);
+                         int* queue_len, int len_stride = 1, int waves = 16, int* redo = nullptr);
 // the same over whole areas (every entry present or marked empty by its id): no lengths
 int launch_select_area(const float* part_d, const int* part_i, int nq, int area, int k, const SelectOut& o, hipStream_t s);
 // lists laid out [n_lists][nq][k] with int64 ids (negative = empty), ordered by (distance, id);
@@ -391,7 +393,8 @@ int launch_row_sort_topk(const float* dist, int nq, int n, int k, float* out_d, 
 
 // PQ
 int launch_pq_lut(const float* q, int ldq, int nq, const float* book, int m, int ksub, int dsub,
-                  const SumPlan& plan, float* lut, hipStream_t s, int* zero_counts = nullptr, float* mins = nullptr);
+                  const SumPlan& plan, float* lut, hipStream_t s, int* zero_counts = nullptr, float* mins = nullptr,
+                  int* zero_more = nullptr, int zero_more_n = 0);
 int launch_pq_encode(const float* x, int64_t n, int ldx, const float* book, int m, int ksub, int dsub,
                      const SumPlan& plan, uint8_t* codes, hipStream_t s);
 // candidate lists come out as [nq][splits * pq_scan_lists_per_split()][k]
