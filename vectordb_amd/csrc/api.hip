@@ -2364,8 +2364,8 @@ static int ivf_search_impl(vdb_ivf* h, const float* d_q, int nq, int k, int n_pr
     if (mfma) {
         VDB_TRY(ws.q16.reserve((size_t)nq * ld16 * 2));
         VDB_TRY(ws.mins.reserve((size_t)q_block * ivf_mfma_subsets() * sizeof(float)));
-        VDB_TRY(ws.thr_d.reserve((size_t)q_block * sizeof(float)));
-        VDB_TRY(ws.queue.reserve((size_t)q_block * queue_cap * 2 * sizeof(int)));      // slots, distances
+        VDB_TRY(ws.thr_d.reserve((size_t)q_block * 2 * sizeof(float)));                // thresholds, slacks
+        VDB_TRY(ws.queue.reserve((size_t)q_block * queue_cap * 3 * sizeof(int)));      // slots, keys, positions
         VDB_TRY(ws.seg.reserve((size_t)ivf_mfma_scan_waves() * IVF_MFMA_SEGMENT * sizeof(int4)));
         VDB_TRY(ws.seg_len.reserve((size_t)ivf_mfma_scan_waves() * sizeof(int)));
         VDB_TRY(ws.queue_cnt.reserve((size_t)q_block * ivf_mfma_len_stride() * sizeof(int)));
@@ -2391,6 +2391,8 @@ static int ivf_search_impl(vdb_ivf* h, const float* d_q, int nq, int k, int n_pr
             mj.row_ids = h->row_ids.as<int>(); mj.mask = d_mask; mj.max_row_nrm = h->max_nrm.as<float>();
             mj.mins = ws.mins.as<float>(); mj.thr = ws.thr_d.as<float>(); mj.queue_slot = ws.queue.as<int>();
             mj.queue_d = ws.queue.as<float>() + (size_t)q_block * queue_cap;
+            mj.queue_pos = ws.queue.as<int>() + (size_t)q_block * queue_cap * 2;
+            mj.slack = ws.thr_d.as<float>() + q_block;
             mj.seg = reinterpret_cast<int4*>(ws.seg.p); mj.seg_len = ws.seg_len.as<int>(); mj.seg_cap = IVF_MFMA_SEGMENT;
             mj.slots = ws.slots.as<int>() + (int64_t)q0 * k;
             mj.queue_len = ws.queue_cnt.as<int>(); mj.queue_cap = queue_cap; mj.overflow = ws.flag.as<int>();

@@ -12,10 +12,13 @@
 //      the test itself: every row that can be among the reference's k best has a key within the threshold.
 //   3. scan pass   (ivf_approx_kernel): the same keys for every (probed list row, query) pair, list-major
 //      (a list chunk is read once for up to 32 queries that probe it); pairs within the threshold (and passing the
-//      filter bit) are appended to the query's queue as (candidate slot, stored position).
-//   4. ivf_exact_dist_kernel recomputes the queued pairs in the reference's own arithmetic (element-wise float32
-//      q - c, square, NumPy's pairwise summation order, sqrtf); one block per query then keeps the k best under
-//      (distance, candidate slot) = (distance, visiting order of index/ivf.py:619-628).
+//      filter bit) are kept with their keys, per wave; ivf_scatter_kernel hands them to the queries' queues.
+//   4. ivf_finish_kernel, one block per query: the k-th smallest key of the queue, A_k, bounds the reference's k-th
+//      best sum as the bound pass's value did (k rows have keys within it), only much tighter, so the same widening
+//      gives a second threshold, and only the pairs within that one (a couple of dozen of several hundred) are
+//      recomputed in the reference's own arithmetic (element-wise float32 q - c, square, NumPy's pairwise summation
+//      order, sqrtf); the k best of those under (distance, candidate slot) = (distance, visiting order of
+//      index/ivf.py:619-628) are the result.
 //
 // Rows, order and distance bits equal those of the scalar scan, because every returned value is computed by the same
 // float32 operations on the same float32 rows; the matrix cores only decide which pairs get computed.  A queue that
@@ -47,7 +50,7 @@ struct IvfApproxParams {
     const int* sq_qid; const int64_t* sq_out;                         // per (list, query): query, first candidate slot
     int64_t cand_stride;                   // sq_out = query * cand_stride + slot of the list's first row
     const float* thr;                      // per query: pairs with key <= thr are kept
-    int4* seg; int* seg_len; int seg_cap;  // per wave of the launch: its kept pairs (query, slot, position, -), and how many
+    int4* seg; int* seg_len; int seg_cap;  // per wave of the launch: its kept pairs (query, slot, position, key), and how many
     int* overflow;
     const int* row_ids; const uint32_t* mask;
 };
@@ -132,6 +135,7 @@ __global__ __launch_bounds__(IA_NT, 2) void ivf_approx_kernel(IvfApproxParams p)
             // keys of one tile's rows from its accumulator; pairs within the threshold go to this wave's segment
             auto finish_tile = [&](int t, const f32x16& acc) {
                 uint32_t hits = 0;
+                float keys[16];
 #pragma unroll
                 for (int g = 0; g < 4; ++g) {
 #pragma unroll
@@ -140,6 +144,7 @@ __global__ __launch_bounds__(IA_NT, 2) void ivf_approx_kernel(IvfApproxParams p)
                         // |c|^2 of row r sits in lane (r mod 256) / 4, component i
                         const float csq = __shfl(cs4[i], (t & 7) * 8 + 2 * g + h);
                         const float key = __fmaf_rn(-2.0f, acc[g * 4 + i], q_sq + csq);
+                        keys[g * 4 + i] = key;
                         if (key <= thr && r < rows) hits |= 1u << (g * 4 + i);
                     }
                 }
@@ -159,7 +164,10 @@ __global__ __launch_bounds__(IA_NT, 2) void ivf_approx_kernel(IvfApproxParams p)
                     const unsigned long long km = __ballot(keep);
                     const int at = seg_n + __popcll(km & ((1ull << lane) - 1ull));
                     if (keep) {
-                        if (at < p.seg_cap) my_seg[at] = make_int4(qid, slot0 + r, (int)pos, 0);
+                        float key = keys[0];
+#pragma unroll
+                        for (int x = 1; x < 16; ++x) key = e == x ? keys[x] : key;
+                        if (at < p.seg_cap) my_seg[at] = make_int4(qid, slot0 + r, (int)pos, __float_as_int(key));
                         else *p.overflow = 1;
                     }
                     seg_n += __popcll(km);
@@ -229,11 +237,16 @@ __global__ __launch_bounds__(IA_NT, 2) void ivf_approx_kernel(IvfApproxParams p)
 }
 
 // --------------------------------------------------------------------------
-// Bound pass.  One wave per (query, unit): unit u covers candidate slots [256 u, 256 u + 256) of the query's visiting
-// order, i.e. rows of its nearest probed lists; every lane finds the stored position of its own slot (slots of one tile
-// may straddle two lists).  The query sits in every column of B, so lanes 0 and 32 hold the keys of the tile's rows
-// 8 g + i and 8 g + 4 + i; each writes the smallest key of its sixteen rows that exist and pass the filter (a key below
-// zero counts as zero: the k-th smallest of larger values is still a bound) to the subset (unit, tile, half).
+// Bound pass.  One wave per (query, unit, tile): unit u covers candidate slots [256 u, 256 u + 256) of the query's
+// visiting order, i.e. rows of its nearest probed lists, in eight tiles of 32; every lane finds the stored position of
+// its own slot (slots of one tile may straddle two lists).  The query sits in every column of B, so lanes 0 and 32 hold
+// the keys of the tile's rows 8 g + i and 8 g + 4 + i; each writes the smallest key of its sixteen rows that exist and
+// pass the filter (a key below zero counts as zero: the k-th smallest of larger values is still a bound) to the subset
+// (unit, tile, half).
+//   A wave is a chain of dependent reads (list offsets -> probed list -> its first position -> rows), so the tiles of a
+// unit are separate waves, and the offsets and numbers of the first eight probed lists (which hold the 2048 slots
+// unless lists are shorter than 256 rows) come in one round of scalar loads.  What is left is the reading itself:
+// every query reads its own 2048 rows (512 KiB in bf16 at 128 columns), half a gigabyte for 1024 queries.
 struct IvfBoundParams {
     const uint16_t* rows16; int ld16; int n_chunks;
     const float* row_sq; const uint16_t* q16; const float* q_sq;
@@ -243,16 +256,32 @@ struct IvfBoundParams {
     int nq;
 };
 
+static constexpr int IB_AHEAD = 8;         // probed lists whose offsets are read ahead
+
 template <int KS, bool MULTI>
 __global__ __launch_bounds__(IA_NT) void ivf_bound_kernel(IvfBoundParams p) {
     const int lane = threadIdx.x & 63;
     const int n = lane & 31, h = lane >> 5;
-    const int w = blockIdx.x * (IA_NT / 64) + (threadIdx.x >> 6);
-    const int q = w / IB_UNITS, u = w - q * IB_UNITS;
+    const int w = blockIdx.x * (IA_NT / 64) + __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    const int q = w / (IB_UNITS * 8), ut = w - q * (IB_UNITS * 8);
     if (q >= p.nq) return;
+    const int u = ut >> 3, t = ut & 7;
     constexpr int CE = KS * 16;
     const int64_t* co = p.cand_off + (int64_t)q * (p.n_probe + 1);
-    const int64_t total = co[p.n_probe];
+    const int* probes = p.probes + (int64_t)q * p.n_probe;
+    const int64_t total = uniform_load(co + p.n_probe);
+    float* out = p.mins + (int64_t)q * IA_SUBSETS + (u * 8 + t) * 2 + h;
+    if ((int64_t)u * 256 + t * 32 >= total) {                  // the same for the whole wave: nothing left to visit
+        if (n == 0) *out = INFINITY;
+        return;
+    }
+    const int ahead = min(p.n_probe, IB_AHEAD);
+    int64_t c_at[IB_AHEAD + 1];
+    int l_at[IB_AHEAD];
+#pragma unroll
+    for (int i = 0; i <= IB_AHEAD; ++i) c_at[i] = uniform_load(co + min(i, ahead));
+#pragma unroll
+    for (int i = 0; i < IB_AHEAD; ++i) l_at[i] = uniform_load(probes + min(i, ahead - 1));
     const float q_sq = p.q_sq[q];
     const uint16_t* brow = p.q16 + (int64_t)q * p.ld16 + h * 8;
     i4v b[KS];
@@ -260,57 +289,61 @@ __global__ __launch_bounds__(IA_NT) void ivf_bound_kernel(IvfBoundParams p) {
 #pragma unroll
         for (int j = 0; j < KS; ++j) b[j] = *reinterpret_cast<const i4v*>(brow + j * 16);
     }
-    int pr = 0;                                    // the probe this lane's slot lies in (slots only grow)
-    for (int t = 0; t < 8; ++t) {
-        const int64_t slot = (int64_t)u * 256 + t * 32 + n;
-        bool ok = slot < total;
-        int64_t pos = 0;
-        if (ok) {
-            while (co[pr + 1] <= slot) ++pr;       // empty lists have equal offsets and are stepped over
-            const int l = p.probes[(int64_t)q * p.n_probe + pr];
-            pos = p.list_beg[l] + (slot - co[pr]);
-            if (p.mask) {
-                const int id = p.row_ids[pos];
-                ok = (p.mask[id >> 5] >> (id & 31)) & 1u;
-            }
+    const int64_t slot = (int64_t)u * 256 + t * 32 + n;
+    bool ok = slot < total;
+    int64_t pos = 0;
+    if (ok) {
+        // the probe this lane's slot lies in: co[pr] <= slot < co[pr + 1] (empty lists have equal offsets and are stepped over)
+        int pr = 0;
+        int64_t first = c_at[0];
+        int l = l_at[0];
+#pragma unroll
+        for (int i = 1; i < IB_AHEAD; ++i)
+            if (i < ahead && c_at[i] <= slot) { pr = i; first = c_at[i]; l = l_at[i]; }
+        if (c_at[IB_AHEAD] <= slot && ahead == IB_AHEAD) {     // beyond the lists read ahead (rare)
+            pr = IB_AHEAD;
+            while (co[pr + 1] <= slot) ++pr;
+            first = co[pr];
+            l = probes[pr];
         }
-        const unsigned long long okm = __ballot(ok);
-        if ((int64_t)u * 256 + t * 32 >= total) {              // the same for the whole wave: nothing left to visit
-            if (n == 0) p.mins[(int64_t)q * IA_SUBSETS + (u * 8 + t) * 2 + h] = INFINITY;
-            continue;
+        pos = p.list_beg[l] + (slot - first);
+        if (p.mask) {
+            const int id = p.row_ids[pos];
+            ok = (p.mask[id >> 5] >> (id & 31)) & 1u;
         }
-        const float csq_own = p.row_sq[pos];
-        const uint16_t* arow = p.rows16 + tiled_at(pos, h, p.ld16 >> 3);
-        f32x16 acc;
-#pragma unroll
-        for (int e = 0; e < 16; ++e) acc[e] = 0.0f;
-        const int chunks = MULTI ? p.n_chunks : 1;
-        for (int c = 0; c < chunks; ++c) {
-            i4v a[KS];
-#pragma unroll
-            for (int j = 0; j < KS; ++j) a[j] = *reinterpret_cast<const i4v*>(arow + (int64_t)(c * (CE / 8) + 2 * j) * 256);
-            if (MULTI) {
-#pragma unroll
-                for (int j = 0; j < KS; ++j) b[j] = *reinterpret_cast<const i4v*>(brow + c * CE + j * 16);
-            }
-#pragma unroll
-            for (int j = 0; j < KS; ++j)
-                acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, a[j]), __builtin_bit_cast(bf16x8, b[j]),
-                                                              acc, 0, 0, 0);
-        }
-        float best = INFINITY;
-#pragma unroll
-        for (int g = 0; g < 4; ++g) {
-#pragma unroll
-            for (int i = 0; i < 4; ++i) {
-                const int r = 8 * g + 4 * h + i;               // the tile's row: lane r (and r + 32) looked it up
-                const float csq = __shfl(csq_own, r);
-                const float key = __fmaf_rn(-2.0f, acc[g * 4 + i], q_sq + csq);
-                if ((okm >> r) & 1ull) best = fminf(best, fmaxf(key, 0.0f));
-            }
-        }
-        if (n == 0) p.mins[(int64_t)q * IA_SUBSETS + (u * 8 + t) * 2 + h] = best;
     }
+    const unsigned long long okm = __ballot(ok);
+    const float csq_own = p.row_sq[pos];
+    const uint16_t* arow = p.rows16 + tiled_at(pos, h, p.ld16 >> 3);
+    f32x16 acc;
+#pragma unroll
+    for (int e = 0; e < 16; ++e) acc[e] = 0.0f;
+    const int chunks = MULTI ? p.n_chunks : 1;
+    for (int c = 0; c < chunks; ++c) {
+        i4v a[KS];
+#pragma unroll
+        for (int j = 0; j < KS; ++j) a[j] = *reinterpret_cast<const i4v*>(arow + (int64_t)(c * (CE / 8) + 2 * j) * 256);
+        if (MULTI) {
+#pragma unroll
+            for (int j = 0; j < KS; ++j) b[j] = *reinterpret_cast<const i4v*>(brow + c * CE + j * 16);
+        }
+#pragma unroll
+        for (int j = 0; j < KS; ++j)
+            acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, a[j]), __builtin_bit_cast(bf16x8, b[j]),
+                                                          acc, 0, 0, 0);
+    }
+    float best = INFINITY;
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int r = 8 * g + 4 * h + i;               // the tile's row: lane r (and r + 32) looked it up
+            const float csq = __shfl(csq_own, r);
+            const float key = __fmaf_rn(-2.0f, acc[g * 4 + i], q_sq + csq);
+            if ((okm >> r) & 1ull) best = fminf(best, fmaxf(key, 0.0f));
+        }
+    }
+    if (n == 0) *out = best;
 }
 
 // --------------------------------------------------------------------------
@@ -330,7 +363,7 @@ __global__ __launch_bounds__(IA_NT) void ivf_bound_kernel(IvfBoundParams p) {
 __global__ __launch_bounds__(256) void ivf_threshold_kernel(const float* __restrict__ mins, int nq, int k, int dim,
                                                             const float* __restrict__ q_sq, const float* __restrict__ q_nrm,
                                                             const float* __restrict__ max_row_nrm, float* __restrict__ thr,
-                                                            int* __restrict__ overflow) {
+                                                            float* __restrict__ slack, int* __restrict__ overflow) {
     const int lane = threadIdx.x & 63;
     const int q = blockIdx.x * 4 + (threadIdx.x >> 6);
     if (q >= nq) return;
@@ -342,11 +375,12 @@ __global__ __launch_bounds__(256) void ivf_threshold_kernel(const float* __restr
     }
     if (lane != 0) return;
     const float qn = q_nrm[q], big = *max_row_nrm;
-    if (!(qn < 1e18f) || !(big < 1e18f)) { *overflow = 1; thr[q] = INFINITY; return; }
+    if (!(qn < 1e18f) || !(big < 1e18f)) { *overflow = 1; thr[q] = INFINITY; slack[q] = INFINITY; return; }
     const float e_dot = (0.0078278f + (float)dim * 2.4e-7f) * 1.0001f * qn * big + sqrtf((float)dim) * 1.2e-38f * (qn + big) + 1e-30f;
     const float s = 2.0f * e_dot + (4.0f * (float)dim + 16.0f) * 6.0e-8f * 1.01f * (q_sq[q] + big * big);
     const float b = top.thr;                     // +inf while fewer than k subsets saw a row
     thr[q] = b < INFINITY ? ((b + s) * 1.000001f + s) : INFINITY;
+    slack[q] = s;                                // the second threshold (ivf_finish_kernel) is widened by the same amount
 }
 
 // --------------------------------------------------------------------------
@@ -405,32 +439,180 @@ __device__ static float exact_sqdiff(const float* __restrict__ x, const float* _
     return stack[0];
 }
 
-struct IvfExactParams {
-    const float* rows; int ld; SumPlan plan;     // the float32 rows, by position
-    const float* q; int ldq;                     // the float32 queries (padded rows)
-    int take_sqrt;                               // VDB_EUCLIDEAN_DIRECT: the distance is the root of the sum
+// Blocks (segment of the scan pass, slice): every kept pair takes a place in its query's queue.  Neighbouring pairs
+// of a segment come from one item, i.e. from a handful of queries: every lane finds the lanes of its wave that hold
+// its query (64 broadcasts), the first of them reserves places for all with one atomic, and the others take theirs
+// behind it: an eighth of the atomics of one per pair, which are what this kernel waits for.
+struct IvfScatterParams {
     const int4* seg; const int* seg_len; int seg_cap;
-    float* queue_d; int* queue_slot; int* queue_len; int queue_cap; int* overflow;   // per query: [nq][queue_cap]
+    float* queue_key; int* queue_slot; int* queue_pos; int* queue_len; int queue_cap; int* overflow;   // per query: [nq][queue_cap]
 };
 
-// Blocks (segment of the scan pass, slice), a pair of lanes per kept (query, row) pair: the reference's distance, then a
-// place in the query's queue (an atomic per pair, spread over thousands of waves that have nothing else to wait for).
-__global__ __launch_bounds__(256) void ivf_exact_dist_kernel(IvfExactParams p) {
+__global__ __launch_bounds__(256) void ivf_scatter_kernel(IvfScatterParams p) {
     const int len = min(p.seg_len[blockIdx.x], p.seg_cap);
-    const int m = threadIdx.x & 1;
+    const int lane = threadIdx.x & 63;
     const int4* seg = p.seg + (int64_t)blockIdx.x * p.seg_cap;
-    for (int e = blockIdx.y * 128 + (threadIdx.x >> 1); e < len; e += 128 * gridDim.y) {
-        const int4 ent = seg[e];
-        const float sum = exact_sqdiff(p.rows + (int64_t)ent.z * p.ld, p.q + (int64_t)ent.x * p.ldq, p.plan, m);
-        if (m == 0) {
-            const int at = atomicAdd(&p.queue_len[ent.x * IA_LEN_STRIDE], 1);
+    for (int e0 = blockIdx.y * 256 + (threadIdx.x & ~63); e0 < len; e0 += 256 * gridDim.y) {      // (the same for a wave)
+        const int e = e0 + lane;
+        const bool have = e < len;
+        const int4 ent = have ? seg[e] : make_int4(-1, 0, 0, 0);
+        unsigned long long same = 0ull;                      // the lanes that hold this lane's query
+#pragma unroll 8
+        for (int l = 0; l < 64; ++l) {
+            const int other = __builtin_amdgcn_readlane(ent.x, l);
+            const unsigned long long m = __ballot(ent.x == other);
+            if (ent.x == other) same = m;
+        }
+        const int leader = __builtin_ctzll(same | (1ull << 63));
+        int base = 0;
+        if (have && lane == leader) base = atomicAdd(&p.queue_len[ent.x * IA_LEN_STRIDE], __popcll(same));
+        base = __shfl(base, leader);
+        const int at = base + __popcll(same & ((1ull << lane) - 1ull));
+        if (have) {
             if (at < p.queue_cap) {
-                p.queue_d[(int64_t)ent.x * p.queue_cap + at] = p.take_sqrt ? sqrtf(sum) : sum;
-                p.queue_slot[(int64_t)ent.x * p.queue_cap + at] = ent.y;
+                const int64_t o = (int64_t)ent.x * p.queue_cap + at;
+                p.queue_key[o] = __int_as_float(ent.w);
+                p.queue_slot[o] = ent.y;
+                p.queue_pos[o] = ent.z;
             } else {
                 *p.overflow = 1;
             }
         }
+    }
+}
+
+// One block of four waves per query, over its queue of (key, slot, position) in any order.
+//   U: every lane's smallest key, a wave's k-th smallest of those (found by counting), the smallest over the waves:
+//      k different pairs have keys within U.
+//   The pairs within U widened (as the threshold kernel widens its bound) are gathered in LDS; among them the k-th
+//   smallest key A_k is found by counting, and the pairs within A_k widened are the finalists: with S the query's
+//   slack, k rows have reference sums R <= A_k + S, so the reference's k-th smallest sum is at most that; rows tying
+//   it after the square root lie within one part in 2^22; and a row with R <= (A_k + S)(1 + 2^-21) has a key of at
+//   most (A_k + S)(1 + 2^-21) + S.
+//   The finalists' distances in the reference's arithmetic (a pair of lanes per finalist), then each finds its place
+//   under (distance, slot) by counting.
+// More than IF_HELD pairs within the first bound (thousands of equal rows): the overflow flag, as for a full queue.
+struct IvfFinishParams {
+    const float* rows; int ld; SumPlan plan;     // the float32 rows, by position
+    const float* q; int ldq;                     // the float32 queries (padded rows)
+    int take_sqrt;                               // VDB_EUCLIDEAN_DIRECT: the distance is the root of the sum
+    const float* queue_key; const int* queue_slot; const int* queue_pos; const int* queue_len; int queue_cap;
+    const float* slack;
+    int k, k_out;
+    float* out_d; int* out_slots;                // [nq][k_out]
+    int* overflow;
+};
+
+static constexpr int IF_HELD = 1024;
+
+__global__ __launch_bounds__(256) void ivf_finish_kernel(IvfFinishParams p) {
+    __shared__ float sh_key[IF_HELD];
+    __shared__ int sh_slot[IF_HELD];
+    __shared__ int sh_pos[IF_HELD];
+    __shared__ float sh_d[IF_HELD];              // the finalists' distances
+    __shared__ int sh_fin[IF_HELD];              // the finalists (places in sh_*)
+    __shared__ float sh_thr[4];
+    __shared__ float sh_kth;
+    __shared__ int sh_cnt, sh_nfin;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int q = blockIdx.x;
+    const int k = p.k;
+    const int total = min(p.queue_len[q * IA_LEN_STRIDE], p.queue_cap);
+    const float* keys = p.queue_key + (int64_t)q * p.queue_cap;
+    const float s = p.slack[q];
+    if (tid == 0) { sh_cnt = 0; sh_nfin = 0; sh_kth = INFINITY; }
+    // every place starts empty (the slots are mapped to rows whatever happens below: none may stay unwritten); the
+    // finalists write theirs behind the barriers that follow
+    for (int f = tid; f < k; f += 256) {
+        p.out_d[(int64_t)q * p.k_out + f] = INFINITY;
+        p.out_slots[(int64_t)q * p.k_out + f] = -1;
+    }
+    // U
+    float hv = INFINITY;                         // lanes without a pair (or with NaN alone) stand at +inf
+    for (int i = tid; i < total; i += 256) {
+        const float v = keys[i];
+        if (v < hv) hv = v;
+    }
+    int before = 0;
+#pragma unroll
+    for (int l = 0; l < 64; ++l) {
+        const float other = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(hv), l));
+        before += (other < hv || (other == hv && l < lane)) ? 1 : 0;
+    }
+    const unsigned long long kth_lane = __ballot(before == k - 1);        // exactly one lane: the counts are a permutation
+    const float wave_thr = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(hv), __builtin_ctzll(kth_lane)));
+    if (lane == 0) sh_thr[wave] = wave_thr;
+    __syncthreads();
+    const float u = fminf(fminf(sh_thr[0], sh_thr[1]), fminf(sh_thr[2], sh_thr[3]));
+    const float first = u < INFINITY ? ((u + s) * 1.000001f + s) : INFINITY;
+    // the pairs within the first bound, in LDS
+    for (int i0 = 0; i0 < total; i0 += 256) {
+        const int i = i0 + tid;
+        const float v = i < total ? keys[i] : INFINITY;
+        const bool in = i < total && v <= first;
+        const unsigned long long m = __ballot(in);
+        if (m != 0ull) {
+            int base = 0;
+            if (lane == 0) base = atomicAdd(&sh_cnt, __popcll(m));
+            base = __builtin_amdgcn_readfirstlane(base);
+            const int at = base + __popcll(m & ((1ull << lane) - 1ull));
+            if (in && at < IF_HELD) {
+                sh_key[at] = v;
+                sh_slot[at] = p.queue_slot[(int64_t)q * p.queue_cap + i];
+                sh_pos[at] = p.queue_pos[(int64_t)q * p.queue_cap + i];
+            }
+        }
+    }
+    __syncthreads();
+    const int held = sh_cnt;
+    if (held > IF_HELD) {                        // the same for every thread of the block
+        if (tid == 0) *p.overflow = 1;
+        return;
+    }
+    // A_k: the held key with k - 1 held pairs before it under (key, place)
+    for (int t = tid; t < held; t += 256) {
+        const float my = sh_key[t];
+        int place = 0;
+        for (int e = 0; e < held; ++e) {
+            const float o = sh_key[e];
+            place += (o < my || (o == my && e < t)) ? 1 : 0;
+        }
+        if (place == k - 1) sh_kth = my;
+    }
+    __syncthreads();
+    const float a_k = sh_kth;                    // +inf with fewer than k pairs: every pair is a finalist
+    const float second = a_k < INFINITY ? ((a_k + s) * 1.000001f + s) : INFINITY;
+    for (int t0 = 0; t0 < held; t0 += 256) {
+        const int t = t0 + tid;
+        const bool in = t < held && sh_key[t] <= second;
+        const unsigned long long m = __ballot(in);
+        if (m != 0ull) {
+            int base = 0;
+            if (lane == 0) base = atomicAdd(&sh_nfin, __popcll(m));
+            base = __builtin_amdgcn_readfirstlane(base);
+            if (in) sh_fin[base + __popcll(m & ((1ull << lane) - 1ull))] = t;
+        }
+    }
+    __syncthreads();
+    const int nfin = sh_nfin;
+    // the reference's distances of the finalists
+    const int half = tid & 1;
+    const float* qrow = p.q + (int64_t)q * p.ldq;
+    for (int f0 = 0; f0 < nfin; f0 += 128) {                 // (the pair of lanes of a finalist stays together)
+        const int f = f0 + (tid >> 1);
+        if (f < nfin) {
+            const float sum = exact_sqdiff(p.rows + (int64_t)sh_pos[sh_fin[f]] * p.ld, qrow, p.plan, half);
+            if (half == 0) sh_d[f] = p.take_sqrt ? sqrtf(sum) : sum;
+        }
+    }
+    __syncthreads();
+    for (int f = tid; f < nfin; f += 256) {
+        const float my = sh_d[f];
+        const int my_slot = sh_slot[sh_fin[f]];
+        if (!(my == my)) continue;                           // not a number: in no result (it precedes nothing and nothing precedes it)
+        int place = 0;
+        for (int e = 0; e < nfin; ++e) place += pair_less(sh_d[e], sh_slot[sh_fin[e]], my, my_slot) ? 1 : 0;
+        if (place < k) { p.out_d[(int64_t)q * p.k_out + place] = my; p.out_slots[(int64_t)q * p.k_out + place] = my_slot; }
     }
 }
 
@@ -531,11 +713,11 @@ int launch_ivf_mfma_search(const IvfMfmaJob& j, hipStream_t s) {
     bp.rows16 = j.rows16; bp.ld16 = j.ld16; bp.n_chunks = n_chunks; bp.row_sq = j.row_sq; bp.q16 = j.q16; bp.q_sq = j.q_sq;
     bp.probes = j.probes; bp.n_probe = j.n_probe; bp.n_lists = j.n_lists; bp.cand_off = j.cand_off; bp.list_beg = j.list_beg;
     bp.row_ids = j.row_ids; bp.mask = j.mask; bp.mins = j.mins; bp.nq = j.nq;
-    VDB_TRY(launch_by_pitch(bp, j.ld16, n_chunks, dim3((unsigned)(((int64_t)j.nq * IB_UNITS + 3) / 4)), s,
+    VDB_TRY(launch_by_pitch(bp, j.ld16, n_chunks, dim3((unsigned)(((int64_t)j.nq * IB_UNITS * 8 + 3) / 4)), s,
                             ivf_bound_kernel<2, false>, ivf_bound_kernel<4, false>, ivf_bound_kernel<6, false>,
                             ivf_bound_kernel<8, false>, ivf_bound_kernel<8, true>));
     hipLaunchKernelGGL(ivf_threshold_kernel, dim3((j.nq + 3) / 4), dim3(256), 0, s, j.mins, j.nq, j.k, j.dim, j.q_sq, j.q_nrm,
-                       j.max_row_nrm, j.thr, j.overflow);
+                       j.max_row_nrm, j.thr, j.slack, j.overflow);
     VDB_HIP(hipGetLastError());
     IvfApproxParams p{};
     p.rows16 = j.rows16; p.ld16 = j.ld16; p.n_chunks = n_chunks;
@@ -570,18 +752,18 @@ int launch_ivf_mfma_search(const IvfMfmaJob& j, hipStream_t s) {
         fprintf(stderr, "[ivf mfma] nq=%d k=%d ld16=%d max|c|=%g thr: %d inf, finite %g..%g; kept pairs: %lld (%.1f per query), "
                 "largest segment %d of %d; flag=%d\n", j.nq, j.k, j.ld16, big, inf, tmin, tmax, tot, (double)tot / j.nq, mx, j.seg_cap, flag);
     }
-    IvfExactParams e{};
-    e.rows = j.rows; e.ld = j.ld; e.plan = j.sum_plan; e.q = j.q; e.ldq = j.ldq; e.take_sqrt = j.take_sqrt ? 1 : 0;
-    e.seg = j.seg; e.seg_len = j.seg_len; e.seg_cap = j.seg_cap;
-    e.queue_d = j.queue_d; e.queue_slot = j.queue_slot; e.queue_len = j.queue_len; e.queue_cap = j.queue_cap; e.overflow = j.overflow;
-    // (a segment's pairs over several blocks: segments differ in length by an order of magnitude)
-    hipLaunchKernelGGL(ivf_exact_dist_kernel, dim3(ivf_mfma_scan_waves(), 8), dim3(256), 0, s, e);
+    IvfScatterParams sc{j.seg, j.seg_len, j.seg_cap, j.queue_d, j.queue_slot, j.queue_pos, j.queue_len, j.queue_cap, j.overflow};
+    // (a segment's pairs over two blocks: segments differ in length by an order of magnitude)
+    hipLaunchKernelGGL(ivf_scatter_kernel, dim3(ivf_mfma_scan_waves(), 2), dim3(256), 0, s, sc);
     VDB_HIP(hipGetLastError());
-    // the k best of every queue under (distance, slot) = (distance, visiting order), then slots -> rows
-    SelectOut o{j.out_d, nullptr, j.slots, j.k_out, 0, nullptr, nullptr, nullptr};
-    // (queues of a few hundred entries: four waves per query keep eight queries on a CU instead of two)
-    VDB_TRY(launch_select_packed(j.queue_d, j.queue_slot, j.nq, j.queue_cap, j.k, o, s, j.queue_len, IA_LEN_STRIDE,
-                                 j.queue_cap <= 2048 || j.nq >= 64 ? 4 : 16));
+    IvfFinishParams e{};
+    e.rows = j.rows; e.ld = j.ld; e.plan = j.sum_plan; e.q = j.q; e.ldq = j.ldq; e.take_sqrt = j.take_sqrt ? 1 : 0;
+    e.queue_key = j.queue_d; e.queue_slot = j.queue_slot; e.queue_pos = j.queue_pos; e.queue_len = j.queue_len;
+    e.queue_cap = j.queue_cap; e.slack = j.slack; e.k = j.k; e.k_out = j.k_out; e.out_d = j.out_d; e.out_slots = j.slots;
+    e.overflow = j.overflow;
+    hipLaunchKernelGGL(ivf_finish_kernel, dim3(j.nq), dim3(256), 0, s, e);
+    VDB_HIP(hipGetLastError());
+    // slots -> rows
     return launch_ivf_rows(j.slots, j.nq, j.k, j.k_out, 0, j.probes, j.n_probe, j.n_lists, j.cand_off, j.list_beg, j.row_ids,
                            j.out_rows, j.out_order, s);
 }

@@ -346,8 +346,8 @@ struct IvfMfmaJob {
     const int* probes; int n_probe; int n_lists; const int64_t* cand_off; const int64_t* list_beg;
     const int* row_ids; const uint32_t* mask;
     const float* max_row_nrm;                                  // device float: the largest |c| over the stored rows
-    float* mins; float* thr; int4* seg; int* seg_len; int seg_cap;                                       // workspaces
-    int* queue_slot; float* queue_d; int* queue_len; int queue_cap; int* overflow;
+    float* mins; float* thr; float* slack; int4* seg; int* seg_len; int seg_cap;                         // workspaces
+    int* queue_slot; float* queue_d; int* queue_pos; int* queue_len; int queue_cap; int* overflow;      // queue_d holds the keys
     int* slots;                                                // workspace [nq][k_out]: the selected candidate slots
     int k, k_out; bool take_sqrt;
     float* out_d; int64_t* out_rows; int64_t* out_order;
