@@ -1093,6 +1093,8 @@ struct vdb_ivf : Handle {
     // same positions as the fp32 rows, brought up to date lazily from the position ranges writes have touched
     int prefilter = VDB_PREFILTER_AUTO;
     DevBuf shadow16, max_nrm;
+    DevBuf cent16, cent_max_nrm;                           // the same of the centroids (row-major), for ranking the lists
+    bool cent16_stale = true;
     int64_t shadow_cap = 0;                                // positions the copy has room for
     bool shadow_stale = true;                              // everything must be converted (no copy yet, or a rebuild)
     std::vector<std::pair<int64_t, int64_t>> shadow_dirty; // [from, to) position ranges written since the last search
@@ -1917,7 +1919,7 @@ int vdb_ivf_destroy(vdb_ivf* h) {
         if (h->last_stream && h->last_stream != h->stream) (void)hipStreamSynchronize(h->last_stream);
         h->lay.dev.release(); h->row_ids.release(); h->ws.release();
         h->app_rows.release(); h->app_sq.release(); h->app_nrm.release(); h->app_dst.release(); h->app_no.release();
-        h->shadow16.release(); h->max_nrm.release();
+        h->shadow16.release(); h->max_nrm.release(); h->cent16.release(); h->cent_max_nrm.release();
     }
     vdb_rows_destroy(h->centroids);
     vdb_rows_destroy(h->members);
@@ -1933,6 +1935,7 @@ int vdb_ivf_set_centroids(vdb_ivf* h, const float* centroids, int n_lists) {
     VDB_TRY(vdb_rows_append(h->centroids, centroids, n_lists));
     h->n_lists = n_lists;
     h->lay.reset(n_lists);
+    h->cent16_stale = true;
     h->shadow_stale = true;
     h->shadow_dirty.clear();
     VDB_TRY(vdb_rows_truncate(h->members, 0));
@@ -2282,6 +2285,20 @@ static int ivf_shadow_sync(vdb_ivf* h, hipStream_t s) {
     return VDB_OK;
 }
 
+// bf16 copy of the centroids (row-major) and their largest norm, made again after vdb_ivf_set_centroids
+static int ivf_cent16_sync(vdb_ivf* h, hipStream_t s) {
+    if (!h->cent16_stale && h->cent16.p) return VDB_OK;
+    const Rows& c = h->centroids->r;
+    const int ld16 = ivf_mfma_pitch(c.dim);
+    VDB_TRY(h->cent16.reserve((size_t)h->n_lists * ld16 * 2));
+    VDB_TRY(h->cent_max_nrm.reserve(sizeof(float)));
+    VDB_TRY(launch_ivf_round_rows(c.data, c.ld, c.dim, h->n_lists, h->cent16.as<uint16_t>(), ld16, s));
+    VDB_HIP(hipMemsetAsync(h->cent_max_nrm.p, 0, sizeof(float), s));
+    VDB_TRY(launch_max_norm(c.nrm, 0, h->n_lists, h->cent_max_nrm.as<float>(), s));
+    h->cent16_stale = false;
+    return VDB_OK;
+}
+
 static constexpr int IVF_MFMA_GROUP = 32;           // queries per item: the columns of one 32 x 32 accumulator
 static constexpr int IVF_MFMA_QUEUE = 8192;         // most (slot, distance) entries per query
 static constexpr int IVF_MFMA_SEGMENT = 2048;       // kept pairs per wave of the scan pass
@@ -2335,14 +2352,35 @@ static int ivf_search_impl(vdb_ivf* h, const float* d_q, int nq, int k, int n_pr
 
     VDB_TRY(ws.probes.reserve((size_t)nq * n_probe * sizeof(int)));
     VDB_TRY(ws.probe_d.reserve((size_t)nq * n_probe * sizeof(float)));
-    {
+    const float* q = nullptr;
+    const int ld16 = ivf_mfma_pitch(m->r.dim);
+    // the lists to probe: ranked on the matrix cores too where the scan is (same lists, same order), else by the
+    // exact search over the centroids
+    static const bool no_mfma_probe = getenv("VDB_IVF_NO_MFMA_PROBE") != nullptr;
+    const Rows& cr = h->centroids->r;
+    const bool mfma_probe = mfma && !no_mfma_probe && n_probe <= 64 && !cr.bf16 && cr.ld == m->r.ld &&
+                            (int64_t)nq * h->n_lists <= ((int64_t)1 << 28);
+    if (mfma_probe) {
+        VDB_TRY(prepare_queries(ws, d_q, nq, m->r.dim, m->r.ld, m->r.plan, &q, s));
+        VDB_TRY(ws.q16.reserve((size_t)nq * ld16 * 2));
+        VDB_TRY(launch_ivf_round_rows(q, m->r.ld, m->r.dim, nq, ws.q16.as<uint16_t>(), ld16, s));
+        VDB_TRY(ivf_cent16_sync(h, s));
+        VDB_TRY(ws.dist.reserve((size_t)nq * h->n_lists * sizeof(float)));
+        IvfProbeJob pj{};
+        pj.cent16 = h->cent16.as<uint16_t>(); pj.cent_sq = cr.sq; pj.max_cent_nrm = h->cent_max_nrm.as<float>();
+        pj.cent = cr.data; pj.ld = cr.ld; pj.dim = cr.dim; pj.sum_plan = cr.plan; pj.n_lists = h->n_lists;
+        pj.q = q; pj.ldq = m->r.ld; pj.q16 = ws.q16.as<uint16_t>(); pj.ld16 = ld16;
+        pj.q_sq = ws.q_sq.as<float>(); pj.q_nrm = ws.q_nrm.as<float>(); pj.nq = nq;
+        pj.n_probe = n_probe; pj.take_sqrt = sm == VDB_EUCLIDEAN_DIRECT;
+        pj.keys = ws.dist.as<float>(); pj.probes = ws.probes.as<int>(); pj.probe_d = ws.probe_d.as<float>();
+        VDB_TRY(launch_ivf_mfma_probe(pj, s));
+    } else {
         ProfileMute only_the_scan(mfma);             // the matrix-core scan is the timed kernel of such a batch
         VDB_TRY(ivf_probe_impl(h, nullptr, d_q, nq, n_probe, ws.probes.as<int>(), ws.probe_d.as<float>(), s));
     }
     h->last_nq = nq; h->last_nprobe = n_probe; h->last_scan_rows = -1; h->last_stream = s;
 
-    const float* q = nullptr;
-    VDB_TRY(prepare_queries(ws, d_q, nq, m->r.dim, m->r.ld, m->r.plan, &q, s));
+    if (!mfma_probe) VDB_TRY(prepare_queries(ws, d_q, nq, m->r.dim, m->r.ld, m->r.plan, &q, s));
     StreamPlanBufs b{};
     // every (query, probe) pair adds at most ceil(list rows / 256) items
     VDB_TRY(reserve_stream_plan(ws, h->n_lists, (int64_t)q_block * n_probe, (int64_t)q_block * (cand_stride / 256 + n_probe), &b));
@@ -2357,7 +2395,6 @@ static int ivf_search_impl(vdb_ivf* h, const float* d_q, int nq, int k, int n_pr
         VDB_TRY(ws.lb_k.reserve((size_t)q_block * sizeof(int64_t)));
     }
     const int64_t avg_tiles = std::max<int64_t>(1, ((int64_t)n_probe * (h->lay.live / std::max(1, h->n_lists)) + 255) / 256);
-    const int ld16 = ivf_mfma_pitch(m->r.dim);
     const int* run_if = nullptr;
     // a queue as long as a query's candidates cannot overflow; longer ones are cut at IVF_MFMA_QUEUE entries
     const int queue_cap = (int)std::min<int64_t>(cand_stride, IVF_MFMA_QUEUE);
@@ -2370,7 +2407,7 @@ static int ivf_search_impl(vdb_ivf* h, const float* d_q, int nq, int k, int n_pr
         VDB_TRY(ws.seg_len.reserve((size_t)ivf_mfma_scan_waves() * sizeof(int)));
         VDB_TRY(ws.queue_cnt.reserve((size_t)q_block * ivf_mfma_len_stride() * sizeof(int)));
         VDB_TRY(ws.flag.reserve(sizeof(int)));
-        VDB_TRY(launch_ivf_round_rows(q, m->r.ld, m->r.dim, nq, ws.q16.as<uint16_t>(), ld16, s));
+        if (!mfma_probe) VDB_TRY(launch_ivf_round_rows(q, m->r.ld, m->r.dim, nq, ws.q16.as<uint16_t>(), ld16, s));
         run_if = ws.flag.as<int>();
     }
 

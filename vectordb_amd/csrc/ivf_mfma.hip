@@ -254,6 +254,7 @@ struct IvfBoundParams {
     const int* row_ids; const uint32_t* mask;
     float* mins;                           // [nq][IA_SUBSETS]
     int nq;
+    int* queue_len; int* overflow;         // cleared here for the passes that follow: the queues' lengths, the flag
 };
 
 static constexpr int IB_AHEAD = 8;         // probed lists whose offsets are read ahead
@@ -265,6 +266,10 @@ __global__ __launch_bounds__(IA_NT) void ivf_bound_kernel(IvfBoundParams p) {
     const int w = blockIdx.x * (IA_NT / 64) + __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
     const int q = w / (IB_UNITS * 8), ut = w - q * (IB_UNITS * 8);
     if (q >= p.nq) return;
+    if (ut == 0 && lane == 0) {
+        p.queue_len[q * IA_LEN_STRIDE] = 0;
+        if (q == 0) *p.overflow = 0;
+    }
     const int u = ut >> 3, t = ut & 7;
     constexpr int CE = KS * 16;
     const int64_t* co = p.cand_off + (int64_t)q * (p.n_probe + 1);
@@ -360,6 +365,12 @@ __global__ __launch_bounds__(IA_NT) void ivf_bound_kernel(IvfBoundParams p) {
 // the reference's k-th smallest sum is at most B + S; rows that tie it after the square root lie within one part in
 // 2^22 of it; and any row with R <= (B + S)(1 + 2^-21) has A <= (B + S)(1 + 2^-21) + S, which is the threshold.
 // Norms whose squares or products could leave float32 (or are not numbers) raise the overflow flag instead.
+// S of the bound above for a query of norm qn (|q|^2 = q_sq) over rows of norms up to `big` (both below 1e18)
+__device__ __forceinline__ float key_slack(int dim, float qn, float big, float q_sq) {
+    const float e_dot = (0.0078278f + (float)dim * 2.4e-7f) * 1.0001f * qn * big + sqrtf((float)dim) * 1.2e-38f * (qn + big) + 1e-30f;
+    return 2.0f * e_dot + (4.0f * (float)dim + 16.0f) * 6.0e-8f * 1.01f * (q_sq + big * big);
+}
+
 __global__ __launch_bounds__(256) void ivf_threshold_kernel(const float* __restrict__ mins, int nq, int k, int dim,
                                                             const float* __restrict__ q_sq, const float* __restrict__ q_nrm,
                                                             const float* __restrict__ max_row_nrm, float* __restrict__ thr,
@@ -376,8 +387,7 @@ __global__ __launch_bounds__(256) void ivf_threshold_kernel(const float* __restr
     if (lane != 0) return;
     const float qn = q_nrm[q], big = *max_row_nrm;
     if (!(qn < 1e18f) || !(big < 1e18f)) { *overflow = 1; thr[q] = INFINITY; slack[q] = INFINITY; return; }
-    const float e_dot = (0.0078278f + (float)dim * 2.4e-7f) * 1.0001f * qn * big + sqrtf((float)dim) * 1.2e-38f * (qn + big) + 1e-30f;
-    const float s = 2.0f * e_dot + (4.0f * (float)dim + 16.0f) * 6.0e-8f * 1.01f * (q_sq[q] + big * big);
+    const float s = key_slack(dim, qn, big, q_sq[q]);
     const float b = top.thr;                     // +inf while fewer than k subsets saw a row
     thr[q] = b < INFINITY ? ((b + s) * 1.000001f + s) : INFINITY;
     slack[q] = s;                                // the second threshold (ivf_finish_kernel) is widened by the same amount
@@ -404,7 +414,18 @@ __device__ __forceinline__ float leaf_sqdiff(const float* __restrict__ x, const 
     }
     f4u r = sqdiff4(x + 4 * m, q + 4 * m);
     int i = 8;
-    // four groups of eight at a time: their loads are in flight together, the sums stay in order
+    // eight, then four groups of eight at a time, then the last few together: their loads are in flight together, the
+    // sums stay in order
+    for (; i + 64 <= len; i += 64) {
+        f4u xv[8], qv[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            xv[u] = *reinterpret_cast<const f4u*>(x + i + 8 * u + 4 * m);
+            qv[u] = *reinterpret_cast<const f4u*>(q + i + 8 * u + 4 * m);
+        }
+#pragma unroll
+        for (int u = 0; u < 8; ++u) { const f4u d = qv[u] - xv[u]; r = r + d * d; }
+    }
     for (; i + 32 <= len; i += 32) {
         f4u xv[4], qv[4];
 #pragma unroll
@@ -415,7 +436,20 @@ __device__ __forceinline__ float leaf_sqdiff(const float* __restrict__ x, const 
 #pragma unroll
         for (int u = 0; u < 4; ++u) { const f4u d = qv[u] - xv[u]; r = r + d * d; }
     }
-    for (; i + 8 <= len; i += 8) r = r + sqdiff4(x + i + 4 * m, q + i + 4 * m);
+    {
+        const int left = (len - i) >> 3;                     // 0 .. 3 whole groups
+        f4u xv[3], qv[3];
+#pragma unroll
+        for (int u = 0; u < 3; ++u) {
+            const int at = u < left ? i + 8 * u : 0;         // (a group that is not there reads the first one again: unused)
+            xv[u] = *reinterpret_cast<const f4u*>(x + at + 4 * m);
+            qv[u] = *reinterpret_cast<const f4u*>(q + at + 4 * m);
+        }
+#pragma unroll
+        for (int u = 0; u < 3; ++u)
+            if (u < left) { const f4u d = qv[u] - xv[u]; r = r + d * d; }
+        i += 8 * left;
+    }
     const float half = (r[0] + r[1]) + (r[2] + r[3]);
     float res = half + __shfl_xor(half, 1);                // the same value in both lanes: addition commutes
     for (; i < len; ++i) { const float d = q[i] - x[i]; res = res + d * d; }
@@ -482,8 +516,8 @@ __global__ __launch_bounds__(256) void ivf_scatter_kernel(IvfScatterParams p) {
 }
 
 // One block of four waves per query, over its queue of (key, slot, position) in any order.
-//   U: every lane's smallest key, a wave's k-th smallest of those (found by counting), the smallest over the waves:
-//      k different pairs have keys within U.
+//   U: every thread's smallest key, then the k-th smallest of those (found by counting) over the block or, for the
+//      short queues of the scan, per wave and the smallest over the waves: k different pairs have keys within U.
 //   The pairs within U widened (as the threshold kernel widens its bound) are gathered in LDS; among them the k-th
 //   smallest key A_k is found by counting, and the pairs within A_k widened are the finalists: with S the query's
 //   slack, k rows have reference sums R <= A_k + S, so the reference's k-th smallest sum is at most that; rows tying
@@ -492,12 +526,18 @@ __global__ __launch_bounds__(256) void ivf_scatter_kernel(IvfScatterParams p) {
 //   The finalists' distances in the reference's arithmetic (a pair of lanes per finalist), then each finds its place
 //   under (distance, slot) by counting.
 // More than IF_HELD pairs within the first bound (thousands of equal rows): the overflow flag, as for a full queue.
+//
+// PROBE: the same over the keys of a query against every centroid (ranking the lists to probe, index/ivf.py:611-616):
+// the "queue" is the query's row of the key matrix, slot = position = the centroid's number, the slack comes from the
+// norms here.  More than IF_HELD centroids within the first bound (norms beyond float32's squares, or over a thousand
+// equal centroids): the block computes every centroid's distance and takes the k smallest one after the other.
 struct IvfFinishParams {
     const float* rows; int ld; SumPlan plan;     // the float32 rows, by position
     const float* q; int ldq;                     // the float32 queries (padded rows)
     int take_sqrt;                               // VDB_EUCLIDEAN_DIRECT: the distance is the root of the sum
-    const float* queue_key; const int* queue_slot; const int* queue_pos; const int* queue_len; int queue_cap;
+    float* queue_key; const int* queue_slot; const int* queue_pos; const int* queue_len; int queue_cap;
     const float* slack;
+    int dim; const float* q_sq; const float* q_nrm; const float* max_row_nrm;      // PROBE: what the slack is made of
     int k, k_out;
     float* out_d; int* out_slots;                // [nq][k_out]
     int* overflow;
@@ -505,74 +545,153 @@ struct IvfFinishParams {
 
 static constexpr int IF_HELD = 1024;
 
+template <bool PROBE>
 __global__ __launch_bounds__(256) void ivf_finish_kernel(IvfFinishParams p) {
     __shared__ float sh_key[IF_HELD];
     __shared__ int sh_slot[IF_HELD];
     __shared__ int sh_pos[IF_HELD];
     __shared__ float sh_d[IF_HELD];              // the finalists' distances
     __shared__ int sh_fin[IF_HELD];              // the finalists (places in sh_*)
-    __shared__ float sh_thr[4];
-    __shared__ float sh_kth;
+    __shared__ float sh_u, sh_kth;
     __shared__ int sh_cnt, sh_nfin;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int q = blockIdx.x;
     const int k = p.k;
-    const int total = min(p.queue_len[q * IA_LEN_STRIDE], p.queue_cap);
-    const float* keys = p.queue_key + (int64_t)q * p.queue_cap;
-    const float s = p.slack[q];
-    if (tid == 0) { sh_cnt = 0; sh_nfin = 0; sh_kth = INFINITY; }
+    const int total = PROBE ? p.queue_cap : min(p.queue_len[q * IA_LEN_STRIDE], p.queue_cap);
+    float* keys = p.queue_key + (int64_t)q * p.queue_cap;
+    float s;
+    if (PROBE) {
+        const float qn = p.q_nrm[q], big = *p.max_row_nrm;
+        s = (qn < 1e18f && big < 1e18f) ? key_slack(p.dim, qn, big, p.q_sq[q]) : INFINITY;     // +inf: no key can be trusted
+    } else {
+        s = p.slack[q];
+    }
+    if (tid == 0) { sh_cnt = 0; sh_nfin = 0; sh_kth = INFINITY; sh_u = INFINITY; }
     // every place starts empty (the slots are mapped to rows whatever happens below: none may stay unwritten); the
     // finalists write theirs behind the barriers that follow
     for (int f = tid; f < k; f += 256) {
         p.out_d[(int64_t)q * p.k_out + f] = INFINITY;
         p.out_slots[(int64_t)q * p.k_out + f] = -1;
     }
-    // U
-    float hv = INFINITY;                         // lanes without a pair (or with NaN alone) stand at +inf
-    for (int i = tid; i < total; i += 256) {
-        const float v = keys[i];
-        if (v < hv) hv = v;
-    }
-    int before = 0;
+    // U: every thread's smallest key (eight loads in flight at a time), then the k-th smallest of the 256 by counting
+    constexpr int AH = 8;
+    float hv = INFINITY;                         // threads without a pair (or with NaN alone) stand at +inf
+    for (int i0 = 0; i0 < total; i0 += 256 * AH) {
+        float v[AH];
 #pragma unroll
-    for (int l = 0; l < 64; ++l) {
-        const float other = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(hv), l));
-        before += (other < hv || (other == hv && l < lane)) ? 1 : 0;
+        for (int a = 0; a < AH; ++a) {
+            const int i = i0 + a * 256 + tid;
+            v[a] = i < total ? keys[i] : INFINITY;
+        }
+#pragma unroll
+        for (int a = 0; a < AH; ++a)
+            if (v[a] < hv) hv = v[a];
     }
-    const unsigned long long kth_lane = __ballot(before == k - 1);        // exactly one lane: the counts are a permutation
-    const float wave_thr = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(hv), __builtin_ctzll(kth_lane)));
-    if (lane == 0) sh_thr[wave] = wave_thr;
+    if (PROBE) {
+        // thousands of keys, k up to 64: the k-th smallest of all 256 threads' minima (little above the k-th smallest key)
+        sh_d[tid] = hv;                          // (free until the finalists' distances)
+        __syncthreads();
+        int before = 0;
+#pragma unroll 8
+        for (int l = 0; l < 256; ++l) {
+            const float other = sh_d[l];
+            before += (other < hv || (other == hv && l < tid)) ? 1 : 0;
+        }
+        if (before == k - 1) sh_u = hv;          // exactly one thread: the counts are a permutation
+    } else {
+        // hundreds of keys: a wave's k-th smallest of its lanes' minima, the smallest over the waves (no pass over LDS)
+        int before = 0;
+#pragma unroll
+        for (int l = 0; l < 64; ++l) {
+            const float other = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(hv), l));
+            before += (other < hv || (other == hv && l < lane)) ? 1 : 0;
+        }
+        const unsigned long long kth_lane = __ballot(before == k - 1);    // exactly one lane
+        const float wave_thr = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(hv), __builtin_ctzll(kth_lane)));
+        if (lane == 0) sh_d[wave] = wave_thr;
+        __syncthreads();
+        if (tid == 0) sh_u = fminf(fminf(sh_d[0], sh_d[1]), fminf(sh_d[2], sh_d[3]));
+    }
     __syncthreads();
-    const float u = fminf(fminf(sh_thr[0], sh_thr[1]), fminf(sh_thr[2], sh_thr[3]));
+    const float u = sh_u;
     const float first = u < INFINITY ? ((u + s) * 1.000001f + s) : INFINITY;
     // the pairs within the first bound, in LDS
-    for (int i0 = 0; i0 < total; i0 += 256) {
-        const int i = i0 + tid;
-        const float v = i < total ? keys[i] : INFINITY;
-        const bool in = i < total && v <= first;
-        const unsigned long long m = __ballot(in);
-        if (m != 0ull) {
-            int base = 0;
-            if (lane == 0) base = atomicAdd(&sh_cnt, __popcll(m));
-            base = __builtin_amdgcn_readfirstlane(base);
-            const int at = base + __popcll(m & ((1ull << lane) - 1ull));
-            if (in && at < IF_HELD) {
-                sh_key[at] = v;
-                sh_slot[at] = p.queue_slot[(int64_t)q * p.queue_cap + i];
-                sh_pos[at] = p.queue_pos[(int64_t)q * p.queue_cap + i];
+    for (int i0 = 0; i0 < total; i0 += 256 * AH) {
+        float v[AH];
+#pragma unroll
+        for (int a = 0; a < AH; ++a) {
+            const int i = i0 + a * 256 + tid;
+            v[a] = i < total ? keys[i] : INFINITY;
+        }
+#pragma unroll
+        for (int a = 0; a < AH; ++a) {
+            const int i = i0 + a * 256 + tid;
+            const bool in = i < total && v[a] <= first;
+            const unsigned long long m = __ballot(in);
+            if (m != 0ull) {
+                int base = 0;
+                if (lane == 0) base = atomicAdd(&sh_cnt, __popcll(m));
+                base = __builtin_amdgcn_readfirstlane(base);
+                const int at = base + __popcll(m & ((1ull << lane) - 1ull));
+                if (in && at < IF_HELD) {
+                    sh_key[at] = v[a];
+                    sh_slot[at] = PROBE ? i : p.queue_slot[(int64_t)q * p.queue_cap + i];
+                    sh_pos[at] = PROBE ? i : p.queue_pos[(int64_t)q * p.queue_cap + i];
+                }
             }
         }
     }
     __syncthreads();
     const int held = sh_cnt;
-    if (held > IF_HELD) {                        // the same for every thread of the block
-        if (tid == 0) *p.overflow = 1;
+    const int half = tid & 1;
+    const float* qrow = p.q + (int64_t)q * p.ldq;
+    if (held > IF_HELD || (PROBE && !(s < INFINITY))) {      // the same for every thread of the block
+        if (!PROBE) {
+            if (tid == 0) *p.overflow = 1;
+            return;
+        }
+        // every centroid's distance over its key, then k times the smallest (distance, number) behind the last one taken
+        for (int i0 = 0; i0 < total; i0 += 128) {
+            const int i = i0 + (tid >> 1);
+            if (i < total) {
+                const float sum = exact_sqdiff(p.rows + (int64_t)i * p.ld, qrow, p.plan, half);
+                if (half == 0) keys[i] = p.take_sqrt ? sqrtf(sum) : sum;
+            }
+        }
+        __syncthreads();
+        float last_d = -INFINITY;
+        int last_i = -1;
+        for (int r = 0; r < k; ++r) {
+            float best_d = INFINITY;
+            int best_i = EMPTY_IDX;
+            for (int i = tid; i < total; i += 256) {
+                const float d = keys[i];
+                if (d == d && pair_less(last_d, last_i, d, i) && pair_less(d, i, best_d, best_i)) { best_d = d; best_i = i; }
+            }
+#pragma unroll
+            for (int off = 32; off > 0; off >>= 1) {
+                const float od = __shfl_xor(best_d, off);
+                const int oi = __shfl_xor(best_i, off);
+                if (pair_less(od, oi, best_d, best_i)) { best_d = od; best_i = oi; }
+            }
+            if (lane == 0) { sh_d[wave] = best_d; sh_fin[wave] = best_i; }
+            __syncthreads();
+#pragma unroll
+            for (int w = 0; w < 4; ++w)
+                if (pair_less(sh_d[w], sh_fin[w], best_d, best_i)) { best_d = sh_d[w]; best_i = sh_fin[w]; }
+            __syncthreads();
+            if (best_i == EMPTY_IDX) break;                  // fewer distances that are numbers than k: the rest stays empty
+            if (tid == 0) { p.out_d[(int64_t)q * p.k_out + r] = best_d; p.out_slots[(int64_t)q * p.k_out + r] = best_i; }
+            last_d = best_d;
+            last_i = best_i;
+        }
         return;
     }
     // A_k: the held key with k - 1 held pairs before it under (key, place)
     for (int t = tid; t < held; t += 256) {
         const float my = sh_key[t];
         int place = 0;
+#pragma unroll 4
         for (int e = 0; e < held; ++e) {
             const float o = sh_key[e];
             place += (o < my || (o == my && e < t)) ? 1 : 0;
@@ -596,8 +715,6 @@ __global__ __launch_bounds__(256) void ivf_finish_kernel(IvfFinishParams p) {
     __syncthreads();
     const int nfin = sh_nfin;
     // the reference's distances of the finalists
-    const int half = tid & 1;
-    const float* qrow = p.q + (int64_t)q * p.ldq;
     for (int f0 = 0; f0 < nfin; f0 += 128) {                 // (the pair of lanes of a finalist stays together)
         const int f = f0 + (tid >> 1);
         if (f < nfin) {
@@ -611,18 +728,12 @@ __global__ __launch_bounds__(256) void ivf_finish_kernel(IvfFinishParams p) {
         const int my_slot = sh_slot[sh_fin[f]];
         if (!(my == my)) continue;                           // not a number: in no result (it precedes nothing and nothing precedes it)
         int place = 0;
+#pragma unroll 4
         for (int e = 0; e < nfin; ++e) place += pair_less(sh_d[e], sh_slot[sh_fin[e]], my, my_slot) ? 1 : 0;
         if (place < k) { p.out_d[(int64_t)q * p.k_out + place] = my; p.out_slots[(int64_t)q * p.k_out + place] = my_slot; }
     }
 }
 
-__global__ void ivf_clear_queues_kernel(int* queue_len, int nq, int* overflow) {
-    const int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i < nq) queue_len[i * IA_LEN_STRIDE] = 0;
-    if (i == 0) *overflow = 0;
-}
-
-// fp32 rows -> bf16 (round to nearest even), zero padded to ld16 columns
 __global__ void ivf_round_rows_kernel(const float* __restrict__ src, int64_t src_ld, int dim, int64_t n,
                                       uint16_t* __restrict__ dst16, int ld16) {
     const int64_t total = n * ld16;
@@ -703,16 +814,85 @@ static int launch_by_pitch(const P& p, int ld16, int n_chunks, dim3 grid, hipStr
     return VDB_OK;
 }
 
+// --------------------------------------------------------------------------
+// Keys of every (query, centroid) pair for the ranking of the lists: one wave per 32 queries x 32 centroids, both read
+// row-major from their bf16 copies (the centroids are a megabyte or so and stay in the caches).  The queries are the
+// A operand here, so a lane holds one centroid's keys for sixteen queries and a store writes 32 neighbouring floats
+// of a query's row.
+struct IvfCentKeysParams {
+    const uint16_t* q16; const uint16_t* c16; int ld16; int n_chunks;
+    const float* q_sq; const float* c_sq; int nq; int n_lists;
+    float* keys;                           // [nq][n_lists]
+};
+
+template <int KS, bool MULTI>
+__global__ __launch_bounds__(IA_NT) void ivf_cent_keys_kernel(IvfCentKeysParams p) {
+    const int lane = threadIdx.x & 63;
+    const int n = lane & 31, h = lane >> 5;
+    const int w = blockIdx.x * (IA_NT / 64) + (threadIdx.x >> 6);
+    const int c_tiles = (p.n_lists + 31) >> 5;
+    const int qt = w / c_tiles, ct = w - qt * c_tiles;
+    if (qt * 32 >= p.nq) return;
+    constexpr int CE = KS * 16;
+    const int q_own = min(qt * 32 + n, p.nq - 1), c_own = min(ct * 32 + n, p.n_lists - 1);      // rows past the end repeat the last
+    const uint16_t* arow = p.q16 + (int64_t)q_own * p.ld16 + h * 8;
+    const uint16_t* brow = p.c16 + (int64_t)c_own * p.ld16 + h * 8;
+    f32x16 acc;
+#pragma unroll
+    for (int e = 0; e < 16; ++e) acc[e] = 0.0f;
+    const int chunks = MULTI ? p.n_chunks : 1;
+    for (int c = 0; c < chunks; ++c) {
+        i4v a[KS], b[KS];
+#pragma unroll
+        for (int j = 0; j < KS; ++j) {
+            a[j] = *reinterpret_cast<const i4v*>(arow + c * CE + j * 16);
+            b[j] = *reinterpret_cast<const i4v*>(brow + c * CE + j * 16);
+        }
+#pragma unroll
+        for (int j = 0; j < KS; ++j)
+            acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, a[j]), __builtin_bit_cast(bf16x8, b[j]),
+                                                          acc, 0, 0, 0);
+    }
+    const float c_sq = p.c_sq[c_own];
+    const bool c_ok = ct * 32 + n < p.n_lists;
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int qrow = qt * 32 + 8 * g + 4 * h + i;
+            if (qrow < p.nq && c_ok)
+                p.keys[(int64_t)qrow * p.n_lists + ct * 32 + n] = __fmaf_rn(-2.0f, acc[g * 4 + i], p.q_sq[qrow] + c_sq);
+        }
+    }
+}
+
+int launch_ivf_mfma_probe(const IvfProbeJob& j, hipStream_t s) {
+    VDB_REQUIRE(j.n_probe >= 1 && j.n_probe <= 64 && j.n_probe <= j.n_lists, "matrix-core list ranking: n_probe in 1..64");
+    VDB_REQUIRE(j.ld16 % 32 == 0 && (j.ld16 <= 128 || j.ld16 % 128 == 0), "bad bf16 row pitch %d", j.ld16);
+    const int n_chunks = j.ld16 <= 128 ? 1 : j.ld16 / 128;
+    IvfCentKeysParams kp{j.q16, j.cent16, j.ld16, n_chunks, j.q_sq, j.cent_sq, j.nq, j.n_lists, j.keys};
+    const int64_t waves = (int64_t)((j.nq + 31) / 32) * ((j.n_lists + 31) / 32);
+    VDB_TRY(launch_by_pitch(kp, j.ld16, n_chunks, dim3((unsigned)((waves + 3) / 4)), s, ivf_cent_keys_kernel<2, false>,
+                            ivf_cent_keys_kernel<4, false>, ivf_cent_keys_kernel<6, false>, ivf_cent_keys_kernel<8, false>,
+                            ivf_cent_keys_kernel<8, true>));
+    IvfFinishParams e{};
+    e.rows = j.cent; e.ld = j.ld; e.plan = j.sum_plan; e.q = j.q; e.ldq = j.ldq; e.take_sqrt = j.take_sqrt ? 1 : 0;
+    e.queue_key = j.keys; e.queue_cap = j.n_lists;
+    e.dim = j.dim; e.q_sq = j.q_sq; e.q_nrm = j.q_nrm; e.max_row_nrm = j.max_cent_nrm;
+    e.k = j.n_probe; e.k_out = j.n_probe; e.out_d = j.probe_d; e.out_slots = j.probes;
+    hipLaunchKernelGGL(ivf_finish_kernel<true>, dim3(j.nq), dim3(256), 0, s, e);
+    VDB_HIP(hipGetLastError());
+    return VDB_OK;
+}
+
 int launch_ivf_mfma_search(const IvfMfmaJob& j, hipStream_t s) {
     VDB_REQUIRE(j.k >= 1 && j.k <= 64 && j.k_out >= j.k, "matrix-core list scan: k in 1..64");
     VDB_REQUIRE(j.ld16 % 32 == 0 && (j.ld16 <= 128 || j.ld16 % 128 == 0), "bad bf16 row pitch %d", j.ld16);
     const int n_chunks = j.ld16 <= 128 ? 1 : j.ld16 / 128;
-    hipLaunchKernelGGL(ivf_clear_queues_kernel, dim3((j.nq + 255) / 256), dim3(256), 0, s, j.queue_len, j.nq, j.overflow);
-    VDB_HIP(hipGetLastError());
     IvfBoundParams bp{};
     bp.rows16 = j.rows16; bp.ld16 = j.ld16; bp.n_chunks = n_chunks; bp.row_sq = j.row_sq; bp.q16 = j.q16; bp.q_sq = j.q_sq;
     bp.probes = j.probes; bp.n_probe = j.n_probe; bp.n_lists = j.n_lists; bp.cand_off = j.cand_off; bp.list_beg = j.list_beg;
-    bp.row_ids = j.row_ids; bp.mask = j.mask; bp.mins = j.mins; bp.nq = j.nq;
+    bp.row_ids = j.row_ids; bp.mask = j.mask; bp.mins = j.mins; bp.nq = j.nq; bp.queue_len = j.queue_len; bp.overflow = j.overflow;
     VDB_TRY(launch_by_pitch(bp, j.ld16, n_chunks, dim3((unsigned)(((int64_t)j.nq * IB_UNITS * 8 + 3) / 4)), s,
                             ivf_bound_kernel<2, false>, ivf_bound_kernel<4, false>, ivf_bound_kernel<6, false>,
                             ivf_bound_kernel<8, false>, ivf_bound_kernel<8, true>));
@@ -761,7 +941,7 @@ int launch_ivf_mfma_search(const IvfMfmaJob& j, hipStream_t s) {
     e.queue_key = j.queue_d; e.queue_slot = j.queue_slot; e.queue_pos = j.queue_pos; e.queue_len = j.queue_len;
     e.queue_cap = j.queue_cap; e.slack = j.slack; e.k = j.k; e.k_out = j.k_out; e.out_d = j.out_d; e.out_slots = j.slots;
     e.overflow = j.overflow;
-    hipLaunchKernelGGL(ivf_finish_kernel, dim3(j.nq), dim3(256), 0, s, e);
+    hipLaunchKernelGGL(ivf_finish_kernel<false>, dim3(j.nq), dim3(256), 0, s, e);
     VDB_HIP(hipGetLastError());
     // slots -> rows
     return launch_ivf_rows(j.slots, j.nq, j.k, j.k_out, 0, j.probes, j.n_probe, j.n_lists, j.cand_off, j.list_beg, j.row_ids,

@@ -354,6 +354,18 @@ struct IvfMfmaJob {
     bool timed;
 };
 int launch_ivf_mfma_search(const IvfMfmaJob& j, hipStream_t s);
+// The lists a batch of queries probes, by the same two steps: keys of every (query, centroid) pair on the matrix cores,
+// then per query the few centroids whose keys can be among the n_probe nearest recomputed in the reference's
+// arithmetic and ranked by (distance, centroid number).
+struct IvfProbeJob {
+    const uint16_t* cent16; const float* cent_sq; const float* max_cent_nrm;     // row-major bf16 copy, |c|^2, largest |c| (device)
+    const float* cent; int ld; int dim; SumPlan sum_plan; int n_lists;           // the fp32 centroids
+    const float* q; int ldq; const uint16_t* q16; int ld16; const float* q_sq; const float* q_nrm; int nq;
+    int n_probe; bool take_sqrt;
+    float* keys;                                                                  // workspace [nq][n_lists]
+    int* probes; float* probe_d;                                                  // [nq][n_probe]
+};
+int launch_ivf_mfma_probe(const IvfProbeJob& j, hipStream_t s);
 int ivf_mfma_pitch(int dim);            // bf16 elements per row of the copy
 int ivf_mfma_subsets();                 // floats of `mins` per query
 int ivf_mfma_len_stride();              // ints of `queue_len` per query
