@@ -137,6 +137,29 @@ def test_magnitudes_and_degenerate_rows(nat):
     lists.close()
 
 
+def test_list_ranking_with_over_a_thousand_equal_centroids(nat):
+    """The lists to probe are ranked behind bf16 keys too.  1300 copies of one centroid leave more candidates within a
+    query's bound than the ranking block holds, so it computes every centroid's distance instead; the ranking among
+    equal distances goes by centroid number, as in the scan without the matrix cores."""
+    rng = np.random.RandomState(12)
+    n, d = 16000, 32
+    x = rng.randn(n, d).astype(np.float32)
+    cent = np.concatenate([np.repeat(x[:1], 1300, axis=0), x[rng.choice(n, 200, replace=False)]]).astype(np.float32)
+    q = np.concatenate([x[:1] + 0.01 * rng.randn(4, d), rng.randn(12, d)]).astype(np.float32)
+    lists, members = build(nat, x, cent)
+    lists.set_prefilter("bf16")
+    dist, rows = lists.search(q, 10, 40)
+    assert lists.search_stats() == (True, False)
+    lists.set_prefilter(None)
+    d2, r2 = lists.search(q, 10, 40)
+    np.testing.assert_array_equal(rows, r2)
+    np.testing.assert_array_equal(dist.view(np.uint32), d2.view(np.uint32))
+    for i in range(len(q)):
+        ref_rows, ref_dist = R.ivf_search(q[i], x, cent, members, 10, 40, "euclidean")
+        np.testing.assert_array_equal(dist[i, :len(ref_rows)], ref_dist.astype(np.float32))
+    lists.close()
+
+
 def test_copy_follows_appends_moves_and_removals(nat):
     """The bf16 copy is refreshed from the position ranges that writes touched: rows appended behind their lists,
     lists that moved to the end of the buffer when they outgrew their place, rows swapped in by removals."""
