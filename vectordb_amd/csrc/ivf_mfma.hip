@@ -544,19 +544,44 @@ struct IvfFinishParams {
 };
 
 static constexpr int IF_HELD = 1024;
+#ifdef VDB_FINISH_TIMING
+__device__ long long g_ft[16];
+__device__ int g_fi[4];
+#define FT(i) if (PROBE && blockIdx.x == 512 && threadIdx.x == 0) g_ft[i] = wall_clock64();
+#else
+#define FT(i)
+#endif
 
 template <bool PROBE>
 __global__ __launch_bounds__(256) void ivf_finish_kernel(IvfFinishParams p) {
-    __shared__ float sh_key[IF_HELD];
+    __shared__ __align__(16) float sh_key[IF_HELD];
     __shared__ int sh_slot[IF_HELD];
     __shared__ int sh_pos[IF_HELD];
-    __shared__ float sh_d[IF_HELD];              // the finalists' distances
-    __shared__ int sh_fin[IF_HELD];              // the finalists (places in sh_*)
+    __shared__ __align__(16) float sh_d[IF_HELD];            // the finalists' distances
+    __shared__ __align__(16) int sh_fs[IF_HELD];             // and slots
+    __shared__ __align__(16) unsigned long long sh_pair[IF_HELD];        // what is being ranked, as packed pairs
+    __shared__ int sh_fin[IF_HELD];              // the finalists (places in sh_key, sh_slot, sh_pos)
     __shared__ float sh_u, sh_kth;
     __shared__ int sh_cnt, sh_nfin;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int q = blockIdx.x;
     const int k = p.k;
+    // (value, id) as one 64-bit number whose unsigned order is the order of the pairs (value ascending, then id; values
+    // that are not numbers behind +inf; -0 counts as +0); the counting loops below compare these, two per LDS read
+    auto packed = [](float v, int id) -> unsigned long long {
+        const uint32_t b = (uint32_t)__float_as_int(v + 0.0f);
+        const uint32_t ordered = v == v ? b ^ ((b >> 31) ? 0xffffffffu : 0x80000000u) : 0xffffffffu;
+        return ((unsigned long long)ordered << 32) | (uint32_t)id;
+    };
+    auto count_before = [](const unsigned long long* pairs, int n, unsigned long long mine) {
+        int c = 0, e = 0;
+        for (; e + 2 <= n; e += 2) {
+            const ulonglong2 v = *reinterpret_cast<const ulonglong2*>(pairs + e);
+            c += (v.x < mine ? 1 : 0) + (v.y < mine ? 1 : 0);
+        }
+        if (e < n) c += pairs[e] < mine ? 1 : 0;
+        return c;
+    };
     const int total = PROBE ? p.queue_cap : min(p.queue_len[q * IA_LEN_STRIDE], p.queue_cap);
     float* keys = p.queue_key + (int64_t)q * p.queue_cap;
     float s;
@@ -573,6 +598,7 @@ __global__ __launch_bounds__(256) void ivf_finish_kernel(IvfFinishParams p) {
         p.out_d[(int64_t)q * p.k_out + f] = INFINITY;
         p.out_slots[(int64_t)q * p.k_out + f] = -1;
     }
+    FT(0)
     // U: every thread's smallest key (eight loads in flight at a time), then the k-th smallest of the 256 by counting
     constexpr int AH = 8;
     float hv = INFINITY;                         // threads without a pair (or with NaN alone) stand at +inf
@@ -587,17 +613,13 @@ __global__ __launch_bounds__(256) void ivf_finish_kernel(IvfFinishParams p) {
         for (int a = 0; a < AH; ++a)
             if (v[a] < hv) hv = v[a];
     }
+    FT(1)
     if (PROBE) {
         // thousands of keys, k up to 64: the k-th smallest of all 256 threads' minima (little above the k-th smallest key)
-        sh_d[tid] = hv;                          // (free until the finalists' distances)
+        const unsigned long long mine = packed(hv, tid);
+        sh_pair[tid] = mine;
         __syncthreads();
-        int before = 0;
-#pragma unroll 8
-        for (int l = 0; l < 256; ++l) {
-            const float other = sh_d[l];
-            before += (other < hv || (other == hv && l < tid)) ? 1 : 0;
-        }
-        if (before == k - 1) sh_u = hv;          // exactly one thread: the counts are a permutation
+        if (count_before(sh_pair, 256, mine) == k - 1) sh_u = hv;       // exactly one thread: the counts are a permutation
     } else {
         // hundreds of keys: a wave's k-th smallest of its lanes' minima, the smallest over the waves (no pass over LDS)
         int before = 0;
@@ -613,6 +635,7 @@ __global__ __launch_bounds__(256) void ivf_finish_kernel(IvfFinishParams p) {
         if (tid == 0) sh_u = fminf(fminf(sh_d[0], sh_d[1]), fminf(sh_d[2], sh_d[3]));
     }
     __syncthreads();
+    FT(2)
     const float u = sh_u;
     const float first = u < INFINITY ? ((u + s) * 1.000001f + s) : INFINITY;
     // the pairs within the first bound, in LDS
@@ -635,6 +658,7 @@ __global__ __launch_bounds__(256) void ivf_finish_kernel(IvfFinishParams p) {
                 const int at = base + __popcll(m & ((1ull << lane) - 1ull));
                 if (in && at < IF_HELD) {
                     sh_key[at] = v[a];
+                    sh_pair[at] = packed(v[a], at);
                     sh_slot[at] = PROBE ? i : p.queue_slot[(int64_t)q * p.queue_cap + i];
                     sh_pos[at] = PROBE ? i : p.queue_pos[(int64_t)q * p.queue_cap + i];
                 }
@@ -642,6 +666,7 @@ __global__ __launch_bounds__(256) void ivf_finish_kernel(IvfFinishParams p) {
         }
     }
     __syncthreads();
+    FT(3)
     const int held = sh_cnt;
     const int half = tid & 1;
     const float* qrow = p.q + (int64_t)q * p.ldq;
@@ -687,18 +712,13 @@ __global__ __launch_bounds__(256) void ivf_finish_kernel(IvfFinishParams p) {
         }
         return;
     }
+    FT(4)
     // A_k: the held key with k - 1 held pairs before it under (key, place)
     for (int t = tid; t < held; t += 256) {
-        const float my = sh_key[t];
-        int place = 0;
-#pragma unroll 4
-        for (int e = 0; e < held; ++e) {
-            const float o = sh_key[e];
-            place += (o < my || (o == my && e < t)) ? 1 : 0;
-        }
-        if (place == k - 1) sh_kth = my;
+        if (count_before(sh_pair, held, sh_pair[t]) == k - 1) sh_kth = sh_key[t];
     }
     __syncthreads();
+    FT(5)
     const float a_k = sh_kth;                    // +inf with fewer than k pairs: every pair is a finalist
     const float second = a_k < INFINITY ? ((a_k + s) * 1.000001f + s) : INFINITY;
     for (int t0 = 0; t0 < held; t0 += 256) {
@@ -713,25 +733,33 @@ __global__ __launch_bounds__(256) void ivf_finish_kernel(IvfFinishParams p) {
         }
     }
     __syncthreads();
+    FT(6)
     const int nfin = sh_nfin;
     // the reference's distances of the finalists
     for (int f0 = 0; f0 < nfin; f0 += 128) {                 // (the pair of lanes of a finalist stays together)
         const int f = f0 + (tid >> 1);
         if (f < nfin) {
             const float sum = exact_sqdiff(p.rows + (int64_t)sh_pos[sh_fin[f]] * p.ld, qrow, p.plan, half);
-            if (half == 0) sh_d[f] = p.take_sqrt ? sqrtf(sum) : sum;
+            if (half == 0) {
+                const float d = p.take_sqrt ? sqrtf(sum) : sum;
+                const int slot = sh_slot[sh_fin[f]];
+                sh_d[f] = d; sh_fs[f] = slot; sh_pair[f] = packed(d, slot);
+            }
         }
     }
     __syncthreads();
+    FT(7)
+#ifdef VDB_FINISH_TIMING
+    if (PROBE && blockIdx.x == 512 && tid == 0) { g_fi[0] = held; g_fi[1] = nfin; }
+#endif
     for (int f = tid; f < nfin; f += 256) {
         const float my = sh_d[f];
-        const int my_slot = sh_slot[sh_fin[f]];
+        const int my_slot = sh_fs[f];
         if (!(my == my)) continue;                           // not a number: in no result (it precedes nothing and nothing precedes it)
-        int place = 0;
-#pragma unroll 4
-        for (int e = 0; e < nfin; ++e) place += pair_less(sh_d[e], sh_slot[sh_fin[e]], my, my_slot) ? 1 : 0;
+        const int place = count_before(sh_pair, nfin, sh_pair[f]);
         if (place < k) { p.out_d[(int64_t)q * p.k_out + place] = my; p.out_slots[(int64_t)q * p.k_out + place] = my_slot; }
     }
+    FT(8)
 }
 
 __global__ void ivf_round_rows_kernel(const float* __restrict__ src, int64_t src_ld, int dim, int64_t n,
@@ -882,6 +910,17 @@ int launch_ivf_mfma_probe(const IvfProbeJob& j, hipStream_t s) {
     e.k = j.n_probe; e.k_out = j.n_probe; e.out_d = j.probe_d; e.out_slots = j.probes;
     hipLaunchKernelGGL(ivf_finish_kernel<true>, dim3(j.nq), dim3(256), 0, s, e);
     VDB_HIP(hipGetLastError());
+#ifdef VDB_FINISH_TIMING
+    {
+        long long t[16]; int v[4];
+        (void)hipStreamSynchronize(s);
+        (void)hipMemcpyFromSymbol(t, HIP_SYMBOL(g_ft), sizeof(t));
+        (void)hipMemcpyFromSymbol(v, HIP_SYMBOL(g_fi), sizeof(v));
+        fprintf(stderr, "[finish timing, 10 ns ticks]");
+        for (int i = 1; i <= 8; ++i) fprintf(stderr, " %lld", t[i] - t[i - 1]);
+        fprintf(stderr, "  held=%d nfin=%d\n", v[0], v[1]);
+    }
+#endif
     return VDB_OK;
 }
 
