@@ -29,7 +29,8 @@ write = per_kernel(glob.glob(src + "/pmc_write/*/*counter_collection.csv")[0], l
 rows = []
 for k, ds in dur.items():
     if not any(s in k for s in ("stream_sums_kernel", "pq_scan_kernel", "pq_scan8_kernel", "topk_cand_kernel", "ivf_approx_kernel",
-                                "ivf_exact_dist_kernel", "ivf_bound_kernel", "rowreg_sums_kernel")):
+                                "ivf_scatter_kernel", "ivf_finish_kernel", "ivf_cent_keys_kernel", "ivf_bound_kernel",
+                                "pq_exact8_kernel", "rowreg_sums_kernel")):
         continue
     if len(fetch.get(k, [])) != len(ds) or len(write.get(k, [])) != len(ds):
         continue
