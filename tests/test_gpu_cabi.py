@@ -765,6 +765,19 @@ def test_ivfpq_vs_oracle_batch(nat):
         if coarse[6] - coarse[5] > 1e-3:
             np.testing.assert_array_equal(rows[i], ref_rows)
             np.testing.assert_array_equal(dist[i], ref_dist)
+    # 200 queries: the lists ranked from the whole distance matrix, 1200 (query, list) units scanned with the codebooks
+    # in LDS; 20 queries: the search over the centroids, one block per unit
+    q2 = rng.randn(200, d).astype(np.float32)
+    dist2, rows2 = h.search(q2, 10, 6)
+    dist3, rows3 = h.search(q2[:20], 10, 6)
+    np.testing.assert_array_equal(rows2[:20], rows3)
+    np.testing.assert_array_equal(dist2[:20].view(np.uint32), dist3.view(np.uint32))
+    for i in range(150, 170):
+        ref_rows, ref_dist = R.hybrid_search(q2[i], cent, book, codes, members, 10, 6)
+        coarse = np.sort(np.sum(q2[i] ** 2) + cs - 2 * (q2[i] @ cent.T))
+        if coarse[6] - coarse[5] > 1e-3:
+            np.testing.assert_array_equal(rows2[i], ref_rows)
+            np.testing.assert_array_equal(dist2[i], ref_dist)
     h.close()
 
 

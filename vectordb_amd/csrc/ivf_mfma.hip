@@ -538,6 +538,7 @@ struct IvfFinishParams {
     float* queue_key; const int* queue_slot; const int* queue_pos; const int* queue_len; int queue_cap;
     const float* slack;
     int dim; const float* q_sq; const float* q_nrm; const float* max_row_nrm;      // PROBE: what the slack is made of
+    int exact_keys;                              // PROBE: the keys are the distances themselves (no slack, nothing recomputed)
     int k, k_out;
     float* out_d; int* out_slots;                // [nq][k_out]
     int* overflow;
@@ -585,7 +586,9 @@ __global__ __launch_bounds__(256) void ivf_finish_kernel(IvfFinishParams p) {
     const int total = PROBE ? p.queue_cap : min(p.queue_len[q * IA_LEN_STRIDE], p.queue_cap);
     float* keys = p.queue_key + (int64_t)q * p.queue_cap;
     float s;
-    if (PROBE) {
+    if (PROBE && p.exact_keys) {
+        s = 0.0f;
+    } else if (PROBE) {
         const float qn = p.q_nrm[q], big = *p.max_row_nrm;
         s = (qn < 1e18f && big < 1e18f) ? key_slack(p.dim, qn, big, p.q_sq[q]) : INFINITY;     // +inf: no key can be trusted
     } else {
@@ -676,7 +679,7 @@ __global__ __launch_bounds__(256) void ivf_finish_kernel(IvfFinishParams p) {
             return;
         }
         // every centroid's distance over its key, then k times the smallest (distance, number) behind the last one taken
-        for (int i0 = 0; i0 < total; i0 += 128) {
+        for (int i0 = 0; i0 < total && !p.exact_keys; i0 += 128) {
             const int i = i0 + (tid >> 1);
             if (i < total) {
                 const float sum = exact_sqdiff(p.rows + (int64_t)i * p.ld, qrow, p.plan, half);
@@ -739,7 +742,9 @@ __global__ __launch_bounds__(256) void ivf_finish_kernel(IvfFinishParams p) {
     for (int f0 = 0; f0 < nfin; f0 += 128) {                 // (the pair of lanes of a finalist stays together)
         const int f = f0 + (tid >> 1);
         if (f < nfin) {
-            const float sum = exact_sqdiff(p.rows + (int64_t)sh_pos[sh_fin[f]] * p.ld, qrow, p.plan, half);
+            float sum;
+            if (PROBE && p.exact_keys) sum = sh_key[sh_fin[f]];
+            else sum = exact_sqdiff(p.rows + (int64_t)sh_pos[sh_fin[f]] * p.ld, qrow, p.plan, half);
             if (half == 0) {
                 const float d = p.take_sqrt ? sqrtf(sum) : sum;
                 const int slot = sh_slot[sh_fin[f]];
@@ -921,6 +926,18 @@ int launch_ivf_mfma_probe(const IvfProbeJob& j, hipStream_t s) {
         fprintf(stderr, "  held=%d nfin=%d\n", v[0], v[1]);
     }
 #endif
+    return VDB_OK;
+}
+
+// the k smallest of every row of a [nq][n] matrix of distances under (distance, column), k <= 64: the same block per
+// query over exact keys
+int launch_rank_rows(float* dist, int nq, int n, int k, float* out_d, int* out_i, hipStream_t s) {
+    if (nq <= 0) return VDB_OK;
+    VDB_REQUIRE(k >= 1 && k <= 64 && k <= n, "row ranking: k in 1..64");
+    IvfFinishParams e{};
+    e.queue_key = dist; e.queue_cap = n; e.exact_keys = 1; e.k = k; e.k_out = k; e.out_d = out_d; e.out_slots = out_i;
+    hipLaunchKernelGGL(ivf_finish_kernel<true>, dim3(nq), dim3(256), 0, s, e);
+    VDB_HIP(hipGetLastError());
     return VDB_OK;
 }
 

@@ -37,6 +37,26 @@ __device__ __forceinline__ static float np_leaf_sqdiff(const float* a, const flo
     return res;
 }
 
+// the same with the elements of a `stride` floats apart (a codebook laid out codeword-fastest in LDS)
+__device__ __forceinline__ static float np_leaf_sqdiff_strided(const float* a, int stride, const float* b, int n) {
+    if (n < 8) {
+        float r = 0.0f;
+        for (int i = 0; i < n; ++i) { const float d = a[i * stride] - b[i]; r = r + d * d; }
+        return r;
+    }
+    float r[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) { const float d = a[j * stride] - b[j]; r[j] = d * d; }
+    int i = 8;
+    for (; i + 8 <= n; i += 8) {
+#pragma unroll
+        for (int j = 0; j < 8; ++j) { const float d = a[(i + j) * stride] - b[i + j]; r[j] = r[j] + d * d; }
+    }
+    float res = ((r[0] + r[1]) + (r[2] + r[3])) + ((r[4] + r[5]) + (r[6] + r[7]));
+    for (; i < n; ++i) { const float d = a[i * stride] - b[i]; res = res + d * d; }
+    return res;
+}
+
 // any n: walk the plan (leaves left to right, fold pending partial sums)
 __device__ static float np_sum_sqdiff(const float* a, const float* b, int n, const SumPlan& plan) {
     if (n <= 128) return np_leaf_sqdiff(a, b, n);
@@ -475,6 +495,117 @@ __global__ __launch_bounds__(256) void ivfpq_scan_kernel(IvfPqScanParams p) {
     }
 }
 
+// The same with the codebooks resident in LDS (m * ksub * dsub floats, 128 KiB at m = 16, dsub = 8): one block of
+// sixteen waves per CU walks the (query, probed list) units.  A unit is a chain of dependent reads (probed list -> its
+// bounds, its centroid -> its codes) in front of a microsecond of LDS work, and the codebooks leave room for one block
+// per CU, so the chain is taken apart over the units: while unit i is summed, the codes of unit i + 1 (the first 3072
+// rows, in registers), the bounds, query and centroid elements of unit i + 2 and the list number of unit i + 3 are on
+// their way.  (One block per unit, nothing read ahead: 10 us per unit and CU, 1.3 ms per 1024 x 32 units.)
+static constexpr int IPQ_NT = 1024;        // threads per block
+static constexpr int IPQ_AHEAD = 3;        // rows per thread whose codes are read a unit ahead
+
+template <int M>
+__global__ __launch_bounds__(IPQ_NT) void ivfpq_scan_lds_kernel(IvfPqScanParams p, int n_units) {
+    extern __shared__ __align__(16) float sm[];
+    float* book = sm;                            // [M][dsub][ksub]: codeword-fastest, so the lanes of a table step read neighbours
+    float* T = book + M * p.ksub * p.dsub;       // [M][ksub]
+    float* qres = T + M * p.ksub;                // [dim]
+    const int tid = threadIdx.x;
+    const int book_n = M * p.ksub * p.dsub;
+    for (int i = tid; i < book_n; i += IPQ_NT) {
+        const int jc = i / p.dsub, d = i - jc * p.dsub;
+        const int j = jc / p.ksub, c = jc - j * p.ksub;
+        book[(j * p.dsub + d) * p.ksub + c] = p.book[i];
+    }
+    constexpr int W = M / 4;
+    struct Named { int l, qi, pr; };                                     // a unit's list (-1: no such unit, or no such list)
+    struct Placed { int64_t pos0, len, out; float q_el, c_el; };         // ... its rows, its output, this thread's elements
+    auto name_of = [&](int64_t unit) {
+        Named a{-1, 0, 0};
+        if (unit < n_units) {
+            a.qi = (int)(unit / p.n_probe);
+            a.pr = (int)(unit - (int64_t)a.qi * p.n_probe);
+            const int l = p.probes[unit];
+            a.l = (l >= 0 && l < p.n_lists) ? l : -1;
+        }
+        return a;
+    };
+    auto place_of = [&](const Named& a) {
+        Placed b{0, 0, 0, 0.0f, 0.0f};
+        if (a.l >= 0) {
+            b.pos0 = p.list_beg[a.l];
+            b.len = p.list_end[a.l] - b.pos0;
+            b.out = (int64_t)a.qi * p.cand_stride + p.cand_off[(int64_t)a.qi * (p.n_probe + 1) + a.pr];
+            if (tid < p.dim) {
+                b.q_el = p.q[(int64_t)a.qi * p.ldq + tid];
+                b.c_el = p.cent[(int64_t)a.l * p.ldc + tid];
+            }
+        }
+        return b;
+    };
+    auto codes_of = [&](const Placed& b, uint32_t (&w)[IPQ_AHEAD][W]) {
+#pragma unroll
+        for (int x = 0; x < IPQ_AHEAD; ++x) {
+            const int64_t r = tid + x * IPQ_NT;
+            if (r < b.len) {
+                const uint32_t* code = reinterpret_cast<const uint32_t*>(p.codes + (b.pos0 + r) * M);
+#pragma unroll
+                for (int i = 0; i < W; ++i) w[x][i] = code[i];
+            }
+        }
+    };
+    auto distance_of = [&](const uint32_t (&w)[W]) {
+        float acc = T[w[0] & 0xffu];
+#pragma unroll
+        for (int j = 1; j < M; ++j) acc = acc + T[j * p.ksub + ((w[j >> 2] >> (8 * (j & 3))) & 0xffu)];
+        return sqrtf(acc);
+    };
+    const int64_t step = gridDim.x;
+    int64_t unit = blockIdx.x;
+    Named n0 = name_of(unit), n1 = name_of(unit + step), named = name_of(unit + 2 * step);
+    Placed cur = place_of(n0), placed = place_of(n1);
+    uint32_t w_cur[IPQ_AHEAD][W] = {}, w_next[IPQ_AHEAD][W] = {};
+    codes_of(cur, w_cur);
+    for (; unit < n_units; unit += step) {
+        __syncthreads();                         // the table and the residual of the unit before are no longer read
+        if (tid < p.dim) qres[tid] = cur.q_el - cur.c_el;
+        // what the coming units need, on its way while this one is summed
+        codes_of(placed, w_next);
+        const Placed placed_next = place_of(named);
+        const Named named_next = name_of(unit + 3 * step);
+        __syncthreads();
+        if (cur.len > 0) {                       // (the same for every thread of the block)
+            for (int e = tid; e < M * p.ksub; e += IPQ_NT) {
+                const int j = e / p.ksub, c = e - j * p.ksub;
+                T[e] = np_leaf_sqdiff_strided(book + j * p.dsub * p.ksub + c, p.ksub, qres + j * p.dsub, p.dsub);   // dsub <= 128: one leaf
+            }
+        }
+        __syncthreads();
+        if (cur.len > 0) {
+            float* out = p.cand + cur.out;
+#pragma unroll
+            for (int x = 0; x < IPQ_AHEAD; ++x) {
+                const int64_t r = tid + x * IPQ_NT;
+                if (r < cur.len) out[r] = distance_of(w_cur[x]);
+            }
+            for (int64_t r = tid + IPQ_AHEAD * IPQ_NT; r < cur.len; r += IPQ_NT) {
+                const uint32_t* code = reinterpret_cast<const uint32_t*>(p.codes + (cur.pos0 + r) * M);
+                uint32_t w[W];
+#pragma unroll
+                for (int i = 0; i < W; ++i) w[i] = code[i];
+                out[r] = distance_of(w);
+            }
+        }
+        cur = placed;
+        placed = placed_next;
+        named = named_next;
+#pragma unroll
+        for (int x = 0; x < IPQ_AHEAD; ++x)
+#pragma unroll
+            for (int i = 0; i < W; ++i) w_cur[x][i] = w_next[x][i];
+    }
+}
+
 int launch_ivfpq_scan(const float* q, int ldq, int dim, int nq, const float* cent, int ldc, const float* book, int m, int ksub,
                       int dsub, const SumPlan& plan, const uint8_t* codes, const int64_t* list_beg, const int64_t* list_end, int n_lists,
                       const int* probes, int n_probe, const int64_t* cand_off, int64_t cand_stride, float* cand, hipStream_t s) {
@@ -483,6 +614,28 @@ int launch_ivfpq_scan(const float* q, int ldq, int dim, int nq, const float* cen
                       cand_off, cand_stride, cand};
     const size_t lds = ((size_t)m * ksub + dim) * sizeof(float);
     VDB_REQUIRE(lds <= 160 * 1024, "%d sub-spaces x %d codewords need %zu bytes of LDS", m, ksub, lds);
+    const size_t lds_book = lds + (size_t)m * ksub * dsub * sizeof(float);
+    static const bool no_lds_book = getenv("VDB_IVFPQ_NO_LDS_BOOK") != nullptr;
+    const int64_t n_units = (int64_t)nq * n_probe;
+    if (!no_lds_book && lds_book <= 160 * 1024 && (m == 4 || m == 8 || m == 16 || m == 32) && dim <= IPQ_NT && dsub <= 128 && n_units >= 4 * (int64_t)ctx().num_cus &&
+        n_units < (int64_t)0x7fffffff) {
+        const dim3 grid((unsigned)ctx().num_cus);
+        KernelTimer timer(s);
+#define VDB_LAUNCH_IPQ(MM)                                                                                   \
+    case MM:                                                                                                  \
+        VDB_TRY(raise_dynamic_lds(reinterpret_cast<const void*>(ivfpq_scan_lds_kernel<MM>), lds_book));       \
+        hipLaunchKernelGGL(ivfpq_scan_lds_kernel<MM>, grid, dim3(IPQ_NT), lds_book, s, p, (int)n_units);         \
+        break;
+        switch (m) {
+            VDB_LAUNCH_IPQ(4)
+            VDB_LAUNCH_IPQ(8)
+            VDB_LAUNCH_IPQ(16)
+            VDB_LAUNCH_IPQ(32)
+        }
+#undef VDB_LAUNCH_IPQ
+        VDB_HIP(hipGetLastError());
+        return VDB_OK;
+    }
     VDB_TRY(raise_dynamic_lds(reinterpret_cast<const void*>(ivfpq_scan_kernel),
                                 lds));
     KernelTimer timer(s);
