@@ -3227,6 +3227,16 @@ static int ivfpq_search_impl(vdb_ivfpq* h, const float* d_q, int nq, int k, int 
                                   h->book.as<float>(), h->m, h->ksub, h->dsub, h->plan, h->codes.as<uint8_t>(),
                                   h->lay.d_beg(), h->lay.d_end(), h->n_lists, probes, n_probe, ws.cand_off.as<int64_t>(),
                                   cand_stride, ws.cand.as<float>(), s));
+        static const bool no_cand_rank = getenv("VDB_NO_CAND_RANK") != nullptr;
+        if (!no_cand_rank && !multi && !d_mask && nb >= 32) {
+            // a batch without a filter: one block per query reads its run of distances once and ranks the few in reach
+            VDB_TRY(launch_cand_rank(ws.cand.as<float>(), cand_stride, ws.cand_off.as<int64_t>(), n_probe, nb, kmax, k,
+                                     d_out_d + (int64_t)q0 * k, ws.slots.as<int>() + (int64_t)q0 * k, s));
+            VDB_TRY(launch_ivf_rows(ws.slots.as<int>() + (int64_t)q0 * k, nb, kmax, k, 0, probes, n_probe, h->n_lists,
+                                    ws.cand_off.as<int64_t>(), h->lay.d_beg(), h->row_ids.as<int>(),
+                                    d_out_i + (int64_t)q0 * k, nullptr, s));
+            continue;
+        }
         const int splits = cand_splits(avg_tiles, nb);
         const int n_cand = splits * topk_cand_lists_per_split();
         VDB_TRY(ws.part_d.reserve((size_t)nb * n_cand * kmax * sizeof(float)));

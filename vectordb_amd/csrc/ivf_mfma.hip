@@ -545,6 +545,23 @@ struct IvfFinishParams {
 };
 
 static constexpr int IF_HELD = 1024;
+
+// (value, id) as one 64-bit number whose unsigned order is the order of the pairs (value ascending, then id; values
+// that are not numbers behind +inf; -0 counts as +0); the counting loops compare these, two per LDS read
+__device__ __forceinline__ unsigned long long packed(float v, int id) {
+    const uint32_t b = (uint32_t)__float_as_int(v + 0.0f);
+    const uint32_t ordered = v == v ? b ^ ((b >> 31) ? 0xffffffffu : 0x80000000u) : 0xffffffffu;
+    return ((unsigned long long)ordered << 32) | (uint32_t)id;
+}
+__device__ __forceinline__ int count_before(const unsigned long long* pairs, int n, unsigned long long mine) {
+    int c = 0, e = 0;
+    for (; e + 2 <= n; e += 2) {
+        const ulonglong2 v = *reinterpret_cast<const ulonglong2*>(pairs + e);
+        c += (v.x < mine ? 1 : 0) + (v.y < mine ? 1 : 0);
+    }
+    if (e < n) c += pairs[e] < mine ? 1 : 0;
+    return c;
+}
 #ifdef VDB_FINISH_TIMING
 __device__ long long g_ft[16];
 __device__ int g_fi[4];
@@ -567,22 +584,6 @@ __global__ __launch_bounds__(256) void ivf_finish_kernel(IvfFinishParams p) {
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int q = blockIdx.x;
     const int k = p.k;
-    // (value, id) as one 64-bit number whose unsigned order is the order of the pairs (value ascending, then id; values
-    // that are not numbers behind +inf; -0 counts as +0); the counting loops below compare these, two per LDS read
-    auto packed = [](float v, int id) -> unsigned long long {
-        const uint32_t b = (uint32_t)__float_as_int(v + 0.0f);
-        const uint32_t ordered = v == v ? b ^ ((b >> 31) ? 0xffffffffu : 0x80000000u) : 0xffffffffu;
-        return ((unsigned long long)ordered << 32) | (uint32_t)id;
-    };
-    auto count_before = [](const unsigned long long* pairs, int n, unsigned long long mine) {
-        int c = 0, e = 0;
-        for (; e + 2 <= n; e += 2) {
-            const ulonglong2 v = *reinterpret_cast<const ulonglong2*>(pairs + e);
-            c += (v.x < mine ? 1 : 0) + (v.y < mine ? 1 : 0);
-        }
-        if (e < n) c += pairs[e] < mine ? 1 : 0;
-        return c;
-    };
     const int total = PROBE ? p.queue_cap : min(p.queue_len[q * IA_LEN_STRIDE], p.queue_cap);
     float* keys = p.queue_key + (int64_t)q * p.queue_cap;
     float s;
@@ -926,6 +927,75 @@ int launch_ivf_mfma_probe(const IvfProbeJob& j, hipStream_t s) {
         fprintf(stderr, "  held=%d nfin=%d\n", v[0], v[1]);
     }
 #endif
+    return VDB_OK;
+}
+
+// --------------------------------------------------------------------------
+// The k best of every query's run of candidate distances (one float per candidate slot, as the IVF-PQ scan leaves
+// them), k <= 64, under (distance, slot).  One block of sixteen waves per query streams the run once, eight loads in
+// flight per lane; every wave keeps its k best in its lanes (a candidate is offered only if it beats the wave's k-th:
+// after the first few hundred nearly none does), and the sixteen lists are ranked together by counting.
+static constexpr int CR_NT = 1024;
+
+__global__ __launch_bounds__(CR_NT) void cand_rank_kernel(const float* __restrict__ cand, int64_t cand_stride,
+                                                          const int64_t* __restrict__ cand_off, int n_probe, int k, int k_out,
+                                                          float* __restrict__ out_d, int* __restrict__ out_slots) {
+    __shared__ __align__(16) unsigned long long sh_pair[CR_NT];          // sixteen lists of k <= 64
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int q = blockIdx.x;
+    const int total = (int)min(cand_off[(int64_t)q * (n_probe + 1) + n_probe], cand_stride);
+    const float* run = cand + (int64_t)q * cand_stride;
+    WaveTopK top;
+    top.init(k);
+    // sixteen bytes per lane and load (a query's run starts on a multiple of 64 floats), four loads in flight
+    constexpr int AH = 4;
+    for (int i0 = 0; i0 < total; i0 += CR_NT * 4 * AH) {
+        float4 v[AH];
+#pragma unroll
+        for (int a = 0; a < AH; ++a) {
+            const int i = i0 + (a * CR_NT + tid) * 4;
+            if (i + 4 <= total) {
+                v[a] = *reinterpret_cast<const float4*>(run + i);
+            } else {
+                v[a].x = i < total ? run[i] : INFINITY;
+                v[a].y = i + 1 < total ? run[i + 1] : INFINITY;
+                v[a].z = i + 2 < total ? run[i + 2] : INFINITY;
+                v[a].w = INFINITY;                           // (i + 3 >= total here)
+            }
+        }
+#pragma unroll
+        for (int a = 0; a < AH; ++a) {
+            const int i = i0 + (a * CR_NT + tid) * 4;
+            if (i0 + (a * CR_NT + wave * 64) * 4 < total) {      // (the same for the whole wave)
+                top.template offer<false, false>(i < total && v[a].x == v[a].x, v[a].x, i, lane);
+                top.template offer<false, false>(i + 1 < total && v[a].y == v[a].y, v[a].y, i + 1, lane);
+                top.template offer<false, false>(i + 2 < total && v[a].z == v[a].z, v[a].z, i + 2, lane);
+                top.template offer<false, false>(i + 3 < total && v[a].w == v[a].w, v[a].w, i + 3, lane);
+            }
+        }
+    }
+    // (empty places of the lists: behind every candidate, and all different, so that every place gets written)
+    if (lane < k) sh_pair[wave * k + lane] = top.eid != EMPTY_IDX ? packed(top.e, top.eid) : (0xffffffff80000000ull + (unsigned)tid);
+    __syncthreads();
+    const int n = (CR_NT / 64) * k;
+    for (int t = tid; t < n; t += CR_NT) {
+        const unsigned long long mine = sh_pair[t];
+        const int place = count_before(sh_pair, n, mine);
+        if (place < k) {
+            const int i = (int)(uint32_t)mine;
+            const bool empty = i < 0;
+            out_d[(int64_t)q * k_out + place] = empty ? INFINITY : run[i];
+            out_slots[(int64_t)q * k_out + place] = empty ? -1 : i;
+        }
+    }
+}
+
+int launch_cand_rank(const float* cand, int64_t cand_stride, const int64_t* cand_off, int n_probe, int nq, int k, int k_out,
+                     float* out_d, int* out_slots, hipStream_t s) {
+    if (nq <= 0) return VDB_OK;
+    VDB_REQUIRE(k >= 1 && k <= 64 && cand_stride < (int64_t)0x7fffffff, "candidate ranking: k in 1..64, fewer than 2^31 candidates");
+    hipLaunchKernelGGL(cand_rank_kernel, dim3(nq), dim3(CR_NT), 0, s, cand, cand_stride, cand_off, n_probe, k, k_out, out_d, out_slots);
+    VDB_HIP(hipGetLastError());
     return VDB_OK;
 }
 

@@ -369,6 +369,10 @@ int launch_ivf_mfma_probe(const IvfProbeJob& j, hipStream_t s);
 // the k <= 64 smallest of every row of a [nq][n] matrix under (value, column): one block per row (rows that hold
 // over a thousand equal smallest values are overwritten in the process)
 int launch_rank_rows(float* dist, int nq, int n, int k, float* out_d, int* out_i, hipStream_t s);
+// the k <= 64 best of every query's run of candidate distances (cand + q * cand_stride, cand_off[q][n_probe] of them, no
+// filter) under (distance, slot): distances and slots at stride k_out
+int launch_cand_rank(const float* cand, int64_t cand_stride, const int64_t* cand_off, int n_probe, int nq, int k, int k_out,
+                     float* out_d, int* out_slots, hipStream_t s);
 int ivf_mfma_pitch(int dim);            // bf16 elements per row of the copy
 int ivf_mfma_subsets();                 // floats of `mins` per query
 int ivf_mfma_len_stride();              // ints of `queue_len` per query
