@@ -1760,7 +1760,31 @@ int vdb_kmeans_init_pp(vdb_kmeans* h, int64_t first_row, const double* uniforms,
     long long* chosen = h->chosen.as<long long>();
     VDB_HIP(hipMemcpyAsync(chosen, &first_row, sizeof(int64_t), hipMemcpyHostToDevice, s));
     VDB_HIP(hipMemsetAsync(chosen + k, 0, sizeof(int64_t), s));
+    // rows that can serve as queries as they lie: the chosen row's stored norms are the query's, the streamed dot
+    // products are finished by the update kernel (four launches per round instead of six)
+    static const bool no_short = getenv("VDB_KMPP_LONG") != nullptr;
+    const bool short_round = !no_short && !x.bf16 && x.ld == x.dim && x.dim % 8 == 0 && x.dim == h->dsub;
+    if (short_round) {
+        VDB_TRY(xs->ws.q_sq.reserve(sizeof(float)));
+        VDB_TRY(xs->ws.q_nrm.reserve(sizeof(float)));
+    }
     for (int j = 1; j < k; ++j) {
+        if (short_round) {
+            // (the first query is gathered here, the later ones by the selection of the round before)
+            if (j == 1)
+                VDB_TRY(launch_km_gather_query(x.data, x.ld, h->dsub, chosen, x.sq, x.nrm, h->qrow.as<float>(),
+                                               xs->ws.q_sq.as<float>(), xs->ws.q_nrm.as<float>(), s));
+            KmNextQuery next;
+            next.x = x.data; next.ldx = x.ld; next.dsub = h->dsub; next.x_sq = x.sq; next.x_nrm = x.nrm;
+            next.q = h->qrow.as<float>(); next.q_sq = xs->ws.q_sq.as<float>(); next.q_nrm = xs->ws.q_nrm.as<float>();
+            StreamJob more{};
+            more.timed = true;
+            if ((j & 1) != 0) more.reverse_items = (x.n + 255) / 256;      // (every other pass back to front, as below)
+            VDB_TRY(stream_flat_sums(xs->ws, x, VDB_EUCLIDEAN, h->qrow.as<float>(), 1, h->dist.as<float>(), s, false, &more));
+            VDB_TRY(launch_km_pp_step(h->dist.as<float>(), x.n, j == 1, h->nearest.as<float>(), h->bsums.as<double>(),
+                                      uniforms[j - 1], chosen + j, chosen + k, s, xs->ws.q_sq.as<float>(), x.sq, &next));
+            continue;
+        }
         // distances of every row to the centroid chosen last: pairwise_euclidean against ONE new centroid; the
         // minimum over all chosen ones is kept as a running minimum (min is exact, so the result is the same)
         VDB_TRY(launch_km_gather(x.data, x.ld, h->dsub, chosen + (j - 1), nullptr, 1, h->qrow.as<float>(), nullptr, s));

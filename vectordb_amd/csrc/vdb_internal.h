@@ -471,7 +471,13 @@ int launch_km_gather(const float* x, int ldx, int dsub, const long long* rows, c
 int launch_km_assign_f64(const float* x, int ldx, int dsub, int64_t n, const float* xsq, const double* cent, double* csq,
                          int k, int* assign, hipStream_t s);
 int64_t km_pp_blocks(int64_t n);
+int launch_km_gather_query(const float* x, int ldx, int dsub, const long long* row, const float* x_sq, const float* x_nrm,
+                           float* q, float* q_sq, float* q_nrm, hipStream_t s);
+// the selection also copies the chosen row out as the next round's query, with the row store's norms of it
+struct KmNextQuery { const float* x = nullptr; int ldx = 0; int dsub = 0; const float* x_sq = nullptr; const float* x_nrm = nullptr;
+                     float* q = nullptr; float* q_sq = nullptr; float* q_nrm = nullptr; };
 int launch_km_pp_step(const float* dist, int64_t n, bool first, float* nearest, double* block_sums, double u,
-                      long long* chosen, long long* bad_weights, hipStream_t s);
+                      long long* chosen, long long* bad_weights, hipStream_t s,
+                      const float* q_sq = nullptr, const float* row_sq = nullptr, const KmNextQuery* next = nullptr);
 
 }  // namespace vdb
