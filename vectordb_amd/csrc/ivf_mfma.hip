@@ -562,13 +562,6 @@ __device__ __forceinline__ int count_before(const unsigned long long* pairs, int
     if (e < n) c += pairs[e] < mine ? 1 : 0;
     return c;
 }
-#ifdef VDB_FINISH_TIMING
-__device__ long long g_ft[16];
-__device__ int g_fi[4];
-#define FT(i) if (PROBE && blockIdx.x == 512 && threadIdx.x == 0) g_ft[i] = wall_clock64();
-#else
-#define FT(i)
-#endif
 
 template <bool PROBE>
 __global__ __launch_bounds__(256) void ivf_finish_kernel(IvfFinishParams p) {
@@ -602,7 +595,6 @@ __global__ __launch_bounds__(256) void ivf_finish_kernel(IvfFinishParams p) {
         p.out_d[(int64_t)q * p.k_out + f] = INFINITY;
         p.out_slots[(int64_t)q * p.k_out + f] = -1;
     }
-    FT(0)
     // U: every thread's smallest key (eight loads in flight at a time), then the k-th smallest of the 256 by counting
     constexpr int AH = 8;
     float hv = INFINITY;                         // threads without a pair (or with NaN alone) stand at +inf
@@ -617,7 +609,6 @@ __global__ __launch_bounds__(256) void ivf_finish_kernel(IvfFinishParams p) {
         for (int a = 0; a < AH; ++a)
             if (v[a] < hv) hv = v[a];
     }
-    FT(1)
     if (PROBE) {
         // thousands of keys, k up to 64: the k-th smallest of all 256 threads' minima (little above the k-th smallest key)
         const unsigned long long mine = packed(hv, tid);
@@ -639,7 +630,6 @@ __global__ __launch_bounds__(256) void ivf_finish_kernel(IvfFinishParams p) {
         if (tid == 0) sh_u = fminf(fminf(sh_d[0], sh_d[1]), fminf(sh_d[2], sh_d[3]));
     }
     __syncthreads();
-    FT(2)
     const float u = sh_u;
     const float first = u < INFINITY ? ((u + s) * 1.000001f + s) : INFINITY;
     // the pairs within the first bound, in LDS
@@ -670,7 +660,6 @@ __global__ __launch_bounds__(256) void ivf_finish_kernel(IvfFinishParams p) {
         }
     }
     __syncthreads();
-    FT(3)
     const int held = sh_cnt;
     const int half = tid & 1;
     const float* qrow = p.q + (int64_t)q * p.ldq;
@@ -716,13 +705,11 @@ __global__ __launch_bounds__(256) void ivf_finish_kernel(IvfFinishParams p) {
         }
         return;
     }
-    FT(4)
     // A_k: the held key with k - 1 held pairs before it under (key, place)
     for (int t = tid; t < held; t += 256) {
         if (count_before(sh_pair, held, sh_pair[t]) == k - 1) sh_kth = sh_key[t];
     }
     __syncthreads();
-    FT(5)
     const float a_k = sh_kth;                    // +inf with fewer than k pairs: every pair is a finalist
     const float second = a_k < INFINITY ? ((a_k + s) * 1.000001f + s) : INFINITY;
     for (int t0 = 0; t0 < held; t0 += 256) {
@@ -737,7 +724,6 @@ __global__ __launch_bounds__(256) void ivf_finish_kernel(IvfFinishParams p) {
         }
     }
     __syncthreads();
-    FT(6)
     const int nfin = sh_nfin;
     // the reference's distances of the finalists
     for (int f0 = 0; f0 < nfin; f0 += 128) {                 // (the pair of lanes of a finalist stays together)
@@ -754,10 +740,6 @@ __global__ __launch_bounds__(256) void ivf_finish_kernel(IvfFinishParams p) {
         }
     }
     __syncthreads();
-    FT(7)
-#ifdef VDB_FINISH_TIMING
-    if (PROBE && blockIdx.x == 512 && tid == 0) { g_fi[0] = held; g_fi[1] = nfin; }
-#endif
     for (int f = tid; f < nfin; f += 256) {
         const float my = sh_d[f];
         const int my_slot = sh_fs[f];
@@ -765,7 +747,6 @@ __global__ __launch_bounds__(256) void ivf_finish_kernel(IvfFinishParams p) {
         const int place = count_before(sh_pair, nfin, sh_pair[f]);
         if (place < k) { p.out_d[(int64_t)q * p.k_out + place] = my; p.out_slots[(int64_t)q * p.k_out + place] = my_slot; }
     }
-    FT(8)
 }
 
 __global__ void ivf_round_rows_kernel(const float* __restrict__ src, int64_t src_ld, int dim, int64_t n,
@@ -916,24 +897,13 @@ int launch_ivf_mfma_probe(const IvfProbeJob& j, hipStream_t s) {
     e.k = j.n_probe; e.k_out = j.n_probe; e.out_d = j.probe_d; e.out_slots = j.probes;
     hipLaunchKernelGGL(ivf_finish_kernel<true>, dim3(j.nq), dim3(256), 0, s, e);
     VDB_HIP(hipGetLastError());
-#ifdef VDB_FINISH_TIMING
-    {
-        long long t[16]; int v[4];
-        (void)hipStreamSynchronize(s);
-        (void)hipMemcpyFromSymbol(t, HIP_SYMBOL(g_ft), sizeof(t));
-        (void)hipMemcpyFromSymbol(v, HIP_SYMBOL(g_fi), sizeof(v));
-        fprintf(stderr, "[finish timing, 10 ns ticks]");
-        for (int i = 1; i <= 8; ++i) fprintf(stderr, " %lld", t[i] - t[i - 1]);
-        fprintf(stderr, "  held=%d nfin=%d\n", v[0], v[1]);
-    }
-#endif
     return VDB_OK;
 }
 
 // --------------------------------------------------------------------------
 // The k best of every query's run of candidate distances (one float per candidate slot, as the IVF-PQ scan leaves
-// them), k <= 64, under (distance, slot).  One block of sixteen waves per query streams the run once, eight loads in
-// flight per lane; every wave keeps its k best in its lanes (a candidate is offered only if it beats the wave's k-th:
+// them), k <= 64, under (distance, slot).  One block of sixteen waves per query streams the run once, four 16-byte
+// loads in flight per lane; every wave keeps its k best in its lanes (a candidate is offered only if it beats the wave's k-th:
 // after the first few hundred nearly none does), and the sixteen lists are ranked together by counting.
 static constexpr int CR_NT = 1024;
 
