@@ -49,6 +49,29 @@ def test_kmeans_pp_and_two_lloyd_steps(nat):
     tr.close(); store.close()
 
 
+@pytest.mark.parametrize("d,scale", [(128, 1.0), (32, 1.0), (40, 1e-3), (64, 1e4), (8, 1.0)])
+def test_kmeans_pp_rounds_over_the_bf16_copy_choose_the_same_rows(nat, d, scale, monkeypatch):
+    """From the second round on k-means++ reads a bf16 copy of the rows and recomputes only the rows a new centroid can
+    come nearer to than their minimum (in the distance pass's arithmetic).  The draws must be those of the rounds
+    that read every row in float32: random rows, tight clusters (most minima lie within the slack of each other),
+    repeated rows."""
+    rng = np.random.RandomState(d)
+    n, k = 50000, 150
+    centres = rng.randn(40, d).astype(np.float32)
+    x = np.concatenate([rng.randn(n // 2, d).astype(np.float32),
+                        centres[rng.randint(0, 40, n // 2)] + 0.01 * rng.randn(n // 2, d).astype(np.float32)]) * np.float32(scale)
+    x[1000:1200] = x[999]
+    u = rng.random_sample(k - 1)
+    store, tr = trainer_for(nat, x, 0, d, k)
+    rows_bf16 = tr.init_pp(123, u)
+    monkeypatch.setenv("VDB_KMPP_NO_BF16", "1")
+    rows_f32 = tr.init_pp(123, u)
+    monkeypatch.delenv("VDB_KMPP_NO_BF16")
+    np.testing.assert_array_equal(rows_bf16, rows_f32)
+    np.testing.assert_array_equal(tr.centroids(), x[rows_f32])
+    tr.close(); store.close()
+
+
 def test_kmeans_class_matches_reference_fit():
     """KMeans.fit end to end against the reference's fitted centroids (kmeans.npz: 600 x 16, 12 clusters, seed 42)."""
     from vectordb_amd.index.ivf import KMeans

@@ -1650,6 +1650,7 @@ struct vdb_kmeans : Handle {
     int last_form = 0;
     DevBuf cur32, next32, cur64, next64, assign, dist, nearest, hist, totals, cluster_off, members, counts, bsums,
            chosen, qrow, csq64, scal, rows_in, dst_in, dense;
+    DevBuf x16, x_max_nrm, q16f;        // k-means++ rounds over a bf16 copy of the rows (launch_km_pp_bf16)
     const Rows& x() const { return (sub ? sub : train)->r; }
     Workspace& xws() { return (sub ? sub : train)->ws; }
 };
@@ -1768,15 +1769,43 @@ int vdb_kmeans_init_pp(vdb_kmeans* h, int64_t first_row, const double* uniforms,
         VDB_TRY(xs->ws.q_sq.reserve(sizeof(float)));
         VDB_TRY(xs->ws.q_nrm.reserve(sizeof(float)));
     }
+    // From the second round on: one pass over a bf16 copy of the rows that rules out the rows a new centroid cannot
+    // come nearer to than their minimum, and the distance pass's own arithmetic for the others (km_pp_bf16_kernel):
+    // half the bytes per round, two launches.  One-leaf rows (up to 128 columns), enough rounds to pay for the copy.
+    // (VDB_KMPP_NO_BF16 is read at every call: tests compare the two ways.)
+    const int ld16 = ivf_mfma_pitch(x.dim);
+    bool bf16_rounds = short_round && !getenv("VDB_KMPP_NO_BF16") && x.dim <= 128 && x.plan.n_leaves == 1 && k >= 16 && x.n >= 4096;
+    if (bf16_rounds) {
+        const int st = h->x16.reserve((size_t)round_up64(x.n, 32) * ld16 * 2);
+        if (st == VDB_ERR_NOMEM) { (void)hipGetLastError(); bf16_rounds = false; }
+        else VDB_TRY(st);
+    }
+    if (bf16_rounds) {
+        VDB_TRY(h->x_max_nrm.reserve(sizeof(float)));
+        VDB_TRY(h->q16f.reserve((size_t)ld16 * sizeof(float)));
+        VDB_TRY(launch_ivf_round_rows_tiled(x.data, x.ld, x.dim, 0, x.n, h->x16.as<uint16_t>(), ld16, s));
+        VDB_HIP(hipMemsetAsync(h->x_max_nrm.p, 0, sizeof(float), s));
+        VDB_TRY(launch_max_norm(x.nrm, 0, x.n, h->x_max_nrm.as<float>(), s));
+    }
     for (int j = 1; j < k; ++j) {
         if (short_round) {
-            // (the first query is gathered here, the later ones by the selection of the round before)
-            if (j == 1)
-                VDB_TRY(launch_km_gather_query(x.data, x.ld, h->dsub, chosen, x.sq, x.nrm, h->qrow.as<float>(),
-                                               xs->ws.q_sq.as<float>(), xs->ws.q_nrm.as<float>(), s));
             KmNextQuery next;
             next.x = x.data; next.ldx = x.ld; next.dsub = h->dsub; next.x_sq = x.sq; next.x_nrm = x.nrm;
             next.q = h->qrow.as<float>(); next.q_sq = xs->ws.q_sq.as<float>(); next.q_nrm = xs->ws.q_nrm.as<float>();
+            if (bf16_rounds) { next.q16f = h->q16f.as<float>(); next.q16f_n = ld16; }
+            // (the first query is gathered here, the later ones by the selection of the round before)
+            if (j == 1)
+                VDB_TRY(launch_km_gather_query(x.data, x.ld, h->dsub, chosen, x.sq, x.nrm, h->qrow.as<float>(),
+                                               xs->ws.q_sq.as<float>(), xs->ws.q_nrm.as<float>(), s, next.q16f, next.q16f_n));
+            if (bf16_rounds && j > 1) {
+                KmBf16Pass bp{h->x16.as<uint16_t>(), ld16 / 8, x.data, x.ld, x.dim, x.sq, h->x_max_nrm.as<float>(),
+                              h->qrow.as<float>(), h->q16f.as<float>(), xs->ws.q_sq.as<float>(), xs->ws.q_nrm.as<float>(),
+                              x.n, h->nearest.as<float>(), h->bsums.as<double>()};
+                VDB_TRY(launch_km_pp_bf16(bp, s));
+                VDB_TRY(launch_km_pp_select(h->nearest.as<float>(), x.n, h->bsums.as<double>(), uniforms[j - 1], chosen + j,
+                                            chosen + k, next, s));
+                continue;
+            }
             StreamJob more{};
             more.timed = true;
             if ((j & 1) != 0) more.reverse_items = (x.n + 255) / 256;      // (every other pass back to front, as below)

@@ -365,12 +365,6 @@ __global__ __launch_bounds__(IA_NT) void ivf_bound_kernel(IvfBoundParams p) {
 // the reference's k-th smallest sum is at most B + S; rows that tie it after the square root lie within one part in
 // 2^22 of it; and any row with R <= (B + S)(1 + 2^-21) has A <= (B + S)(1 + 2^-21) + S, which is the threshold.
 // Norms whose squares or products could leave float32 (or are not numbers) raise the overflow flag instead.
-// S of the bound above for a query of norm qn (|q|^2 = q_sq) over rows of norms up to `big` (both below 1e18)
-__device__ __forceinline__ float key_slack(int dim, float qn, float big, float q_sq) {
-    const float e_dot = (0.0078278f + (float)dim * 2.4e-7f) * 1.0001f * qn * big + sqrtf((float)dim) * 1.2e-38f * (qn + big) + 1e-30f;
-    return 2.0f * e_dot + (4.0f * (float)dim + 16.0f) * 6.0e-8f * 1.01f * (q_sq + big * big);
-}
-
 __global__ __launch_bounds__(256) void ivf_threshold_kernel(const float* __restrict__ mins, int nq, int k, int dim,
                                                             const float* __restrict__ q_sq, const float* __restrict__ q_nrm,
                                                             const float* __restrict__ max_row_nrm, float* __restrict__ thr,

@@ -4,6 +4,7 @@
 // the order of additions is free but the fp64 sums agree with a sequential
 // fp32/fp64 accumulation far below fp32 resolution.
 #include "vdb_internal.h"
+#include "vdb_device.h"
 
 namespace vdb {
 
@@ -199,19 +200,28 @@ __global__ void km_gather_kernel(const float* __restrict__ x, int ldx, int dsub,
     if (dst64) dst64[at] = (double)v;
 }
 
+// a float rounded to bf16 (nearest even), as a float
+__device__ __forceinline__ float bf16_rounded(float f) {
+    const uint32_t v = __float_as_uint(f);
+    const uint32_t b = ((v & 0x7fffffffu) > 0x7f800000u) ? ((v >> 16) | 0x40u) : ((v + 0x7fffu + ((v >> 16) & 1u)) >> 16);
+    return __uint_as_float(b << 16);
+}
+
 // one training row as the query of the pass that follows, with the norms the row store keeps for it (the values a
 // norm pass over the copy would compute again)
 __global__ void km_gather_query_kernel(const float* __restrict__ x, int ldx, int dsub, const long long* __restrict__ row,
                                        const float* __restrict__ x_sq, const float* __restrict__ x_nrm,
-                                       float* __restrict__ q, float* __restrict__ q_sq, float* __restrict__ q_nrm) {
+                                       float* __restrict__ q, float* __restrict__ q_sq, float* __restrict__ q_nrm,
+                                       float* __restrict__ q16f, int q16f_n) {
     const long long r = row[0];
     for (int j = threadIdx.x; j < dsub; j += blockDim.x) q[j] = x[r * ldx + j];
+    for (int j = threadIdx.x; j < q16f_n; j += blockDim.x) q16f[j] = j < dsub ? bf16_rounded(x[r * ldx + j]) : 0.0f;
     if (threadIdx.x == 0) { q_sq[0] = x_sq[r]; q_nrm[0] = x_nrm[r]; }
 }
 
 int launch_km_gather_query(const float* x, int ldx, int dsub, const long long* row, const float* x_sq, const float* x_nrm,
-                           float* q, float* q_sq, float* q_nrm, hipStream_t s) {
-    hipLaunchKernelGGL(km_gather_query_kernel, dim3(1), dim3(256), 0, s, x, ldx, dsub, row, x_sq, x_nrm, q, q_sq, q_nrm);
+                           float* q, float* q_sq, float* q_nrm, hipStream_t s, float* q16f, int q16f_n) {
+    hipLaunchKernelGGL(km_gather_query_kernel, dim3(1), dim3(256), 0, s, x, ldx, dsub, row, x_sq, x_nrm, q, q_sq, q_nrm, q16f, q16f_n);
     VDB_HIP(hipGetLastError());
     return VDB_OK;
 }
@@ -333,6 +343,101 @@ __global__ __launch_bounds__(256) void km_pp_update_kernel(const float* __restri
     if (threadIdx.x == 0) block_sums[blockIdx.x] = sh[0];
 }
 
+// The round's pass and update in one, over bf16 copies of the rows (tiled as the IVF scan's copy: the 16-byte pieces of
+// 32 consecutive rows lie together).  A new centroid lowers the running minimum of few rows.  For every row the key
+// A = |q|^2 + |x|^2 - 2 bf16(q).bf16(x) lies within S (key_slack) of the float32 value R the distance pass computes
+// before its square root, and the update's value is sqrtf(R)^2 >= R (1 - 4 * 2^-24): a row with
+// (A - S) * 0.999999 >= nearest[row] keeps its minimum and is not read in float32 at all.  The others (the rows near the
+// new centroid, and those whose minimum lies within the slack) get the distance pass's own arithmetic: the streaming
+// kernel's dot product of a one-leaf row (eight fused partial sums, elements j, j + 8, ...; ((r0+r1)+(r2+r3)) +
+// ((r4+r5)+(r6+r7))), fma(-2, dot, |q|^2 + |x|^2), max 0, sqrtf, square.  Same minima, same block sums (a thread's four
+// rows in float64, then the tree over the block) as km_pp_update_kernel.
+// (KmBf16Pass: x16 = the tiled copy, `pieces` 16-byte pieces per row; x = the float32 rows, dim a multiple of 8 and at
+// most 128; q16f = the new centroid's elements rounded to bf16, as floats, pieces * 8 of them.)
+template <int PIECES>
+__global__ __launch_bounds__(256) void km_pp_bf16_kernel(KmBf16Pass p) {
+    __shared__ double sh[256];
+    const float q_sq = p.q_sq[0], qn = p.q_nrm[0], big = p.max_nrm[0];
+    const bool trusted = qn < 1e18f && big < 1e18f;                       // else every row takes the float32 way
+    const float slack = trusted ? key_slack(p.dim, qn, big, q_sq) : 0.0f;
+    const int64_t base = (int64_t)blockIdx.x * PP_BLOCK;
+    double acc_sum = 0.0;
+    uint4 w[PIECES];
+    auto load_row = [&](int64_t i) {
+        const int64_t at = (((i >> 5) * PIECES) * 32 + (i & 31)) * 8;      // piece 0 of row i; piece c lies c * 256 elements on
+#pragma unroll
+        for (int c = 0; c < PIECES; ++c) w[c] = *reinterpret_cast<const uint4*>(p.x16 + at + (int64_t)c * 256);
+    };
+    if (base + threadIdx.x < p.n) load_row(base + threadIdx.x);
+#pragma unroll 1
+    for (int ps = 0; ps < 4; ++ps) {
+        const int64_t i = base + ps * 256 + threadIdx.x;
+        if (i < p.n) {
+            float a = 0.0f;
+#pragma unroll
+            for (int c = 0; c < PIECES; ++c) {
+                const uint32_t v[4] = {w[c].x, w[c].y, w[c].z, w[c].w};
+                // (the centroid's elements through the scalar cache, eight at a time: in vector registers all 128 of them
+                // would leave a wave per SIMD)
+                typedef int km_i8 __attribute__((ext_vector_type(8)));
+                const km_i8 qw = *reinterpret_cast<const __attribute__((address_space(4))) km_i8*>(reinterpret_cast<uintptr_t>(p.q16f + c * 8));
+                const float qs[8] = {__int_as_float(qw[0]), __int_as_float(qw[1]), __int_as_float(qw[2]), __int_as_float(qw[3]),
+                                     __int_as_float(qw[4]), __int_as_float(qw[5]), __int_as_float(qw[6]), __int_as_float(qw[7])};
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    a = __fmaf_rn(__uint_as_float(v[e] << 16), qs[2 * e], a);
+                    a = __fmaf_rn(__uint_as_float(v[e] & 0xffff0000u), qs[2 * e + 1], a);
+                }
+            }
+            const int64_t next = i + 256;
+            if (ps < 3 && next < p.n) load_row(next);                     // on its way while this row is decided
+            const float x_sq = p.x_sq[i];
+            const float old = p.nearest[i];
+            const float key = __fmaf_rn(-2.0f, a, q_sq + x_sq);
+            float v = old;
+            if (!(trusted && (key - slack) * 0.999999f >= old)) {
+                const float* xr = p.x + i * p.ldx;
+                float r[8];
+#pragma unroll
+                for (int j = 0; j < 8; ++j) r[j] = 0.0f;
+                for (int g = 0; g < p.dim; g += 8) {
+                    const float4 xa = *reinterpret_cast<const float4*>(xr + g), xb = *reinterpret_cast<const float4*>(xr + g + 4);
+                    const float4 qa = *reinterpret_cast<const float4*>(p.q + g), qb = *reinterpret_cast<const float4*>(p.q + g + 4);
+                    r[0] = __fmaf_rn(xa.x, qa.x, r[0]); r[1] = __fmaf_rn(xa.y, qa.y, r[1]);
+                    r[2] = __fmaf_rn(xa.z, qa.z, r[2]); r[3] = __fmaf_rn(xa.w, qa.w, r[3]);
+                    r[4] = __fmaf_rn(xb.x, qb.x, r[4]); r[5] = __fmaf_rn(xb.y, qb.y, r[5]);
+                    r[6] = __fmaf_rn(xb.z, qb.z, r[6]); r[7] = __fmaf_rn(xb.w, qb.w, r[7]);
+                }
+                const float dot = ((r[0] + r[1]) + (r[2] + r[3])) + ((r[4] + r[5]) + (r[6] + r[7]));
+                const float d = sqrtf(fmaxf(__fmaf_rn(-2.0f, dot, q_sq + x_sq), 0.0f));
+                v = fminf(old, d * d);
+                if (v != old) p.nearest[i] = v;
+            }
+            acc_sum += (double)v;
+        }
+    }
+    sh[threadIdx.x] = acc_sum;
+    __syncthreads();
+    for (int o = 128; o > 0; o >>= 1) {
+        if (threadIdx.x < o) sh[threadIdx.x] += sh[threadIdx.x + o];
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) p.block_sums[blockIdx.x] = sh[0];
+}
+
+int launch_km_pp_bf16(const KmBf16Pass& p, hipStream_t s) {
+    const dim3 grid((unsigned)km_pp_blocks(p.n));
+    switch (p.pieces) {
+        case 4: hipLaunchKernelGGL(km_pp_bf16_kernel<4>, grid, dim3(256), 0, s, p); break;
+        case 8: hipLaunchKernelGGL(km_pp_bf16_kernel<8>, grid, dim3(256), 0, s, p); break;
+        case 12: hipLaunchKernelGGL(km_pp_bf16_kernel<12>, grid, dim3(256), 0, s, p); break;
+        case 16: hipLaunchKernelGGL(km_pp_bf16_kernel<16>, grid, dim3(256), 0, s, p); break;
+        default: set_error("bf16 k-means++ pass: %d pieces per row", p.pieces); return VDB_ERR_INVALID;
+    }
+    VDB_HIP(hipGetLastError());
+    return VDB_OK;
+}
+
 // rng.choice(n, p = nearest / nearest.sum()) for the uniform draw u (mtrand: cdf = cumsum(p); cdf /= cdf[-1];
 // index = searchsorted(cdf, u, side="right")): the first row whose cumulative share exceeds u.
 // One block: scan of the block sums, then of the 1024 entries of the block the draw falls into.
@@ -415,12 +520,14 @@ __global__ __launch_bounds__(1024) void km_pp_select_kernel(const float* __restr
                                                             long long* __restrict__ chosen, long long* __restrict__ bad_weights,
                                                             const float* __restrict__ x, int ldx, int dsub,
                                                             const float* __restrict__ x_sq, const float* __restrict__ x_nrm,
-                                                            float* __restrict__ q, float* __restrict__ q_sq, float* __restrict__ q_nrm) {
+                                                            float* __restrict__ q, float* __restrict__ q_sq, float* __restrict__ q_nrm,
+                                                            float* __restrict__ q16f, int q16f_n) {
     km_pp_select_body(nearest, n, block_sums, nb, u, chosen, bad_weights);
     if (!q) return;
     __syncthreads();
     const long long r = __hip_atomic_load(chosen, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);     // written by one thread above
     for (int j = threadIdx.x; j < dsub; j += 1024) q[j] = x[r * ldx + j];
+    for (int j = threadIdx.x; j < q16f_n; j += 1024) q16f[j] = j < dsub ? bf16_rounded(x[r * ldx + j]) : 0.0f;
     if (threadIdx.x == 0) { q_sq[0] = x_sq[r]; q_nrm[0] = x_nrm[r]; }
 }
 
@@ -514,7 +621,16 @@ int launch_km_pp_step(const float* dist, int64_t n, bool first, float* nearest, 
     const KmNextQuery none{};
     const KmNextQuery& nx = next ? *next : none;
     hipLaunchKernelGGL(km_pp_select_kernel, dim3(1), dim3(1024), 0, s, nearest, n, block_sums, nb, u, chosen, bad_weights,
-                       nx.x, nx.ldx, nx.dsub, nx.x_sq, nx.x_nrm, nx.q, nx.q_sq, nx.q_nrm);
+                       nx.x, nx.ldx, nx.dsub, nx.x_sq, nx.x_nrm, nx.q, nx.q_sq, nx.q_nrm, nx.q16f, nx.q16f_n);
+    VDB_HIP(hipGetLastError());
+    return VDB_OK;
+}
+
+// the selection of a round alone (the pass above has written the block sums)
+int launch_km_pp_select(const float* nearest, int64_t n, const double* block_sums, double u, long long* chosen,
+                        long long* bad_weights, const KmNextQuery& nx, hipStream_t s) {
+    hipLaunchKernelGGL(km_pp_select_kernel, dim3(1), dim3(1024), 0, s, nearest, n, block_sums, km_pp_blocks(n), u, chosen,
+                       bad_weights, nx.x, nx.ldx, nx.dsub, nx.x_sq, nx.x_nrm, nx.q, nx.q_sq, nx.q_nrm, nx.q16f, nx.q16f_n);
     VDB_HIP(hipGetLastError());
     return VDB_OK;
 }

@@ -150,6 +150,15 @@ __device__ __noinline__ static unsigned long long wave_merge_candidates(float e,
     return ((unsigned long long)(unsigned)eid << 32) | (unsigned)__float_as_int(e);
 }
 
+// How far the key |q|^2 + |c|^2 - 2 bf16(q).bf16(c) (products and sums in float32, any order) can lie from the float32
+// forms of the squared distance, direct (sum of squared differences) or identity (|q|^2 + |c|^2 - 2 q.c with float32
+// sums): S = 2 E + (4 D + 16) u (|q|^2 + |c|^2), u = 2^-24, E = (2^-7 + 2^-16 + D 2^-22) |q||c| for rounding both
+// operands to 8 significant bits and accumulating D products.  qn = |q| (|q|^2 = q_sq), big >= |c|, both below 1e18.
+__device__ __forceinline__ float key_slack(int dim, float qn, float big, float q_sq) {
+    const float e_dot = (0.0078278f + (float)dim * 2.4e-7f) * 1.0001f * qn * big + sqrtf((float)dim) * 1.2e-38f * (qn + big) + 1e-30f;
+    return 2.0f * e_dot + (4.0f * (float)dim + 16.0f) * 6.0e-8f * 1.01f * (q_sq + big * big);
+}
+
 struct WaveTopK {
     float e; int eid;            // this lane's element
     float thr; int thr_id;       // the k-th element (wave-uniform)

@@ -472,12 +472,26 @@ int launch_km_assign_f64(const float* x, int ldx, int dsub, int64_t n, const flo
                          int k, int* assign, hipStream_t s);
 int64_t km_pp_blocks(int64_t n);
 int launch_km_gather_query(const float* x, int ldx, int dsub, const long long* row, const float* x_sq, const float* x_nrm,
-                           float* q, float* q_sq, float* q_nrm, hipStream_t s);
+                           float* q, float* q_sq, float* q_nrm, hipStream_t s, float* q16f = nullptr, int q16f_n = 0);
 // the selection also copies the chosen row out as the next round's query, with the row store's norms of it
 struct KmNextQuery { const float* x = nullptr; int ldx = 0; int dsub = 0; const float* x_sq = nullptr; const float* x_nrm = nullptr;
-                     float* q = nullptr; float* q_sq = nullptr; float* q_nrm = nullptr; };
+                     float* q = nullptr; float* q_sq = nullptr; float* q_nrm = nullptr;
+                     float* q16f = nullptr; int q16f_n = 0; };      // ... and its elements rounded to bf16, zero-padded to q16f_n
+// k-means++ round over a bf16 copy of the rows (kmeans.hip): distances, running minima and block sums in one pass
+struct KmBf16Pass {
+    const uint16_t* x16; int pieces;
+    const float* x; int ldx; int dim;
+    const float* x_sq; const float* max_nrm;
+    const float* q; const float* q16f;
+    const float* q_sq; const float* q_nrm;
+    int64_t n;
+    float* nearest; double* block_sums;
+};
+int launch_km_pp_bf16(const KmBf16Pass& p, hipStream_t s);
 int launch_km_pp_step(const float* dist, int64_t n, bool first, float* nearest, double* block_sums, double u,
                       long long* chosen, long long* bad_weights, hipStream_t s,
                       const float* q_sq = nullptr, const float* row_sq = nullptr, const KmNextQuery* next = nullptr);
+int launch_km_pp_select(const float* nearest, int64_t n, const double* block_sums, double u, long long* chosen,
+                        long long* bad_weights, const KmNextQuery& nx, hipStream_t s);
 
 }  // namespace vdb
