@@ -10,7 +10,7 @@ R=${GRAFT_REPO_ROOT:-$(pwd)}
 OUT=$R/gpurun_out/prof_$TAG
 mkdir -p "$OUT"
 cd "$R"
-ARGS="bench.py --steps 10 --warmup 2 --cpu-sample 0"
+ARGS="bench.py --steps 20 --warmup 3 --cpu-sample 0"       # bench.py's default step counts
 timeout -k 10 200 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/stats" -- python3 $ARGS > "$OUT/stats.log" 2>&1 || exit 1
 PMCARGS="bench.py --steps 3 --warmup 1 --cpu-sample 0"
 timeout -s KILL 120 rocprofv3 --pmc SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_VALU_MFMA_BUSY_CYCLES SQ_INSTS_VALU_MFMA_MOPS_F32 SQ_WAIT_INST_ANY SQ_WAIT_ANY SQ_ACTIVE_INST_ANY SQ_LDS_BANK_CONFLICT --output-format csv -d "$OUT/pmc_sq1" -- python3 $PMCARGS > "$OUT/pmc_sq1.log" 2>&1 || exit 1
