@@ -4,7 +4,8 @@ pytest):   python tests/fuzz_ivf_pq.py --seconds 300 [--seed 0]
 IVF: random rows, centroids drawn from them, the oracle's assignment on both sides, random n_probe / k /
 batch size / filter; rows and fp32 distances must equal the oracle's, in its visiting order (cosine: 1e-4).  A case whose
 probe ranking has two centroid distances closer than 1e-5 relative at the n_probe boundary is skipped (the
-ranking is a matrix form with a 1e-4 bar).  PQ: random codebooks and codes; rows and distances bit for bit."""
+ranking is a matrix form with a 1e-4 bar).  PQ: random codebooks and codes; rows and distances bit for bit.
+IVF-PQ: batches of up to 300 queries (list ranking, scan and selection of batches), rows and distances bit for bit."""
 import argparse, os, sys, time
 import numpy as np
 
@@ -97,9 +98,54 @@ def pq_case():
     return label
 
 
+def hybrid_case():
+    """IVF-PQ: encode on the device, the oracle's search over the same codes and lists; a query whose coarse ranking
+    (a matrix form in the reference) is near-tied at the n_probe boundary is skipped."""
+    global skipped
+    m = int(rng.choice([4, 8, 16]))
+    dsub = int(rng.choice([2, 4, 8]))
+    d = m * dsub
+    n = int(rng.choice([3000, 20000, 60000]))
+    nlist = int(rng.choice([16, 64, 200]))
+    x = rng.standard_normal((n, d), dtype=np.float32)
+    cent = x[rng.choice(n, nlist, replace=False)].copy()
+    book = (0.5 * rng.standard_normal((m, 256, dsub))).astype(np.float32)
+    nq = int(rng.choice([1, 9, 40, 120, 300]))
+    q = rng.standard_normal((nq, d), dtype=np.float32)
+    k = int(rng.choice([1, 10, 32, 50]))
+    n_probe = int(min(nlist, rng.choice([1, 4, 8, 20])))
+    mask = (rng.random(n) < 0.3) if rng.random() < 0.25 else None
+    label = f"ivfpq n={n} m={m} dsub={dsub} nlist={nlist} nq={nq} k={k} n_probe={n_probe} mask={'none' if mask is None else int(mask.sum())}"
+    h = nat.IvfPqLists(d, m, 256)
+    h.set_quantizers(cent, book)
+    lists, codes = h.encode(x)
+    order = np.argsort(lists, kind="stable")
+    offs = np.searchsorted(lists[order], np.arange(nlist + 1))
+    h.build(codes, order, offs)
+    members = [order[offs[l]:offs[l + 1]] for l in range(nlist)]
+    dist, rows = h.search(q, k, n_probe, nat.pack_mask(mask))
+    h.close()
+    cs = np.sum(cent ** 2, axis=1)
+    for i in list(range(min(nq, 3))) + ([nq - 1] if nq > 3 else []):
+        coarse = np.sort(np.sum(q[i] ** 2) + cs - 2 * (q[i] @ cent.T))
+        if n_probe < nlist and coarse[n_probe] - coarse[n_probe - 1] <= 1e-3:
+            skipped += 1
+            continue
+        if n_probe > 1 and np.min(np.diff(coarse[:n_probe])) <= 1e-4:
+            skipped += 1
+            continue
+        ref_rows, ref_dist = R.hybrid_search(q[i], cent, book, codes, members, k, n_probe, mask=mask)
+        mm = len(ref_rows)
+        assert (rows[i, :mm] == ref_rows).all(), label
+        assert (dist[i, :mm] == ref_dist).all(), label
+        assert (rows[i, mm:] == -1).all(), label
+    return label
+
+
 while time.time() - t0 < args.seconds:
     case += 1
-    fn = ivf_case if rng.random() < 0.6 else pq_case
+    pick = rng.random()
+    fn = ivf_case if pick < 0.5 else (pq_case if pick < 0.8 else hybrid_case)
     try:
         label = fn()
     except Exception:       # noqa: BLE001
