@@ -19,6 +19,7 @@ from conftest import same_ids_or_near_ties
 ap = argparse.ArgumentParser()
 ap.add_argument("--seconds", type=float, default=120)
 ap.add_argument("--seed", type=int, default=0)
+ap.add_argument("--hybrid-only", action="store_true", help="IVF-PQ cases only")
 args = ap.parse_args()
 nat.init(0)
 rng = np.random.default_rng(args.seed)
@@ -103,7 +104,7 @@ def hybrid_case():
     (a matrix form in the reference) is near-tied at the n_probe boundary is skipped."""
     global skipped
     m = int(rng.choice([4, 8, 16]))
-    dsub = int(rng.choice([2, 4, 8]))
+    dsub = int(rng.choice([2, 4, 8, 16]))
     d = m * dsub
     n = int(rng.choice([3000, 20000, 60000]))
     nlist = int(rng.choice([16, 64, 200]))
@@ -145,7 +146,7 @@ def hybrid_case():
 while time.time() - t0 < args.seconds:
     case += 1
     pick = rng.random()
-    fn = ivf_case if pick < 0.5 else (pq_case if pick < 0.8 else hybrid_case)
+    fn = hybrid_case if args.hybrid_only else (ivf_case if pick < 0.5 else (pq_case if pick < 0.8 else hybrid_case))
     try:
         label = fn()
     except Exception:       # noqa: BLE001

@@ -781,6 +781,43 @@ def test_ivfpq_vs_oracle_batch(nat):
     h.close()
 
 
+@pytest.mark.parametrize("m,dsub", [(4, 4), (4, 8), (4, 16), (8, 4), (8, 8), (8, 16), (16, 4), (16, 8)])
+def test_ivfpq_two_table_scan_every_shape(nat, m, dsub):
+    """The batch scan with the codebooks and two tables in LDS, for every (sub-spaces, sub-space width) it is compiled
+    for: 1200 (query, list) units over lists of a few thousand rows, some past the 4096 whose codes are read a unit
+    ahead, one list empty; distances and rows equal to the oracle's wherever the probed lists are not a near-tie."""
+    rng = np.random.RandomState(100 * m + dsub)
+    d = m * dsub
+    n, n_lists, n_probe, k = 30000, 9, 4, 10
+    x = rng.randn(n, d).astype(np.float32)
+    cent = x[rng.choice(n, n_lists, replace=False)].copy()
+    cent[8] = 50.0                                   # far from every row: an empty list
+    cent[0] *= 0.25                                  # near the origin: a long list
+    book = (0.5 * rng.randn(m, 256, dsub)).astype(np.float32)
+    h = nat.IvfPqLists(d, m, 256)
+    h.set_quantizers(cent, book)
+    lists, codes = h.encode(x)
+    order = np.argsort(lists, kind="stable")
+    offs = np.searchsorted(lists[order], np.arange(n_lists + 1))
+    sizes = np.diff(offs)
+    assert sizes.max() > 4096 and sizes.min() == 0
+    h.build(codes, order, offs)
+    members = [order[offs[l]:offs[l + 1]] for l in range(n_lists)]
+    q = rng.randn(300, d).astype(np.float32)
+    dist, rows = h.search(q, k, n_probe)
+    cs = np.sum(cent ** 2, axis=1)
+    checked = 0
+    for i in list(range(0, 300, 25)) + [299]:
+        ref_rows, ref_dist = R.hybrid_search(q[i], cent, book, codes, members, k, n_probe)
+        coarse = np.sort(np.sum(q[i] ** 2) + cs - 2 * (q[i] @ cent.T))
+        if coarse[n_probe] - coarse[n_probe - 1] > 1e-3:
+            np.testing.assert_array_equal(rows[i], ref_rows)
+            np.testing.assert_array_equal(dist[i], ref_dist)
+            checked += 1
+    assert checked >= 8
+    h.close()
+
+
 def test_sharded_merge_with_short_shards(nat):
     """Shards holding fewer rows than k: their lists end in empty entries (row -1), which the
     packed merge skips before it adds the shard's first global row."""

@@ -606,6 +606,258 @@ __global__ __launch_bounds__(IPQ_NT) void ivfpq_scan_lds_kernel(IvfPqScanParams 
     }
 }
 
+// The same again with two tables: while unit i is summed from one, the table of unit i + 1 is built in the other, so
+// the table arithmetic and the LDS gathers of the sums run side by side and a unit costs one barrier instead of three.
+// The second table takes the room of the residual query, which moves into registers: with 256 codewords and 1024
+// threads a wave builds entries of a few sub-spaces only, so lane x * DSUB + d holds element d of the residual in the
+// wave's x-th sub-space and the build reads it with a lane broadcast.  Both halves work on two values at a time with
+// packed fp32 instructions (the IEEE operations of the one-value code, two per instruction): the build on codewords
+// c and c + 128 of a sub-space, the sums on rows r and r + 64.  At m = 16, dsub = 8 the codebooks and the two tables
+// fill the 160 KiB of LDS to the byte.
+typedef float v2f __attribute__((ext_vector_type(2)));
+
+// np.sum((a - b)**2) over DSUB elements for one codeword (V = float) or two at once (V = v2f, packed fp32 instructions:
+// the same IEEE operations in the same order, two results per instruction); a(i) is element i of the codeword(s)
+template <int DSUB, typename V, typename A>
+__device__ __forceinline__ static V np_leaf_sqdiff_cols(A a, const float (&b)[DSUB]) {
+    if constexpr (DSUB < 8) {
+        V r = V(0.0f);
+#pragma unroll
+        for (int i = 0; i < DSUB; ++i) { const V d = a(i) - V(b[i]); r = r + d * d; }
+        return r;
+    } else {
+        V r[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) { const V d = a(j) - V(b[j]); r[j] = d * d; }
+#pragma unroll
+        for (int i = 8; i + 8 <= DSUB; i += 8) {
+#pragma unroll
+            for (int j = 0; j < 8; ++j) { const V d = a(i + j) - V(b[i + j]); r[j] = r[j] + d * d; }
+        }
+        V res = ((r[0] + r[1]) + (r[2] + r[3])) + ((r[4] + r[5]) + (r[6] + r[7]));
+#pragma unroll
+        for (int i = DSUB / 8 * 8; i < DSUB; ++i) { const V d = a(i) - V(b[i]); res = res + d * d; }
+        return res;
+    }
+}
+
+static constexpr int IPQ2_AHEAD = 4;       // rows per thread whose codes are read a unit ahead, with two tables
+
+template <int M, int DSUB>
+__global__ __launch_bounds__(IPQ_NT) void ivfpq_scan_lds2_kernel(IvfPqScanParams p, int n_units) {
+    constexpr int KS = 256;                      // codewords per sub-space (checked by the launcher)
+    constexpr int W = M / 4;                     // 32-bit words of a row's codes
+    constexpr int XS = M * KS / IPQ_NT;          // table entries per thread, one sub-space each
+    constexpr int XP = XS >= 2 ? XS / 2 : 1;    // ... as pairs of codewords c, c + 128 of one sub-space where there are two
+    constexpr int JW = XS >= 2 ? 7 : 8;          // a thread's sub-spaces are (tid >> JW) + (IPQ_NT >> JW) * x, x < XP
+    constexpr int RL = XP * DSUB;                // lanes of a wave that hold an element of the residual
+    static_assert(RL <= 64 && XS >= 1 && (XS == 1 || XS % 2 == 0), "the residual of a wave's sub-spaces must fit its lanes");
+    constexpr int PAIRS = IPQ2_AHEAD / 2;
+    static_assert(IPQ2_AHEAD % 2 == 0, "rows are summed two at a time");
+    extern __shared__ __align__(16) float sm[];
+    float* tables = sm;                          // [2][M][KS], at LDS address 0 (the kernel has no other LDS; the launcher
+                                                 // checks): a table read is a byte * 4 plus a constant offset
+    typedef __attribute__((address_space(3))) const float lds_float;
+    float* book = tables + 2 * M * KS;           // [M][DSUB][KS], codeword-fastest
+    const int tid = threadIdx.x, lane = tid & 63;
+    for (int i = tid; i < M * KS * DSUB; i += IPQ_NT) {
+        const int jc = i / DSUB, d = i - jc * DSUB;
+        const int j = jc / KS, c = jc - j * KS;
+        book[(j * DSUB + d) * KS + c] = p.book[i];
+    }
+    const int res_col = ((tid >> JW) + (IPQ_NT >> JW) * (lane / DSUB)) * DSUB + lane % DSUB;     // (for lane < RL)
+    // the rows a thread sums, two at a time so that the gathers of one hide behind the other's: pair x of wave w holds
+    // rows x * 2048 + w * 128 + lane and 64 further on (a wave is then either busy in both or, at a list's end, idle)
+    const int row0 = (tid >> 6) * 128 + lane;
+    // What a unit needs from memory is read with per-lane loads of one address, not scalar loads: scalar loads share
+    // their counter with the LDS reads and return in any order, so the first wait for a table entry would wait for
+    // every scalar load on its way as well, a trip to memory per unit that nothing hides.  The zero below is one the
+    // compiler has to take for a per-lane value.
+    int lane_zero;
+    asm volatile("v_mov_b32 %0, 0" : "=v"(lane_zero));
+    auto lane_load = [&](auto* at) {             // *at, at the same for every lane
+        typedef std::remove_reference_t<decltype(*at)> T;
+        return *reinterpret_cast<T*>(reinterpret_cast<const char*>(at) + (uint32_t)lane_zero);
+    };
+    auto uniform64 = [](int64_t v) {
+        const uint32_t lo = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)v);
+        const uint32_t hi = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)((uint64_t)v >> 32));
+        return (int64_t)(((uint64_t)hi << 32) | lo);
+    };
+    struct Named { int l, qi, pr; };                                     // a unit's list as read (per lane; -1: no such unit)
+    struct Placed { int64_t pos0, end, off; float q_el, c_el; int qi; bool ok; };   // its bounds and output as read (per lane)
+    struct Ready { int64_t pos0; int len; int64_t out; };               // ... and as the block uses them a unit later
+    // the unit three ahead of the one being summed, counted on without a division per unit
+    const int step = (int)gridDim.x, step_q = step / p.n_probe, step_r = step - step_q * p.n_probe;
+    int64_t ahead = blockIdx.x;
+    int ahead_qi = (int)(blockIdx.x / (uint32_t)p.n_probe), ahead_pr = (int)blockIdx.x - ahead_qi * p.n_probe;
+    auto name_next = [&]() {
+        Named a{-1, ahead_qi, ahead_pr};
+        if (ahead < n_units) a.l = lane_load(p.probes + ahead);
+        ahead += step;
+        ahead_qi += step_q;
+        ahead_pr += step_r;
+        if (ahead_pr >= p.n_probe) { ahead_pr -= p.n_probe; ++ahead_qi; }
+        return a;
+    };
+    auto place_of = [&](const Named& a) {
+        Placed b{0, 0, 0, 0.0f, 0.0f, a.qi, false};
+        const int l = __builtin_amdgcn_readfirstlane(a.l);
+        b.ok = l >= 0 && l < p.n_lists;
+        if (b.ok) {
+            b.pos0 = lane_load(p.list_beg + l);
+            b.end = lane_load(p.list_end + l);
+            b.off = lane_load(p.cand_off + ((int64_t)a.qi * (p.n_probe + 1) + a.pr));
+            if (lane < RL) {
+                b.q_el = *reinterpret_cast<const float*>(reinterpret_cast<const char*>(p.q + (int64_t)a.qi * p.ldq) + (uint32_t)(res_col * 4));
+                b.c_el = *reinterpret_cast<const float*>(reinterpret_cast<const char*>(p.cent + (int64_t)l * p.ldc) + (uint32_t)(res_col * 4));
+            }
+        }
+        return b;
+    };
+    auto ready_of = [&](const Placed& b) {
+        Ready r{0, 0, 0};
+        if (b.ok) {
+            r.pos0 = uniform64(b.pos0);
+            r.len = (int)(uniform64(b.end) - r.pos0);                 // (a device holds fewer than 2^31 rows)
+            r.out = (int64_t)b.qi * p.cand_stride + uniform64(b.off);
+        }
+        return r;
+    };
+    auto codes_of = [&](const Ready& b, uint32_t (&w)[IPQ2_AHEAD][W]) {
+        const uint8_t* rows = p.codes + b.pos0 * M;
+#pragma unroll
+        for (int x = 0; x < IPQ2_AHEAD; ++x) {
+            const int r = (x >> 1) * (2 * IPQ_NT) + row0 + (x & 1) * 64;
+            if (r < b.len) {
+                const uint32_t* code = reinterpret_cast<const uint32_t*>(rows + (uint32_t)(r * M));
+#pragma unroll
+                for (int i = 0; i < W; ++i) w[x][i] = code[i];
+            } else {
+#pragma unroll
+                for (int i = 0; i < W; ++i) w[x][i] = 0u;             // (summed all the same beside a row that is there)
+            }
+        }
+    };
+    auto table_of = [&](const Placed& b, float* T) {
+        const int res = __float_as_int(b.q_el - b.c_el);
+#pragma unroll
+        for (int x = 0; x < XP; ++x) {
+            float el[DSUB];
+#pragma unroll
+            for (int d = 0; d < DSUB; ++d) el[d] = __int_as_float(__builtin_amdgcn_readlane(res, x * DSUB + d));
+            const int j = (tid >> JW) + (IPQ_NT >> JW) * x;
+            if constexpr (XS >= 2) {
+                const int c = tid & 127;
+                const float* a = book + j * DSUB * KS + c;
+                const v2f t = np_leaf_sqdiff_cols<DSUB, v2f>([&](int i) { return v2f{a[i * KS], a[i * KS + 128]}; }, el);
+                T[j * KS + c] = t.x;
+                T[j * KS + c + 128] = t.y;
+            } else {
+                const int c = tid & 255;
+                const float* a = book + j * DSUB * KS + c;
+                T[j * KS + c] = np_leaf_sqdiff_cols<DSUB, float>([&](int i) { return a[i * KS]; }, el);
+            }
+        }
+    };
+    auto byte_of = [](const uint32_t (&w)[W], int j) { return (w[j >> 2] >> (8 * (j & 3))) & 0xffu; };
+    const uint32_t two = 2u;
+    auto quad_of = [&](uint32_t w, int k) {      // 4 * byte k of w: a table offset in one instruction
+        uint32_t r;
+        if (k == 0)
+            asm("v_lshlrev_b32_sdwa %0, %1, %2 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:BYTE_0" : "=v"(r) : "v"(two), "v"(w));
+        else if (k == 1)
+            asm("v_lshlrev_b32_sdwa %0, %1, %2 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:BYTE_1" : "=v"(r) : "v"(two), "v"(w));
+        else if (k == 2)
+            asm("v_lshlrev_b32_sdwa %0, %1, %2 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:BYTE_2" : "=v"(r) : "v"(two), "v"(w));
+        else
+            asm("v_lshlrev_b32_sdwa %0, %1, %2 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:BYTE_3" : "=v"(r) : "v"(two), "v"(w));
+        return r;
+    };
+    int64_t unit = blockIdx.x;
+    const Named n0 = name_next(), n1 = name_next();
+    Named named = name_next();
+    const Placed first = place_of(n0);
+    Placed placed = place_of(n1);
+    Ready cur = ready_of(first);
+    uint32_t w_a[IPQ2_AHEAD][W] = {}, w_b[IPQ2_AHEAD][W] = {};
+    codes_of(cur, w_a);
+    __syncthreads();                             // the codebooks are in place
+    if (cur.len > 0) table_of(first, tables);
+    __syncthreads();
+    // one unit, summed from table SIDE while the next one's table is built in the other
+    auto unit_of = [&](auto side_tag, const uint32_t (&w_cur)[IPQ2_AHEAD][W], uint32_t (&w_next)[IPQ2_AHEAD][W]) {
+        constexpr int SIDE = decltype(side_tag)::value;
+        const float* T = tables + SIDE * (M * KS);
+        const Ready next = ready_of(placed);
+        auto build = [&]() {
+            if (next.len > 0) table_of(placed, tables + (SIDE ^ 1) * (M * KS));   // (the same for every thread of the block)
+        };
+        auto sum_rows = [&]() {
+        if (cur.len > 0) {
+            float* out = p.cand + cur.out;
+#pragma unroll
+            for (int x = 0; x < PAIRS; ++x) {
+                const int r = x * (2 * IPQ_NT) + row0;
+                if (r < cur.len) {
+                    // two rows side by side: one packed addition per sub-space
+                    uint32_t at[2][M];
+#pragma unroll
+                    for (int j = 0; j < M; ++j) {
+                        at[0][j] = quad_of(w_cur[2 * x][j >> 2], j & 3);
+                        at[1][j] = quad_of(w_cur[2 * x + 1][j >> 2], j & 3);
+                    }
+                    v2f t[M];
+#pragma unroll
+                    for (int j = 0; j < M; ++j) {
+                        t[j].x = *(lds_float*)(uintptr_t)(at[0][j] + (uint32_t)((SIDE * M + j) * KS * sizeof(float)));
+                        t[j].y = *(lds_float*)(uintptr_t)(at[1][j] + (uint32_t)((SIDE * M + j) * KS * sizeof(float)));
+                    }
+                    v2f sum = t[0];
+#pragma unroll
+                    for (int j = 1; j < M; ++j) sum = sum + t[j];
+                    const float a = sum.x, b = sum.y;
+                    const bool both = r + 64 < cur.len;
+                    const float da = sqrtf(a), db = sqrtf(b);
+                    // (one value twice rather than a branch round the second row)
+                    *reinterpret_cast<float*>(reinterpret_cast<char*>(out) + (uint32_t)(r * 4)) = da;
+                    *reinterpret_cast<float*>(reinterpret_cast<char*>(out) + (uint32_t)((both ? r + 64 : r) * 4)) = both ? db : da;
+                }
+            }
+            for (int r = tid + IPQ2_AHEAD * IPQ_NT; r < cur.len; r += IPQ_NT) {
+                const uint32_t* code = reinterpret_cast<const uint32_t*>(p.codes + (cur.pos0 + r) * M);
+                uint32_t w[W];
+#pragma unroll
+                for (int i = 0; i < W; ++i) w[i] = code[i];
+                float a = T[byte_of(w, 0)];
+#pragma unroll
+                for (int j = 1; j < M; ++j) a = a + T[j * KS + byte_of(w, j)];
+                out[r] = sqrtf(a);
+            }
+        }
+        };
+        build();
+        __builtin_amdgcn_sched_barrier(0);
+        // what the coming units need, on its way while this one is summed (asked for here, not at the top, where
+        // all sixteen waves would ask at once, straight after the barrier)
+        codes_of(next, w_next);
+        const Placed placed_next = place_of(named);
+        const Named named_next = name_next();
+        __builtin_amdgcn_sched_barrier(0);
+        sum_rows();
+        __syncthreads();                         // the next table is whole, this one is no longer read
+        cur = next;
+        placed = placed_next;
+        named = named_next;
+        unit += step;
+    };
+    while (unit < n_units) {                     // (the two sets of code registers change places, like the two tables)
+        unit_of(std::integral_constant<int, 0>{}, w_a, w_b);
+        if (unit >= n_units) break;
+        unit_of(std::integral_constant<int, 1>{}, w_b, w_a);
+    }
+}
+
 int launch_ivfpq_scan(const float* q, int ldq, int dim, int nq, const float* cent, int ldc, const float* book, int m, int ksub,
                       int dsub, const SumPlan& plan, const uint8_t* codes, const int64_t* list_beg, const int64_t* list_end, int n_lists,
                       const int* probes, int n_probe, const int64_t* cand_off, int64_t cand_stride, float* cand, hipStream_t s) {
@@ -617,6 +869,31 @@ int launch_ivfpq_scan(const float* q, int ldq, int dim, int nq, const float* cen
     const size_t lds_book = lds + (size_t)m * ksub * dsub * sizeof(float);
     static const bool no_lds_book = getenv("VDB_IVFPQ_NO_LDS_BOOK") != nullptr;
     const int64_t n_units = (int64_t)nq * n_probe;
+    static const bool no_two_tables = getenv("VDB_IVFPQ_ONE_TABLE") != nullptr;
+    const size_t lds_two = ((size_t)m * ksub * dsub + 2 * (size_t)m * ksub) * sizeof(float);
+    const bool busy = n_units >= 4 * (int64_t)ctx().num_cus && n_units < (int64_t)0x7fffffff;
+    if (!no_lds_book && !no_two_tables && busy && ksub == 256 && lds_two <= 160 * 1024 && (m == 4 || m == 8 || m == 16) &&
+        (dsub == 4 || dsub == 8 || dsub == 16) && m * dsub == dim) {
+        const dim3 grid((unsigned)ctx().num_cus);
+        KernelTimer timer(s);
+        bool launched = true;
+#define VDB_LAUNCH_IPQ2(MM, DD)                                                                               \
+    if (m == MM && dsub == DD) {                                                                              \
+        hipFuncAttributes fa;                                                                                 \
+        VDB_HIP(hipFuncGetAttributes(&fa, reinterpret_cast<const void*>(ivfpq_scan_lds2_kernel<MM, DD>)));    \
+        VDB_REQUIRE(fa.sharedSizeBytes == 0, "the tables must start the kernel's LDS");                       \
+        VDB_TRY(raise_dynamic_lds(reinterpret_cast<const void*>(ivfpq_scan_lds2_kernel<MM, DD>), lds_two));   \
+        hipLaunchKernelGGL((ivfpq_scan_lds2_kernel<MM, DD>), grid, dim3(IPQ_NT), lds_two, s, p, (int)n_units); \
+    } else
+        VDB_LAUNCH_IPQ2(4, 4) VDB_LAUNCH_IPQ2(4, 8) VDB_LAUNCH_IPQ2(4, 16)
+        VDB_LAUNCH_IPQ2(8, 4) VDB_LAUNCH_IPQ2(8, 8) VDB_LAUNCH_IPQ2(8, 16)
+        VDB_LAUNCH_IPQ2(16, 4) VDB_LAUNCH_IPQ2(16, 8) launched = false;
+#undef VDB_LAUNCH_IPQ2
+        if (launched) {
+            VDB_HIP(hipGetLastError());
+            return VDB_OK;
+        }
+    }
     if (!no_lds_book && lds_book <= 160 * 1024 && (m == 4 || m == 8 || m == 16 || m == 32) && dim <= IPQ_NT && dsub <= 128 && n_units >= 4 * (int64_t)ctx().num_cus &&
         n_units < (int64_t)0x7fffffff) {
         const dim3 grid((unsigned)ctx().num_cus);
