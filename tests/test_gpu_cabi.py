@@ -766,7 +766,7 @@ def test_ivfpq_vs_oracle_batch(nat):
             np.testing.assert_array_equal(rows[i], ref_rows)
             np.testing.assert_array_equal(dist[i], ref_dist)
     # 200 queries: the lists ranked from the whole distance matrix, 1200 (query, list) units scanned with the codebooks
-    # in LDS; 20 queries: the search over the centroids, one block per unit
+    # in LDS and the candidates ranked by one block per query; 20 queries: one block per unit, then the slot selection
     q2 = rng.randn(200, d).astype(np.float32)
     dist2, rows2 = h.search(q2, 10, 6)
     dist3, rows3 = h.search(q2[:20], 10, 6)

@@ -3242,9 +3242,9 @@ static int ivfpq_search_impl(vdb_ivfpq* h, const float* d_q, int nq, int k, int 
     VDB_TRY(ws.probe_d.reserve((size_t)nq * n_probe * sizeof(float)));
     const bool few_small = nq <= 8 && h->n_lists <= 1024;      // as in ivf_probe_impl
     static const bool no_rank_rows = getenv("VDB_NO_RANK_ROWS") != nullptr;
-    if (!no_rank_rows && nq >= 32 && n_probe <= 64 && (int64_t)nq * h->n_lists <= ((int64_t)1 << 28)) {
-        // a batch: the whole distance matrix from the matrix cores, then one block per query that ranks its row
-        // (the search's fused top-32 lists cost 0.32 ms per 1024 x 4096, this 0.04)
+    if (!no_rank_rows && n_probe <= 64 && (int64_t)nq * h->n_lists <= ((int64_t)1 << 28)) {
+        // the whole distance matrix, then one block per query that ranks its row (the search's fused top-32 lists
+        // cost 0.32 ms per 1024 x 4096, this 0.04; for one query over 4096 lists 52 us against 18)
         VDB_TRY(ws.dist.reserve((size_t)nq * h->n_lists * sizeof(float)));
         VDB_TRY(flat_distances_impl(h->centroids, VDB_EUCLIDEAN_SQ, d_q, nq, ws.dist.as<float>(), s));
         VDB_TRY(launch_rank_rows(ws.dist.as<float>(), nq, h->n_lists, n_probe, ws.probe_d.as<float>(), ws.probes.as<int>(), s));
@@ -3258,13 +3258,9 @@ static int ivfpq_search_impl(vdb_ivfpq* h, const float* d_q, int nq, int k, int 
         VDB_TRY(launch_row_sort_topk(ws.dist.as<float>(), nq, h->n_lists, n_probe, ws.probe_d.as<float>(), ws.probes.as<int>(), s));
     }
 
-    StreamPlanBufs b{};
-    VDB_TRY(reserve_stream_plan(ws, h->n_lists, (int64_t)q_block * n_probe, 1, &b));   // only the slot offsets of the plan are used
     VDB_TRY(ws.cand.reserve((size_t)q_block * cand_stride * sizeof(float)));
     VDB_TRY(ws.cand_off.reserve((size_t)q_block * (n_probe + 1) * sizeof(int64_t)));
     VDB_TRY(ws.tile_off.reserve((size_t)q_block * (n_probe + 1) * sizeof(int)));
-    VDB_TRY(ws.list_cnt.reserve((size_t)h->n_lists * sizeof(int)));
-    VDB_TRY(ws.cursor.reserve((size_t)h->n_lists * sizeof(int)));
     VDB_TRY(ws.slots.reserve((size_t)nq * k * sizeof(int)));
     if (multi) {
         VDB_TRY(ws.lb_d.reserve((size_t)q_block * sizeof(float)));
@@ -3274,14 +3270,14 @@ static int ivfpq_search_impl(vdb_ivfpq* h, const float* d_q, int nq, int k, int 
     for (int q0 = 0; q0 < nq; q0 += q_block) {
         const int nb = std::min(q_block, nq - q0);
         const int* probes = ws.probes.as<int>() + (int64_t)q0 * n_probe;
-        VDB_TRY(launch_ivf_plan(probes, nb, n_probe, h->lay.d_beg(), h->lay.d_end(), h->n_lists, 8, cand_stride,
-                                ws.list_cnt.as<int>(), ws.cursor.as<int>(), ws.cand_off.as<int64_t>(), ws.tile_off.as<int>(), b, s));
+        VDB_TRY(launch_ivf_slot_offsets(probes, nb, n_probe, h->lay.d_beg(), h->lay.d_end(), h->n_lists,
+                                        ws.cand_off.as<int64_t>(), ws.tile_off.as<int>(), s));
         VDB_TRY(launch_ivfpq_scan(d_q + (int64_t)q0 * h->dim, h->dim, h->dim, nb, h->centroids->r.data, h->centroids->r.ld,
                                   h->book.as<float>(), h->m, h->ksub, h->dsub, h->plan, h->codes.as<uint8_t>(),
                                   h->lay.d_beg(), h->lay.d_end(), h->n_lists, probes, n_probe, ws.cand_off.as<int64_t>(),
                                   cand_stride, ws.cand.as<float>(), s));
         static const bool no_cand_rank = getenv("VDB_NO_CAND_RANK") != nullptr;
-        if (!no_cand_rank && !multi && !d_mask && nb >= 32) {
+        if (!no_cand_rank && !multi && !d_mask && nb >= 32) {      // (one block per query: slower than the slot selection for a few)
             // a batch without a filter: one block per query reads its run of distances once and ranks the few in reach
             VDB_TRY(launch_cand_rank(ws.cand.as<float>(), cand_stride, ws.cand_off.as<int64_t>(), n_probe, nb, kmax, k,
                                      d_out_d + (int64_t)q0 * k, ws.slots.as<int>() + (int64_t)q0 * k, s));

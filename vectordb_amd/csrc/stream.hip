@@ -1057,7 +1057,7 @@ __global__ __launch_bounds__(256) void ivf_plan_count_kernel(const int* __restri
             cand_off[(int64_t)q * (n_probe + 1) + pr] = run + sum_len - len;
             tile_off[(int64_t)q * (n_probe + 1) + pr] = tiles + sum_t - t;
         }
-        if (ok) atomicAdd(&list_cnt[l], 1);
+        if (ok && list_cnt) atomicAdd(&list_cnt[l], 1);
         run += __shfl(sum_len, 63);
         tiles += __shfl(sum_t, 63);
     }
@@ -1138,6 +1138,17 @@ int launch_ivf_plan(const int* probes, int nq, int n_probe, const int64_t* list_
                        n_lists, cand_stride, cand_off, cursor, b.sq_qid, b.sq_out);
     VDB_HIP(hipGetLastError());
     return launch_build_items(b, list_beg, list_end, n_lists, group, s);
+}
+
+// only the offsets of every (query, probe) in the query's run of candidate slots and tiles (what a scan that walks
+// the units itself needs of the plan)
+int launch_ivf_slot_offsets(const int* probes, int nq, int n_probe, const int64_t* list_beg, const int64_t* list_end, int n_lists,
+                            int64_t* cand_off, int* tile_off, hipStream_t s) {
+    if (nq <= 0) return VDB_OK;
+    hipLaunchKernelGGL(ivf_plan_count_kernel, dim3((nq + 3) / 4), dim3(256), 0, s, probes, nq, n_probe, n_lists,
+                       list_beg, list_end, nullptr, cand_off, tile_off);
+    VDB_HIP(hipGetLastError());
+    return VDB_OK;
 }
 
 // --------------------------------------------------------------------------

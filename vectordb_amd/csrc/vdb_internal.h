@@ -281,6 +281,8 @@ int stream_batch_group(int dim, int ld, const SumPlan& plan, int op, int nq, int
 int launch_row_norms(const float* data, int ld, int dim, int64_t n, const SumPlan& plan, const StreamPlanBufs& b,
                      float* sq, float* nrm, hipStream_t s);
 int launch_flat_plan(int64_t n, int nq, int group, int64_t out_stride, const StreamPlanBufs& b, hipStream_t s);
+int launch_ivf_slot_offsets(const int* probes, int nq, int n_probe, const int64_t* list_beg, const int64_t* list_end, int n_lists,
+                            int64_t* cand_off, int* tile_off, hipStream_t s);
 int launch_ivf_plan(const int* probes, int nq, int n_probe, const int64_t* list_beg, const int64_t* list_end, int n_lists, int group,
                     int64_t cand_stride, int* list_cnt, int* cursor, int64_t* cand_off, int* tile_off,
                     const StreamPlanBufs& b, hipStream_t s);
