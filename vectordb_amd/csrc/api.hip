@@ -3277,10 +3277,21 @@ static int ivfpq_search_impl(vdb_ivfpq* h, const float* d_q, int nq, int k, int 
                                   h->lay.d_beg(), h->lay.d_end(), h->n_lists, probes, n_probe, ws.cand_off.as<int64_t>(),
                                   cand_stride, ws.cand.as<float>(), s));
         static const bool no_cand_rank = getenv("VDB_NO_CAND_RANK") != nullptr;
-        if (!no_cand_rank && !multi && !d_mask && nb >= 32) {      // (one block per query: slower than the slot selection for a few)
-            // a batch without a filter: one block per query reads its run of distances once and ranks the few in reach
+        if (!no_cand_rank && !multi && !d_mask) {
+            // no filter: one block per query reads its run of distances once and ranks the few in reach; a few queries
+            // share their runs out over several blocks each, whose lists are merged
+            const int parts = nb >= 32 ? 1 : std::max(1, std::min(16, 256 / nb));
+            if (parts > 1) {
+                VDB_TRY(ws.part_d.reserve((size_t)nb * parts * kmax * sizeof(float)));
+                VDB_TRY(ws.part_i.reserve((size_t)nb * parts * kmax * sizeof(int)));
+            }
             VDB_TRY(launch_cand_rank(ws.cand.as<float>(), cand_stride, ws.cand_off.as<int64_t>(), n_probe, nb, kmax, k,
-                                     d_out_d + (int64_t)q0 * k, ws.slots.as<int>() + (int64_t)q0 * k, s));
+                                     d_out_d + (int64_t)q0 * k, ws.slots.as<int>() + (int64_t)q0 * k, s, parts,
+                                     ws.part_d.as<float>(), ws.part_i.as<int>()));
+            if (parts > 1) {
+                SelectOut o{d_out_d + (int64_t)q0 * k, nullptr, ws.slots.as<int>() + (int64_t)q0 * k, k, 0, nullptr, nullptr};
+                VDB_TRY(launch_select(ws.part_d.as<float>(), ws.part_i.as<int>(), nb, parts, kmax, 1 << 30, nullptr, 0, o, s, ws.mid));
+            }
             VDB_TRY(launch_ivf_rows(ws.slots.as<int>() + (int64_t)q0 * k, nb, kmax, k, 0, probes, n_probe, h->n_lists,
                                     ws.cand_off.as<int64_t>(), h->lay.d_beg(), h->row_ids.as<int>(),
                                     d_out_i + (int64_t)q0 * k, nullptr, s));

@@ -898,22 +898,31 @@ int launch_ivf_mfma_probe(const IvfProbeJob& j, hipStream_t s) {
 // The k best of every query's run of candidate distances (one float per candidate slot, as the IVF-PQ scan leaves
 // them), k <= 64, under (distance, slot).  One block of sixteen waves per query streams the run once, four 16-byte
 // loads in flight per lane; every wave keeps its k best in its lanes (a candidate is offered only if it beats the wave's k-th:
-// after the first few hundred nearly none does), and the sixteen lists are ranked together by counting.
+// after the first few hundred nearly none does), and the sixteen lists are ranked together by counting.  A few queries
+// cannot fill the device with a block each: then gridDim.y blocks share a query's run, every one leaves the k best of
+// its part as a list of (distance, slot) for the list merge.
 static constexpr int CR_NT = 1024;
 
 __global__ __launch_bounds__(CR_NT) void cand_rank_kernel(const float* __restrict__ cand, int64_t cand_stride,
                                                           const int64_t* __restrict__ cand_off, int n_probe, int k, int k_out,
-                                                          float* __restrict__ out_d, int* __restrict__ out_slots) {
+                                                          float* __restrict__ out_d, int* __restrict__ out_slots,
+                                                          float* __restrict__ part_d, int* __restrict__ part_i) {
     __shared__ __align__(16) unsigned long long sh_pair[CR_NT];          // sixteen lists of k <= 64
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int q = blockIdx.x;
-    const int total = (int)min(cand_off[(int64_t)q * (n_probe + 1) + n_probe], cand_stride);
+    const int whole = (int)min(cand_off[(int64_t)q * (n_probe + 1) + n_probe], cand_stride);
+    // this block's part of the run: a multiple of the 4096 floats the block reads at a time
+    const int parts = gridDim.y;
+    const int chunk = parts > 1 ? ((whole + parts - 1) / parts + CR_NT * 4 - 1) / (CR_NT * 4) * (CR_NT * 4) : whole;
+    const int first = min((int)blockIdx.y * chunk, whole);
+    const int total = min(first + chunk, whole);
     const float* run = cand + (int64_t)q * cand_stride;
     WaveTopK top;
     top.init(k);
+    bool seeded = false;
     // sixteen bytes per lane and load (a query's run starts on a multiple of 64 floats), four loads in flight
     constexpr int AH = 4;
-    for (int i0 = 0; i0 < total; i0 += CR_NT * 4 * AH) {
+    for (int i0 = first; i0 < total; i0 += CR_NT * 4 * AH) {
         float4 v[AH];
 #pragma unroll
         for (int a = 0; a < AH; ++a) {
@@ -931,10 +940,15 @@ __global__ __launch_bounds__(CR_NT) void cand_rank_kernel(const float* __restric
         for (int a = 0; a < AH; ++a) {
             const int i = i0 + (a * CR_NT + tid) * 4;
             if (i0 + (a * CR_NT + wave * 64) * 4 < total) {      // (the same for the whole wave)
-                top.template offer<false, false>(i < total && v[a].x == v[a].x, v[a].x, i, lane);
-                top.template offer<false, false>(i + 1 < total && v[a].y == v[a].y, v[a].y, i + 1, lane);
-                top.template offer<false, false>(i + 2 < total && v[a].z == v[a].z, v[a].z, i + 2, lane);
-                top.template offer<false, false>(i + 3 < total && v[a].w == v[a].w, v[a].w, i + 3, lane);
+                if (a == 0 && !seeded) {                         // (the list is empty: sixty-four at once)
+                    top.seed(i < total && v[a].x == v[a].x, v[a].x, i, lane);
+                    seeded = true;
+                } else {
+                    top.template offer<false, true>(i < total && v[a].x == v[a].x, v[a].x, i, lane);
+                }
+                top.template offer<false, true>(i + 1 < total && v[a].y == v[a].y, v[a].y, i + 1, lane);
+                top.template offer<false, true>(i + 2 < total && v[a].z == v[a].z, v[a].z, i + 2, lane);
+                top.template offer<false, true>(i + 3 < total && v[a].w == v[a].w, v[a].w, i + 3, lane);
             }
         }
     }
@@ -948,17 +962,25 @@ __global__ __launch_bounds__(CR_NT) void cand_rank_kernel(const float* __restric
         if (place < k) {
             const int i = (int)(uint32_t)mine;
             const bool empty = i < 0;
-            out_d[(int64_t)q * k_out + place] = empty ? INFINITY : run[i];
-            out_slots[(int64_t)q * k_out + place] = empty ? -1 : i;
+            if (parts > 1) {
+                const int64_t at = ((int64_t)q * parts + blockIdx.y) * k + place;
+                part_d[at] = empty ? INFINITY : run[i];
+                part_i[at] = empty ? EMPTY_IDX : i;
+            } else {
+                out_d[(int64_t)q * k_out + place] = empty ? INFINITY : run[i];
+                out_slots[(int64_t)q * k_out + place] = empty ? -1 : i;
+            }
         }
     }
 }
 
 int launch_cand_rank(const float* cand, int64_t cand_stride, const int64_t* cand_off, int n_probe, int nq, int k, int k_out,
-                     float* out_d, int* out_slots, hipStream_t s) {
+                     float* out_d, int* out_slots, hipStream_t s, int parts, float* part_d, int* part_i) {
     if (nq <= 0) return VDB_OK;
     VDB_REQUIRE(k >= 1 && k <= 64 && cand_stride < (int64_t)0x7fffffff, "candidate ranking: k in 1..64, fewer than 2^31 candidates");
-    hipLaunchKernelGGL(cand_rank_kernel, dim3(nq), dim3(CR_NT), 0, s, cand, cand_stride, cand_off, n_probe, k, k_out, out_d, out_slots);
+    VDB_REQUIRE(parts >= 1 && (parts == 1 || (part_d && part_i)), "candidate ranking in parts needs room for the lists");
+    hipLaunchKernelGGL(cand_rank_kernel, dim3(nq, parts), dim3(CR_NT), 0, s, cand, cand_stride, cand_off, n_probe, k, k_out, out_d, out_slots,
+                       part_d, part_i);
     VDB_HIP(hipGetLastError());
     return VDB_OK;
 }

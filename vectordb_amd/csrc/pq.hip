@@ -468,7 +468,9 @@ struct IvfPqScanParams {
     float* cand;
 };
 
-__global__ __launch_bounds__(256) void ivfpq_scan_kernel(IvfPqScanParams p) {
+static constexpr int IPQ1_NT = 1024;       // threads per (query, list) unit
+
+__global__ __launch_bounds__(IPQ1_NT) void ivfpq_scan_kernel(IvfPqScanParams p) {
     extern __shared__ __align__(16) float sm[];
     float* T = sm;                               // [m][ksub]
     float* qres = T + p.m * p.ksub;              // [dim]
@@ -480,14 +482,33 @@ __global__ __launch_bounds__(256) void ivfpq_scan_kernel(IvfPqScanParams p) {
     const int64_t pos0 = p.list_beg[l];
     const int64_t len = p.list_end[l] - pos0;
     if (len == 0) return;
-    for (int i = tid; i < p.dim; i += 256) qres[i] = p.q[(int64_t)qi * p.ldq + i] - p.cent[(int64_t)l * p.ldc + i];
+    for (int i = tid; i < p.dim; i += IPQ1_NT) qres[i] = p.q[(int64_t)qi * p.ldq + i] - p.cent[(int64_t)l * p.ldc + i];
     __syncthreads();
-    for (int c = tid; c < p.ksub; c += 256)
-        for (int j = 0; j < p.m; ++j)
-            T[j * p.ksub + c] = np_sum_sqdiff(p.book + ((int64_t)j * p.ksub + c) * p.dsub, qres + j * p.dsub, p.dsub, p.plan);
+    for (int e = tid; e < p.m * p.ksub; e += IPQ1_NT) {
+        const int j = e / p.ksub;
+        T[e] = np_sum_sqdiff(p.book + (int64_t)e * p.dsub, qres + j * p.dsub, p.dsub, p.plan);
+    }
     __syncthreads();
     float* out = p.cand + (int64_t)qi * p.cand_stride + p.cand_off[(int64_t)qi * (p.n_probe + 1) + pr];
-    for (int64_t r = tid; r < len; r += 256) {
+    if ((p.m & 3) == 0) {                        // four codes per load
+        for (int64_t r = tid; r < len; r += IPQ1_NT) {
+            const uint32_t* code = reinterpret_cast<const uint32_t*>(p.codes + (pos0 + r) * p.m);
+            float acc = 0.0f;
+            for (int j = 0; j < p.m; j += 4) {
+                const uint32_t w = code[j >> 2];
+                const float* Tj = T + j * p.ksub;
+                const float t0 = Tj[w & 0xffu], t1 = Tj[p.ksub + ((w >> 8) & 0xffu)];
+                const float t2 = Tj[2 * p.ksub + ((w >> 16) & 0xffu)], t3 = Tj[3 * p.ksub + (w >> 24)];
+                acc = j == 0 ? t0 : acc + t0;
+                acc = acc + t1;
+                acc = acc + t2;
+                acc = acc + t3;
+            }
+            out[r] = sqrtf(acc);
+        }
+        return;
+    }
+    for (int64_t r = tid; r < len; r += IPQ1_NT) {
         const uint8_t* code = p.codes + (pos0 + r) * p.m;
         float acc = T[code[0]];
         for (int j = 1; j < p.m; ++j) acc = acc + T[j * p.ksub + code[j]];
@@ -916,7 +937,7 @@ int launch_ivfpq_scan(const float* q, int ldq, int dim, int nq, const float* cen
     VDB_TRY(raise_dynamic_lds(reinterpret_cast<const void*>(ivfpq_scan_kernel),
                                 lds));
     KernelTimer timer(s);
-    hipLaunchKernelGGL(ivfpq_scan_kernel, dim3((unsigned)((int64_t)nq * n_probe)), dim3(256), lds, s, p);
+    hipLaunchKernelGGL(ivfpq_scan_kernel, dim3((unsigned)((int64_t)nq * n_probe)), dim3(IPQ1_NT), lds, s, p);
     VDB_HIP(hipGetLastError());
     return VDB_OK;
 }

@@ -166,6 +166,16 @@ struct WaveTopK {
 
     __device__ __forceinline__ void init(int k_) { e = INFINITY; eid = EMPTY_IDX; thr = INFINITY; thr_id = EMPTY_IDX; k = k_; }
 
+    // the first candidates of an empty list, one per lane (want = this lane has one): sorted across the lanes in
+    // registers instead of inserted one by one
+    __device__ __forceinline__ void seed(bool want, float d, int id, int lane) {
+        e = want ? d : INFINITY;
+        eid = want ? id : EMPTY_IDX;
+        bitonic_sort_upto<64>(e, eid, lane);
+        thr = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(e), k - 1));
+        thr_id = __builtin_amdgcn_readlane(eid, k - 1);
+    }
+
     // insert one pair; v / vid must be wave-uniform.  Pairs equal to a stored one go behind it.
     template <bool INL = false>
     __device__ __forceinline__ void insert(float v, int vid, int lane) {
