@@ -3280,7 +3280,7 @@ static int ivfpq_search_impl(vdb_ivfpq* h, const float* d_q, int nq, int k, int 
         if (!no_cand_rank && !multi && !d_mask) {
             // no filter: one block per query reads its run of distances once and ranks the few in reach; a few queries
             // share their runs out over several blocks each, whose lists are merged
-            const int parts = nb >= 32 ? 1 : std::max(1, std::min(16, 256 / nb));
+            const int parts = nb >= 32 ? 1 : std::max(2, std::min(64, 1024 / nb));     // (blocks of four waves)
             if (parts > 1) {
                 VDB_TRY(ws.part_d.reserve((size_t)nb * parts * kmax * sizeof(float)));
                 VDB_TRY(ws.part_i.reserve((size_t)nb * parts * kmax * sizeof(int)));
