@@ -896,26 +896,27 @@ int launch_ivf_mfma_probe(const IvfProbeJob& j, hipStream_t s) {
 
 // --------------------------------------------------------------------------
 // The k best of every query's run of candidate distances (one float per candidate slot, as the IVF-PQ scan leaves
-// them), k <= 64, under (distance, slot).  One block of sixteen waves per query streams the run once, four 16-byte
+// them), k <= 64, under (distance, slot).  One block of four waves per query streams the run once, four 16-byte
 // loads in flight per lane; every wave keeps its k best in its lanes (a candidate is offered only if it beats the wave's k-th:
-// after the first few hundred nearly none does), and the sixteen lists are ranked together by counting.  A few queries
+// after the first few hundred nearly none does), and the four lists are ranked together by counting.  A few queries
 // cannot fill the device with a block each: then gridDim.y blocks share a query's run, every one leaves the k best of
 // its part as a list of (distance, slot) for the list merge.
-static constexpr int CR_NT = 1024;         // threads of a block that ranks a whole run
-static constexpr int CR_PART_NT = 256;     // ... of one that ranks a part: a wave per SIMD, the insertions are serial chains
+// Four waves per block: a wave's insertions are serial chains of dependent instructions, every list costs its own
+// k log(n / k) of them, and a SIMD shared by four such waves runs each at a quarter of the speed (1024 x 78 000
+// candidates, k = 10: 169 us with sixteen waves per query, 125 with four; one query in 64 parts: 31 -> 20 us).
+static constexpr int CR_NT = 256;
 
-template <int NT>
-__global__ __launch_bounds__(NT) void cand_rank_kernel(const float* __restrict__ cand, int64_t cand_stride,
+__global__ __launch_bounds__(CR_NT) void cand_rank_kernel(const float* __restrict__ cand, int64_t cand_stride,
                                                           const int64_t* __restrict__ cand_off, int n_probe, int k, int k_out,
                                                           float* __restrict__ out_d, int* __restrict__ out_slots,
                                                           float* __restrict__ part_d, int* __restrict__ part_i) {
-    __shared__ __align__(16) unsigned long long sh_pair[NT];          // sixteen lists of k <= 64
+    __shared__ __align__(16) unsigned long long sh_pair[CR_NT];          // four lists of k <= 64
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int q = blockIdx.x;
     const int whole = (int)min(cand_off[(int64_t)q * (n_probe + 1) + n_probe], cand_stride);
-    // this block's part of the run: a multiple of the 4096 floats the block reads at a time
+    // this block's part of the run: a multiple of the 1024 floats the block reads at a time
     const int parts = gridDim.y;
-    const int chunk = parts > 1 ? ((whole + parts - 1) / parts + NT * 4 - 1) / (NT * 4) * (NT * 4) : whole;
+    const int chunk = parts > 1 ? ((whole + parts - 1) / parts + CR_NT * 4 - 1) / (CR_NT * 4) * (CR_NT * 4) : whole;
     const int first = min((int)blockIdx.y * chunk, whole);
     const int total = min(first + chunk, whole);
     const float* run = cand + (int64_t)q * cand_stride;
@@ -924,11 +925,11 @@ __global__ __launch_bounds__(NT) void cand_rank_kernel(const float* __restrict__
     bool seeded = false;
     // sixteen bytes per lane and load (a query's run starts on a multiple of 64 floats), four loads in flight
     constexpr int AH = 4;
-    for (int i0 = first; i0 < total; i0 += NT * 4 * AH) {
+    for (int i0 = first; i0 < total; i0 += CR_NT * 4 * AH) {
         float4 v[AH];
 #pragma unroll
         for (int a = 0; a < AH; ++a) {
-            const int i = i0 + (a * NT + tid) * 4;
+            const int i = i0 + (a * CR_NT + tid) * 4;
             if (i + 4 <= total) {
                 v[a] = *reinterpret_cast<const float4*>(run + i);
             } else {
@@ -940,8 +941,8 @@ __global__ __launch_bounds__(NT) void cand_rank_kernel(const float* __restrict__
         }
 #pragma unroll
         for (int a = 0; a < AH; ++a) {
-            const int i = i0 + (a * NT + tid) * 4;
-            if (i0 + (a * NT + wave * 64) * 4 < total) {      // (the same for the whole wave)
+            const int i = i0 + (a * CR_NT + tid) * 4;
+            if (i0 + (a * CR_NT + wave * 64) * 4 < total) {      // (the same for the whole wave)
                 if (a == 0 && !seeded) {                         // (the list is empty: sixty-four at once)
                     top.seed(i < total && v[a].x == v[a].x, v[a].x, i, lane);
                     seeded = true;
@@ -957,8 +958,8 @@ __global__ __launch_bounds__(NT) void cand_rank_kernel(const float* __restrict__
     // (empty places of the lists: behind every candidate, and all different, so that every place gets written)
     if (lane < k) sh_pair[wave * k + lane] = top.eid != EMPTY_IDX ? packed(top.e, top.eid) : (0xffffffff80000000ull + (unsigned)tid);
     __syncthreads();
-    const int n = (NT / 64) * k;
-    for (int t = tid; t < n; t += NT) {
+    const int n = (CR_NT / 64) * k;
+    for (int t = tid; t < n; t += CR_NT) {
         const unsigned long long mine = sh_pair[t];
         const int place = count_before(sh_pair, n, mine);
         if (place < k) {
@@ -981,12 +982,8 @@ int launch_cand_rank(const float* cand, int64_t cand_stride, const int64_t* cand
     if (nq <= 0) return VDB_OK;
     VDB_REQUIRE(k >= 1 && k <= 64 && cand_stride < (int64_t)0x7fffffff, "candidate ranking: k in 1..64, fewer than 2^31 candidates");
     VDB_REQUIRE(parts >= 1 && (parts == 1 || (part_d && part_i)), "candidate ranking in parts needs room for the lists");
-    if (parts > 1)
-        hipLaunchKernelGGL(cand_rank_kernel<CR_PART_NT>, dim3(nq, parts), dim3(CR_PART_NT), 0, s, cand, cand_stride, cand_off, n_probe, k, k_out,
-                           out_d, out_slots, part_d, part_i);
-    else
-        hipLaunchKernelGGL(cand_rank_kernel<CR_NT>, dim3(nq, parts), dim3(CR_NT), 0, s, cand, cand_stride, cand_off, n_probe, k, k_out,
-                           out_d, out_slots, part_d, part_i);
+    hipLaunchKernelGGL(cand_rank_kernel, dim3(nq, parts), dim3(CR_NT), 0, s, cand, cand_stride, cand_off, n_probe, k, k_out, out_d, out_slots,
+                       part_d, part_i);
     VDB_HIP(hipGetLastError());
     return VDB_OK;
 }
