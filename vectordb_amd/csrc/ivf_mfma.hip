@@ -903,7 +903,7 @@ int launch_ivf_mfma_probe(const IvfProbeJob& j, hipStream_t s) {
 // its part as a list of (distance, slot) for the list merge.
 // Four waves per block: a wave's insertions are serial chains of dependent instructions, every list costs its own
 // k log(n / k) of them, and a SIMD shared by four such waves runs each at a quarter of the speed (1024 x 78 000
-// candidates, k = 10: 169 us with sixteen waves per query, 125 with four; one query in 64 parts: 31 -> 20 us).
+// candidates, k = 10: a batch 0.04 ms shorter than with sixteen waves per query; one query in parts: 31 -> 15 us).
 static constexpr int CR_NT = 256;
 
 __global__ __launch_bounds__(CR_NT) void cand_rank_kernel(const float* __restrict__ cand, int64_t cand_stride,
