@@ -1,3 +1,7 @@
+#!/bin/bash
+# bench.py's JSON line and every bench_paths.py line of one build, written under gpurun_out/final/ on the GPU box:
+#   gpurun --timeout 1200 -- 'bash tools/final_evidence.sh'
+# Copy gpurun_out/final/bench.json (last line) and paths.jsonl into profiles/ under the build's tag afterwards.
 set -u
 cd $GRAFT_REPO_ROOT
 mkdir -p gpurun_out/final
