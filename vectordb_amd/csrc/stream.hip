@@ -1072,11 +1072,11 @@ __global__ __launch_bounds__(1024) void ivf_plan_scan_kernel(const int* __restri
                                                              const int64_t* __restrict__ list_end,
                                                              int n_lists, int group, int* __restrict__ seg_q_off,
                                                              int64_t* __restrict__ seg_item_off, int* __restrict__ cursor) {
-    __shared__ int64_t sh_items[1024];
-    __shared__ int sh_cnt[1024];
+    __shared__ int64_t sh_items[16];             // the waves' totals
+    __shared__ int sh_cnt[16];
     __shared__ int64_t carry_items;
     __shared__ int carry_cnt;
-    const int tid = threadIdx.x;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     if (tid == 0) { carry_items = 0; carry_cnt = 0; }
     __syncthreads();
     for (int base = 0; base < n_lists; base += 1024) {
@@ -1088,25 +1088,27 @@ __global__ __launch_bounds__(1024) void ivf_plan_scan_kernel(const int* __restri
             const int64_t len = list_end[l] - list_beg[l];
             items = ((len + S_NT - 1) / S_NT) * ((c + group - 1) / group);
         }
-        sh_cnt[tid] = c;
-        sh_items[tid] = items;
-        __syncthreads();
-        for (int off = 1; off < 1024; off <<= 1) {
-            int a = 0;
-            int64_t b = 0;
-            if (tid >= off) { a = sh_cnt[tid - off]; b = sh_items[tid - off]; }
-            __syncthreads();
-            sh_cnt[tid] += a;
-            sh_items[tid] += b;
-            __syncthreads();
+        // inclusive sums over the wave, then over the sixteen waves' totals
+        int sum_c = c;
+        int64_t sum_i = items;
+#pragma unroll
+        for (int off = 1; off < 64; off <<= 1) {
+            const int a = __shfl_up(sum_c, off);
+            const int64_t b = __shfl_up(sum_i, off);
+            if (lane >= off) { sum_c += a; sum_i += b; }
         }
+        if (lane == 63) { sh_cnt[wave] = sum_c; sh_items[wave] = sum_i; }
+        __syncthreads();
+        int before_c = carry_cnt;
+        int64_t before_i = carry_items;
+        for (int w = 0; w < wave; ++w) { before_c += sh_cnt[w]; before_i += sh_items[w]; }
         if (l < n_lists) {
-            seg_q_off[l] = carry_cnt + sh_cnt[tid] - c;
-            seg_item_off[l] = carry_items + sh_items[tid] - items;
-            cursor[l] = carry_cnt + sh_cnt[tid] - c;
+            seg_q_off[l] = before_c + sum_c - c;
+            seg_item_off[l] = before_i + sum_i - items;
+            cursor[l] = before_c + sum_c - c;
         }
         __syncthreads();
-        if (tid == 1023) { carry_cnt += sh_cnt[1023]; carry_items += sh_items[1023]; }
+        if (tid == 1023) { carry_cnt = before_c + sum_c; carry_items = before_i + sum_i; }
         __syncthreads();
     }
     if (tid == 0) { seg_q_off[n_lists] = carry_cnt; seg_item_off[n_lists] = carry_items; }
