@@ -250,11 +250,11 @@ struct Workspace {
     // item table of the last flat scan, kept between calls: it depends on (rows, queries, group) only
     DevBuf fp_seg_row_off, fp_seg_q_off, fp_seg_item_off, fp_sq_qid, fp_sq_out, fp_items;
     int64_t fp_n = -1; int fp_nq = -1, fp_group = -1;
-    DevBuf round32, q16, cand, seg_row_off, seg_q_off, seg_item_off, sq_qid, sq_out, cand_off, tile_off, list_cnt, cursor, slots, items;
+    DevBuf round32, q16, cand, seg_row_off, seg_q_off, seg_item_off, sq_qid, sq_out, cand_off, tile_off, list_cnt, cursor, slots, items, slot_list;
     template <class F> void each(F&& f) {
         DevBuf* all[] = {&q_buf, &q_sq, &q_nrm, &part_d, &part_i, &lb_d, &lb_k, &thr_d, &thr_k, &mask, &out_d, &out_i, &dist,
                          &probes, &probe_d, &lut, &stage, &round32, &q16, &cand, &seg_row_off, &seg_q_off, &seg_item_off, &sq_qid, &sq_out,
-                         &cand_off, &tile_off, &list_cnt, &cursor, &slots, &items,
+                         &cand_off, &tile_off, &list_cnt, &cursor, &slots, &items, &slot_list,
                          &queue, &queue_cnt, &flag, &mins, &seg, &seg_len, &redo_mark, &redo_list, &redo_q, &redo_terms, &redo_out, &ticket, &mid[0], &mid[1], &mid[2], &mid[3],
                          &fp_seg_row_off, &fp_seg_q_off, &fp_seg_item_off, &fp_sq_qid, &fp_sq_out, &fp_items};
         for (DevBuf* b : all) f(b);
@@ -3270,12 +3270,29 @@ static int ivfpq_search_impl(vdb_ivfpq* h, const float* d_q, int nq, int k, int 
     for (int q0 = 0; q0 < nq; q0 += q_block) {
         const int nb = std::min(q_block, nq - q0);
         const int* probes = ws.probes.as<int>() + (int64_t)q0 * n_probe;
-        VDB_TRY(launch_ivf_slot_offsets(probes, nb, n_probe, h->lay.d_beg(), h->lay.d_end(), h->n_lists,
-                                        ws.cand_off.as<int64_t>(), ws.tile_off.as<int>(), s));
+        static const bool query_order = getenv("VDB_IVFPQ_QUERY_ORDER") != nullptr;
+        IvfPqUnits units{};
+        const bool by_list = !query_order && ivfpq_scan_takes_units(h->m, h->ksub, h->dsub, h->dim, nb, n_probe);
+        if (by_list) {
+            // a batch for the two-table scan: its (query, list) units in list order, so that the queries that probe a
+            // list follow each other on one CU and the list's codes are read once for them
+            StreamPlanBufs b{};
+            VDB_TRY(reserve_stream_plan(ws, h->n_lists, (int64_t)nb * n_probe, 1, &b));
+            VDB_TRY(ws.list_cnt.reserve((size_t)h->n_lists * sizeof(int)));
+            VDB_TRY(ws.cursor.reserve((size_t)h->n_lists * sizeof(int)));
+            VDB_TRY(ws.slot_list.reserve((size_t)nb * n_probe * sizeof(int)));
+            VDB_TRY(launch_ivf_units_by_list(probes, nb, n_probe, h->lay.d_beg(), h->lay.d_end(), h->n_lists, cand_stride,
+                                             ws.list_cnt.as<int>(), ws.cursor.as<int>(), ws.cand_off.as<int64_t>(),
+                                             ws.tile_off.as<int>(), b, ws.slot_list.as<int>(), s));
+            units = IvfPqUnits{ws.slot_list.as<int>(), b.sq_qid, b.sq_out, b.seg_q_off + h->n_lists};
+        } else {
+            VDB_TRY(launch_ivf_slot_offsets(probes, nb, n_probe, h->lay.d_beg(), h->lay.d_end(), h->n_lists,
+                                            ws.cand_off.as<int64_t>(), ws.tile_off.as<int>(), s));
+        }
         VDB_TRY(launch_ivfpq_scan(d_q + (int64_t)q0 * h->dim, h->dim, h->dim, nb, h->centroids->r.data, h->centroids->r.ld,
                                   h->book.as<float>(), h->m, h->ksub, h->dsub, h->plan, h->codes.as<uint8_t>(),
                                   h->lay.d_beg(), h->lay.d_end(), h->n_lists, probes, n_probe, ws.cand_off.as<int64_t>(),
-                                  cand_stride, ws.cand.as<float>(), s));
+                                  cand_stride, ws.cand.as<float>(), s, by_list ? &units : nullptr));
         static const bool no_cand_rank = getenv("VDB_NO_CAND_RANK") != nullptr;
         if (!no_cand_rank && !multi && !d_mask) {
             // no filter: one block per query reads its run of distances once and ranks the few in reach; a few queries

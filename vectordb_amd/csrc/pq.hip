@@ -466,6 +466,9 @@ struct IvfPqScanParams {
     const int* probes; int n_probe;
     const int64_t* cand_off; int64_t cand_stride;
     float* cand;
+    // the units in list order (launch_ivf_units_by_list), or null: per unit its list, its query and the start of its
+    // candidate slots in `cand`; their number
+    const int* u_list; const int* u_q; const int64_t* u_out; const int* u_count;
 };
 
 static constexpr int IPQ1_NT = 1024;       // threads per (query, list) unit
@@ -664,7 +667,7 @@ __device__ __forceinline__ static V np_leaf_sqdiff_cols(A a, const float (&b)[DS
 
 static constexpr int IPQ2_AHEAD = 4;       // rows per thread whose codes are read a unit ahead, with two tables
 
-template <int M, int DSUB>
+template <int M, int DSUB, bool BY_LIST>
 __global__ __launch_bounds__(IPQ_NT) void ivfpq_scan_lds2_kernel(IvfPqScanParams p, int n_units) {
     constexpr int KS = 256;                      // codewords per sub-space (checked by the launcher)
     constexpr int W = M / 4;                     // 32-bit words of a row's codes
@@ -705,16 +708,40 @@ __global__ __launch_bounds__(IPQ_NT) void ivfpq_scan_lds2_kernel(IvfPqScanParams
         const uint32_t hi = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)((uint64_t)v >> 32));
         return (int64_t)(((uint64_t)hi << 32) | lo);
     };
-    struct Named { int l, qi, pr; };                                     // a unit's list as read (per lane; -1: no such unit)
-    struct Placed { int64_t pos0, end, off; float q_el, c_el; int qi; bool ok; };   // its bounds and output as read (per lane)
-    struct Ready { int64_t pos0; int len; int64_t out; };               // ... and as the block uses them a unit later
+    struct Named { int l, qi, pr; int64_t at; };                         // a unit's list as read (per lane; -1: no such unit)
+    struct Placed { int64_t pos0, end, off; float q_el, c_el; int qi, l; bool ok; };   // its bounds and output as read (per lane)
+    struct Ready { int64_t pos0; int len; int64_t out; int l; };        // ... and as the block uses them a unit later
+    // BY_LIST: the units come in list order, a block takes a run of them, and a unit of the list of the unit before it
+    // keeps that unit's codes (a list is probed by several queries of a batch: its codes are then read once per
+    // block instead of once per query).  Otherwise unit u = query u / n_probe, probe u % n_probe, dealt round-robin.
+    constexpr bool by_list = BY_LIST;
+    int64_t unit, last;                          // this block's units: unit, unit + step, ... < last
+    int step;
+    if (by_list) {
+        const int64_t all = __builtin_amdgcn_readfirstlane(lane_load(p.u_count));
+        const int64_t per = (all + gridDim.x - 1) / gridDim.x;
+        unit = blockIdx.x * per;
+        last = unit + per < all ? unit + per : all;
+        step = 1;
+    } else {
+        unit = blockIdx.x;
+        last = n_units;
+        step = (int)gridDim.x;
+    }
     // the unit three ahead of the one being summed, counted on without a division per unit
-    const int step = (int)gridDim.x, step_q = step / p.n_probe, step_r = step - step_q * p.n_probe;
-    int64_t ahead = blockIdx.x;
-    int ahead_qi = (int)(blockIdx.x / (uint32_t)p.n_probe), ahead_pr = (int)blockIdx.x - ahead_qi * p.n_probe;
+    const int step_q = step / p.n_probe, step_r = step - step_q * p.n_probe;
+    int64_t ahead = unit;
+    int ahead_qi = (int)((uint32_t)unit / (uint32_t)p.n_probe), ahead_pr = (int)unit - ahead_qi * p.n_probe;
     auto name_next = [&]() {
-        Named a{-1, ahead_qi, ahead_pr};
-        if (ahead < n_units) a.l = lane_load(p.probes + ahead);
+        Named a{-1, ahead_qi, ahead_pr, ahead};
+        if (ahead < last) {
+            if (by_list) {
+                a.l = lane_load(p.u_list + ahead);
+                a.qi = lane_load(p.u_q + ahead);
+            } else {
+                a.l = lane_load(p.probes + ahead);
+            }
+        }
         ahead += step;
         ahead_qi += step_q;
         ahead_pr += step_r;
@@ -722,26 +749,28 @@ __global__ __launch_bounds__(IPQ_NT) void ivfpq_scan_lds2_kernel(IvfPqScanParams
         return a;
     };
     auto place_of = [&](const Named& a) {
-        Placed b{0, 0, 0, 0.0f, 0.0f, a.qi, false};
         const int l = __builtin_amdgcn_readfirstlane(a.l);
+        const int qi = by_list ? __builtin_amdgcn_readfirstlane(a.qi) : a.qi;
+        Placed b{0, 0, 0, 0.0f, 0.0f, qi, l, false};
         b.ok = l >= 0 && l < p.n_lists;
         if (b.ok) {
             b.pos0 = lane_load(p.list_beg + l);
             b.end = lane_load(p.list_end + l);
-            b.off = lane_load(p.cand_off + ((int64_t)a.qi * (p.n_probe + 1) + a.pr));
+            b.off = by_list ? lane_load(p.u_out + a.at) : lane_load(p.cand_off + ((int64_t)qi * (p.n_probe + 1) + a.pr));
             if (lane < RL) {
-                b.q_el = *reinterpret_cast<const float*>(reinterpret_cast<const char*>(p.q + (int64_t)a.qi * p.ldq) + (uint32_t)(res_col * 4));
+                b.q_el = *reinterpret_cast<const float*>(reinterpret_cast<const char*>(p.q + (int64_t)qi * p.ldq) + (uint32_t)(res_col * 4));
                 b.c_el = *reinterpret_cast<const float*>(reinterpret_cast<const char*>(p.cent + (int64_t)l * p.ldc) + (uint32_t)(res_col * 4));
             }
         }
         return b;
     };
     auto ready_of = [&](const Placed& b) {
-        Ready r{0, 0, 0};
+        Ready r{0, 0, 0, -1};
         if (b.ok) {
             r.pos0 = uniform64(b.pos0);
             r.len = (int)(uniform64(b.end) - r.pos0);                 // (a device holds fewer than 2^31 rows)
-            r.out = (int64_t)b.qi * p.cand_stride + uniform64(b.off);
+            r.out = by_list ? uniform64(b.off) : (int64_t)b.qi * p.cand_stride + uniform64(b.off);
+            r.l = b.l;
         }
         return r;
     };
@@ -795,7 +824,6 @@ __global__ __launch_bounds__(IPQ_NT) void ivfpq_scan_lds2_kernel(IvfPqScanParams
             asm("v_lshlrev_b32_sdwa %0, %1, %2 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:BYTE_3" : "=v"(r) : "v"(two), "v"(w));
         return r;
     };
-    int64_t unit = blockIdx.x;
     const Named n0 = name_next(), n1 = name_next();
     Named named = name_next();
     const Placed first = place_of(n0);
@@ -861,7 +889,14 @@ __global__ __launch_bounds__(IPQ_NT) void ivfpq_scan_lds2_kernel(IvfPqScanParams
         __builtin_amdgcn_sched_barrier(0);
         // what the coming units need, on its way while this one is summed (asked for here, not at the top, where
         // all sixteen waves would ask at once, straight after the barrier)
-        codes_of(next, w_next);
+        if (by_list && next.l == cur.l && cur.len > 0) {       // the same list again: its codes are here
+#pragma unroll
+            for (int x = 0; x < IPQ2_AHEAD; ++x)
+#pragma unroll
+                for (int i = 0; i < W; ++i) w_next[x][i] = w_cur[x][i];
+        } else {
+            codes_of(next, w_next);
+        }
         const Placed placed_next = place_of(named);
         const Named named_next = name_next();
         __builtin_amdgcn_sched_barrier(0);
@@ -872,39 +907,51 @@ __global__ __launch_bounds__(IPQ_NT) void ivfpq_scan_lds2_kernel(IvfPqScanParams
         named = named_next;
         unit += step;
     };
-    while (unit < n_units) {                     // (the two sets of code registers change places, like the two tables)
+    while (unit < last) {                        // (the two sets of code registers change places, like the two tables)
         unit_of(std::integral_constant<int, 0>{}, w_a, w_b);
-        if (unit >= n_units) break;
+        if (unit >= last) break;
         unit_of(std::integral_constant<int, 1>{}, w_b, w_a);
     }
 }
 
+// whether a scan of these shapes goes to the two-table kernel (which can take its units in list order)
+bool ivfpq_scan_takes_units(int m, int ksub, int dsub, int dim, int nq, int n_probe) {
+    static const bool off = getenv("VDB_IVFPQ_NO_LDS_BOOK") != nullptr || getenv("VDB_IVFPQ_ONE_TABLE") != nullptr;
+    const int64_t n_units = (int64_t)nq * n_probe;
+    const size_t lds_two = ((size_t)m * ksub * dsub + 2 * (size_t)m * ksub) * sizeof(float);
+    return !off && n_units >= 4 * (int64_t)ctx().num_cus && n_units < (int64_t)0x7fffffff && ksub == 256 && lds_two <= 160 * 1024 &&
+           (m == 4 || m == 8 || m == 16) && (dsub == 4 || dsub == 8 || dsub == 16) && m * dsub == dim;
+}
+
 int launch_ivfpq_scan(const float* q, int ldq, int dim, int nq, const float* cent, int ldc, const float* book, int m, int ksub,
                       int dsub, const SumPlan& plan, const uint8_t* codes, const int64_t* list_beg, const int64_t* list_end, int n_lists,
-                      const int* probes, int n_probe, const int64_t* cand_off, int64_t cand_stride, float* cand, hipStream_t s) {
+                      const int* probes, int n_probe, const int64_t* cand_off, int64_t cand_stride, float* cand, hipStream_t s,
+                      const IvfPqUnits* units) {
     if (nq <= 0) return VDB_OK;
     IvfPqScanParams p{q, ldq, dim, cent, ldc, book, m, ksub, dsub, plan, codes, list_beg, list_end, n_lists, probes, n_probe,
-                      cand_off, cand_stride, cand};
+                      cand_off, cand_stride, cand, nullptr, nullptr, nullptr, nullptr};
     const size_t lds = ((size_t)m * ksub + dim) * sizeof(float);
     VDB_REQUIRE(lds <= 160 * 1024, "%d sub-spaces x %d codewords need %zu bytes of LDS", m, ksub, lds);
     const size_t lds_book = lds + (size_t)m * ksub * dsub * sizeof(float);
     static const bool no_lds_book = getenv("VDB_IVFPQ_NO_LDS_BOOK") != nullptr;
     const int64_t n_units = (int64_t)nq * n_probe;
-    static const bool no_two_tables = getenv("VDB_IVFPQ_ONE_TABLE") != nullptr;
     const size_t lds_two = ((size_t)m * ksub * dsub + 2 * (size_t)m * ksub) * sizeof(float);
-    const bool busy = n_units >= 4 * (int64_t)ctx().num_cus && n_units < (int64_t)0x7fffffff;
-    if (!no_lds_book && !no_two_tables && busy && ksub == 256 && lds_two <= 160 * 1024 && (m == 4 || m == 8 || m == 16) &&
-        (dsub == 4 || dsub == 8 || dsub == 16) && m * dsub == dim) {
+    VDB_REQUIRE(units == nullptr || ivfpq_scan_takes_units(m, ksub, dsub, dim, nq, n_probe), "units in list order are for the two-table scan");
+    if (ivfpq_scan_takes_units(m, ksub, dsub, dim, nq, n_probe)) {
+        if (units) { p.u_list = units->list; p.u_q = units->query; p.u_out = units->out; p.u_count = units->count; }
         const dim3 grid((unsigned)ctx().num_cus);
         KernelTimer timer(s);
         bool launched = true;
 #define VDB_LAUNCH_IPQ2(MM, DD)                                                                               \
     if (m == MM && dsub == DD) {                                                                              \
+        const void* kern = units ? reinterpret_cast<const void*>(ivfpq_scan_lds2_kernel<MM, DD, true>)        \
+                                 : reinterpret_cast<const void*>(ivfpq_scan_lds2_kernel<MM, DD, false>);      \
         hipFuncAttributes fa;                                                                                 \
-        VDB_HIP(hipFuncGetAttributes(&fa, reinterpret_cast<const void*>(ivfpq_scan_lds2_kernel<MM, DD>)));    \
+        VDB_HIP(hipFuncGetAttributes(&fa, kern));                                                             \
         VDB_REQUIRE(fa.sharedSizeBytes == 0, "the tables must start the kernel's LDS");                       \
-        VDB_TRY(raise_dynamic_lds(reinterpret_cast<const void*>(ivfpq_scan_lds2_kernel<MM, DD>), lds_two));   \
-        hipLaunchKernelGGL((ivfpq_scan_lds2_kernel<MM, DD>), grid, dim3(IPQ_NT), lds_two, s, p, (int)n_units); \
+        VDB_TRY(raise_dynamic_lds(kern, lds_two));                                                            \
+        if (units) hipLaunchKernelGGL((ivfpq_scan_lds2_kernel<MM, DD, true>), grid, dim3(IPQ_NT), lds_two, s, p, (int)n_units);   \
+        else hipLaunchKernelGGL((ivfpq_scan_lds2_kernel<MM, DD, false>), grid, dim3(IPQ_NT), lds_two, s, p, (int)n_units);        \
     } else
         VDB_LAUNCH_IPQ2(4, 4) VDB_LAUNCH_IPQ2(4, 8) VDB_LAUNCH_IPQ2(4, 16)
         VDB_LAUNCH_IPQ2(8, 4) VDB_LAUNCH_IPQ2(8, 8) VDB_LAUNCH_IPQ2(8, 16)

@@ -1116,7 +1116,7 @@ __global__ __launch_bounds__(1024) void ivf_plan_scan_kernel(const int* __restri
 
 __global__ void ivf_plan_fill_kernel(const int* __restrict__ probes, int nq, int n_probe, int n_lists, int64_t cand_stride,
                                      const int64_t* __restrict__ cand_off, int* __restrict__ cursor,
-                                     int* __restrict__ sq_qid, int64_t* __restrict__ sq_out) {
+                                     int* __restrict__ sq_qid, int64_t* __restrict__ sq_out, int* __restrict__ sq_list) {
     const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (t >= (int64_t)nq * n_probe) return;
     const int q = (int)(t / n_probe), pr = (int)(t - (int64_t)q * n_probe);
@@ -1125,6 +1125,7 @@ __global__ void ivf_plan_fill_kernel(const int* __restrict__ probes, int nq, int
     const int slot = atomicAdd(&cursor[l], 1);
     sq_qid[slot] = q;
     sq_out[slot] = (int64_t)q * cand_stride + cand_off[(int64_t)q * (n_probe + 1) + pr];
+    if (sq_list) sq_list[slot] = l;
 }
 
 int launch_ivf_plan(const int* probes, int nq, int n_probe, const int64_t* list_beg, const int64_t* list_end, int n_lists, int group,
@@ -1137,9 +1138,27 @@ int launch_ivf_plan(const int* probes, int nq, int n_probe, const int64_t* list_
                        b.seg_item_off, cursor);
     const int64_t total = (int64_t)nq * n_probe;
     hipLaunchKernelGGL(ivf_plan_fill_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, probes, nq, n_probe,
-                       n_lists, cand_stride, cand_off, cursor, b.sq_qid, b.sq_out);
+                       n_lists, cand_stride, cand_off, cursor, b.sq_qid, b.sq_out, (int*)nullptr);
     VDB_HIP(hipGetLastError());
     return launch_build_items(b, list_beg, list_end, n_lists, group, s);
+}
+
+// The (query, probe) units in list order, for a scan that walks them itself: slot offsets as above, then per unit its
+// query, the start of its candidate slots and its list (b.sq_qid, b.sq_out, sq_list), the units of one list side by
+// side; b.seg_q_off[n_lists] = the number of units (probes of no list are left out).  No item table.
+int launch_ivf_units_by_list(const int* probes, int nq, int n_probe, const int64_t* list_beg, const int64_t* list_end, int n_lists,
+                             int64_t cand_stride, int* list_cnt, int* cursor, int64_t* cand_off, int* tile_off,
+                             const StreamPlanBufs& b, int* sq_list, hipStream_t s) {
+    VDB_HIP(hipMemsetAsync(list_cnt, 0, (size_t)n_lists * sizeof(int), s));
+    hipLaunchKernelGGL(ivf_plan_count_kernel, dim3((nq + 3) / 4), dim3(256), 0, s, probes, nq, n_probe, n_lists,
+                       list_beg, list_end, list_cnt, cand_off, tile_off);
+    hipLaunchKernelGGL(ivf_plan_scan_kernel, dim3(1), dim3(1024), 0, s, list_cnt, list_beg, list_end, n_lists, 1, b.seg_q_off,
+                       b.seg_item_off, cursor);
+    const int64_t total = (int64_t)nq * n_probe;
+    hipLaunchKernelGGL(ivf_plan_fill_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, probes, nq, n_probe,
+                       n_lists, cand_stride, cand_off, cursor, b.sq_qid, b.sq_out, sq_list);
+    VDB_HIP(hipGetLastError());
+    return VDB_OK;
 }
 
 // only the offsets of every (query, probe) in the query's run of candidate slots and tiles (what a scan that walks
