@@ -250,11 +250,11 @@ struct Workspace {
     // item table of the last flat scan, kept between calls: it depends on (rows, queries, group) only
     DevBuf fp_seg_row_off, fp_seg_q_off, fp_seg_item_off, fp_sq_qid, fp_sq_out, fp_items;
     int64_t fp_n = -1; int fp_nq = -1, fp_group = -1;
-    DevBuf round32, q16, cand, seg_row_off, seg_q_off, seg_item_off, sq_qid, sq_out, cand_off, tile_off, list_cnt, cursor, slots, items, slot_list;
+    DevBuf round32, q16, cand, seg_row_off, seg_q_off, seg_item_off, sq_qid, sq_out, cand_off, tile_off, list_cnt, cursor, slots, items, slot_list, unit_first;
     template <class F> void each(F&& f) {
         DevBuf* all[] = {&q_buf, &q_sq, &q_nrm, &part_d, &part_i, &lb_d, &lb_k, &thr_d, &thr_k, &mask, &out_d, &out_i, &dist,
                          &probes, &probe_d, &lut, &stage, &round32, &q16, &cand, &seg_row_off, &seg_q_off, &seg_item_off, &sq_qid, &sq_out,
-                         &cand_off, &tile_off, &list_cnt, &cursor, &slots, &items, &slot_list,
+                         &cand_off, &tile_off, &list_cnt, &cursor, &slots, &items, &slot_list, &unit_first,
                          &queue, &queue_cnt, &flag, &mins, &seg, &seg_len, &redo_mark, &redo_list, &redo_q, &redo_terms, &redo_out, &ticket, &mid[0], &mid[1], &mid[2], &mid[3],
                          &fp_seg_row_off, &fp_seg_q_off, &fp_seg_item_off, &fp_sq_qid, &fp_sq_out, &fp_items};
         for (DevBuf* b : all) f(b);
@@ -3281,10 +3281,12 @@ static int ivfpq_search_impl(vdb_ivfpq* h, const float* d_q, int nq, int k, int 
             VDB_TRY(ws.list_cnt.reserve((size_t)h->n_lists * sizeof(int)));
             VDB_TRY(ws.cursor.reserve((size_t)h->n_lists * sizeof(int)));
             VDB_TRY(ws.slot_list.reserve((size_t)nb * n_probe * sizeof(int)));
+            VDB_TRY(ws.unit_first.reserve((size_t)(ivfpq_scan_blocks() + 1) * sizeof(int)));
             VDB_TRY(launch_ivf_units_by_list(probes, nb, n_probe, h->lay.d_beg(), h->lay.d_end(), h->n_lists, cand_stride,
                                              ws.list_cnt.as<int>(), ws.cursor.as<int>(), ws.cand_off.as<int64_t>(),
-                                             ws.tile_off.as<int>(), b, ws.slot_list.as<int>(), s));
-            units = IvfPqUnits{ws.slot_list.as<int>(), b.sq_qid, b.sq_out, b.seg_q_off + h->n_lists};
+                                             ws.tile_off.as<int>(), b, ws.slot_list.as<int>(), ivfpq_scan_blocks(),
+                                             ws.unit_first.as<int>(), s));
+            units = IvfPqUnits{ws.slot_list.as<int>(), b.sq_qid, b.sq_out, ws.unit_first.as<int>()};
         } else {
             VDB_TRY(launch_ivf_slot_offsets(probes, nb, n_probe, h->lay.d_beg(), h->lay.d_end(), h->n_lists,
                                             ws.cand_off.as<int64_t>(), ws.tile_off.as<int>(), s));

@@ -467,8 +467,8 @@ struct IvfPqScanParams {
     const int64_t* cand_off; int64_t cand_stride;
     float* cand;
     // the units in list order (launch_ivf_units_by_list), or null: per unit its list, its query and the start of its
-    // candidate slots in `cand`; their number
-    const int* u_list; const int* u_q; const int64_t* u_out; const int* u_count;
+    // candidate slots in `cand`; the first unit of every block (and, behind the last block's, their number)
+    const int* u_list; const int* u_q; const int64_t* u_out; const int* u_first;
 };
 
 static constexpr int IPQ1_NT = 1024;       // threads per (query, list) unit
@@ -718,10 +718,8 @@ __global__ __launch_bounds__(IPQ_NT) void ivfpq_scan_lds2_kernel(IvfPqScanParams
     int64_t unit, last;                          // this block's units: unit, unit + step, ... < last
     int step;
     if (by_list) {
-        const int64_t all = __builtin_amdgcn_readfirstlane(lane_load(p.u_count));
-        const int64_t per = (all + gridDim.x - 1) / gridDim.x;
-        unit = blockIdx.x * per;
-        last = unit + per < all ? unit + per : all;
+        unit = __builtin_amdgcn_readfirstlane(lane_load(p.u_first + blockIdx.x));
+        last = __builtin_amdgcn_readfirstlane(lane_load(p.u_first + blockIdx.x + 1));
         step = 1;
     } else {
         unit = blockIdx.x;
@@ -914,6 +912,8 @@ __global__ __launch_bounds__(IPQ_NT) void ivfpq_scan_lds2_kernel(IvfPqScanParams
     }
 }
 
+int ivfpq_scan_blocks() { return ctx().num_cus; }
+
 // whether a scan of these shapes goes to the two-table kernel (which can take its units in list order)
 bool ivfpq_scan_takes_units(int m, int ksub, int dsub, int dim, int nq, int n_probe) {
     static const bool off = getenv("VDB_IVFPQ_NO_LDS_BOOK") != nullptr || getenv("VDB_IVFPQ_ONE_TABLE") != nullptr;
@@ -938,7 +938,7 @@ int launch_ivfpq_scan(const float* q, int ldq, int dim, int nq, const float* cen
     const size_t lds_two = ((size_t)m * ksub * dsub + 2 * (size_t)m * ksub) * sizeof(float);
     VDB_REQUIRE(units == nullptr || ivfpq_scan_takes_units(m, ksub, dsub, dim, nq, n_probe), "units in list order are for the two-table scan");
     if (ivfpq_scan_takes_units(m, ksub, dsub, dim, nq, n_probe)) {
-        if (units) { p.u_list = units->list; p.u_q = units->query; p.u_out = units->out; p.u_count = units->count; }
+        if (units) { p.u_list = units->list; p.u_q = units->query; p.u_out = units->out; p.u_first = units->first; }
         const dim3 grid((unsigned)ctx().num_cus);
         KernelTimer timer(s);
         bool launched = true;

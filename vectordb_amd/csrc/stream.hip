@@ -1143,12 +1143,34 @@ int launch_ivf_plan(const int* probes, int nq, int n_probe, const int64_t* list_
     return launch_build_items(b, list_beg, list_end, n_lists, group, s);
 }
 
+// Where each of `blocks` blocks starts in the units in list order so that all get about the same number of
+// (256-row tile, query) items: seg_item_off is the running item count over the lists (group = 1), seg_q_off the running
+// unit count.  first[b] = block b's first unit, first[blocks] = the number of units.
+__global__ void ivf_unit_ranges_kernel(const int* __restrict__ seg_q_off, const int64_t* __restrict__ seg_item_off,
+                                       const int64_t* __restrict__ list_beg, const int64_t* __restrict__ list_end,
+                                       int n_lists, int blocks, int* __restrict__ first) {
+    const int b = blockIdx.x * blockDim.x + threadIdx.x;
+    if (b > blocks) return;
+    const int64_t all = seg_item_off[n_lists];
+    if (b == blocks) { first[b] = seg_q_off[n_lists]; return; }
+    const int64_t want = all * b / blocks;       // items in front of block b
+    int lo = 0, hi = n_lists;                    // the list the want-th item falls into: seg_item_off[lo] <= want < seg_item_off[hi]
+    while (hi - lo > 1) {
+        const int mid = (lo + hi) >> 1;
+        if (seg_item_off[mid] <= want) lo = mid; else hi = mid;
+    }
+    const int64_t tiles = (list_end[lo] - list_beg[lo] + S_NT - 1) / S_NT;
+    const int cnt = seg_q_off[lo + 1] - seg_q_off[lo];
+    const int64_t into = tiles > 0 ? (want - seg_item_off[lo] + tiles - 1) / tiles : 0;      // whole units of the list before the block
+    first[b] = b == 0 ? 0 : seg_q_off[lo] + (int)(into < cnt ? into : cnt);
+}
+
 // The (query, probe) units in list order, for a scan that walks them itself: slot offsets as above, then per unit its
 // query, the start of its candidate slots and its list (b.sq_qid, b.sq_out, sq_list), the units of one list side by
-// side; b.seg_q_off[n_lists] = the number of units (probes of no list are left out).  No item table.
+// side (probes of no list are left out), and first[0..blocks]: the unit each of `blocks` blocks starts at.  No item table.
 int launch_ivf_units_by_list(const int* probes, int nq, int n_probe, const int64_t* list_beg, const int64_t* list_end, int n_lists,
                              int64_t cand_stride, int* list_cnt, int* cursor, int64_t* cand_off, int* tile_off,
-                             const StreamPlanBufs& b, int* sq_list, hipStream_t s) {
+                             const StreamPlanBufs& b, int* sq_list, int blocks, int* first, hipStream_t s) {
     VDB_HIP(hipMemsetAsync(list_cnt, 0, (size_t)n_lists * sizeof(int), s));
     hipLaunchKernelGGL(ivf_plan_count_kernel, dim3((nq + 3) / 4), dim3(256), 0, s, probes, nq, n_probe, n_lists,
                        list_beg, list_end, list_cnt, cand_off, tile_off);
@@ -1157,6 +1179,8 @@ int launch_ivf_units_by_list(const int* probes, int nq, int n_probe, const int64
     const int64_t total = (int64_t)nq * n_probe;
     hipLaunchKernelGGL(ivf_plan_fill_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, probes, nq, n_probe,
                        n_lists, cand_stride, cand_off, cursor, b.sq_qid, b.sq_out, sq_list);
+    hipLaunchKernelGGL(ivf_unit_ranges_kernel, dim3((blocks + 256) / 256), dim3(256), 0, s, b.seg_q_off, b.seg_item_off, list_beg, list_end,
+                       n_lists, blocks, first);
     VDB_HIP(hipGetLastError());
     return VDB_OK;
 }

@@ -285,7 +285,7 @@ int launch_ivf_slot_offsets(const int* probes, int nq, int n_probe, const int64_
                             int64_t* cand_off, int* tile_off, hipStream_t s);
 int launch_ivf_units_by_list(const int* probes, int nq, int n_probe, const int64_t* list_beg, const int64_t* list_end, int n_lists,
                              int64_t cand_stride, int* list_cnt, int* cursor, int64_t* cand_off, int* tile_off,
-                             const StreamPlanBufs& b, int* sq_list, hipStream_t s);
+                             const StreamPlanBufs& b, int* sq_list, int blocks, int* first, hipStream_t s);
 int launch_ivf_plan(const int* probes, int nq, int n_probe, const int64_t* list_beg, const int64_t* list_end, int n_lists, int group,
                     int64_t cand_stride, int* list_cnt, int* cursor, int64_t* cand_off, int* tile_off,
                     const StreamPlanBufs& b, hipStream_t s);
@@ -455,7 +455,8 @@ int launch_pq_scan8(const PqScan8Job& j, hipStream_t s);
 // IVF-PQ (index/hybrid.py): residuals, and the per-(query, probe) table + list scan into candidate slots
 int launch_residual(const float* x, int64_t ldx, const float* cent, int ldc, const int* list, int dim, int64_t n,
                     float* out, hipStream_t s);
-struct IvfPqUnits { const int* list; const int* query; const int64_t* out; const int* count; };   // launch_ivf_units_by_list
+struct IvfPqUnits { const int* list; const int* query; const int64_t* out; const int* first; };   // launch_ivf_units_by_list
+int ivfpq_scan_blocks();             // blocks of the two-table scan: first[0..blocks] of the units in list order
 bool ivfpq_scan_takes_units(int m, int ksub, int dsub, int dim, int nq, int n_probe);
 int launch_ivfpq_scan(const float* q, int ldq, int dim, int nq, const float* cent, int ldc, const float* book, int m, int ksub,
                       int dsub, const SumPlan& plan, const uint8_t* codes, const int64_t* list_beg, const int64_t* list_end, int n_lists,
