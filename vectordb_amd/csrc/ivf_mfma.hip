@@ -905,6 +905,7 @@ int launch_ivf_mfma_probe(const IvfProbeJob& j, hipStream_t s) {
 // k log(n / k) of them, and a SIMD shared by four such waves runs each at a quarter of the speed (1024 x 78 000
 // candidates, k = 10: a batch 0.04 ms shorter than with sixteen waves per query; one query in parts: 31 -> 15 us).
 static constexpr int CR_NT = 256;
+static_assert(CR_NT == 256, "cand_rank_kernel reads four waves' bounds");
 
 __global__ __launch_bounds__(CR_NT) void cand_rank_kernel(const float* __restrict__ cand, int64_t cand_stride,
                                                           const int64_t* __restrict__ cand_off, int n_probe, int k, int k_out,
@@ -920,12 +921,17 @@ __global__ __launch_bounds__(CR_NT) void cand_rank_kernel(const float* __restric
     const int first = min((int)blockIdx.y * chunk, whole);
     const int total = min(first + chunk, whole);
     const float* run = cand + (int64_t)q * cand_stride;
+    __shared__ float sh_kth[CR_NT / 64];         // every wave's k-th so far: none of the block's k best lies above any of them
     WaveTopK top;
     top.init(k);
     bool seeded = false;
+    if (lane == 0) sh_kth[wave] = INFINITY;
+    __syncthreads();
     // sixteen bytes per lane and load (a query's run starts on a multiple of 64 floats), four loads in flight
     constexpr int AH = 4;
     for (int i0 = first; i0 < total; i0 += CR_NT * 4 * AH) {
+        // (read without a barrier: a wave's k-th only falls, and any value it has had is a valid bound)
+        const float gate = fminf(fminf(sh_kth[0], sh_kth[1]), fminf(sh_kth[2], sh_kth[3]));
         float4 v[AH];
 #pragma unroll
         for (int a = 0; a < AH; ++a) {
@@ -947,13 +953,14 @@ __global__ __launch_bounds__(CR_NT) void cand_rank_kernel(const float* __restric
                     top.seed(i < total && v[a].x == v[a].x, v[a].x, i, lane);
                     seeded = true;
                 } else {
-                    top.template offer<false, true>(i < total && v[a].x == v[a].x, v[a].x, i, lane);
+                    top.template offer<false, true>(i < total && v[a].x <= gate, v[a].x, i, lane);
                 }
-                top.template offer<false, true>(i + 1 < total && v[a].y == v[a].y, v[a].y, i + 1, lane);
-                top.template offer<false, true>(i + 2 < total && v[a].z == v[a].z, v[a].z, i + 2, lane);
-                top.template offer<false, true>(i + 3 < total && v[a].w == v[a].w, v[a].w, i + 3, lane);
+                top.template offer<false, true>(i + 1 < total && v[a].y <= gate, v[a].y, i + 1, lane);
+                top.template offer<false, true>(i + 2 < total && v[a].z <= gate, v[a].z, i + 2, lane);
+                top.template offer<false, true>(i + 3 < total && v[a].w <= gate, v[a].w, i + 3, lane);
             }
         }
+        if (lane == 0) sh_kth[wave] = top.thr;
     }
     // (empty places of the lists: behind every candidate, and all different, so that every place gets written)
     if (lane < k) sh_pair[wave * k + lane] = top.eid != EMPTY_IDX ? packed(top.e, top.eid) : (0xffffffff80000000ull + (unsigned)tid);
