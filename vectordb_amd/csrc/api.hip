@@ -3306,7 +3306,7 @@ static int ivfpq_search_impl(vdb_ivfpq* h, const float* d_q, int nq, int k, int 
             }
             VDB_TRY(launch_cand_rank(ws.cand.as<float>(), cand_stride, ws.cand_off.as<int64_t>(), n_probe, nb, kmax, k,
                                      d_out_d + (int64_t)q0 * k, ws.slots.as<int>() + (int64_t)q0 * k, s, parts,
-                                     ws.part_d.as<float>(), ws.part_i.as<int>()));
+                                     ws.part_d.as<float>(), ws.part_i.as<int>(), true));
             if (parts > 1) {
                 SelectOut o{d_out_d + (int64_t)q0 * k, nullptr, ws.slots.as<int>() + (int64_t)q0 * k, k, 0, nullptr, nullptr};
                 VDB_TRY(launch_select(ws.part_d.as<float>(), ws.part_i.as<int>(), nb, parts, kmax, 1 << 30, nullptr, 0, o, s, ws.mid));
@@ -3327,7 +3327,8 @@ static int ivfpq_search_impl(vdb_ivfpq* h, const float* d_q, int nq, int k, int 
             c.probes = probes; c.n_probe = n_probe; c.n_lists = h->n_lists; c.list_beg = h->lay.d_beg(); c.list_end = h->lay.d_end();
             c.cand_off = ws.cand_off.as<int64_t>(); c.tile_off = ws.tile_off.as<int>();
             c.row_ids = h->row_ids.as<int>(); c.mask = d_mask;
-            c.metric = VDB_MANHATTAN;                 // the slots already hold final distances
+            c.metric = VDB_EUCLIDEAN_DIRECT;          // the slots hold the squares of the distances
+            c.sqrt_here = true;
             c.lb_d = done > 0 ? ws.lb_d.as<float>() : nullptr; c.lb_k = done > 0 ? ws.lb_k.as<int64_t>() : nullptr;
             c.k = kk; c.splits = splits; c.part_d = ws.part_d.as<float>(); c.part_i = ws.part_i.as<int>();
             VDB_TRY(launch_topk_cand(c, s));

@@ -910,7 +910,7 @@ static_assert(CR_NT == 256, "cand_rank_kernel reads four waves' bounds");
 __global__ __launch_bounds__(CR_NT) void cand_rank_kernel(const float* __restrict__ cand, int64_t cand_stride,
                                                           const int64_t* __restrict__ cand_off, int n_probe, int k, int k_out,
                                                           float* __restrict__ out_d, int* __restrict__ out_slots,
-                                                          float* __restrict__ part_d, int* __restrict__ part_i) {
+                                                          float* __restrict__ part_d, int* __restrict__ part_i, int squares) {
     __shared__ __align__(16) unsigned long long sh_pair[CR_NT];          // four lists of k <= 64
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int q = blockIdx.x;
@@ -932,6 +932,9 @@ __global__ __launch_bounds__(CR_NT) void cand_rank_kernel(const float* __restric
     for (int i0 = first; i0 < total; i0 += CR_NT * 4 * AH) {
         // (read without a barrier: a wave's k-th only falls, and any value it has had is a valid bound)
         const float gate = fminf(fminf(sh_kth[0], sh_kth[1]), fminf(sh_kth[2], sh_kth[3]));
+        // squares: the run holds squares of the distances; whatever has a root <= gate is <= pass_to (the product and
+        // the correctly rounded root are each within 2^-24), and only that gets its root taken
+        const float pass_to = squares ? gate * gate * 1.0000005f + 1e-37f : gate;
         float4 v[AH];
 #pragma unroll
         for (int a = 0; a < AH; ++a) {
@@ -949,15 +952,22 @@ __global__ __launch_bounds__(CR_NT) void cand_rank_kernel(const float* __restric
         for (int a = 0; a < AH; ++a) {
             const int i = i0 + (a * CR_NT + tid) * 4;
             if (i0 + (a * CR_NT + wave * 64) * 4 < total) {      // (the same for the whole wave)
+                auto offer_one = [&](float x, int at) {
+                    const bool pass = at < total && x <= pass_to;
+                    if (__ballot(pass) == 0ull) return;           // (nearly always, after the first few hundred)
+                    const float d = squares ? sqrtf(x) : x;
+                    top.template offer<false, true>(pass && d <= gate, d, at, lane);
+                };
                 if (a == 0 && !seeded) {                         // (the list is empty: sixty-four at once)
-                    top.seed(i < total && v[a].x == v[a].x, v[a].x, i, lane);
+                    const float d = squares ? sqrtf(v[a].x) : v[a].x;
+                    top.seed(i < total && d == d, d, i, lane);
                     seeded = true;
                 } else {
-                    top.template offer<false, true>(i < total && v[a].x <= gate, v[a].x, i, lane);
+                    offer_one(v[a].x, i);
                 }
-                top.template offer<false, true>(i + 1 < total && v[a].y <= gate, v[a].y, i + 1, lane);
-                top.template offer<false, true>(i + 2 < total && v[a].z <= gate, v[a].z, i + 2, lane);
-                top.template offer<false, true>(i + 3 < total && v[a].w <= gate, v[a].w, i + 3, lane);
+                offer_one(v[a].y, i + 1);
+                offer_one(v[a].z, i + 2);
+                offer_one(v[a].w, i + 3);
             }
         }
         if (lane == 0) sh_kth[wave] = top.thr;
@@ -972,12 +982,13 @@ __global__ __launch_bounds__(CR_NT) void cand_rank_kernel(const float* __restric
         if (place < k) {
             const int i = (int)(uint32_t)mine;
             const bool empty = i < 0;
+            const float d = empty ? INFINITY : (squares ? sqrtf(run[i]) : run[i]);
             if (parts > 1) {
                 const int64_t at = ((int64_t)q * parts + blockIdx.y) * k + place;
-                part_d[at] = empty ? INFINITY : run[i];
+                part_d[at] = d;
                 part_i[at] = empty ? EMPTY_IDX : i;
             } else {
-                out_d[(int64_t)q * k_out + place] = empty ? INFINITY : run[i];
+                out_d[(int64_t)q * k_out + place] = d;
                 out_slots[(int64_t)q * k_out + place] = empty ? -1 : i;
             }
         }
@@ -985,12 +996,12 @@ __global__ __launch_bounds__(CR_NT) void cand_rank_kernel(const float* __restric
 }
 
 int launch_cand_rank(const float* cand, int64_t cand_stride, const int64_t* cand_off, int n_probe, int nq, int k, int k_out,
-                     float* out_d, int* out_slots, hipStream_t s, int parts, float* part_d, int* part_i) {
+                     float* out_d, int* out_slots, hipStream_t s, int parts, float* part_d, int* part_i, bool squares) {
     if (nq <= 0) return VDB_OK;
     VDB_REQUIRE(k >= 1 && k <= 64 && cand_stride < (int64_t)0x7fffffff, "candidate ranking: k in 1..64, fewer than 2^31 candidates");
     VDB_REQUIRE(parts >= 1 && (parts == 1 || (part_d && part_i)), "candidate ranking in parts needs room for the lists");
     hipLaunchKernelGGL(cand_rank_kernel, dim3(nq, parts), dim3(CR_NT), 0, s, cand, cand_stride, cand_off, n_probe, k, k_out, out_d, out_slots,
-                       part_d, part_i);
+                       part_d, part_i, squares ? 1 : 0);
     VDB_HIP(hipGetLastError());
     return VDB_OK;
 }

@@ -455,8 +455,9 @@ int launch_residual(const float* x, int64_t ldx, const float* cent, int ldc, con
 
 // One block per (query, probed list): the table of the residual query q - centroid
 // (hybrid.py:303-318) is built in LDS in NumPy order, then the list's codes are
-// scanned one row per thread: fp32 sum in sub-space order, sqrt (hybrid.py:320-326).
-// Distances go to the query's candidate slots in visiting order.
+// scanned one row per thread: fp32 sum in sub-space order (hybrid.py:320-326).
+// The sums go to the query's candidate slots in visiting order WITHOUT their square root: the selection takes it,
+// of the few candidates in reach of the k-th only (a correctly rounded root is twenty instructions per row here).
 struct IvfPqScanParams {
     const float* q; int ldq; int dim;
     const float* cent; int ldc;
@@ -507,7 +508,7 @@ __global__ __launch_bounds__(IPQ1_NT) void ivfpq_scan_kernel(IvfPqScanParams p) 
                 acc = acc + t2;
                 acc = acc + t3;
             }
-            out[r] = sqrtf(acc);
+            out[r] = acc;
         }
         return;
     }
@@ -515,7 +516,7 @@ __global__ __launch_bounds__(IPQ1_NT) void ivfpq_scan_kernel(IvfPqScanParams p) 
         const uint8_t* code = p.codes + (pos0 + r) * p.m;
         float acc = T[code[0]];
         for (int j = 1; j < p.m; ++j) acc = acc + T[j * p.ksub + code[j]];
-        out[r] = sqrtf(acc);
+        out[r] = acc;
     }
 }
 
@@ -582,7 +583,7 @@ __global__ __launch_bounds__(IPQ_NT) void ivfpq_scan_lds_kernel(IvfPqScanParams 
         float acc = T[w[0] & 0xffu];
 #pragma unroll
         for (int j = 1; j < M; ++j) acc = acc + T[j * p.ksub + ((w[j >> 2] >> (8 * (j & 3))) & 0xffu)];
-        return sqrtf(acc);
+        return acc;
     };
     const int64_t step = gridDim.x;
     int64_t unit = blockIdx.x;
@@ -865,7 +866,7 @@ __global__ __launch_bounds__(IPQ_NT) void ivfpq_scan_lds2_kernel(IvfPqScanParams
                     for (int j = 1; j < M; ++j) sum = sum + t[j];
                     const float a = sum.x, b = sum.y;
                     const bool both = r + 64 < cur.len;
-                    const float da = sqrtf(a), db = sqrtf(b);
+                    const float da = a, db = b;
                     // (one value twice rather than a branch round the second row)
                     *reinterpret_cast<float*>(reinterpret_cast<char*>(out) + (uint32_t)(r * 4)) = da;
                     *reinterpret_cast<float*>(reinterpret_cast<char*>(out) + (uint32_t)((both ? r + 64 : r) * 4)) = both ? db : da;
@@ -879,7 +880,7 @@ __global__ __launch_bounds__(IPQ_NT) void ivfpq_scan_lds2_kernel(IvfPqScanParams
                 float a = T[byte_of(w, 0)];
 #pragma unroll
                 for (int j = 1; j < M; ++j) a = a + T[j * KS + byte_of(w, j)];
-                out[r] = sqrtf(a);
+                out[r] = a;
             }
         }
         };

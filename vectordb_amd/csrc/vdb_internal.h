@@ -377,7 +377,8 @@ int launch_rank_rows(float* dist, int nq, int n, int k, float* out_d, int* out_i
 // the k <= 64 best of every query's run of candidate distances (cand + q * cand_stride, cand_off[q][n_probe] of them, no
 // filter) under (distance, slot): distances and slots at stride k_out
 int launch_cand_rank(const float* cand, int64_t cand_stride, const int64_t* cand_off, int n_probe, int nq, int k, int k_out,
-                     float* out_d, int* out_slots, hipStream_t s, int parts = 1, float* part_d = nullptr, int* part_i = nullptr);
+                     float* out_d, int* out_slots, hipStream_t s, int parts = 1, float* part_d = nullptr, int* part_i = nullptr,
+                     bool squares = false);   // squares: the run holds squares of the distances
 int ivf_mfma_pitch(int dim);            // bf16 elements per row of the copy
 int ivf_mfma_subsets();                 // floats of `mins` per query
 int ivf_mfma_len_stride();              // ints of `queue_len` per query
